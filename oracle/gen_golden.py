@@ -1,0 +1,334 @@
+"""ORACLE -- TEST INFRASTRUCTURE.  Generates tests/golden/*.npz.  Runs ONLY in the build
+container (needs /root/reference); the GPU box never runs it.
+
+    python oracle/gen_golden.py            # regenerate every fixture
+
+For every case it (1) runs the reference's own, unmodified Python from /root/reference
+(imported over oracle/pyg_shim, because `torch_geometric` is absent/un-pinned), (2) checks the
+result against the independent float64 dense formulas of oracle/dense_f64.py (<= 2e-6 * scale)
+and refuses to write the fixture otherwise, (3) records inputs, parameters, the operator the
+layer built, outputs and input/parameter gradients.  Fixtures are data only.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "pyg_shim"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from torch_geometric_signed_directed.nn.directed.MagNetConv import MagNetConv  # noqa: E402
+from torch_geometric_signed_directed.nn.general.MSConv import MSConv  # noqa: E402
+from torch_geometric_signed_directed.nn.directed.DiGCNConv import DiGCNConv  # noqa: E402
+from torch_geometric_signed_directed.nn.directed.DGCNConv import DGCNConv  # noqa: E402
+from torch_geometric_signed_directed.nn.general.conv_base import Conv_Base  # noqa: E402
+from torch_geometric_signed_directed.nn.signed.SIMPA import SIMPA  # noqa: E402
+from torch_geometric_signed_directed.nn.directed.DIMPA import DIMPA  # noqa: E402
+from torch_geometric_signed_directed.nn.signed.SGCNConv import SGCNConv  # noqa: E402
+from torch_geometric_signed_directed.nn.directed.complex_relu import complex_relu_layer  # noqa: E402
+from torch_geometric_signed_directed.utils.directed.get_magnetic_Laplacian import \
+    get_magnetic_Laplacian  # noqa: E402
+from torch_geometric_signed_directed.utils.general.get_magnetic_signed_Laplacian import \
+    get_magnetic_signed_Laplacian  # noqa: E402
+
+from oracle import dense_f64 as D  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+TOL = 2e-6
+
+
+def toy_graph(seed, n=40, e=170, isolated=3, loops=4, dups=6, recip=10, signed=False,
+              weighted=True):
+    """Small digraph with every structural edge case: self loops, multi-edges, reciprocal
+    pairs, isolated nodes (the last `isolated` ids never appear)."""
+    rng = np.random.default_rng(seed)
+    m = n - isolated
+    src = rng.integers(0, m, e)
+    dst = rng.integers(0, m, e)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    src = np.concatenate([src, dst[:recip], src[:dups], rng.integers(0, m, loops)])
+    dst = np.concatenate([dst, src[:recip], dst[:dups], src[-loops:]])
+    perm = rng.permutation(src.size)
+    ei = np.stack([src[perm], dst[perm]]).astype(np.int64)
+    w = rng.uniform(0.5, 2.0, ei.shape[1]).astype(np.float32)
+    if signed:
+        w *= rng.choice([-1.0, 1.0], ei.shape[1]).astype(np.float32)
+    return ei, (w if weighted else None)
+
+
+def close(name, got, want, scale=None):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    s = max(1.0, float(np.abs(want).max())) if scale is None else scale
+    err = float(np.abs(got - want).max()) / s
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert err <= TOL, f"{name}: reference-over-shim vs dense float64 differ by {err:.3e}"
+    return err
+
+
+def t(x):
+    return None if x is None else torch.from_numpy(np.asarray(x))
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    arrs = {k: v for k, v in arrs.items() if v is not None}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print(f"  wrote {name}.npz ({len(arrs)} arrays)")
+
+
+# ------------------------------------------------------------------ MagNetConv / MSConv
+def magnet_case(name, seed, K, normalization, weighted, signed=False, absolute_degree=True,
+                fin=6, fout=5, q=0.25, bias=True):
+    ei, w = toy_graph(seed, signed=signed, weighted=weighted)
+    n = 40
+    g = torch.Generator().manual_seed(seed)
+    xr = torch.randn(n, fin, generator=g)
+    xi = torch.randn(n, fin, generator=g)
+    gr = torch.randn(n, fout, generator=g)
+    gi = torch.randn(n, fout, generator=g)
+    torch.manual_seed(seed)
+    if signed:
+        layer = MSConv(fin, fout, K, q, False, normalization=normalization, bias=bias,
+                       absolute_degree=absolute_degree)
+    else:
+        layer = MagNetConv(fin, fout, K, q, False, normalization=normalization, bias=bias)
+    if bias:
+        with torch.no_grad():
+            layer.bias.uniform_(-0.5, 0.5)
+    lam = None
+    if normalization is None:
+        fn = get_magnetic_signed_Laplacian if signed else get_magnetic_Laplacian
+        kw = dict(absolute_degree=absolute_degree) if signed else {}
+        lam = fn(t(ei), t(w), None, q=q, return_lambda_max=True, **kw)[3]
+    xr.requires_grad_(True)
+    xi.requires_grad_(True)
+    out_r, out_i = layer(xr, xi, t(ei), t(w), lambda_max=lam)
+    ((out_r * gr).sum() + (out_i * gi).sum()).backward()
+    op = layer.cached_result
+    # independent check
+    S = D.magnetic_operator(ei, w, n, q, normalization, 2.0 if lam is None else lam, signed,
+                            absolute_degree)
+    dr, di = D.magnet_conv(npy(xr), npy(xi), S, npy(layer.weight),
+                           npy(layer.bias) if bias else None)
+    close(name + ".out_real", npy(out_r), dr)
+    close(name + ".out_imag", npy(out_i), di)
+    # the recorded operator must equal the dense S entry-wise
+    for ei_k, val, part in ((op[0], op[2], S.real), (op[1], op[3], S.imag)):
+        acc = np.zeros((n, n))
+        np.add.at(acc, (npy(ei_k[0]), npy(ei_k[1])), npy(val).astype(np.float64))
+        close(name + ".operator", acc, part)
+    save(name, edge_index=ei, edge_weight=w, x_real=npy(xr), x_imag=npy(xi), grad_real=npy(gr),
+         grad_imag=npy(gi), weight=npy(layer.weight), bias=npy(layer.bias) if bias else None,
+         q=np.float64(q), K=np.int64(K), lambda_max=None if lam is None else np.float64(lam),
+         normalization=np.array("none" if normalization is None else normalization),
+         signed=np.bool_(signed), absolute_degree=np.bool_(absolute_degree),
+         op_index_real=npy(op[0]), op_index_imag=npy(op[1]), op_real=npy(op[2]), op_imag=npy(op[3]),
+         out_real=npy(out_r), out_imag=npy(out_i), dx_real=npy(xr.grad), dx_imag=npy(xi.grad),
+         dweight=npy(layer.weight.grad), dbias=npy(layer.bias.grad) if bias else None)
+
+
+# ------------------------------------------------------------------ DiGCNConv / DGCNConv / Conv_Base
+def digcn_case(name, seed, fin=7, fout=4, bias=True):
+    ei, w = toy_graph(seed)
+    n = 40
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, fin, generator=g, requires_grad=True)
+    go = torch.randn(n, fout, generator=g)
+    torch.manual_seed(seed)
+    layer = DiGCNConv(fin, fout, bias=bias)
+    if bias:
+        with torch.no_grad():
+            layer.bias.uniform_(-0.5, 0.5)
+    out = layer(x, t(ei), t(w))
+    (out * go).sum().backward()
+    close(name, npy(out), D.digcn_conv(npy(x), ei, w, npy(layer.weight),
+                                       npy(layer.bias) if bias else None))
+    save(name, edge_index=ei, edge_weight=w, x=npy(x), grad_out=npy(go), weight=npy(layer.weight),
+         bias=npy(layer.bias) if bias else None, out=npy(out), dx=npy(x.grad),
+         dweight=npy(layer.weight.grad), dbias=npy(layer.bias.grad) if bias else None)
+
+
+def dgcn_case(name, seed, weighted, improved, add_self_loops, f=6):
+    ei, w = toy_graph(seed, weighted=weighted)
+    n = 40
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, f, generator=g, requires_grad=True)
+    go = torch.randn(n, f, generator=g)
+    layer = DGCNConv(improved=improved, add_self_loops=add_self_loops)
+    out = layer(x, t(ei), t(w))
+    (out * go).sum().backward()
+    close(name, npy(out), D.dgcn_conv(npy(x), ei, w, improved, add_self_loops))
+    save(name, edge_index=ei, edge_weight=w, x=npy(x), grad_out=npy(go), out=npy(out),
+         dx=npy(x.grad), improved=np.bool_(improved), add_self_loops=np.bool_(add_self_loops))
+
+
+def conv_base_case(name, seed, weighted, fill, f=6):
+    ei, w = toy_graph(seed, weighted=weighted)
+    n = 40
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, f, generator=g, requires_grad=True)
+    go = torch.randn(n, f, generator=g)
+    layer = Conv_Base(fill)
+    out = layer(x, t(ei), t(w))
+    (out * go).sum().backward()
+    close(name, npy(out), D.conv_base(npy(x), ei, w, fill))
+    save(name, edge_index=ei, edge_weight=w, x=npy(x), grad_out=npy(go), out=npy(out),
+         dx=npy(x.grad), fill_value=np.float64(fill))
+
+
+# ------------------------------------------------------------------ SIMPA / DIMPA
+def simpa_case(name, seed, hop, directed, fill=0.5, f=5):
+    ei_p, w_p = toy_graph(seed)
+    ei_n, w_n = toy_graph(seed + 100, e=90)
+    n = 40
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn(n, f, generator=g, requires_grad=True) for _ in range(4)]
+    layer = SIMPA(hop, fill, directed)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+    params = {k: npy(v) for k, v in layer.state_dict().items()}
+    args = (t(ei_p), t(w_p), t(ei_n), t(w_n), xs[0], xs[1]) + ((xs[2], xs[3]) if directed else ())
+    out = layer(*args)
+    go = torch.randn(out.shape, generator=g)
+    (out * go).sum().backward()
+    close(name, npy(out), D.simpa(ei_p, w_p, ei_n, w_n, npy(xs[0]), npy(xs[1]), params, hop, fill,
+                                  directed, npy(xs[2]), npy(xs[3])))
+    save(name, edge_index_p=ei_p, edge_weight_p=w_p, edge_index_n=ei_n, edge_weight_n=w_n,
+         x_p=npy(xs[0]), x_n=npy(xs[1]), x_pt=npy(xs[2]) if directed else None,
+         x_nt=npy(xs[3]) if directed else None, grad_out=npy(go), out=npy(out),
+         dx_p=npy(xs[0].grad), dx_n=npy(xs[1].grad),
+         dx_pt=npy(xs[2].grad) if directed else None, dx_nt=npy(xs[3].grad) if directed else None,
+         hop=np.int64(hop), directed=np.bool_(directed), fill_value=np.float64(fill),
+         **{"param" + k: v for k, v in params.items()},
+         **{"dparam" + k: npy(p.grad) for k, p in layer.named_parameters()})
+
+
+def dimpa_case(name, seed, hop, fill=0.5, f=5):
+    ei, w = toy_graph(seed)
+    n = 40
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.randn(n, f, generator=g, requires_grad=True)
+    xt = torch.randn(n, f, generator=g, requires_grad=True)
+    layer = DIMPA(hop, fill)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+    out = layer(xs, xt, t(ei), t(w))
+    go = torch.randn(out.shape, generator=g)
+    (out * go).sum().backward()
+    close(name, npy(out), D.dimpa(npy(xs), npy(xt), ei, w, npy(layer._w_s), npy(layer._w_t), hop,
+                                  fill))
+    save(name, edge_index=ei, edge_weight=w, x_s=npy(xs), x_t=npy(xt), grad_out=npy(go),
+         out=npy(out), dx_s=npy(xs.grad), dx_t=npy(xt.grad), w_s=npy(layer._w_s),
+         w_t=npy(layer._w_t), dw_s=npy(layer._w_s.grad), dw_t=npy(layer._w_t.grad),
+         hop=np.int64(hop), fill_value=np.float64(fill))
+
+
+# ------------------------------------------------------------------ SGCNConv
+def sgcn_case(name, seed, first_aggr, norm_emb, in_dim=6, out_dim=4):
+    pos, _ = toy_graph(seed, weighted=False)
+    neg, _ = toy_graph(seed + 50, e=100, weighted=False)
+    n = 40
+    g = torch.Generator().manual_seed(seed)
+    fx = in_dim if first_aggr else 2 * in_dim
+    x = torch.randn(n, fx, generator=g, requires_grad=True)
+    torch.manual_seed(seed)
+    layer = SGCNConv(in_dim, out_dim, first_aggr, norm_emb=norm_emb)
+    out = layer(x, t(pos), t(neg))
+    go = torch.randn(out.shape, generator=g)
+    (out * go).sum().backward()
+    lb = (npy(layer.lin_b.weight), npy(layer.lin_b.bias))
+    lu = (npy(layer.lin_u.weight), npy(layer.lin_u.bias))
+    close(name, npy(out), D.sgcn_conv(npy(x), pos, neg, lb, lu, first_aggr, in_dim, norm_emb))
+    save(name, pos_edge_index=pos, neg_edge_index=neg, x=npy(x), grad_out=npy(go), out=npy(out),
+         dx=npy(x.grad), lin_b_weight=lb[0], lin_b_bias=lb[1], lin_u_weight=lu[0], lin_u_bias=lu[1],
+         dlin_b_weight=npy(layer.lin_b.weight.grad), dlin_u_weight=npy(layer.lin_u.weight.grad),
+         dlin_b_bias=npy(layer.lin_b.bias.grad), dlin_u_bias=npy(layer.lin_u.bias.grad),
+         first_aggr=np.bool_(first_aggr), norm_emb=np.bool_(norm_emb), in_dim=np.int64(in_dim))
+
+
+def relu_case(name, seed):
+    g = torch.Generator().manual_seed(seed)
+    re = torch.randn(40, 6, generator=g)
+    im = torch.randn(40, 6, generator=g)
+    re[3, 2] = 0.0  # boundary: real == 0 passes
+    o_r, o_i = complex_relu_layer()(re, im)
+    save(name, real=npy(re), imag=npy(im), out_real=npy(o_r), out_imag=npy(o_i))
+
+
+def kat_case():
+    """SURVEY.md Appendix B known-answer vector, re-derived here from the reference and checked
+    digit for digit against the hand-checked numbers printed in the survey."""
+    ei = np.array([[0, 1, 2, 0, 3], [1, 2, 0, 2, 3]], dtype=np.int64)
+    w = np.array([1, 2, 1, 3, 5], dtype=np.float32)
+    oei, re, im = get_magnetic_Laplacian(t(ei), t(w), "sym", None, 4, 0.25)
+    want_re = [1.128623e-08, 0.7302967, 1.128623e-08, 0.4714045, 0.7302967, 0.4714045, 1, 1, 1, 1]
+    want_im = [-0.2581989, 6.384457e-08, 0.2581989, 4.121149e-08, -6.384457e-08, -4.121149e-08,
+               0, 0, 0, 0]
+    assert npy(oei).tolist() == [[0, 0, 1, 1, 2, 2, 0, 1, 2, 3], [1, 2, 0, 2, 0, 1, 0, 1, 2, 3]]
+    assert np.allclose(npy(re), want_re, rtol=2e-6, atol=1e-12)
+    assert np.allclose(npy(im), want_im, rtol=2e-6, atol=1e-12)
+    layer = MagNetConv(2, 2, 1, 0.25, False)
+    with torch.no_grad():
+        layer.weight.copy_(torch.tensor([[[1, 0], [0, 1]], [[.5, -1], [2, .25]]]))
+        layer.bias.copy_(torch.tensor([.1, -.2]))
+    xr = torch.tensor([[1., 2], [3, 4], [5, 6], [7, 8]])
+    xi = torch.tensor([[-1, .5], [.25, 2], [1.5, -3], [0, 1]])
+    o_r, o_i = layer(xr, xi, t(ei), t(w))
+    want_or = [[11.624232, -1.320588], [9.814465, 0.440558], [11.364678, 7.492043], [7.1, 6.8]]
+    want_oi = [[11.754375, -0.191489], [10.056267, 3.859610], [14.364678, 1.492042], [7.1, 8.8]]
+    assert np.allclose(npy(o_r), want_or, atol=2e-6) and np.allclose(npy(o_i), want_oi, atol=2e-6)
+    ws = np.array([1, -2, 1, -3, 5], dtype=np.float32)
+    _, sre, sim = get_magnetic_signed_Laplacian(t(ei), t(ws), "sym", None, 4, 0.25)
+    save("kat_appendix_b", edge_index=ei, edge_weight=w, lap_index=npy(oei), lap_real=npy(re),
+         lap_imag=npy(im), weight=npy(layer.weight), bias=npy(layer.bias), x_real=npy(xr),
+         x_imag=npy(xi), out_real=npy(o_r), out_imag=npy(o_i), signed_weight=ws,
+         signed_lap_real=npy(sre), signed_lap_imag=npy(sim),
+         op_real=npy(layer.cached_result[2]), op_imag=npy(layer.cached_result[3]))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    print("MagNetConv / MSConv")
+    magnet_case("magnet_k1_sym_w", 1, 1, "sym", True)
+    magnet_case("magnet_k1_sym_unw", 2, 1, "sym", False)
+    magnet_case("magnet_k2_sym_w", 3, 2, "sym", True, q=0.1)
+    magnet_case("magnet_k3_sym_w_nobias", 4, 3, "sym", True, bias=False)
+    magnet_case("magnet_k2_none_w", 5, 2, None, True, q=0.2)
+    magnet_case("msconv_k1_sym_abs", 6, 1, "sym", True, signed=True)
+    magnet_case("msconv_k2_sym_noabs", 7, 2, "sym", True, signed=True, absolute_degree=False)
+    magnet_case("msconv_k2_none_abs", 8, 2, None, True, signed=True, q=0.15)
+    print("DiGCNConv / DGCNConv / Conv_Base")
+    digcn_case("digcn_bias", 11)
+    digcn_case("digcn_nobias", 12, bias=False)
+    dgcn_case("dgcn_w_improved", 13, True, True, True)
+    dgcn_case("dgcn_unw", 14, False, False, True)
+    dgcn_case("dgcn_w_noloops", 15, True, False, False)
+    conv_base_case("conv_base_w_fill05", 16, True, 0.5)
+    conv_base_case("conv_base_unw_fill0", 17, False, 0.0)
+    print("SIMPA / DIMPA")
+    simpa_case("simpa_undirected_hop2", 21, 2, False)
+    simpa_case("simpa_undirected_hop3", 22, 3, False)
+    simpa_case("simpa_directed_hop2", 23, 2, True)
+    dimpa_case("dimpa_hop2", 24, 2)
+    print("SGCNConv")
+    sgcn_case("sgcn_first", 31, True, False)
+    sgcn_case("sgcn_deep", 32, False, False)
+    sgcn_case("sgcn_first_normemb", 33, True, True)
+    relu_case("complex_relu", 41)
+    kat_case()
+
+
+if __name__ == "__main__":
+    main()
