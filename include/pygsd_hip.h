@@ -1,0 +1,143 @@
+/*
+ * pygsd_hip.h -- C-ABI of libpygsd_hip.so: the MI355X (gfx950) implementation of the sparse
+ * message-passing hot path of SherylHYX/pytorch_geometric_signed_directed.
+ *
+ * The reference has NO native layer and NO FFI: every conv layer calls
+ * torch_geometric.nn.conv.MessagePassing.propagate (gather -> scale -> scatter-reduce) from
+ * Python.  Each entry point below names the reference call site(s) it replaces
+ * (paths relative to torch_geometric_signed_directed/).  Plain pointers and sizes only:
+ * device pointers are raw HIP device addresses, `stream` is a hipStream_t passed as void*.
+ * No torch types cross this boundary.  The host-side binding a reference maintainer would add
+ * is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, nonzero on failure; pygsd_last_error() then holds a
+ *     thread-local message (the Python host raises RuntimeError with it).
+ *   - all work is enqueued asynchronously on `stream`; nothing synchronises the device except
+ *     pygsd_prof_collect.
+ *   - CSR indices are int32 (n_rows < 2^31, nnz < 2^31 per shard); feature matrices are
+ *     row-major with a row stride `ld*` given in ELEMENTS (so column slices are addressable).
+ *   - the library is stateless apart from the thread-local error string and the optional
+ *     kernel-timing recorder (pygsd_prof_*).
+ */
+#ifndef PYGSD_HIP_H
+#define PYGSD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYGSD_ABI_VERSION 1
+
+/* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
+int pygsd_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char* pygsd_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * SpMM / segment-reduce over a CSR grouped by OUTPUT row.
+ *
+ *   Y[r, :] = alpha * scale_r * sum_{e = rowptr[r] .. rowptr[r+1]-1} val[e] * X[col[e], :]
+ *             + beta * Z[r, :]
+ *   scale_r = 1                               (mean == 0)
+ *           = 1 / max(rowptr[r+1]-rowptr[r],1) (mean != 0)
+ *   val == NULL means all ones; Z == NULL means no beta term.
+ *
+ * Replaces MessagePassing.propagate(edge_index, x=..., norm=|edge_weight=...) with
+ * message() = norm.view(-1,1) * x_j and aggr in {add, mean}:
+ *   nn/directed/MagNetConv.py:196-240 (message :251), nn/general/MSConv.py:193-221 (:233),
+ *   nn/directed/DiGCNConv.py:86 (:88), nn/directed/DGCNConv.py:95 (:99),
+ *   nn/general/conv_base.py:111 (:116), nn/signed/SGCNConv.py:101-119 (:128, aggr='mean' :73).
+ * alpha/beta/Z fuse the Chebyshev recurrence T_k = 2 S T_{k-1} - T_{k-2}
+ *   (MagNetConv.py:216,222,228,234).
+ * The same entry point computes the backward dX = S^T dY when handed the CSR grouped by source.
+ * Deterministic: no atomics; the summation order inside a row is fixed by the CSR order.
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                       const float* X, int64_t ldx,
+                       float* Y, int64_t ldy,
+                       const float* Z, int64_t ldz,
+                       int32_t n_rows, int32_t n_feat,
+                       float alpha, float beta, int32_t mean,
+                       void* stream);
+
+/* Two operators sharing ONE sparsity pattern, two inputs, two outputs, one traversal:
+ *   Ya = alpha * sum val_a[e] * Xa[col[e]] + beta * Za ;  Yb likewise with val_b / Xb / Zb.
+ * This is the complex Hermitian (magnetic) Laplacian product of MagNetConv / MSConv: the real
+ * and imaginary operators (MagNetConv.py:196-203; duplicates :204-211) walk the same pattern.
+ * Xa/Xb share ldx, Ya/Yb share ldy, Za/Zb share ldz. */
+int pygsd_spmm2_csr_f32(const int32_t* rowptr, const int32_t* col,
+                        const float* val_a, const float* val_b,
+                        const float* Xa, const float* Xb, int64_t ldx,
+                        float* Ya, float* Yb, int64_t ldy,
+                        const float* Za, const float* Zb, int64_t ldz,
+                        int32_t n_rows, int32_t n_feat,
+                        float alpha, float beta,
+                        void* stream);
+
+/* Per-edge gradient of the edge values (SDDMM): out[e] = < A[ia[e], :], B[ib[e], :] >.
+ * Backward of message() w.r.t. `norm` (needed by trainable_q, MagNetConv.py:58-59,141-142, and by
+ * any edge_weight that requires grad). */
+int pygsd_sddmm_coo_f32(const int32_t* ia, const int32_t* ib, int64_t nnz,
+                        const float* A, int64_t lda, const float* B, int64_t ldb,
+                        int32_t n_feat, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * COO -> CSR (operator build).  Groups the nnz entries by seg[e] (stable: entries of one group
+ * keep their COO order, which is the order torch's scatter_add_ sums them in the reference) and
+ * emits rowptr[n_seg+1], col[e'] = (int32) other[perm[e']], perm[e'] = original entry id.
+ * Replaces the implicit grouping done by scatter(..., index=edge_index[i]) inside
+ * MessagePassing.propagate.  seg/other are the int64 rows of the caller's edge_index.
+ * Workspace: call pygsd_csr_from_coo_workspace first; pass a device buffer of that many bytes.
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_csr_from_coo_workspace(int64_t nnz, int32_t n_seg, size_t* bytes);
+int pygsd_csr_from_coo(const int64_t* seg, const int64_t* other, int64_t nnz, int32_t n_seg,
+                       int32_t* rowptr, int32_t* col, int32_t* perm,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[i] = src[perm[i]]  (re-order edge values into CSR order). */
+int pygsd_gather_f32(const float* src, const int32_t* perm, int64_t n, float* out, void* stream);
+
+/* Stable sort of (key, payload = entry id) pairs by a 64-bit key using only bits
+ * [0, key_bits): the sort inside torch_geometric.utils.coalesce
+ * (utils/directed/get_magnetic_Laplacian.py:60, utils/general/get_magnetic_signed_Laplacian.py:64). */
+int pygsd_sort_keys_u64_workspace(int64_t n, size_t* bytes);
+int pygsd_sort_keys_u64(const uint64_t* keys_in, uint64_t* keys_out, int32_t* perm_out,
+                        int64_t n, int32_t key_bits,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Element-wise epilogues of the path.
+ * complex ReLU: mask = (real >= 0); out_real = mask*real; out_imag = mask*imag
+ *   (nn/directed/complex_relu.py:21-22).  In-place allowed (out == in). */
+int pygsd_complex_relu_f32(const float* real, const float* imag, float* out_real, float* out_imag,
+                           int64_t n, void* stream);
+/* backward of the above: g_real_in = mask*g_real, g_imag_in = mask*g_imag (mask from `real`). */
+int pygsd_complex_relu_bwd_f32(const float* real, const float* g_real, const float* g_imag,
+                               float* gi_real, float* gi_imag, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel-timing recorder (measurement only; used by bench.py for the roofline object).
+ * When enabled, every kernel launch of this library is bracketed by a pair of hipEvents on the
+ * launch stream.  pygsd_prof_collect synchronises those events and returns, for kernel class
+ * `kernel_id` (PYGSD_K_*), the number of launches and their summed duration in milliseconds.
+ * ------------------------------------------------------------------------------------------- */
+enum {
+    PYGSD_K_SPMM = 0,
+    PYGSD_K_SPMM2 = 1,
+    PYGSD_K_SDDMM = 2,
+    PYGSD_K_BUILD = 3,
+    PYGSD_K_ELEMENTWISE = 4,
+    PYGSD_K_COUNT = 5
+};
+int pygsd_prof_enable(int32_t on);
+int pygsd_prof_reset(void);
+int pygsd_prof_collect(int32_t kernel_id, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYGSD_HIP_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libpygsd_hip.so (include/pygsd_hip.h).  No torch types cross this boundary:
+tensors are handed over as raw device addresses (`tensor.data_ptr()`), the stream as the raw
+hipStream_t of torch's current stream.
+
+The library is REQUIRED: there is no CPU or eager-PyTorch fallback behind these functions.  If the
+shared object is missing or fails to load, importing an op raises immediately.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpygsd_hip.so")
+_lib = None
+
+K_SPMM, K_SPMM2, K_SDDMM, K_BUILD, K_ELEMENTWISE = range(5)
+KERNEL_IDS = {"spmm": K_SPMM, "spmm2": K_SPMM2, "sddmm": K_SDDMM, "build": K_BUILD,
+              "elementwise": K_ELEMENTWISE}
+
+# name -> (restype, argtypes); must list every symbol include/pygsd_hip.h declares
+PROTOTYPES = {
+    "pygsd_version": (c_int32, []),
+    "pygsd_last_error": (ctypes.c_char_p, []),
+    "pygsd_spmm_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                     c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_int32,
+                                     c_void_p]),
+    "pygsd_spmm2_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                      c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
+                                      c_int32, c_float, c_float, c_void_p]),
+    "pygsd_sddmm_coo_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                      c_int32, c_void_p, c_void_p]),
+    "pygsd_csr_from_coo_workspace": (c_int32, [c_int64, c_int32, ctypes.POINTER(c_size_t)]),
+    "pygsd_csr_from_coo": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
+    "pygsd_gather_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "pygsd_sort_keys_u64_workspace": (c_int32, [c_int64, ctypes.POINTER(c_size_t)]),
+    "pygsd_sort_keys_u64": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_size_t,
+                                      c_void_p]),
+    "pygsd_complex_relu_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "pygsd_complex_relu_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                             c_void_p]),
+    "pygsd_prof_enable": (c_int32, [c_int32]),
+    "pygsd_prof_reset": (c_int32, []),
+    "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
+}
+ABI_VERSION = 1
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"pytorch_geometric_signed_directed_amd: HIP library not built ({_LIB_PATH} is missing). "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root. "
+            "There is no CPU fallback for this path.")
+    handle = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = handle.pygsd_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libpygsd_hip.so ABI version {got} != expected {ABI_VERSION}; rebuild it")
+    _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().pygsd_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed: {msg}")
+
+
+def stream_ptr():
+    """Raw hipStream_t of torch's current stream on the current device."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def require_gpu(*tensors):
+    """The path only exists on the GPU: refuse CPU tensors instead of silently computing elsewhere."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "pytorch_geometric_signed_directed_amd ops run on MI355X (HIP) only; got a "
+                f"{t.device} tensor. There is no CPU fallback (the CPU restatement lives in oracle/ "
+                "and is test infrastructure).")
+
+
+# ---- kernel-timing recorder (bench.py) --------------------------------------------------------
+def prof_enable(on=True):
+    check(lib().pygsd_prof_enable(1 if on else 0), "pygsd_prof_enable")
+
+
+def prof_reset():
+    check(lib().pygsd_prof_reset(), "pygsd_prof_reset")
+
+
+def prof_collect(kernel):
+    n, ms = c_int64(0), c_double(0.0)
+    check(lib().pygsd_prof_collect(KERNEL_IDS[kernel], ctypes.byref(n), ctypes.byref(ms)),
+          "pygsd_prof_collect")
+    return n.value, ms.value

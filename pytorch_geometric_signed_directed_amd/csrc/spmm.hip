@@ -1,0 +1,320 @@
+// CSR SpMM / segment-reduce kernels for gfx950 (CDNA4, wave64) -- the gather -> scale -> reduce
+// hot path.  HBM-bound: ~0.5 flop per byte, so no MFMA here; what matters is 16-byte-per-lane
+// coalesced gathers of whole feature rows, many independent row fetches in flight per wave, and no
+// atomics (one wavefront owns an output row, deterministic summation order).
+//
+// Mapping (vector path, F % 4 == 0, 16-byte aligned rows):
+//   one wavefront  <-> one output row r
+//   LPR lanes      <-> one gathered feature row (LPR * float4 = F floats; F = 64 -> 16 lanes)
+//   NPW = 64 / LPR <-> neighbours fetched by ONE wave-wide global_load_dwordx4 (F = 64 -> 4 rows,
+//                      1 KiB per instruction)
+//   the row's (col, val) entries are loaded 64 at a time with one coalesced load each, kept in
+//   registers, and handed to the lane groups through the LDS crossbar (ds_bpermute) -- the
+//   per-wavefront "row tile" never touches LDS memory or HBM twice.
+//   UNROLL independent gathers are issued before the first FMA (8 x 16 B per lane in flight).
+//   Epilogue: butterfly over the NPW lane groups, fused alpha / mean / beta*Z, one float4 store.
+#include "common.hpp"
+
+namespace pygsd {
+namespace {
+
+struct SpmmArgs {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const float* va;
+    const float* vb;
+    const float* xa;
+    const float* xb;
+    float* ya;
+    float* yb;
+    const float* za;
+    const float* zb;
+    int64_t ldx, ldy, ldz;
+    int32_t n_rows, n_feat;
+    float alpha, beta;
+    int32_t mean;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4& v)
+{
+    acc.x = fmaf(s, v.x, acc.x);
+    acc.y = fmaf(s, v.y, acc.y);
+    acc.z = fmaf(s, v.z, acc.z);
+    acc.w = fmaf(s, v.w, acc.w);
+}
+
+template <int LPR>
+__device__ __forceinline__ void reduce_groups(float4& a)
+{
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        a.x += __shfl_xor(a.x, off);
+        a.y += __shfl_xor(a.y, off);
+        a.z += __shfl_xor(a.z, off);
+        a.w += __shfl_xor(a.w, off);
+    }
+}
+
+__device__ __forceinline__ float4 finish(float4 acc, float alpha, float beta, bool mean, int deg,
+                                         const float* z)
+{
+    if (mean) {
+        const float d = static_cast<float>(deg > 1 ? deg : 1);
+        acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d;
+    }
+    acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+    if (z) {
+        const float4 zz = ld4(z);
+        acc.x = fmaf(beta, zz.x, acc.x);
+        acc.y = fmaf(beta, zz.y, acc.y);
+        acc.z = fmaf(beta, zz.z, acc.z);
+        acc.w = fmaf(beta, zz.w, acc.w);
+    }
+    return acc;
+}
+
+constexpr int kWavesPerBlock = 4;
+
+template <int LPR, bool DUAL>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_kernel(SpmmArgs p)
+{
+    constexpr int NPW = 64 / LPR;
+    constexpr int UNROLL = DUAL ? 4 : 8;
+    const int lane = threadIdx.x & 63;
+    // wave-uniform row id -> rowptr is fetched with scalar loads
+    const int row = __builtin_amdgcn_readfirstlane(
+        static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+    if (row >= p.n_rows) return;
+    const int sub = lane / LPR;
+    const int fl = static_cast<int>(blockIdx.y) * (LPR * 4) + (lane % LPR) * 4;
+    const bool fact = fl < p.n_feat;
+    const int beg = p.rowptr[row];
+    const int end = p.rowptr[row + 1];
+
+    float4 acc_a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xa = p.xa + fl;
+    const float* xb = DUAL ? p.xb + fl : nullptr;
+
+    for (int base = beg; base < end; base += 64) {
+        const int cnt = (end - base) < 64 ? (end - base) : 64;
+        int c = 0;
+        float wa = 0.f, wb = 0.f;
+        if (lane < cnt) {
+            c = p.col[base + lane];
+            wa = p.va ? p.va[base + lane] : 1.f;
+            if (DUAL) wb = p.vb[base + lane];
+        }
+        for (int u = 0; u < cnt; u += NPW * UNROLL) {
+            float4 ga[UNROLL];
+            float4 gb[UNROLL];
+            float sa[UNROLL];
+            float sb[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const int idx = u + k * NPW + sub;
+                const bool ok = fact && idx < cnt;
+                const int cj = __shfl(c, idx & 63);
+                const float ta = __shfl(wa, idx & 63);
+                sa[k] = ok ? ta : 0.f;
+                ga[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (DUAL) {
+                    const float tb = __shfl(wb, idx & 63);
+                    sb[k] = ok ? tb : 0.f;
+                    gb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (ok) {
+                    const int64_t off = static_cast<int64_t>(cj) * p.ldx;
+                    ga[k] = ld4(xa + off);
+                    if (DUAL) gb[k] = ld4(xb + off);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                fma4(acc_a, sa[k], ga[k]);
+                if (DUAL) fma4(acc_b, sb[k], gb[k]);
+            }
+        }
+    }
+
+    reduce_groups<LPR>(acc_a);
+    if (DUAL) reduce_groups<LPR>(acc_b);
+
+    if (sub == 0 && fact) {
+        const int deg = end - beg;
+        const int64_t yo = static_cast<int64_t>(row) * p.ldy + fl;
+        const int64_t zo = static_cast<int64_t>(row) * p.ldz + fl;
+        st4(p.ya + yo, finish(acc_a, p.alpha, p.beta, p.mean != 0, deg, p.za ? p.za + zo : nullptr));
+        if (DUAL)
+            st4(p.yb + yo, finish(acc_b, p.alpha, p.beta, false, deg, p.zb ? p.zb + zo : nullptr));
+    }
+}
+
+// Generic fallback (any F, any alignment): lane <-> feature, neighbours walked sequentially with
+// wave-uniform (scalar) col/val loads, 256-byte coalesced row reads.
+template <bool DUAL>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_scalar_kernel(SpmmArgs p)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(
+        static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+    if (row >= p.n_rows) return;
+    const int beg = p.rowptr[row];
+    const int end = p.rowptr[row + 1];
+    const int deg = end - beg;
+    for (int f0 = 0; f0 < p.n_feat; f0 += 64) {
+        const int f = f0 + lane;
+        const bool ok = f < p.n_feat;
+        float acc_a = 0.f, acc_b = 0.f;
+#pragma unroll 4
+        for (int e = beg; e < end; ++e) {
+            const int64_t off = static_cast<int64_t>(p.col[e]) * p.ldx + f;
+            const float wa = p.va ? p.va[e] : 1.f;
+            if (ok) acc_a = fmaf(wa, p.xa[off], acc_a);
+            if (DUAL) {
+                const float wb = p.vb[e];
+                if (ok) acc_b = fmaf(wb, p.xb[off], acc_b);
+            }
+        }
+        if (ok) {
+            if (p.mean) acc_a /= static_cast<float>(deg > 1 ? deg : 1);
+            acc_a *= p.alpha;
+            if (p.za) acc_a = fmaf(p.beta, p.za[static_cast<int64_t>(row) * p.ldz + f], acc_a);
+            p.ya[static_cast<int64_t>(row) * p.ldy + f] = acc_a;
+            if (DUAL) {
+                acc_b *= p.alpha;
+                if (p.zb) acc_b = fmaf(p.beta, p.zb[static_cast<int64_t>(row) * p.ldz + f], acc_b);
+                p.yb[static_cast<int64_t>(row) * p.ldy + f] = acc_b;
+            }
+        }
+    }
+}
+
+template <bool DUAL>
+int launch_spmm(const SpmmArgs& a, hipStream_t stream)
+{
+    if (a.n_rows == 0 || a.n_feat == 0) return 0;
+    const dim3 block(kWavesPerBlock * 64);
+    const unsigned gx = (static_cast<unsigned>(a.n_rows) + kWavesPerBlock - 1) / kWavesPerBlock;
+    bool vec = (a.n_feat % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && aligned16(a.xa) &&
+               aligned16(a.ya);
+    if (a.za) vec = vec && (a.ldz % 4 == 0) && aligned16(a.za);
+    if (DUAL) {
+        vec = vec && aligned16(a.xb) && aligned16(a.yb);
+        if (a.zb) vec = vec && aligned16(a.zb);
+    }
+    ProfScope prof(DUAL ? PYGSD_K_SPMM2 : PYGSD_K_SPMM, stream);
+    if (!vec) {
+        hipLaunchKernelGGL(spmm_scalar_kernel<DUAL>, dim3(gx), block, 0, stream, a);
+        return check_launch("spmm_scalar_kernel");
+    }
+    const int quads = a.n_feat / 4;
+    if (quads <= 4) {
+        hipLaunchKernelGGL((spmm_vec_kernel<4, DUAL>), dim3(gx), block, 0, stream, a);
+    } else if (quads <= 8) {
+        hipLaunchKernelGGL((spmm_vec_kernel<8, DUAL>), dim3(gx), block, 0, stream, a);
+    } else if (quads <= 16) {
+        hipLaunchKernelGGL((spmm_vec_kernel<16, DUAL>), dim3(gx), block, 0, stream, a);
+    } else if (quads <= 32) {
+        hipLaunchKernelGGL((spmm_vec_kernel<32, DUAL>), dim3(gx), block, 0, stream, a);
+    } else {
+        const unsigned gy = (static_cast<unsigned>(quads) + 63) / 64;
+        hipLaunchKernelGGL((spmm_vec_kernel<64, DUAL>), dim3(gx, gy), block, 0, stream, a);
+    }
+    return check_launch("spmm_vec_kernel");
+}
+
+// ------------------------------------------------------------------------------------------
+// SDDMM: out[e] = <A[ia[e]], B[ib[e]]>; 16 lanes per edge, 4 edges per wavefront.
+// ------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void sddmm_kernel(const int32_t* __restrict__ ia,
+                                                    const int32_t* __restrict__ ib, int64_t nnz,
+                                                    const float* __restrict__ A, int64_t lda,
+                                                    const float* __restrict__ B, int64_t ldb,
+                                                    int32_t n_feat, float* __restrict__ out)
+{
+    const int t = threadIdx.x & 15;
+    const int64_t e = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 4;
+    float acc = 0.f;
+    if (e < nnz) {
+        const float* a = A + static_cast<int64_t>(ia[e]) * lda;
+        const float* b = B + static_cast<int64_t>(ib[e]) * ldb;
+        if (VEC) {
+            for (int f = t * 4; f < n_feat; f += 64) {
+                const float4 x = ld4(a + f);
+                const float4 y = ld4(b + f);
+                acc = fmaf(x.x, y.x, acc);
+                acc = fmaf(x.y, y.y, acc);
+                acc = fmaf(x.z, y.z, acc);
+                acc = fmaf(x.w, y.w, acc);
+            }
+        } else {
+            for (int f = t; f < n_feat; f += 16) acc = fmaf(a[f], b[f], acc);
+        }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if (e < nnz && t == 0) out[e] = acc;
+}
+
+}  // namespace
+}  // namespace pygsd
+
+using namespace pygsd;
+
+extern "C" int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                                  const float* X, int64_t ldx, float* Y, int64_t ldy,
+                                  const float* Z, int64_t ldz, int32_t n_rows, int32_t n_feat,
+                                  float alpha, float beta, int32_t mean, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_spmm_csr_f32: negative size");
+    if (n_rows == 0 || n_feat == 0) return 0;
+    PYGSD_REQUIRE(rowptr && col && X && Y, "pygsd_spmm_csr_f32: null pointer");
+    PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat),
+                  "pygsd_spmm_csr_f32: row stride smaller than n_feat");
+    SpmmArgs a{rowptr, col, val, nullptr, X, nullptr, Y, nullptr, Z, nullptr,
+               ldx, ldy, ldz, n_rows, n_feat, alpha, beta, mean};
+    return launch_spmm<false>(a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pygsd_spmm2_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val_a,
+                                   const float* val_b, const float* Xa, const float* Xb, int64_t ldx,
+                                   float* Ya, float* Yb, int64_t ldy, const float* Za,
+                                   const float* Zb, int64_t ldz, int32_t n_rows, int32_t n_feat,
+                                   float alpha, float beta, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_spmm2_csr_f32: negative size");
+    if (n_rows == 0 || n_feat == 0) return 0;
+    PYGSD_REQUIRE(rowptr && col && val_a && val_b && Xa && Xb && Ya && Yb,
+                  "pygsd_spmm2_csr_f32: null pointer");
+    PYGSD_REQUIRE((Za == nullptr) == (Zb == nullptr), "pygsd_spmm2_csr_f32: Za/Zb must both be set");
+    PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Za || ldz >= n_feat),
+                  "pygsd_spmm2_csr_f32: row stride smaller than n_feat");
+    SpmmArgs a{rowptr, col, val_a, val_b, Xa, Xb, Ya, Yb, Za, Zb,
+               ldx, ldy, ldz, n_rows, n_feat, alpha, beta, 0};
+    return launch_spmm<true>(a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pygsd_sddmm_coo_f32(const int32_t* ia, const int32_t* ib, int64_t nnz, const float* A,
+                                   int64_t lda, const float* B, int64_t ldb, int32_t n_feat,
+                                   float* out, void* stream)
+{
+    PYGSD_REQUIRE(nnz >= 0 && n_feat >= 0, "pygsd_sddmm_coo_f32: negative size");
+    if (nnz == 0) return 0;
+    PYGSD_REQUIRE(ia && ib && A && B && out, "pygsd_sddmm_coo_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t threads = nnz * 16;
+    const unsigned grid = static_cast<unsigned>((threads + 255) / 256);
+    const bool vec = (n_feat % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B);
+    ProfScope prof(PYGSD_K_SDDMM, s);
+    if (vec)
+        hipLaunchKernelGGL(sddmm_kernel<true>, dim3(grid), dim3(256), 0, s, ia, ib, nnz, A, lda, B, ldb,
+                           n_feat, out);
+    else
+        hipLaunchKernelGGL(sddmm_kernel<false>, dim3(grid), dim3(256), 0, s, ia, ib, nnz, A, lda, B, ldb,
+                           n_feat, out);
+    return check_launch("sddmm_kernel");
+}

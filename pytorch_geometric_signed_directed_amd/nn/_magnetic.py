@@ -1,0 +1,218 @@
+"""Shared implementation of MagNetConv / MSConv.
+
+Dataflow of the reference (nn/directed/MagNetConv.py:185-249, nn/general/MSConv.py:182-230), with
+S_r, S_i the real / imaginary COO operators of the scaled magnetic Laplacian:
+    A = sum_k T_k(S_r^T) X_r W_k ,  B = sum_k T_k(S_i^T) X_i W_k          (T_k Chebyshev)
+    out_real = A - B + b ,  out_imag = A + B + b
+The reference evaluates each of A and B twice (four propagates per order, two are duplicates) and
+materialises a [nnz, F] message tensor per propagate.  Here S_r and S_i share ONE sparsity pattern
+(off-diagonals of the symmetrised graph + the diagonal; the reference's two self-loop sets
+2/lambda and -1 are folded into one diagonal entry, its explicit imaginary zeros dropped into the
+same slot), so one fused dual-value HIP SpMM per Chebyshev order produces both T_k parts in a
+single traversal; the recurrence 2 S T_{k-1} - T_{k-2} is fused into the kernel epilogue.
+"""
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+from torch.nn import Parameter
+
+from .. import _cabi
+from ..message_passing import MessagePassing
+from ..sparse import Pattern, spmm2
+from ..utils._laplacian import laplacian_parts, laplacian_values
+
+Tensor = torch.Tensor
+
+
+def glorot(t: Optional[Tensor]):
+    if t is not None:
+        a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+        t.data.uniform_(-a, a)
+
+
+def zeros(t: Optional[Tensor]):
+    if t is not None:
+        t.data.fill_(0)
+
+
+class MagneticOperator:
+    """The scaled operator 2L/lambda_max - I in HBM: one Pattern + real / imaginary value arrays
+    (COO order: E_s off-diagonals sorted by (row, col), then the N diagonal entries)."""
+
+    def __init__(self, pattern, values_real, values_imag, off_index, off_real, off_imag, diag_scaled, n):
+        self.pattern, self.values_real, self.values_imag = pattern, values_real, values_imag
+        self._off_index, self._off_real, self._off_imag = off_index, off_real, off_imag
+        self._diag_scaled, self.n = diag_scaled, n
+        self._ref_format = None
+
+    def reference_format(self):
+        """(edge_index_real, edge_index_imag, norm_real, norm_imag) exactly as
+        MagNetConv.__norm__ returns them (MagNetConv.py:100-120)."""
+        if self._ref_format is None:
+            dev = self._off_index.device
+            loops = torch.arange(self.n, dtype=torch.long, device=dev).unsqueeze(0).repeat(2, 1)
+            ei_imag = torch.cat([self._off_index, loops], dim=1)
+            ei_real = torch.cat([ei_imag, loops], dim=1)
+            norm_real = torch.cat([self._off_real, self._diag_scaled,
+                                   self._off_real.new_full((self.n,), -1.0)])
+            norm_imag = torch.cat([self._off_imag, self._off_imag.new_zeros(self.n)])
+            self._ref_format = (ei_real, ei_imag, norm_real, norm_imag)
+        return self._ref_format
+
+
+class MagneticChebConv(MessagePassing):
+    edge_weight_arg = "norm"
+    _fused_message = True
+    _signed = False
+
+    def _init_common(self, in_channels, out_channels, K, q, trainable_q, normalization, cached, bias):
+        assert K > 0
+        assert normalization in [None, 'sym'], 'Invalid normalization'
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.normalization = normalization
+        self.cached = cached
+        self.trainable_q = trainable_q
+        if trainable_q:
+            self.q = Parameter(torch.Tensor(1).fill_(q))
+        else:
+            self.q = q
+        self.weight = Parameter(torch.Tensor(K + 1, in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot(self.weight)
+        zeros(self.bias)
+        self._operator = None
+        self.cached_num_edges = None
+        self.cached_q = None
+
+    # reference attribute: the 4-tuple built by __norm__ (None until the first forward)
+    @property
+    def cached_result(self):
+        return None if self._operator is None else self._operator.reference_format()
+
+    @cached_result.setter
+    def cached_result(self, value):
+        if value is not None:
+            raise AttributeError("cached_result can only be reset to None")
+        self._operator = None
+
+    # ------------------------------------------------------------------------------------------
+    def _laplacian_kwargs(self):
+        return dict(signed=self._signed, absolute_degree=getattr(self, "absolute_degree", True))
+
+    def _build_operator(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype):
+        parts = laplacian_parts(edge_index, edge_weight, num_nodes, dtype=dtype, **self._laplacian_kwargs())
+        off_r, off_i, diag = laplacian_values(parts, q, normalization)
+        lam = lambda_max
+        off_r = (2.0 * off_r) / lam
+        off_r = off_r.masked_fill(off_r == float("inf"), 0)
+        off_i = (2.0 * off_i) / lam
+        off_i = off_i.masked_fill(off_i == float("inf"), 0)
+        diag_s = (2.0 * diag) / lam
+        diag_s = diag_s.masked_fill(diag_s == float("inf"), 0)
+        loops = torch.arange(num_nodes, dtype=torch.long, device=edge_index.device).unsqueeze(0).repeat(2, 1)
+        index = torch.cat([parts.index, loops], dim=1)
+        values_real = torch.cat([off_r, diag_s - 1.0])
+        values_imag = torch.cat([off_i, torch.zeros_like(diag_s)])
+        pattern = Pattern(index, num_nodes, num_nodes, "source_to_target")
+        return MagneticOperator(pattern, values_real, values_imag, parts.index, off_r, off_i, diag_s,
+                                num_nodes)
+
+    def __norm__(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype=None):
+        """Reference-format operator (MagNetConv.py:78-120): edge_index_real, edge_index_imag,
+        edge_weight_real, edge_weight_imag."""
+        if not isinstance(lambda_max, torch.Tensor):
+            lambda_max = torch.tensor(lambda_max, dtype=dtype or torch.float32, device=edge_index.device)
+        return self._build_operator(edge_index, num_nodes, edge_weight, q, normalization, lambda_max,
+                                    dtype).reference_format()
+
+    def _lambda_max_eigsh(self, edge_index, edge_weight, num_nodes):
+        """normalization=None: largest-magnitude eigenvalue of the un-normalised Laplacian by
+        scipy eigsh on the host, as the reference does (get_magnetic_Laplacian.py:88-92)."""
+        import scipy.sparse as sp
+        from scipy.sparse.linalg import eigsh
+        n = int(edge_index.max()) + 1 if num_nodes is None and edge_index.numel() else (num_nodes or 0)
+        parts = laplacian_parts(edge_index, edge_weight, n, dtype=torch.float32, **self._laplacian_kwargs())
+        off_r, off_i, diag = laplacian_values(parts, self.q, None)
+        val = torch.complex(off_r, off_i).cpu().numpy()
+        idx = parts.index.cpu().numpy()
+        loops = np.arange(n)
+        L = sp.coo_matrix((np.concatenate([val, diag.cpu().numpy().astype(np.complex64)]),
+                           (np.concatenate([idx[0], loops]), np.concatenate([idx[1], loops]))), (n, n))
+        lam = eigsh(L, k=1, which='LM', return_eigenvectors=False)
+        return float(np.asarray(lam).real.item())
+
+    def forward(self, x_real, x_imag, edge_index, edge_weight=None, lambda_max=None):
+        _cabi.require_gpu(x_real, x_imag, edge_index, edge_weight)
+        if self.trainable_q:
+            self.q = Parameter(torch.clamp(self.q, 0, 0.25))
+
+        if self.cached and self._operator is not None:
+            if edge_index.size(1) != self.cached_num_edges:
+                raise RuntimeError(
+                    'Cached {} number of edges, but found {}. Please '
+                    'disable the caching behavior of this layer by removing '
+                    'the `cached=True` argument in its constructor.'.format(
+                        self.cached_num_edges, edge_index.size(1)))
+            if self.q != self.cached_q:
+                raise RuntimeError(
+                    'Cached q is {}, but found {} in input. Please '
+                    'disable the caching behavior of this layer by removing '
+                    'the `cached=True` argument in its constructor.'.format(
+                        self.cached_q, self.q))
+        if not self.cached or self._operator is None:
+            self.cached_num_edges = edge_index.size(1)
+            if self.trainable_q:
+                self.cached_q = self.q.detach().item()
+            else:
+                self.cached_q = self.q
+            if self.normalization != 'sym' and lambda_max is None:
+                if self.trainable_q:
+                    raise RuntimeError(
+                        'Cannot train q while not calculating maximum eigenvalue of Laplacian!')
+                lambda_max = self._lambda_max_eigsh(edge_index, edge_weight, None)
+            if lambda_max is None:
+                lambda_max = torch.tensor(2.0, dtype=x_real.dtype, device=x_real.device)
+            if not isinstance(lambda_max, torch.Tensor):
+                lambda_max = torch.tensor(lambda_max, dtype=x_real.dtype, device=x_real.device)
+            self._operator = self._build_operator(edge_index, x_real.size(self.node_dim), edge_weight,
+                                                  self.q, self.normalization, lambda_max, x_real.dtype)
+
+        op = self._operator
+        w_r, w_i = op.values_real, op.values_imag
+        # A-chain on (S_r, X_r), B-chain on (S_i, X_i); one fused traversal per Chebyshev order
+        t0_r, t0_i = x_real, x_imag
+        acc_a = torch.matmul(t0_r, self.weight[0])
+        acc_b = torch.matmul(t0_i, self.weight[0])
+        if self.weight.size(0) > 1:
+            t1_r, t1_i = spmm2(op.pattern, t0_r, t0_i, w_r, w_i)
+            acc_a = torch.addmm(acc_a, t1_r, self.weight[1])
+            acc_b = torch.addmm(acc_b, t1_i, self.weight[1])
+        for k in range(2, self.weight.size(0)):
+            t2_r, t2_i = spmm2(op.pattern, t1_r, t1_i, w_r, w_i, za=t0_r, zb=t0_i, alpha=2.0, beta=-1.0)
+            acc_a = torch.addmm(acc_a, t2_r, self.weight[k])
+            acc_b = torch.addmm(acc_b, t2_i, self.weight[k])
+            t0_r, t0_i, t1_r, t1_i = t1_r, t1_i, t2_r, t2_i
+
+        out_real = acc_a - acc_b
+        out_imag = acc_a + acc_b
+        if self.bias is not None:
+            out_real += self.bias
+            out_imag += self.bias
+        return out_real, out_imag
+
+    def message(self, x_j, norm):
+        return norm.view(-1, 1) * x_j
+
+    def __repr__(self):
+        return '{}({}, {}, filter size={}, normalization={})'.format(
+            self.__class__.__name__, self.in_channels, self.out_channels,
+            self.weight.size(0), self.normalization)

@@ -1,0 +1,61 @@
+"""DGCNConv -- drop-in for torch_geometric_signed_directed/nn/directed/DGCNConv.py:11 (edge_index
+path; the torch_sparse.SparseTensor path is out of scope: torch_sparse is not part of this stack)."""
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from ... import _cabi
+from ...message_passing import MessagePassing
+from ...sparse import Pattern, spmm
+from ...utils._norm import gcn_norm
+
+
+class DGCNConv(MessagePassing):
+    edge_weight_arg = "edge_weight"
+    _fused_message = True
+
+    def __init__(self, improved: bool = False, cached: bool = False, add_self_loops: bool = True,
+                 normalize: bool = True, **kwargs):
+        kwargs.setdefault('aggr', 'add')
+        super().__init__(**kwargs)
+        self.improved = improved
+        self.cached = cached
+        self.add_self_loops = add_self_loops
+        self.normalize = normalize
+        self._cached_edge_index = None
+        self._cached_adj_t = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self._cached_edge_index = None
+        self._cached_adj_t = None
+        self._cached_pattern = None
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> Tensor:
+        if not isinstance(edge_index, Tensor):
+            raise NotImplementedError("DGCNConv: only the edge_index (Tensor) path exists on the HIP "
+                                      "stack; torch_sparse.SparseTensor is not supported")
+        _cabi.require_gpu(x, edge_index, edge_weight)
+        n = x.size(self.node_dim)
+        pattern = None
+        if self.normalize:
+            cache = self._cached_edge_index
+            if cache is None:
+                edge_index, edge_weight = gcn_norm(edge_index, edge_weight, n, self.improved,
+                                                   self.add_self_loops, x.dtype)
+                if self.cached:
+                    # one shared instance called with several operators keeps the FIRST one
+                    # (DGCNConv.py:71-81)
+                    self._cached_edge_index = (edge_index, edge_weight)
+                    self._cached_pattern = Pattern(edge_index, n, n, self.flow)
+                    pattern = self._cached_pattern
+            else:
+                edge_index, edge_weight = cache[0], cache[1]
+                pattern = self._cached_pattern
+        if pattern is None:
+            pattern = Pattern(edge_index, n, n, self.flow)
+        return spmm(pattern, x, edge_weight)
+
+    def message(self, x_j: Tensor, edge_weight: Optional[Tensor]) -> Tensor:
+        return x_j if edge_weight is None else edge_weight.view(-1, 1) * x_j

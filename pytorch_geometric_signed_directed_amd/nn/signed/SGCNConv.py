@@ -1,0 +1,68 @@
+"""SGCNConv -- drop-in for torch_geometric_signed_directed/nn/signed/SGCNConv.py:16: mean
+aggregation over positive / negative incoming edges (value-less segment-mean HIP kernel), concat
+with the node's own features, Linear."""
+from typing import Tuple, Union
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from ... import _cabi
+from ...message_passing import MessagePassing
+from ...sparse import GLOBAL_PATTERNS, spmm
+
+
+class SGCNConv(MessagePassing):
+    edge_weight_arg = None
+    _fused_message = True
+
+    def __init__(self, in_dim: int, out_dim: int, first_aggr: bool, bias: bool = True,
+                 norm_emb: bool = False, **kwargs):
+        kwargs.setdefault('aggr', 'mean')
+        super().__init__(**kwargs)
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.first_aggr = first_aggr
+        self.norm_emb = norm_emb
+        k = 2 if first_aggr else 3
+        self.lin_b = torch.nn.Linear(k * in_dim, out_dim, bias)
+        self.lin_u = torch.nn.Linear(k * in_dim, out_dim, bias)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin_b.reset_parameters()
+        self.lin_u.reset_parameters()
+
+    def _mean_in(self, x_src: Tensor, n_dst: int, edge_index: Tensor) -> Tensor:
+        pat = GLOBAL_PATTERNS.get(edge_index, x_src.size(0), n_dst, self.flow)
+        return spmm(pat, x_src, None, reduce=self.aggr)
+
+    def forward(self, x: Union[Tensor, Tuple[Tensor, Tensor]], pos_edge_index: Tensor,
+                neg_edge_index: Tensor) -> Tensor:
+        if isinstance(x, Tensor):
+            x = (x, x)
+        if not isinstance(pos_edge_index, Tensor) or not isinstance(neg_edge_index, Tensor):
+            raise NotImplementedError("SGCNConv: only the edge_index (Tensor) path exists on the HIP stack")
+        _cabi.require_gpu(x[0], x[1], pos_edge_index, neg_edge_index)
+        n = x[1].size(0)
+        if self.first_aggr:
+            out_b = self.lin_b(torch.cat([self._mean_in(x[0], n, pos_edge_index), x[1]], dim=-1))
+            out_u = self.lin_u(torch.cat([self._mean_in(x[0], n, neg_edge_index), x[1]], dim=-1))
+        else:
+            f = self.in_dim
+            lo, hi = x[0][..., :f], x[0][..., f:]   # column slices: passed by row stride, no copy
+            out_b = self.lin_b(torch.cat([self._mean_in(lo, n, pos_edge_index),
+                                          self._mean_in(hi, n, neg_edge_index), x[1][..., :f]], dim=-1))
+            out_u = self.lin_u(torch.cat([self._mean_in(hi, n, pos_edge_index),
+                                          self._mean_in(lo, n, neg_edge_index), x[1][..., f:]], dim=-1))
+        out = torch.cat([out_b, out_u], dim=-1)
+        if self.norm_emb:
+            out = F.normalize(out, p=2, dim=-1)
+        return out
+
+    def message(self, x_j: Tensor) -> Tensor:
+        return x_j
+
+    def __repr__(self) -> str:
+        return (f'{self.__class__.__name__}({self.in_dim}, '
+                f'{self.out_dim}, first_aggr={self.first_aggr})')

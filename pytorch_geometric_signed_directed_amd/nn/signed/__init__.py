@@ -1,0 +1,2 @@
+from .SGCNConv import SGCNConv  # noqa: F401
+from .SIMPA import SIMPA  # noqa: F401

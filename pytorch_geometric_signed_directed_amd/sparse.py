@@ -1,0 +1,333 @@
+"""Host side of the hot path: CSR operators living in HBM and the autograd wrappers around the
+C-ABI SpMM / SDDMM entry points (include/pygsd_hip.h).
+
+Data layout in HBM (per operator):
+  * `Pattern`  -- the sparsity structure of one COO `edge_index`, grouped both ways:
+        fwd: CSR by OUTPUT row  (rowptr int32[n_out+1], col int32[nnz] = input row ids,
+                                 perm int32[nnz] = COO entry id of each CSR slot)
+        bwd: CSR by INPUT row   (same arrays with the roles swapped) -- used for dX = S^T dY
+    Grouping is stable, so the entries of one output row keep their COO order: the summation order
+    of the reference's scatter_add_.
+  * edge values stay in COO order in the caller's tensors; `Pattern.values_for` re-orders them once
+    per (tensor, version) into CSR order (fp32) and caches the copy.
+  * feature matrices are fp32 row-major [N, F] with an arbitrary row stride (column slices are
+    passed without a copy).
+
+Everything here runs on the GPU through libpygsd_hip.so; CPU tensors are rejected.
+"""
+import ctypes
+import weakref
+from typing import Optional, Tuple
+
+import torch
+
+from . import _cabi
+from ._cabi import check, ptr, stream_ptr
+
+Tensor = torch.Tensor
+
+
+def _rows(t: Tensor) -> Tuple[Tensor, int]:
+    """Return (tensor with unit inner stride, row stride in elements)."""
+    if t.dim() != 2:
+        raise ValueError(f"expected a [N, F] feature matrix, got shape {tuple(t.shape)}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"the HIP path computes in float32; got {t.dtype}")
+    if t.size(1) > 0 and (t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1))):
+        t = t.contiguous()
+    ld = t.stride(0) if t.size(0) > 1 else max(t.size(1), 1)
+    return t, max(ld, t.size(1), 1)
+
+
+class CSR:
+    """One orientation of a pattern: int32 rowptr / col / perm on the device."""
+    __slots__ = ("n_rows", "n_cols", "nnz", "rowptr", "col", "perm")
+
+    def __init__(self, n_rows, n_cols, nnz, rowptr, col, perm):
+        self.n_rows, self.n_cols, self.nnz = n_rows, n_cols, nnz
+        self.rowptr, self.col, self.perm = rowptr, col, perm
+
+
+def csr_from_coo(seg: Tensor, other: Tensor, n_seg: int, n_other: int) -> CSR:
+    """Group COO entries by `seg` (stable) on the device -> CSR.  seg/other: int64 [nnz]."""
+    _cabi.require_gpu(seg, other)
+    if seg.dtype != torch.int64 or other.dtype != torch.int64:
+        raise TypeError("edge_index must be int64 (torch.long)")
+    seg, other = seg.contiguous(), other.contiguous()
+    nnz = seg.numel()
+    dev = seg.device
+    lib = _cabi.lib()
+    with torch.cuda.device(dev):
+        rowptr = torch.empty(n_seg + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(nnz, dtype=torch.int32, device=dev)
+        perm = torch.empty(nnz, dtype=torch.int32, device=dev)
+        need = ctypes.c_size_t(0)
+        check(lib.pygsd_csr_from_coo_workspace(nnz, n_seg, ctypes.byref(need)), "pygsd_csr_from_coo_workspace")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        check(lib.pygsd_csr_from_coo(ptr(seg), ptr(other), nnz, n_seg, ptr(rowptr), ptr(col), ptr(perm),
+                                     ptr(ws), need.value, stream_ptr()), "pygsd_csr_from_coo")
+    return CSR(n_seg, n_other, nnz, rowptr, col, perm)
+
+
+def gather_values(src: Tensor, perm: Tensor) -> Tensor:
+    """out[i] = src[perm[i]] on the device (fp32)."""
+    _cabi.require_gpu(src, perm)
+    src = src.contiguous()
+    if src.dtype != torch.float32:
+        src = src.float()
+    out = torch.empty(perm.numel(), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        check(_cabi.lib().pygsd_gather_f32(ptr(src), ptr(perm), perm.numel(), ptr(out), stream_ptr()),
+              "pygsd_gather_f32")
+    return out
+
+
+class Pattern:
+    """Sparsity structure of out[scatter[e]] (+)= w[e] * x[gather[e]] for one COO edge_index.
+
+    flow = 'source_to_target': gather = edge_index[0], scatter = edge_index[1]  (PyG default)
+    flow = 'target_to_source': gather = edge_index[1], scatter = edge_index[0]  (Conv_Base)
+    """
+
+    def __init__(self, edge_index: Tensor, n_in: int, n_out: int, flow: str = "source_to_target"):
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
+        if flow not in ("source_to_target", "target_to_source"):
+            raise ValueError(f"unknown flow {flow!r}")
+        _cabi.require_gpu(edge_index)
+        g, s = (0, 1) if flow == "source_to_target" else (1, 0)
+        self.n_in, self.n_out, self.nnz = int(n_in), int(n_out), int(edge_index.size(1))
+        self.device = edge_index.device
+        self._gather = edge_index[g].contiguous()
+        self._scatter = edge_index[s].contiguous()
+        self.fwd = csr_from_coo(self._scatter, self._gather, self.n_out, self.n_in)
+        self._bwd: Optional[CSR] = None
+        self._coo32: Optional[Tuple[Tensor, Tensor]] = None
+        self._inv_deg: Optional[Tensor] = None
+        self._vcache = {}
+
+    @property
+    def bwd(self) -> CSR:
+        if self._bwd is None:
+            self._bwd = csr_from_coo(self._gather, self._scatter, self.n_in, self.n_out)
+        return self._bwd
+
+    @property
+    def coo32(self) -> Tuple[Tensor, Tensor]:
+        """(gather, scatter) row ids as int32, COO order (SDDMM operands)."""
+        if self._coo32 is None:
+            self._coo32 = (self._gather.to(torch.int32), self._scatter.to(torch.int32))
+        return self._coo32
+
+    def mean_values(self) -> Tensor:
+        """Per-entry 1 / max(in-degree of the output row, 1), COO order (backward of aggr='mean')."""
+        if self._inv_deg is None:
+            rp = self.fwd.rowptr
+            deg = (rp[1:] - rp[:-1]).clamp(min=1).to(torch.float32)
+            self._inv_deg = (1.0 / deg)[self._scatter]
+        return self._inv_deg
+
+    def values_for(self, w: Optional[Tensor], which: str) -> Optional[Tensor]:
+        """`w` (COO order) re-ordered for the `which` in {'fwd','bwd'} CSR; cached per tensor version."""
+        if w is None:
+            return None
+        key = (id(w), which)
+        hit = self._vcache.get(key)
+        if hit is not None and hit[0]() is w and hit[1] == w._version:
+            return hit[2]
+        if w.numel() != self.nnz:
+            raise ValueError(f"edge value array has {w.numel()} entries, pattern has {self.nnz}")
+        csr = self.fwd if which == "fwd" else self.bwd
+        out = gather_values(w.detach().reshape(-1), csr.perm)
+        if len(self._vcache) > 16:
+            self._vcache.clear()
+        self._vcache[key] = (weakref.ref(w), w._version, out)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launches
+# ------------------------------------------------------------------------------------------------
+def _spmm_raw(csr: CSR, val: Optional[Tensor], x: Tensor, z: Optional[Tensor], alpha: float, beta: float,
+              mean: bool) -> Tensor:
+    _cabi.require_gpu(x, z, val)
+    x, ldx = _rows(x)
+    if x.size(0) != csr.n_cols:
+        raise ValueError(f"x has {x.size(0)} rows, operator expects {csr.n_cols}")
+    f = x.size(1)
+    y = torch.empty((csr.n_rows, f), dtype=torch.float32, device=x.device)
+    zp, ldz = None, 0
+    if z is not None:
+        z, ldz = _rows(z)
+        if tuple(z.shape) != (csr.n_rows, f):
+            raise ValueError(f"z has shape {tuple(z.shape)}, expected {(csr.n_rows, f)}")
+        zp = ptr(z)
+    with torch.cuda.device(x.device):
+        check(_cabi.lib().pygsd_spmm_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(val), ptr(x), ldx, ptr(y),
+                                             max(f, 1), zp, ldz, csr.n_rows, f, float(alpha), float(beta),
+                                             1 if mean else 0, stream_ptr()), "pygsd_spmm_csr_f32")
+    return y
+
+
+def _spmm2_raw(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, za: Optional[Tensor],
+               zb: Optional[Tensor], alpha: float, beta: float) -> Tuple[Tensor, Tensor]:
+    _cabi.require_gpu(xa, xb, za, zb, val_a, val_b)
+    if xa.shape != xb.shape:
+        raise ValueError("spmm2: the two inputs must have the same shape")
+    xa, lda = _rows(xa)
+    xb, ldb = _rows(xb)
+    if lda != ldb:
+        xa, xb = xa.contiguous(), xb.contiguous()
+        lda = max(xa.size(1), 1)
+    if xa.size(0) != csr.n_cols:
+        raise ValueError(f"x has {xa.size(0)} rows, operator expects {csr.n_cols}")
+    f = xa.size(1)
+    ya = torch.empty((csr.n_rows, f), dtype=torch.float32, device=xa.device)
+    yb = torch.empty_like(ya)
+    zap = zbp = None
+    ldz = 0
+    if za is not None:
+        za, ldz = _rows(za)
+        zb, ldz_b = _rows(zb)
+        if ldz != ldz_b:
+            za, zb = za.contiguous(), zb.contiguous()
+            ldz = max(f, 1)
+        zap, zbp = ptr(za), ptr(zb)
+    with torch.cuda.device(xa.device):
+        check(_cabi.lib().pygsd_spmm2_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(val_a), ptr(val_b), ptr(xa),
+                                              ptr(xb), lda, ptr(ya), ptr(yb), max(f, 1), zap, zbp, ldz,
+                                              csr.n_rows, f, float(alpha), float(beta), stream_ptr()),
+              "pygsd_spmm2_csr_f32")
+    return ya, yb
+
+
+def _sddmm_raw(ia: Tensor, ib: Tensor, a: Tensor, b: Tensor) -> Tensor:
+    """out[e] = <a[ia[e]], b[ib[e]]>."""
+    _cabi.require_gpu(ia, ib, a, b)
+    a, lda = _rows(a)
+    b, ldb = _rows(b)
+    out = torch.empty(ia.numel(), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(_cabi.lib().pygsd_sddmm_coo_f32(ptr(ia), ptr(ib), ia.numel(), ptr(a), lda, ptr(b), ldb,
+                                              a.size(1), ptr(out), stream_ptr()), "pygsd_sddmm_coo_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd
+# ------------------------------------------------------------------------------------------------
+class _Spmm(torch.autograd.Function):
+    """y = alpha * reduce_{e -> row} w[e] * x[gather[e]] + beta * z   (reduce = add | mean)."""
+
+    @staticmethod
+    def forward(ctx, x, w, z, pat: Pattern, alpha: float, beta: float, mean: bool):
+        y = _spmm_raw(pat.fwd, pat.values_for(w, "fwd"), x, z, alpha, beta, mean)
+        ctx.pat, ctx.alpha, ctx.beta, ctx.mean = pat, alpha, beta, mean
+        ctx.has_w = w is not None
+        ctx.save_for_backward(x if (w is not None and w.requires_grad) else None, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        pat, alpha = ctx.pat, ctx.alpha
+        x_saved, w = ctx.saved_tensors
+        gx = gw = gz = None
+        gy = gy.contiguous()
+        if ctx.needs_input_grad[0]:
+            if ctx.mean:
+                wb = pat.mean_values() if w is None else w * pat.mean_values()
+                gx = _spmm_raw(pat.bwd, pat.values_for(wb, "bwd"), gy, None, alpha, 0.0, False)
+            else:
+                gx = _spmm_raw(pat.bwd, pat.values_for(w, "bwd"), gy, None, alpha, 0.0, False)
+        if ctx.has_w and ctx.needs_input_grad[1]:
+            gi, si = pat.coo32
+            gw = _sddmm_raw(gi, si, x_saved, gy)
+            if ctx.mean:
+                gw = gw * pat.mean_values()
+            if alpha != 1.0:
+                gw = gw * alpha
+            gw = gw.view_as(w)
+        if ctx.needs_input_grad[2]:
+            gz = gy * ctx.beta
+        return gx, gw, gz, None, None, None, None
+
+
+class _Spmm2(torch.autograd.Function):
+    """(ya, yb) = alpha * (S_a xa, S_b xb) + beta * (za, zb); S_a, S_b share one pattern."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, wa, wb, za, zb, pat: Pattern, alpha: float, beta: float):
+        ya, yb = _spmm2_raw(pat.fwd, pat.values_for(wa, "fwd"), pat.values_for(wb, "fwd"), xa, xb, za, zb,
+                            alpha, beta)
+        ctx.pat, ctx.alpha, ctx.beta = pat, alpha, beta
+        need_x = wa.requires_grad or wb.requires_grad
+        ctx.save_for_backward(xa if need_x else None, xb if need_x else None, wa, wb)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        pat, alpha = ctx.pat, ctx.alpha
+        xa, xb, wa, wb = ctx.saved_tensors
+        ga, gb = ga.contiguous(), gb.contiguous()
+        gxa = gxb = gwa = gwb = gza = gzb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gxa, gxb = _spmm2_raw(pat.bwd, pat.values_for(wa, "bwd"), pat.values_for(wb, "bwd"), ga, gb,
+                                  None, None, alpha, 0.0)
+        if ctx.needs_input_grad[2]:
+            gi, si = pat.coo32
+            gwa = (_sddmm_raw(gi, si, xa, ga) * alpha).view_as(wa)
+        if ctx.needs_input_grad[3]:
+            gi, si = pat.coo32
+            gwb = (_sddmm_raw(gi, si, xb, gb) * alpha).view_as(wb)
+        if ctx.needs_input_grad[4]:
+            gza = ga * ctx.beta
+        if ctx.needs_input_grad[5]:
+            gzb = gb * ctx.beta
+        return gxa, gxb, gwa, gwb, gza, gzb, None, None, None
+
+
+def spmm(pat: Pattern, x: Tensor, w: Optional[Tensor] = None, *, z: Optional[Tensor] = None,
+         alpha: float = 1.0, beta: float = 0.0, reduce: str = "add") -> Tensor:
+    """Differentiable gather-scale-reduce over `pat`: the fused replacement of
+    MessagePassing.propagate for message = w * x_j."""
+    if reduce not in ("add", "sum", "mean"):
+        raise ValueError(f"unsupported reduce {reduce!r}")
+    return _Spmm.apply(x, w, z, pat, float(alpha), float(beta), reduce == "mean")
+
+
+def spmm2(pat: Pattern, xa: Tensor, xb: Tensor, wa: Tensor, wb: Tensor, *, za: Optional[Tensor] = None,
+          zb: Optional[Tensor] = None, alpha: float = 1.0, beta: float = 0.0) -> Tuple[Tensor, Tensor]:
+    """Two operators on one pattern in one traversal (real / imaginary magnetic Laplacian)."""
+    if (za is None) != (zb is None):
+        raise ValueError("spmm2: za and zb must be given together")
+    return _Spmm2.apply(xa, xb, wa, wb, za, zb, pat, float(alpha), float(beta))
+
+
+# ------------------------------------------------------------------------------------------------
+# pattern cache for raw-tensor callers (MessagePassing.propagate with a plain edge_index)
+# ------------------------------------------------------------------------------------------------
+class PatternCache:
+    """Small LRU keyed on the edge_index TENSOR OBJECT (held alive, so its address cannot be reused)
+    and its in-place version counter.  Pure function of the tensor's content: never changes results,
+    only avoids re-sorting when a caller passes the same edge_index again (e.g. SIMPA's 7 calls)."""
+
+    def __init__(self, capacity: int = 8):
+        self.capacity = capacity
+        self._items = []  # (edge_index, version, n_in, n_out, flow, pattern)
+
+    def get(self, edge_index: Tensor, n_in: int, n_out: int, flow: str) -> Pattern:
+        for k, it in enumerate(self._items):
+            if it[0] is edge_index and it[1] == edge_index._version and it[2:5] == (n_in, n_out, flow):
+                self._items.append(self._items.pop(k))
+                return it[5]
+        pat = Pattern(edge_index, n_in, n_out, flow)
+        self._items.append((edge_index, edge_index._version, n_in, n_out, flow, pat))
+        if len(self._items) > self.capacity:
+            self._items.pop(0)
+        return pat
+
+    def clear(self):
+        self._items.clear()
+
+
+GLOBAL_PATTERNS = PatternCache()

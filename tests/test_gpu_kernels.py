@@ -1,0 +1,284 @@
+"""GPU: the HIP kernels, called through the C-ABI host wrappers, against the CPU oracle
+(oracle/ref_layers.py) on the same seeded inputs.
+
+Bars: index / structure work (COO->CSR, sort, complex-ReLU masks) is BIT-EXACT; floating-point
+aggregation is held to 1e-5 * scale (north_star: "within 1e-5 fp32"); summation order differs from
+the reference only inside a row's lane groups.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_layers as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rand_graph(n_in, n_out, nnz, seed, long_row=0, empty_tail=0):
+    """COO (gather=src in [0,n_in), scatter=dst in [0,n_out)) with ragged rows, `empty_tail` output
+    rows that receive nothing, and optionally one very long row (> 64 and > 256 entries)."""
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n_in, (nnz,), generator=g)
+    hi = max(n_out - empty_tail, 1)
+    dst = torch.randint(0, hi, (nnz,), generator=g)
+    if long_row:
+        dst[:long_row] = min(3, hi - 1)
+    return torch.stack([src, dst])
+
+
+def close(got, want, tol=TOL):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = max(1.0, float(want.abs().max())) if want.numel() else 1.0
+    err = float((got - want).abs().max()) / scale if want.numel() else 0.0
+    assert err <= tol, f"max err {err:.3e} > {tol}"
+
+
+# ------------------------------------------------------------------ structure (bit-exact)
+@pytest.mark.parametrize("n,nnz,seed", [(1, 1, 0), (7, 0, 1), (50, 400, 2), (1000, 30000, 3), (4097, 100001, 4)])
+def test_csr_from_coo_exact(n, nnz, seed):
+    from pytorch_geometric_signed_directed_amd.sparse import csr_from_coo
+    ei = rand_graph(n, n, nnz, seed, empty_tail=min(3, n - 1))
+    csr = csr_from_coo(ei[1].to(dev()), ei[0].to(dev()), n, n)
+    rowptr, col, perm = csr.rowptr.cpu().long(), csr.col.cpu().long(), csr.perm.cpu().long()
+    # oracle: stable argsort by the segment id
+    order = torch.sort(ei[1], stable=True).indices
+    assert torch.equal(perm, order)
+    assert torch.equal(col, ei[0][order])
+    want_ptr = torch.zeros(n + 1, dtype=torch.long)
+    want_ptr[1:] = torch.bincount(ei[1], minlength=n).cumsum(0)
+    assert torch.equal(rowptr, want_ptr)
+
+
+@pytest.mark.parametrize("n,bits,seed", [(0, 8, 0), (1, 1, 1), (1000, 10, 2), (200000, 40, 3)])
+def test_sort_keys_exact_and_stable(n, bits, seed):
+    from pytorch_geometric_signed_directed_amd.sparse_build import sort_keys
+    g = torch.Generator().manual_seed(seed)
+    keys = torch.randint(0, 2 ** min(bits, 20), (n,), generator=g)  # many duplicates -> stability visible
+    if bits > 20 and n:
+        keys = keys * (2 ** (bits - 20)) + torch.randint(0, 3, (n,), generator=g)
+    skeys, perm = sort_keys(keys.to(dev()), bits)
+    want = torch.sort(keys, stable=True)
+    assert torch.equal(skeys.cpu(), want.values)
+    assert torch.equal(perm.cpu().long(), want.indices)
+
+
+def test_coalesce_matches_oracle():
+    from pytorch_geometric_signed_directed_amd.sparse_build import coalesce_sum
+    g = torch.Generator().manual_seed(5)
+    n = 300
+    ei = torch.randint(0, n, (2, 5000), generator=g)
+    attr = torch.randn(5000, 3, generator=g)
+    got_i, got_a = coalesce_sum(ei.to(dev()), attr.to(dev()), n)
+    want_i, want_a = R.coalesce_add(ei, attr, n)
+    assert torch.equal(got_i.cpu(), want_i)
+    close(got_a, want_a, 1e-6)
+
+
+def test_complex_relu_bit_exact():
+    from pytorch_geometric_signed_directed_amd.nn import complex_relu_layer
+    g = torch.Generator().manual_seed(6)
+    for shape in [(1, 1), (37, 5), (1000, 64)]:
+        re, im = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+        re[0, 0] = 0.0
+        re.view(-1)[-1] = -0.0
+        o_r, o_i = complex_relu_layer()(re.to(dev()), im.to(dev()))
+        w_r, w_i = R.complex_relu(re, im)
+        assert np.array_equal(o_r.cpu().numpy().view(np.uint32), w_r.numpy().view(np.uint32))
+        assert np.array_equal(o_i.cpu().numpy().view(np.uint32), w_i.numpy().view(np.uint32))
+    # backward = same mask on the upstream gradients
+    re = torch.randn(50, 8, generator=g)
+    im = torch.randn(50, 8, generator=g)
+    a, b = re.clone().requires_grad_(), im.clone().requires_grad_()
+    o = R.complex_relu(a, b)
+    gr, gi = torch.randn(50, 8, generator=g), torch.randn(50, 8, generator=g)
+    ((o[0] * gr).sum() + (o[1] * gi).sum()).backward()
+    c, d = re.to(dev()).requires_grad_(), im.to(dev()).requires_grad_()
+    o2 = complex_relu_layer()(c, d)
+    ((o2[0] * gr.to(dev())).sum() + (o2[1] * gi.to(dev())).sum()).backward()
+    assert torch.equal(c.grad.cpu(), a.grad) and torch.equal(d.grad.cpu(), b.grad)
+
+
+# ------------------------------------------------------------------ SpMM vs oracle propagate
+FEATS = [1, 3, 4, 8, 16, 20, 32, 64, 96, 128, 256, 260, 300, 512]
+
+
+@pytest.mark.parametrize("f", FEATS)
+@pytest.mark.parametrize("weighted", [True, False])
+def test_spmm_add_matches_oracle(f, weighted):
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
+    n_in, n_out, nnz = 211, 173, 3000
+    ei = rand_graph(n_in, n_out, nnz, seed=f, long_row=300, empty_tail=5)
+    g = torch.Generator().manual_seed(100 + f)
+    x = torch.randn(n_in, f, generator=g)
+    w = torch.randn(nnz, generator=g) if weighted else None
+    want = R.propagate(x, ei, w, n_out)
+    pat = Pattern(ei.to(dev()), n_in, n_out)
+    got = spmm(pat, x.to(dev()), None if w is None else w.to(dev()))
+    close(got, want)
+    assert float(got[-5:].abs().max()) == 0.0  # rows that receive nothing are exactly zero
+
+
+@pytest.mark.parametrize("f", [5, 16, 64, 128])
+def test_spmm_mean_and_flow(f):
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
+    n, nnz = 150, 2500
+    ei = rand_graph(n, n, nnz, seed=7 + f, long_row=100, empty_tail=4)
+    g = torch.Generator().manual_seed(f)
+    x = torch.randn(n, f, generator=g)
+    for flow in ("source_to_target", "target_to_source"):
+        want = R.propagate(x, ei, None, n, flow=flow, reduce="mean")
+        got = spmm(Pattern(ei.to(dev()), n, n, flow), x.to(dev()), None, reduce="mean")
+        close(got, want)
+
+
+@pytest.mark.parametrize("f", [6, 64, 128])
+def test_spmm_chebyshev_epilogue(f):
+    """alpha * S x + beta * z  with (alpha, beta) = (2, -1): T_k = 2 S T_{k-1} - T_{k-2}."""
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
+    n, nnz = 120, 1500
+    ei = rand_graph(n, n, nnz, seed=11)
+    g = torch.Generator().manual_seed(f)
+    x, z, w = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g), torch.randn(nnz, generator=g)
+    want = 2.0 * R.propagate(x, ei, w, n) - z
+    got = spmm(Pattern(ei.to(dev()), n, n), x.to(dev()), w.to(dev()), z=z.to(dev()), alpha=2.0, beta=-1.0)
+    close(got, want)
+
+
+def test_spmm_strided_column_slices():
+    """SGCNConv deep layers aggregate x[..., :F] / x[..., F:] -- passed by row stride, no copy."""
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
+    n, nnz = 90, 800
+    ei = rand_graph(n, n, nnz, seed=13)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, 24, generator=g)
+    xd = x.to(dev())
+    pat = Pattern(ei.to(dev()), n, n)
+    for sl in (slice(0, 12), slice(12, 24), slice(3, 10)):
+        close(spmm(pat, xd[:, sl], None, reduce="mean"), R.propagate(x[:, sl], ei, None, n, reduce="mean"))
+
+
+@pytest.mark.parametrize("f", [3, 16, 64, 72, 128, 256])
+def test_spmm2_matches_two_propagates(f):
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm2
+    n, nnz = 160, 2600
+    ei = rand_graph(n, n, nnz, seed=17 + f, long_row=130, empty_tail=3)
+    g = torch.Generator().manual_seed(f)
+    xa, xb = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    wa, wb = torch.randn(nnz, generator=g), torch.randn(nnz, generator=g)
+    za, zb = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    pat = Pattern(ei.to(dev()), n, n)
+    d = dev()
+    ya, yb = spmm2(pat, xa.to(d), xb.to(d), wa.to(d), wb.to(d))
+    close(ya, R.propagate(xa, ei, wa, n))
+    close(yb, R.propagate(xb, ei, wb, n))
+    ya, yb = spmm2(pat, xa.to(d), xb.to(d), wa.to(d), wb.to(d), za=za.to(d), zb=zb.to(d), alpha=2.0, beta=-1.0)
+    close(ya, 2.0 * R.propagate(xa, ei, wa, n) - za)
+    close(yb, 2.0 * R.propagate(xb, ei, wb, n) - zb)
+
+
+def test_empty_and_degenerate_inputs():
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
+    d = dev()
+    # no edges at all
+    ei = torch.zeros(2, 0, dtype=torch.long)
+    out = spmm(Pattern(ei.to(d), 5, 4), torch.randn(5, 8).to(d), None)
+    assert out.shape == (4, 8) and float(out.abs().max()) == 0.0
+    # zero feature columns
+    ei = rand_graph(10, 10, 30, 1)
+    out = spmm(Pattern(ei.to(d), 10, 10), torch.zeros(10, 0).to(d), None)
+    assert out.shape == (10, 0)
+    # single node, self loop
+    ei = torch.zeros(2, 1, dtype=torch.long)
+    out = spmm(Pattern(ei.to(d), 1, 1), torch.full((1, 4), 3.0).to(d), torch.tensor([0.5]).to(d))
+    assert out.cpu().tolist() == [[1.5] * 4]
+
+
+# ------------------------------------------------------------------ autograd through the kernels
+@pytest.mark.parametrize("f", [7, 64])
+@pytest.mark.parametrize("reduce", ["add", "mean"])
+def test_spmm_backward_matches_oracle(f, reduce):
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
+    n_in, n_out, nnz = 130, 110, 1700
+    ei = rand_graph(n_in, n_out, nnz, seed=23, long_row=90, empty_tail=2)
+    g = torch.Generator().manual_seed(f)
+    x0, w0 = torch.randn(n_in, f, generator=g), torch.randn(nnz, generator=g)
+    go = torch.randn(n_out, f, generator=g)
+    x, w = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+    (R.propagate(x, ei, w, n_out, reduce=reduce) * go).sum().backward()
+    d = dev()
+    xg, wg = x0.to(d).requires_grad_(), w0.to(d).requires_grad_()
+    (spmm(Pattern(ei.to(d), n_in, n_out), xg, wg, reduce=reduce) * go.to(d)).sum().backward()
+    close(xg.grad, x.grad)
+    close(wg.grad, w.grad)  # SDDMM
+
+
+def test_spmm2_backward_matches_oracle():
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm2
+    n, nnz, f = 140, 2100, 64
+    ei = rand_graph(n, n, nnz, seed=29, long_row=70)
+    g = torch.Generator().manual_seed(29)
+    t = [torch.randn(n, f, generator=g) for _ in range(4)]
+    w = [torch.randn(nnz, generator=g) for _ in range(2)]
+    xa, xb = t[0].clone().requires_grad_(), t[1].clone().requires_grad_()
+    wa, wb = w[0].clone().requires_grad_(), w[1].clone().requires_grad_()
+    ((R.propagate(xa, ei, wa, n) * t[2]).sum() + (R.propagate(xb, ei, wb, n) * t[3]).sum()).backward()
+    d = dev()
+    ga, gb = t[0].to(d).requires_grad_(), t[1].to(d).requires_grad_()
+    va, vb = w[0].to(d).requires_grad_(), w[1].to(d).requires_grad_()
+    ya, yb = spmm2(Pattern(ei.to(d), n, n), ga, gb, va, vb)
+    ((ya * t[2].to(d)).sum() + (yb * t[3].to(d)).sum()).backward()
+    close(ga.grad, xa.grad)
+    close(gb.grad, xb.grad)
+    close(va.grad, wa.grad)
+    close(vb.grad, wb.grad)
+
+
+# ------------------------------------------------------------------ seeded mid-size vs oracle
+def test_spmm2_midsize_f64_vs_oracle():
+    """N = 20k, nnz = 800k, F = 64: the benchmark's kernel configuration at a size the oracle
+    finishes in seconds."""
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm2
+    n, nnz, f = 20000, 800000, 64
+    g = torch.Generator().manual_seed(31)
+    ei = torch.randint(0, n, (2, nnz), generator=g)
+    xa, xb = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    wa, wb = torch.randn(nnz, generator=g) * 0.1, torch.randn(nnz, generator=g) * 0.1
+    d = dev()
+    ya, yb = spmm2(Pattern(ei.to(d), n, n), xa.to(d), xb.to(d), wa.to(d), wb.to(d))
+    close(ya, R.propagate(xa, ei, wa, n))
+    close(yb, R.propagate(xb, ei, wb, n))
+
+
+# ------------------------------------------------------------------ full-size properties
+def test_fullsize_linearity_and_adjoint():
+    """BASELINE configs[1] size (100k nodes / ~4.1M operator entries / F = 64) through
+    size-independent properties: linearity S(ax+by) = aSx + bSy, the adjoint identity
+    <y, S x> = <S^T y, x> tying the forward (by-target) and backward (by-source) CSRs together,
+    and S 1 = row sums."""
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
+    n, nnz, f = 100000, 4100000, 64
+    d = dev()
+    g = torch.Generator(device="cpu").manual_seed(37)
+    ei = torch.randint(0, n, (2, nnz), generator=g).to(d)
+    w = (torch.rand(nnz, generator=g) - 0.5).to(d)
+    x = torch.randn(n, f, generator=g).to(d)
+    y = torch.randn(n, f, generator=g).to(d)
+    pat = Pattern(ei, n, n)
+    sx, sy = spmm(pat, x, w), spmm(pat, y, w)
+    lin = spmm(pat, 0.75 * x - 1.5 * y, w)
+    close(lin, 0.75 * sx - 1.5 * sy, 2e-5)
+    xg = x.clone().requires_grad_()
+    (spmm(pat, xg, w) * y).sum().backward()           # xg.grad = S^T y via the by-source CSR
+    lhs = float((y.double() * sx.double()).sum())
+    rhs = float((xg.grad.double() * x.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+    ones = torch.ones(n, 4, device=d)
+    rowsum = torch.zeros(n, device=d, dtype=torch.float64).index_add_(0, ei[1], w.double())
+    close(spmm(pat, ones, w)[:, 0], rowsum.float(), 2e-5)

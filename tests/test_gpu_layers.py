@@ -1,0 +1,293 @@
+"""GPU: the drop-in layers (HIP path) against the golden vectors recorded from the reference's own
+Python (tests/golden/*.npz, written by oracle/gen_golden.py) and against the oracle at seeded
+mid-size inputs.  Tolerance 1e-5 * scale on outputs and gradients (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from oracle import ref_layers as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+D = "cuda:0"
+
+
+def close(got, want, tol=TOL):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    want = want.detach().cpu().double().numpy() if isinstance(want, torch.Tensor) else np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = max(1.0, float(np.abs(want).max())) if want.size else 1.0
+    err = float(np.abs(got - want).max()) / scale if want.size else 0.0
+    assert err <= tol, f"max err {err:.3e} > {tol}"
+
+
+def dense(index, vals, n):
+    acc = np.zeros((n, n))
+    np.add.at(acc, (index[0].cpu().numpy(), index[1].cpu().numpy()), vals.detach().cpu().double().numpy())
+    return acc
+
+
+def make_magnetic(g):
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv, MSConv
+    norm = None if str(g["normalization"]) == "none" else "sym"
+    k, fin, fout = int(g["K"]), g["weight"].shape[1], g["weight"].shape[2]
+    has_bias = "bias" in g
+    if bool(g["signed"]):
+        layer = MSConv(fin, fout, k, float(g["q"]), False, normalization=norm, bias=has_bias,
+                       absolute_degree=bool(g["absolute_degree"]))
+    else:
+        layer = MagNetConv(fin, fout, k, float(g["q"]), False, normalization=norm, bias=has_bias)
+    sd = {"weight": g.t("weight")}
+    if has_bias:
+        sd["bias"] = g.t("bias")
+    layer.load_state_dict(sd)
+    return layer.to(D)
+
+
+@pytest.mark.parametrize("name", golden_names("magnet_") + golden_names("msconv_"))
+def test_magnetic_layers_match_reference(name):
+    g = load_golden(name)
+    layer = make_magnetic(g)
+    xr, xi = g.t("x_real", D).requires_grad_(), g.t("x_imag", D).requires_grad_()
+    lam = float(g["lambda_max"]) if "lambda_max" in g else None
+    o_r, o_i = layer(xr, xi, g.t("edge_index", D), g.t("edge_weight", D), lambda_max=lam)
+    close(o_r, g["out_real"])
+    close(o_i, g["out_imag"])
+    ((o_r * g.t("grad_real", D)).sum() + (o_i * g.t("grad_imag", D)).sum()).backward()
+    close(xr.grad, g["dx_real"])
+    close(xi.grad, g["dx_imag"])
+    close(layer.weight.grad, g["dweight"])
+    if "bias" in g:
+        close(layer.bias.grad, g["dbias"])
+    # operator in the reference's own format: identical index layout, values within 1e-6
+    ei_r, ei_i, n_r, n_i = layer.cached_result
+    assert ei_r.cpu().tolist() == g["op_index_real"].tolist()
+    assert ei_i.cpu().tolist() == g["op_index_imag"].tolist()
+    close(n_r, g["op_real"], 1e-6)
+    close(n_i, g["op_imag"], 1e-6)
+
+
+def test_magnetic_lambda_max_eigsh_path():
+    """normalization=None without lambda_max: the layer computes it by eigsh like the reference."""
+    g = load_golden("magnet_k2_none_w")
+    layer = make_magnetic(g)
+    o_r, o_i = layer(g.t("x_real", D), g.t("x_imag", D), g.t("edge_index", D), g.t("edge_weight", D))
+    close(o_r, g["out_real"], 2e-5)
+    close(o_i, g["out_imag"], 2e-5)
+
+
+def test_kat_appendix_b():
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    from pytorch_geometric_signed_directed_amd.utils import get_magnetic_Laplacian, get_magnetic_signed_Laplacian
+    g = load_golden("kat_appendix_b")
+    ei, re, im = get_magnetic_Laplacian(g.t("edge_index", D), g.t("edge_weight", D), "sym", None, 4, 0.25)
+    assert ei.cpu().tolist() == g["lap_index"].tolist()
+    close(re, g["lap_real"], 1e-6)
+    close(im, g["lap_imag"], 1e-6)
+    _, sre, sim = get_magnetic_signed_Laplacian(g.t("edge_index", D), g.t("signed_weight", D), "sym", None, 4, 0.25)
+    close(sre, g["signed_lap_real"], 1e-6)
+    close(sim, g["signed_lap_imag"], 1e-6)
+    layer = MagNetConv(2, 2, 1, 0.25, False)
+    layer.load_state_dict({"weight": g.t("weight"), "bias": g.t("bias")})
+    layer.to(D)
+    o_r, o_i = layer(g.t("x_real", D), g.t("x_imag", D), g.t("edge_index", D), g.t("edge_weight", D))
+    np.testing.assert_allclose(o_r.detach().cpu().numpy(), [[11.624232, -1.320588], [9.814465, 0.440558],
+                                                            [11.364678, 7.492043], [7.1, 6.8]], atol=1e-5)
+    np.testing.assert_allclose(o_i.detach().cpu().numpy(), [[11.754375, -0.191489], [10.056267, 3.859610],
+                                                            [14.364678, 1.492042], [7.1, 8.8]], atol=1e-5)
+
+
+def test_magnetic_cached_semantics():
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    g = load_golden("magnet_k1_sym_w")
+    layer = MagNetConv(6, 5, 1, 0.25, False, cached=True).to(D)
+    args = (g.t("x_real", D), g.t("x_imag", D), g.t("edge_index", D), g.t("edge_weight", D))
+    a = layer(*args)
+    b = layer(*args)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with pytest.raises(RuntimeError, match="Cached .* number of edges"):
+        layer(args[0], args[1], args[2][:, :-1], args[3][:-1])
+    layer.reset_parameters()
+    assert layer.cached_result is None
+
+
+def test_magnetic_trainable_q_gradient():
+    """q gets a gradient through the SDDMM edge-value gradient and the phase (MagNetConv.py:58-59)."""
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    g = load_golden("magnet_k2_sym_w")
+    layer = MagNetConv(6, 5, 2, 0.2, True)
+    layer.load_state_dict({"q": torch.tensor([0.2]), "weight": g.t("weight"), "bias": g.t("bias")})
+    layer.to(D)
+    o_r, o_i = layer(g.t("x_real", D), g.t("x_imag", D), g.t("edge_index", D), g.t("edge_weight", D))
+    ((o_r * g.t("grad_real", D)).sum() + (o_i * g.t("grad_imag", D)).sum()).backward()
+    # oracle: same computation on CPU with autograd through q
+    q = torch.tensor([0.2], requires_grad=True)
+    op = R.magnet_operator(g.t("edge_index"), g.t("edge_weight"), 40, q, "sym", 2.0)
+    w_r, w_i = R.magnet_conv(g.t("x_real"), g.t("x_imag"), op, g.t("weight"), g.t("bias"))
+    ((w_r * g.t("grad_real")).sum() + (w_i * g.t("grad_imag")).sum()).backward()
+    close(o_r, w_r)
+    close(layer.q.grad, q.grad, 2e-5)
+    with pytest.raises(RuntimeError, match="Cannot train q"):
+        MagNetConv(6, 5, 1, 0.2, True, normalization=None).to(D)(
+            g.t("x_real", D), g.t("x_imag", D), g.t("edge_index", D), g.t("edge_weight", D))
+
+
+@pytest.mark.parametrize("name", golden_names("digcn_"))
+def test_digcn(name):
+    from pytorch_geometric_signed_directed_amd.nn import DiGCNConv
+    g = load_golden(name)
+    layer = DiGCNConv(g["weight"].shape[0], g["weight"].shape[1], bias="bias" in g)
+    layer.load_state_dict({k: g.t(k) for k in ("weight", "bias") if k in g})
+    layer.to(D)
+    x = g.t("x", D).requires_grad_()
+    out = layer(x, g.t("edge_index", D), g.t("edge_weight", D))
+    close(out, g["out"])
+    (out * g.t("grad_out", D)).sum().backward()
+    close(x.grad, g["dx"])
+    close(layer.weight.grad, g["dweight"])
+    if "bias" in g:
+        close(layer.bias.grad, g["dbias"])
+    assert repr(layer) == f"DiGCNConv({g['weight'].shape[0]}, {g['weight'].shape[1]})"
+    with pytest.raises(RuntimeError, match="Normalized adj matrix cannot be None"):
+        DiGCNConv(7, 4).to(D)(x.detach(), g.t("edge_index", D), None)
+
+
+@pytest.mark.parametrize("name", golden_names("dgcn_"))
+def test_dgcn(name):
+    from pytorch_geometric_signed_directed_amd.nn import DGCNConv
+    g = load_golden(name)
+    layer = DGCNConv(improved=bool(g["improved"]), add_self_loops=bool(g["add_self_loops"]))
+    x = g.t("x", D).requires_grad_()
+    out = layer(x, g.t("edge_index", D), g.t("edge_weight", D))
+    close(out, g["out"])
+    (out * g.t("grad_out", D)).sum().backward()
+    close(x.grad, g["dx"])
+
+
+def test_dgcn_cached_keeps_first_operator():
+    """Appendix C.4: a shared cached instance silently reuses the first operator."""
+    from pytorch_geometric_signed_directed_amd.nn import DGCNConv
+    g1, g2 = load_golden("dgcn_unw"), load_golden("dgcn_w_improved")
+    layer = DGCNConv(cached=True)
+    x = g1.t("x", D)
+    a = layer(x, g1.t("edge_index", D), None)
+    b = layer(x, g2.t("edge_index", D), g2.t("edge_weight", D))
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", golden_names("conv_base_"))
+def test_conv_base(name):
+    from pytorch_geometric_signed_directed_amd.nn import Conv_Base
+    g = load_golden(name)
+    layer = Conv_Base(float(g["fill_value"]))
+    x = g.t("x", D).requires_grad_()
+    out = layer(x, g.t("edge_index", D), g.t("edge_weight", D))
+    close(out, g["out"])
+    (out * g.t("grad_out", D)).sum().backward()
+    close(x.grad, g["dx"])
+
+
+@pytest.mark.parametrize("name", golden_names("simpa_"))
+def test_simpa(name):
+    from pytorch_geometric_signed_directed_amd.nn import SIMPA
+    g = load_golden(name)
+    directed = bool(g["directed"])
+    layer = SIMPA(int(g["hop"]), float(g["fill_value"]), directed)
+    layer.load_state_dict({k[5:]: g.t(k) for k in g if k.startswith("param")})
+    layer.to(D)
+    xs = [g.t(k, D).requires_grad_() if k in g else None for k in ("x_p", "x_n", "x_pt", "x_nt")]
+    out = layer(g.t("edge_index_p", D), g.t("edge_weight_p", D), g.t("edge_index_n", D),
+                g.t("edge_weight_n", D), *xs)
+    close(out, g["out"])
+    (out * g.t("grad_out", D)).sum().backward()
+    close(xs[0].grad, g["dx_p"])
+    close(xs[1].grad, g["dx_n"])
+    if directed:
+        close(xs[2].grad, g["dx_pt"])
+        close(xs[3].grad, g["dx_nt"])
+    for k, p in layer.named_parameters():
+        close(p.grad, g["dparam" + k], 2e-5)
+
+
+def test_dimpa():
+    from pytorch_geometric_signed_directed_amd.nn import DIMPA
+    g = load_golden("dimpa_hop2")
+    layer = DIMPA(int(g["hop"]), float(g["fill_value"]))
+    layer.load_state_dict({"_w_s": g.t("w_s"), "_w_t": g.t("w_t")})
+    layer.to(D)
+    xs, xt = g.t("x_s", D).requires_grad_(), g.t("x_t", D).requires_grad_()
+    out = layer(xs, xt, g.t("edge_index", D), g.t("edge_weight", D))
+    close(out, g["out"])
+    (out * g.t("grad_out", D)).sum().backward()
+    close(xs.grad, g["dx_s"])
+    close(xt.grad, g["dx_t"])
+    close(layer._w_s.grad, g["dw_s"], 2e-5)
+    close(layer._w_t.grad, g["dw_t"], 2e-5)
+
+
+@pytest.mark.parametrize("name", golden_names("sgcn_"))
+def test_sgcn(name):
+    from pytorch_geometric_signed_directed_amd.nn import SGCNConv
+    g = load_golden(name)
+    first = bool(g["first_aggr"])
+    layer = SGCNConv(int(g["in_dim"]), g["lin_b_weight"].shape[0], first, norm_emb=bool(g["norm_emb"]))
+    layer.load_state_dict({"lin_b.weight": g.t("lin_b_weight"), "lin_b.bias": g.t("lin_b_bias"),
+                           "lin_u.weight": g.t("lin_u_weight"), "lin_u.bias": g.t("lin_u_bias")})
+    layer.to(D)
+    x = g.t("x", D).requires_grad_()
+    out = layer(x, g.t("pos_edge_index", D), g.t("neg_edge_index", D))
+    close(out, g["out"])
+    (out * g.t("grad_out", D)).sum().backward()
+    close(x.grad, g["dx"])
+    close(layer.lin_b.weight.grad, g["dlin_b_weight"])
+    close(layer.lin_u.weight.grad, g["dlin_u_weight"])
+    assert repr(layer) == f"SGCNConv({int(g['in_dim'])}, {g['lin_b_weight'].shape[0]}, first_aggr={first})"
+
+
+def test_message_passing_propagate_surface():
+    """The PyG-free MessagePassing.propagate(edge_index, x=..., <w>=...) entry the reference's layers
+    call, for both flows and aggr add / mean, vs the oracle."""
+    from pytorch_geometric_signed_directed_amd import MessagePassing
+    g = torch.Generator().manual_seed(3)
+    n, e, f = 70, 600, 12
+    ei = torch.randint(0, n, (2, e), generator=g)
+    x, w = torch.randn(n, f, generator=g), torch.rand(e, generator=g)
+    for flow in ("source_to_target", "target_to_source"):
+        for aggr in ("add", "mean"):
+            mp = MessagePassing(aggr=aggr, flow=flow)
+            got = mp.propagate(ei.to(D), x=x.to(D), edge_weight=w.to(D))
+            close(got, R.propagate(x, ei, w, n, flow=flow, reduce=aggr))
+
+    class Custom(MessagePassing):
+        def message(self, x_j):
+            return x_j * 2
+
+    with pytest.raises(NotImplementedError):
+        Custom().propagate(ei.to(D), x=x.to(D))
+
+
+def test_magnet_midsize_vs_oracle():
+    """MagNetConv K=2, N=20k, E=400k, h=64 on a seeded random digraph: forward + gradients vs the
+    oracle's reference op sequence."""
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    n, e, f = 20000, 400000, 64
+    g = torch.Generator().manual_seed(41)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    w = torch.rand(e, generator=g) + 0.5
+    xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    torch.manual_seed(41)
+    layer = MagNetConv(f, f, 2, 0.25, False)
+    weight, bias = layer.weight.detach().clone(), layer.bias.detach().clone()
+    op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0)
+    a, b = xr.clone().requires_grad_(), xi.clone().requires_grad_()
+    w_r, w_i = R.magnet_conv(a, b, op, weight, bias, duplicate=False)
+    (w_r.sum() + w_i.sum()).backward()
+    layer.to(D)
+    c, d = xr.to(D).requires_grad_(), xi.to(D).requires_grad_()
+    o_r, o_i = layer(c, d, ei.to(D), w.to(D))
+    (o_r.sum() + o_i.sum()).backward()
+    close(o_r, w_r)
+    close(o_i, w_i)
+    close(c.grad, a.grad)
+    close(d.grad, b.grad)

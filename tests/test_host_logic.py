@@ -1,0 +1,89 @@
+"""CPU: host-side contract of the drop-in layers -- constructor signatures, __repr__ strings,
+state_dict keys / shapes / initialisation, error behaviour, and that the product
+path refuses CPU tensors instead of silently falling back."""
+import math
+
+import pytest
+import torch
+
+from pytorch_geometric_signed_directed_amd.nn import (DIMPA, SIMPA, Conv_Base, DGCNConv, DiGCNConv, MagNetConv,
+                                                      MSConv, SGCNConv, complex_relu_layer)
+
+
+def test_repr_strings_asserted_by_the_reference_tests():
+    # reference test/directed_test.py:73-74, :281; test/signed_test.py (SGCNConv repr)
+    assert repr(MagNetConv(3, 2, 2, 0.25, False)) == 'MagNetConv(3, 2, filter size=3, normalization=sym)'
+    assert repr(MSConv(3, 2, 2, 0.25, False)) == 'MSConv(3, 2, filter size=3, normalization=sym)'
+    assert repr(DiGCNConv(3, 4)) == 'DiGCNConv(3, 4)'
+    assert repr(SGCNConv(4, 3, first_aggr=True)) == 'SGCNConv(4, 3, first_aggr=True)'
+
+
+def test_state_dict_layout_and_init():
+    m = MagNetConv(7, 5, 3, 0.1, True)
+    sd = m.state_dict()
+    assert list(sd) == ['q', 'weight', 'bias']
+    assert sd['weight'].shape == (4, 7, 5) and sd['bias'].shape == (5,) and sd['q'].shape == (1,)
+    a = math.sqrt(6.0 / (7 + 5))
+    assert float(sd['weight'].abs().max()) <= a and float(sd['bias'].abs().max()) == 0.0
+    assert list(MagNetConv(7, 5, 1, 0.1, False, bias=False).state_dict()) == ['weight']
+    assert list(MSConv(7, 5, 1, 0.1, False).state_dict()) == ['weight', 'bias']
+    d = DiGCNConv(6, 4)
+    assert {k: tuple(v.shape) for k, v in d.state_dict().items()} == {'weight': (6, 4), 'bias': (4,)}
+    s = SGCNConv(4, 3, first_aggr=False)
+    assert {k: tuple(v.shape) for k, v in s.state_dict().items()} == {
+        'lin_b.weight': (3, 12), 'lin_b.bias': (3,), 'lin_u.weight': (3, 12), 'lin_u.bias': (3,)}
+    assert SGCNConv(4, 3, first_aggr=True).lin_b.weight.shape == (3, 8)
+    u = SIMPA(2, 0.5)
+    assert {k: tuple(v.shape) for k, v in u.state_dict().items()} == {'_w_p': (3, 1), '_w_n': (3, 1)}
+    assert all(float(v.min()) == 1.0 == float(v.max()) for v in u.state_dict().values())
+    assert list(SIMPA(2, 0.5, directed=True).state_dict()) == ['_w_sp', '_w_sn', '_w_tp', '_w_tn']
+    assert {k: tuple(v.shape) for k, v in DIMPA(3).state_dict().items()} == {'_w_s': (4, 1), '_w_t': (4, 1)}
+    assert len(DGCNConv().state_dict()) == 0 and len(Conv_Base().state_dict()) == 0
+
+
+def test_constructor_defaults_match_the_reference():
+    m = MagNetConv(3, 2, 1, 0.25, False)
+    assert (m.normalization, m.cached, m.trainable_q, m.flow, m.aggr) == ('sym', False, False,
+                                                                          'source_to_target', 'add')
+    ms = MSConv(3, 2, 1, 0.25, False)
+    assert ms.absolute_degree is True and ms.cached is False
+    assert DiGCNConv(3, 2).cached is True and DiGCNConv(3, 2).improved is False
+    d = DGCNConv()
+    assert (d.improved, d.cached, d.add_self_loops, d.normalize) == (False, False, True, True)
+    c = Conv_Base()
+    assert (c.fill_value, c.flow, c.aggr) == (0.5, 'target_to_source', 'add')
+    assert SGCNConv(4, 3, True).aggr == 'mean'
+    with pytest.raises(AssertionError):
+        MagNetConv(3, 2, 0, 0.25, False)
+    with pytest.raises(AssertionError):
+        MagNetConv(3, 2, 1, 0.25, False, normalization='rw')
+
+
+def test_reference_checkpoint_roundtrip():
+    a, b = MagNetConv(4, 4, 2, 0.25, False), MagNetConv(4, 4, 2, 0.25, False)
+    b.load_state_dict(a.state_dict())
+    assert torch.equal(a.weight, b.weight)
+
+
+def test_cpu_tensors_are_refused_loudly():
+    x = torch.randn(5, 3)
+    ei = torch.tensor([[0, 1, 2], [1, 2, 3]])
+    w = torch.ones(3)
+    for call in (lambda: MagNetConv(3, 2, 1, 0.25, False)(x, x, ei, w),
+                 lambda: MSConv(3, 2, 1, 0.25, False)(x, x, ei, w),
+                 lambda: DiGCNConv(3, 2)(x, ei, w),
+                 lambda: DGCNConv()(x, ei, w),
+                 lambda: Conv_Base()(x, ei, w),
+                 lambda: SGCNConv(3, 2, True)(x, ei, ei),
+                 lambda: complex_relu_layer()(x, x)):
+        with pytest.raises(RuntimeError, match="no CPU fallback|HIP"):
+            call()
+
+
+def test_product_package_does_not_import_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys, pytorch_geometric_signed_directed_amd as p, pytorch_geometric_signed_directed_amd.nn;"
+            "bad=[m for m in sys.modules if m=='oracle' or m.startswith('oracle.')];"
+            "assert not bad, bad")
+    subprocess.run([sys.executable, "-c", code], check=True)
