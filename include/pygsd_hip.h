@@ -120,6 +120,32 @@ int pygsd_complex_relu_bwd_f32(const float* real, const float* g_real, const flo
                                float* gi_real, float* gi_imag, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused dense stage of MagNetConv / MSConv on the MFMA matrix cores (exact fp32 MFMA).
+ *   forward : out_real = sum_k (A_k - B_k) W_k + bias ;  out_imag = sum_k (A_k + B_k) W_k + bias
+ *   backward: P = g_real + g_imag, M = g_imag - g_real;
+ *             dA_k = P W_k^T, dB_k = M W_k^T, dW_k = A_k^T P + B_k^T M, dbias = colsum(P)
+ * A_k / B_k are the k-th Chebyshev terms of the real / imaginary chain ([n_rows, f_in], contiguous,
+ * 16-byte aligned); W is [k1, f_in, f_out]; a / b / da / db are HOST arrays of k1 device pointers.
+ * Replaces the four matmuls per Chebyshev order, the out_real = rr - ii / out_imag = ir + ri
+ * combination and the in-place bias adds of nn/directed/MagNetConv.py:189-192,198-211,217-247
+ * (nn/general/MSConv.py:185-230), and their autograd backward.
+ * pygsd_magnetic_dense_supported: 1 if (f_in, f_out, k1) is covered by the fused kernels
+ * (multiples of 16, f_out in {16,32,48,64,128}, f_in < 64 or a multiple of 64, k1 <= 4).
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_magnetic_dense_supported(int32_t f_in, int32_t f_out, int32_t k1);
+int pygsd_magnetic_dense_fwd_f32(const float* const* a, const float* const* b, int32_t k1,
+                                 const float* w, const float* bias,
+                                 float* out_real, float* out_imag,
+                                 int32_t n_rows, int32_t f_in, int32_t f_out, void* stream);
+int pygsd_magnetic_dense_bwd_workspace(int32_t n_rows, int32_t f_in, int32_t f_out, int32_t k1,
+                                       size_t* bytes);
+int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* const* b, int32_t k1,
+                                 const float* w, const float* g_real, const float* g_imag,
+                                 float* const* da, float* const* db, float* dw, float* dbias,
+                                 int32_t n_rows, int32_t f_in, int32_t f_out,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Kernel-timing recorder (measurement only; used by bench.py for the roofline object).
  * When enabled, every kernel launch of this library is bracketed by a pair of hipEvents on the
  * launch stream.  pygsd_prof_collect synchronises those events and returns, for kernel class
@@ -131,7 +157,8 @@ enum {
     PYGSD_K_SDDMM = 2,
     PYGSD_K_BUILD = 3,
     PYGSD_K_ELEMENTWISE = 4,
-    PYGSD_K_COUNT = 5
+    PYGSD_K_DENSE = 5,
+    PYGSD_K_COUNT = 6
 };
 int pygsd_prof_enable(int32_t on);
 int pygsd_prof_reset(void);

@@ -14,9 +14,9 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpygsd_hip.so")
 _lib = None
 
-K_SPMM, K_SPMM2, K_SDDMM, K_BUILD, K_ELEMENTWISE = range(5)
+K_SPMM, K_SPMM2, K_SDDMM, K_BUILD, K_ELEMENTWISE, K_DENSE = range(6)
 KERNEL_IDS = {"spmm": K_SPMM, "spmm2": K_SPMM2, "sddmm": K_SDDMM, "build": K_BUILD,
-              "elementwise": K_ELEMENTWISE}
+              "elementwise": K_ELEMENTWISE, "dense": K_DENSE}
 
 # name -> (restype, argtypes); must list every symbol include/pygsd_hip.h declares
 PROTOTYPES = {
@@ -40,6 +40,14 @@ PROTOTYPES = {
     "pygsd_complex_relu_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pygsd_complex_relu_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                              c_void_p]),
+    "pygsd_magnetic_dense_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "pygsd_magnetic_dense_fwd_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "pygsd_magnetic_dense_bwd_workspace": (c_int32, [c_int32, c_int32, c_int32, c_int32,
+                                                     ctypes.POINTER(c_size_t)]),
+    "pygsd_magnetic_dense_bwd_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                               c_int32, c_void_p, c_size_t, c_void_p]),
     "pygsd_prof_enable": (c_int32, [c_int32]),
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),

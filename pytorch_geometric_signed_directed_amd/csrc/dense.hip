@@ -1,0 +1,452 @@
+// Fused dense stage of MagNetConv / MSConv on the MFMA matrix cores (exact fp32:
+// v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) -- the only GEMM-shaped work on the path.
+//
+//   forward :  out_real = sum_k (A_k - B_k) W_k + b ,  out_imag = sum_k (A_k + B_k) W_k + b
+//              (A_k / B_k = k-th Chebyshev terms of the real / imaginary chain; reference
+//               nn/directed/MagNetConv.py:189-192,198-211,217-247: four matmuls per order, then
+//               out_real = rr - ii, out_imag = ir + ri, += bias.  By linearity the +- is applied
+//               to the GEMM inputs, so one pass reads A_k, B_k once and writes both outputs once.)
+//   backward:  P = G_r + G_i , M = G_i - G_r ;  dA_k = P W_k^T , dB_k = M W_k^T ,
+//              dW_k = A_k^T P + B_k^T M , db = colsum(P)
+//
+// Tiling: one wavefront owns 16 node rows.  The A operand of mfma_16x16x4 is ONE f32 per lane
+// (lane l: row l&15, k-slot l>>4), so a lane's float4 global load of 4 consecutive features feeds
+// four successive MFMAs directly (k-slots are summed, their order is free): 16 B per lane, 64 B
+// contiguous per row per instruction, no LDS staging of activations.  W (or W^T) lives in LDS with a
+// +4-float row pad (conflict-free ds_read_b32 of a B fragment).  Weight-gradient partials stay in
+// MFMA accumulators across a persistent row loop, are combined per block through LDS and finished by
+// a small deterministic tree kernel -- no atomics.
+#include "common.hpp"
+
+namespace pygsd {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxOrder = 4;   // K + 1 <= 4
+constexpr int kChunk = 64;     // output-column / input-column chunk handled by one block
+constexpr int kPad = 4;
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+struct DenseFwdArgs {
+    const float* a[kMaxOrder];
+    const float* b[kMaxOrder];
+    const float* w;      // [k1][f_in][f_out]
+    const float* bias;   // [f_out] or null
+    float* out_r;
+    float* out_i;
+    int32_t n_rows, f_in, f_out, k1;
+};
+
+// grid = (row blocks, ceil(f_out / 64)); block = 256 threads = 4 wavefronts x 16 rows.
+template <int NT>
+__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int n0 = static_cast<int>(blockIdx.y) * kChunk;
+    constexpr int nc = NT * 16;
+    constexpr int ws = nc + kPad;
+    const int wrows = p.k1 * p.f_in;
+    for (int idx = tid; idx < wrows * nc; idx += 256) {
+        const int r = idx / nc, c = idx - r * nc;
+        lds[r * ws + c] = p.w[static_cast<int64_t>(r) * p.f_out + n0 + c];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int n_tiles = (p.n_rows + 15) >> 4;
+    for (int tile = static_cast<int>(blockIdx.x) * 4 + (tid >> 6); tile < n_tiles;
+         tile += static_cast<int>(gridDim.x) * 4) {
+        const int r0 = tile << 4;
+        const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;  // clamped: stores are masked
+        f32x4 acc_r[NT], acc_i[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc_r[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc_i[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int k = 0; k < p.k1; ++k) {
+            const float* ap = p.a[k] + static_cast<int64_t>(lrow) * p.f_in + 4 * g;
+            const float* bp = p.b[k] + static_cast<int64_t>(lrow) * p.f_in + 4 * g;
+            const float* wk = lds + (k * p.f_in + 4 * g) * ws + i;
+            for (int t = 0; t < p.f_in; t += 16) {
+                const float4 a = ldg4(ap + t);
+                const float4 b = ldg4(bp + t);
+                const float d[4] = {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w};
+                const float s[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+                const float* wt = wk + t * ws;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float w = wt[m * ws + nt * 16];
+                        acc_r[nt] = mfma(d[m], w, acc_r[nt]);
+                        acc_i[nt] = mfma(s[m], w, acc_i[nt]);
+                    }
+                }
+            }
+        }
+        // C/D layout of mfma_16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + nt * 16 + i;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = r0 + 4 * g + r;
+                if (orow < p.n_rows) {
+                    const int64_t o = static_cast<int64_t>(orow) * p.f_out + col;
+                    p.out_r[o] = acc_r[nt][r] + bv;
+                    p.out_i[o] = acc_i[nt][r] + bv;
+                }
+            }
+        }
+    }
+}
+
+struct DenseBwdArgs {
+    const float* a[kMaxOrder];
+    const float* b[kMaxOrder];
+    float* da[kMaxOrder];
+    float* db[kMaxOrder];
+    const float* gr;     // [n][f_out]
+    const float* gi;
+    const float* w;      // [k1][f_in][f_out]
+    float* partial;      // [n_partials][k1 * f_in * f_out + f_out]
+    int32_t n_rows, f_in, f_out, k1;
+};
+
+// grid = (row blocks, k1, ceil(f_in / 64)); block = 256 threads.  Block (x, k, ci) produces
+// dA_k[:, chunk ci], dB_k[:, chunk ci] for its rows and one partial of dW_k[chunk ci, :] (+ db when
+// k == 0 and ci == 0).  NTI = f_in-chunk tiles (<= 4), NTO = f_out tiles (<= 8).
+template <int NTI, int NTO>
+__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int k = blockIdx.y;
+    const int c0 = static_cast<int>(blockIdx.z) * kChunk;   // first f_in column of this chunk
+    constexpr int fc = NTI * 16;
+    constexpr int fo = NTO * 16;
+    constexpr int ws = fc + kPad;
+    // W_k^T slice: wt[kk][j] = W[k][c0 + j][kk]
+    const float* wsrc = p.w + (static_cast<int64_t>(k) * p.f_in + c0) * p.f_out;
+    for (int idx = tid; idx < fc * fo; idx += 256) {
+        const int j = idx / fo, kk = idx - j * fo;   // coalesced read along kk
+        lds[kk * ws + j] = wsrc[static_cast<int64_t>(j) * p.f_out + kk];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const bool do_bias = (k == 0) && (blockIdx.z == 0);
+    const float* ak = p.a[k];
+    const float* bk = p.b[k];
+    float* dak = p.da[k];
+    float* dbk = p.db[k];
+
+    f32x4 acc_w[NTI][NTO];
+    float acc_bias[NTO];
+#pragma unroll
+    for (int ft = 0; ft < NTI; ++ft)
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) acc_w[ft][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt) acc_bias[nt] = 0.f;
+
+    const int n_tiles = (p.n_rows + 15) >> 4;
+    for (int tile = static_cast<int>(blockIdx.x) * 4 + (tid >> 6); tile < n_tiles;
+         tile += static_cast<int>(gridDim.x) * 4) {
+        const int r0 = tile << 4;
+        // ---- phase 1: dA_k, dB_k tile = [P | M] (16 x f_out) . W_k^T (f_out x fc) --------------
+        {
+            const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;
+            const float* grp = p.gr + static_cast<int64_t>(lrow) * p.f_out + 4 * g;
+            const float* gip = p.gi + static_cast<int64_t>(lrow) * p.f_out + 4 * g;
+            f32x4 acc_a[NTI], acc_b[NTI];
+#pragma unroll
+            for (int ft = 0; ft < NTI; ++ft) {
+                acc_a[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc_b[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const float* wk = lds + (4 * g) * ws + i;
+#pragma unroll
+            for (int t = 0; t < fo; t += 16) {
+                const float4 x = ldg4(grp + t);
+                const float4 y = ldg4(gip + t);
+                const float pp[4] = {x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w};
+                const float mm[4] = {y.x - x.x, y.y - x.y, y.z - x.z, y.w - x.w};
+                const float* wt = wk + t * ws;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                    for (int ft = 0; ft < NTI; ++ft) {
+                        const float w = wt[m * ws + ft * 16];
+                        acc_a[ft] = mfma(pp[m], w, acc_a[ft]);
+                        acc_b[ft] = mfma(mm[m], w, acc_b[ft]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ft = 0; ft < NTI; ++ft) {
+                const int col = c0 + ft * 16 + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int orow = r0 + 4 * g + r;
+                    if (orow < p.n_rows) {
+                        const int64_t o = static_cast<int64_t>(orow) * p.f_in + col;
+                        dak[o] = acc_a[ft][r];
+                        dbk[o] = acc_b[ft][r];
+                    }
+                }
+            }
+        }
+        // ---- phase 2: dW_k[chunk, :] += A_tile^T P + B_tile^T M  (reduction over the 16 rows) ----
+        // MFMA step s consumes rows {4 g + s : g = 0..3}; lane (i, g) supplies column i of that row.
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = r0 + 4 * g + s;
+            const bool live = row < p.n_rows;
+            const int64_t ro = static_cast<int64_t>(live ? row : 0);
+            float pb[NTO], mb[NTO], av[NTI], bv[NTI];
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) {
+                const float x = live ? p.gr[ro * p.f_out + nt * 16 + i] : 0.f;
+                const float y = live ? p.gi[ro * p.f_out + nt * 16 + i] : 0.f;
+                pb[nt] = x + y;
+                mb[nt] = y - x;
+            }
+#pragma unroll
+            for (int ft = 0; ft < NTI; ++ft) {
+                av[ft] = live ? ak[ro * p.f_in + c0 + ft * 16 + i] : 0.f;
+                bv[ft] = live ? bk[ro * p.f_in + c0 + ft * 16 + i] : 0.f;
+            }
+#pragma unroll
+            for (int ft = 0; ft < NTI; ++ft)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    acc_w[ft][nt] = mfma(av[ft], pb[nt], acc_w[ft][nt]);
+                    acc_w[ft][nt] = mfma(bv[ft], mb[nt], acc_w[ft][nt]);
+                }
+            if (do_bias) {
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) acc_bias[nt] += pb[nt];
+            }
+        }
+    }
+
+    // ---- combine the 4 wavefronts of the block through LDS (W^T is dead now), then one partial ----
+    __syncthreads();
+    const int wave = tid >> 6;
+    constexpr int wsz = fc * fo;   // floats of this block's dW chunk
+    // element (f_in index 16 ft + 4 g + r, f_out index 16 nt + i) -> lds[(..) * fo + ..]
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int ft = 0; ft < NTI; ++ft)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = (ft * 16 + 4 * g + r) * fo + nt * 16 + i;
+                        lds[e] = (turn == 0 ? 0.f : lds[e]) + acc_w[ft][nt][r];
+                    }
+            if (do_bias) {
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    float v = acc_bias[nt];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (g == 0) lds[wsz + nt * 16 + i] = (turn == 0 ? 0.f : lds[wsz + nt * 16 + i]) + v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t pstride = static_cast<int64_t>(p.k1) * p.f_in * p.f_out + p.f_out;
+    float* part = p.partial + static_cast<int64_t>(blockIdx.x) * pstride;
+    float* dst = part + (static_cast<int64_t>(k) * p.f_in + c0) * p.f_out;
+    for (int e = tid; e < wsz; e += 256) dst[e] = lds[e];
+    if (do_bias)
+        for (int e = tid; e < fo; e += 256) part[pstride - p.f_out + e] = lds[wsz + e];
+}
+
+// out[e] = sum_p partial[p][e], fixed order (deterministic): 64 elements per block, 4 partial
+// groups per element combined through LDS.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                              int n_partials, int64_t stride,
+                                                              int64_t n_elem, float* __restrict__ out)
+{
+    __shared__ float sm[256];
+    const int tid = threadIdx.x;
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * 64 + (tid & 63);
+    const int pg = tid >> 6;
+    float acc = 0.f;
+    if (e < n_elem) {
+#pragma unroll 8
+        for (int q = pg; q < n_partials; q += 4) acc += partial[static_cast<int64_t>(q) * stride + e];
+    }
+    sm[tid] = acc;
+    __syncthreads();
+    if (pg == 0 && e < n_elem) out[e] = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
+}
+
+unsigned row_blocks(int n_rows, unsigned cap)
+{
+    unsigned g = (static_cast<unsigned>(n_rows) + 63u) / 64u;
+    if (g > cap) g = cap;
+    return g ? g : 1u;
+}
+
+template <typename Kern>
+int set_lds(Kern kern, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+    return 0;
+}
+
+template <int NT>
+int launch_fwd(const DenseFwdArgs& a, unsigned gy, hipStream_t s)
+{
+    const size_t lds_bytes = static_cast<size_t>(a.k1) * a.f_in * (NT * 16 + kPad) * sizeof(float);
+    PYGSD_REQUIRE(lds_bytes <= 160 * 1024 - 1024, "pygsd_magnetic_dense_fwd_f32: W slice needs %zu B of LDS", lds_bytes);
+    if (int rc = set_lds(dense_fwd_kernel<NT>, lds_bytes)) return rc;
+    hipLaunchKernelGGL(dense_fwd_kernel<NT>, dim3(row_blocks(a.n_rows, 2048), gy), dim3(256), lds_bytes, s, a);
+    return check_launch("dense_fwd_kernel");
+}
+
+template <int NTI, int NTO>
+int launch_bwd(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
+{
+    size_t lds_floats = static_cast<size_t>(NTO * 16) * (NTI * 16 + kPad);
+    const size_t red = static_cast<size_t>(NTI * 16) * (NTO * 16) + NTO * 16;
+    if (red > lds_floats) lds_floats = red;
+    const size_t lds_bytes = lds_floats * sizeof(float);
+    if (int rc = set_lds(dense_bwd_kernel<NTI, NTO>, lds_bytes)) return rc;
+    hipLaunchKernelGGL((dense_bwd_kernel<NTI, NTO>), dim3(gx, a.k1, gz), dim3(256), lds_bytes, s, a);
+    return check_launch("dense_bwd_kernel");
+}
+
+template <int NTI>
+int dispatch_bwd_nto(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
+{
+    switch (a.f_out / 16) {
+        case 1: return launch_bwd<NTI, 1>(a, gx, gz, s);
+        case 2: return launch_bwd<NTI, 2>(a, gx, gz, s);
+        case 3: return launch_bwd<NTI, 3>(a, gx, gz, s);
+        case 4: return launch_bwd<NTI, 4>(a, gx, gz, s);
+        case 8: return launch_bwd<NTI, 8>(a, gx, gz, s);
+        default: return fail("pygsd_magnetic_dense_bwd_f32: unsupported f_out=%d", a.f_out);
+    }
+}
+
+}  // namespace
+}  // namespace pygsd
+
+using namespace pygsd;
+
+extern "C" int pygsd_magnetic_dense_supported(int32_t f_in, int32_t f_out, int32_t k1)
+{
+    if (k1 < 1 || k1 > kMaxOrder) return 0;
+    if (f_in < 16 || f_out < 16 || f_in % 16 || f_out % 16) return 0;
+    const int fo16 = f_out / 16;
+    if (!(fo16 == 1 || fo16 == 2 || fo16 == 3 || fo16 == 4 || fo16 == 8)) return 0;
+    if (f_in % 64 != 0 && f_in > 64) return 0;   // f_in chunks of 64 (or one chunk of 16/32/48)
+    if (static_cast<size_t>(k1) * f_in * (kChunk + kPad) * sizeof(float) > 150 * 1024) return 0;
+    return 1;
+}
+
+extern "C" int pygsd_magnetic_dense_fwd_f32(const float* const* a, const float* const* b, int32_t k1,
+                                            const float* w, const float* bias, float* out_real,
+                                            float* out_imag, int32_t n_rows, int32_t f_in, int32_t f_out,
+                                            void* stream)
+{
+    PYGSD_REQUIRE(pygsd_magnetic_dense_supported(f_in, f_out, k1),
+                  "pygsd_magnetic_dense_fwd_f32: unsupported shape f_in=%d f_out=%d k1=%d", f_in, f_out, k1);
+    PYGSD_REQUIRE(n_rows >= 0, "pygsd_magnetic_dense_fwd_f32: negative size");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(a && b && w && out_real && out_imag, "pygsd_magnetic_dense_fwd_f32: null pointer");
+    DenseFwdArgs args{};
+    for (int k = 0; k < k1; ++k) {
+        PYGSD_REQUIRE(a[k] && b[k] && aligned16(a[k]) && aligned16(b[k]),
+                      "pygsd_magnetic_dense_fwd_f32: operand %d null or not 16-byte aligned", k);
+        args.a[k] = a[k];
+        args.b[k] = b[k];
+    }
+    args.w = w; args.bias = bias; args.out_r = out_real; args.out_i = out_imag;
+    args.n_rows = n_rows; args.f_in = f_in; args.f_out = f_out; args.k1 = k1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_DENSE, s);
+    const unsigned gy = (static_cast<unsigned>(f_out) + kChunk - 1) / kChunk;
+    // every y-chunk is a full 64 columns except possibly a single-chunk narrow output
+    if (f_out >= kChunk) {
+        PYGSD_REQUIRE(f_out % kChunk == 0 || gy == 1, "pygsd_magnetic_dense_fwd_f32: f_out=%d not chunkable", f_out);
+        if (f_out % kChunk == 0) return launch_fwd<4>(args, gy, s);
+    }
+    switch (f_out / 16) {
+        case 1: return launch_fwd<1>(args, 1, s);
+        case 2: return launch_fwd<2>(args, 1, s);
+        case 3: return launch_fwd<3>(args, 1, s);
+        default: return fail("pygsd_magnetic_dense_fwd_f32: f_out=%d not chunkable", f_out);
+    }
+}
+
+extern "C" int pygsd_magnetic_dense_bwd_workspace(int32_t n_rows, int32_t f_in, int32_t f_out, int32_t k1,
+                                                  size_t* bytes)
+{
+    PYGSD_REQUIRE(bytes, "pygsd_magnetic_dense_bwd_workspace: null output");
+    const size_t per = static_cast<size_t>(k1) * f_in * f_out + f_out;
+    *bytes = per * sizeof(float) * row_blocks(n_rows, 256);
+    return 0;
+}
+
+extern "C" int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* const* b, int32_t k1,
+                                            const float* w, const float* g_real, const float* g_imag,
+                                            float* const* da, float* const* db, float* dw, float* dbias,
+                                            int32_t n_rows, int32_t f_in, int32_t f_out, void* workspace,
+                                            size_t workspace_bytes, void* stream)
+{
+    PYGSD_REQUIRE(pygsd_magnetic_dense_supported(f_in, f_out, k1),
+                  "pygsd_magnetic_dense_bwd_f32: unsupported shape f_in=%d f_out=%d k1=%d", f_in, f_out, k1);
+    PYGSD_REQUIRE(n_rows > 0, "pygsd_magnetic_dense_bwd_f32: n_rows must be positive");
+    PYGSD_REQUIRE(a && b && w && g_real && g_imag && da && db && dw && dbias && workspace,
+                  "pygsd_magnetic_dense_bwd_f32: null pointer");
+    PYGSD_REQUIRE(aligned16(g_real) && aligned16(g_imag), "pygsd_magnetic_dense_bwd_f32: gradients not 16-byte aligned");
+    size_t need = 0;
+    pygsd_magnetic_dense_bwd_workspace(n_rows, f_in, f_out, k1, &need);
+    PYGSD_REQUIRE(workspace_bytes >= need, "pygsd_magnetic_dense_bwd_f32: workspace too small (%zu < %zu)",
+                  workspace_bytes, need);
+    DenseBwdArgs args{};
+    for (int k = 0; k < k1; ++k) {
+        PYGSD_REQUIRE(a[k] && b[k] && da[k] && db[k], "pygsd_magnetic_dense_bwd_f32: operand %d null", k);
+        args.a[k] = a[k]; args.b[k] = b[k]; args.da[k] = da[k]; args.db[k] = db[k];
+    }
+    args.gr = g_real; args.gi = g_imag; args.w = w; args.partial = static_cast<float*>(workspace);
+    args.n_rows = n_rows; args.f_in = f_in; args.f_out = f_out; args.k1 = k1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_DENSE, s);
+    const unsigned gx = row_blocks(n_rows, 256);
+    const unsigned gz = (static_cast<unsigned>(f_in) + kChunk - 1) / kChunk;
+    int rc;
+    if (f_in >= kChunk) rc = dispatch_bwd_nto<4>(args, gx, gz, s);
+    else if (f_in == 48) rc = dispatch_bwd_nto<3>(args, gx, 1, s);
+    else if (f_in == 32) rc = dispatch_bwd_nto<2>(args, gx, 1, s);
+    else rc = dispatch_bwd_nto<1>(args, gx, 1, s);
+    if (rc) return rc;
+    // dw [k1][f_in][f_out] followed by dbias [f_out] in the partial layout
+    const int64_t n_w = static_cast<int64_t>(k1) * f_in * f_out;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((n_w + 63) / 64)), dim3(256), 0, s,
+                       args.partial, static_cast<int>(gx), n_w + f_out, n_w, dw);
+    if (int rc2 = check_launch("reduce_partials_kernel")) return rc2;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((f_out + 63) / 64)), dim3(256), 0, s,
+                       args.partial + n_w, static_cast<int>(gx), n_w + f_out, static_cast<int64_t>(f_out), dbias);
+    return check_launch("reduce_partials_kernel");
+}

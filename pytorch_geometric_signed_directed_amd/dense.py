@@ -1,0 +1,113 @@
+"""Host wrappers of the fused MFMA dense stage (csrc/dense.hip; include/pygsd_hip.h
+pygsd_magnetic_dense_*) and the single autograd node of a whole MagNetConv / MSConv layer."""
+import ctypes
+from ctypes import c_void_p
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _cabi
+from ._cabi import check, ptr, stream_ptr
+from .sparse import Pattern, _spmm2_raw
+
+Tensor = torch.Tensor
+
+
+def dense_supported(f_in: int, f_out: int, k1: int) -> bool:
+    return bool(_cabi.lib().pygsd_magnetic_dense_supported(int(f_in), int(f_out), int(k1)))
+
+
+def _ptr_array(ts: Sequence[Tensor]):
+    return (c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def dense_fwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, bias: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    """out_real = sum_k (a_k - b_k) W_k + bias ; out_imag = sum_k (a_k + b_k) W_k + bias."""
+    k1, f_in, f_out = weight.shape
+    a = [t.contiguous() for t in a]
+    b = [t.contiguous() for t in b]
+    n = a[0].size(0)
+    w = weight.detach().contiguous()
+    out_r = torch.empty((n, f_out), dtype=torch.float32, device=w.device)
+    out_i = torch.empty_like(out_r)
+    bias_c = None if bias is None else bias.detach().contiguous()
+    with torch.cuda.device(w.device):
+        check(_cabi.lib().pygsd_magnetic_dense_fwd_f32(_ptr_array(a), _ptr_array(b), k1, ptr(w), ptr(bias_c),
+                                                       ptr(out_r), ptr(out_i), n, f_in, f_out, stream_ptr()),
+              "pygsd_magnetic_dense_fwd_f32")
+    return out_r, out_i
+
+
+def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor, g_i: Tensor):
+    """-> (da list, db list, dW [k1, f_in, f_out], dbias [f_out])."""
+    k1, f_in, f_out = weight.shape
+    a = [t.contiguous() for t in a]
+    b = [t.contiguous() for t in b]
+    g_r, g_i = g_r.contiguous(), g_i.contiguous()
+    n = a[0].size(0)
+    dev = weight.device
+    w = weight.detach().contiguous()
+    da = [torch.empty((n, f_in), dtype=torch.float32, device=dev) for _ in range(k1)]
+    db = [torch.empty((n, f_in), dtype=torch.float32, device=dev) for _ in range(k1)]
+    dw = torch.empty((k1, f_in, f_out), dtype=torch.float32, device=dev)
+    dbias = torch.empty(f_out, dtype=torch.float32, device=dev)
+    lib = _cabi.lib()
+    with torch.cuda.device(dev):
+        need = ctypes.c_size_t(0)
+        check(lib.pygsd_magnetic_dense_bwd_workspace(n, f_in, f_out, k1, ctypes.byref(need)),
+              "pygsd_magnetic_dense_bwd_workspace")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        check(lib.pygsd_magnetic_dense_bwd_f32(_ptr_array(a), _ptr_array(b), k1, ptr(w), ptr(g_r), ptr(g_i),
+                                               _ptr_array(da), _ptr_array(db), ptr(dw), ptr(dbias), n, f_in,
+                                               f_out, ptr(ws), need.value, stream_ptr()),
+              "pygsd_magnetic_dense_bwd_f32")
+    return da, db, dw, dbias
+
+
+class MagneticConvFunction(torch.autograd.Function):
+    """One autograd node for a whole MagNetConv / MSConv layer with fixed operator values:
+    K fused dual-value SpMMs (Chebyshev recurrence in the kernel epilogue) + one fused MFMA dense
+    pass forward; one fused MFMA dense pass + K SpMMs over the by-source CSR backward (the adjoint
+    recurrence gT_{k-1} += 2 S^T gT_k, gT_{k-2} -= gT_k and the final gX = gT_0 + S^T gT_1 ride on
+    the SpMM's beta*Z epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x_real, x_imag, weight, bias, pattern: Pattern, values_real, values_imag):
+        k1 = weight.size(0)
+        fwd = pattern.fwd
+        vr, vi = pattern.values_for(values_real, "fwd"), pattern.values_for(values_imag, "fwd")
+        ta, tb = [x_real.contiguous()], [x_imag.contiguous()]
+        for k in range(1, k1):
+            if k == 1:
+                ya, yb = _spmm2_raw(fwd, vr, vi, ta[0], tb[0], None, None, 1.0, 0.0)
+            else:
+                ya, yb = _spmm2_raw(fwd, vr, vi, ta[k - 1], tb[k - 1], ta[k - 2], tb[k - 2], 2.0, -1.0)
+            ta.append(ya)
+            tb.append(yb)
+        out_r, out_i = dense_fwd_raw(ta, tb, weight, bias)
+        ctx.pattern, ctx.k1, ctx.has_bias = pattern, k1, bias is not None
+        ctx.values = (values_real, values_imag)
+        ctx.save_for_backward(weight, *ta, *tb)
+        return out_r, out_i
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_r, g_i):
+        saved = ctx.saved_tensors
+        weight, k1 = saved[0], ctx.k1
+        ta, tb = list(saved[1:1 + k1]), list(saved[1 + k1:1 + 2 * k1])
+        da, db, dw, dbias = dense_bwd_raw(ta, tb, weight, g_r, g_i)
+        gx_r = gx_i = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            pat = ctx.pattern
+            bwd = pat.bwd
+            vr, vi = pat.values_for(ctx.values[0], "bwd"), pat.values_for(ctx.values[1], "bwd")
+            for k in range(k1 - 1, 1, -1):
+                da[k - 1], db[k - 1] = _spmm2_raw(bwd, vr, vi, da[k], db[k], da[k - 1], db[k - 1], 2.0, 1.0)
+                da[k - 2].sub_(da[k])
+                db[k - 2].sub_(db[k])
+            if k1 > 1:
+                gx_r, gx_i = _spmm2_raw(bwd, vr, vi, da[1], db[1], da[0], db[0], 1.0, 1.0)
+            else:
+                gx_r, gx_i = da[0], db[0]
+        return gx_r, gx_i, dw, (dbias if ctx.has_bias else None), None, None, None

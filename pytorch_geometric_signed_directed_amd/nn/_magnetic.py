@@ -20,6 +20,7 @@ from torch.nn import Parameter
 
 from .. import _cabi
 from ..message_passing import MessagePassing
+from ..dense import MagneticConvFunction, dense_supported
 from ..sparse import Pattern, spmm2
 from ..utils._laplacian import laplacian_parts, laplacian_values
 
@@ -188,6 +189,14 @@ class MagneticChebConv(MessagePassing):
 
         op = self._operator
         w_r, w_i = op.values_real, op.values_imag
+        fused = (not (w_r.requires_grad or w_i.requires_grad) and x_real.dim() == 2
+                 and x_real.dtype == torch.float32
+                 and dense_supported(self.in_channels, self.out_channels, self.weight.size(0)))
+        if fused:
+            # whole layer as one autograd node: K dual SpMMs + one MFMA dense pass each way
+            return MagneticConvFunction.apply(x_real, x_imag, self.weight, self.bias, op.pattern, w_r, w_i)
+        # general path (trainable q -> edge-value gradients through SDDMM; shapes the MFMA kernels
+        # do not tile): same HIP SpMMs, dense stage composed from library GEMMs
         # A-chain on (S_r, X_r), B-chain on (S_i, X_i); one fused traversal per Chebyshev order
         t0_r, t0_i = x_real, x_imag
         acc_a = torch.matmul(t0_r, self.weight[0])

@@ -155,12 +155,15 @@ def _spmm_raw(csr: CSR, val: Optional[Tensor], x: Tensor, z: Optional[Tensor], a
     if x.size(0) != csr.n_cols:
         raise ValueError(f"x has {x.size(0)} rows, operator expects {csr.n_cols}")
     f = x.size(1)
+    if z is not None and tuple(z.shape) != (csr.n_rows, f):
+        raise ValueError(f"z has shape {tuple(z.shape)}, expected {(csr.n_rows, f)}")
+    if csr.nnz == 0 or f == 0 or csr.n_rows == 0:  # edgeless operator: nothing to gather
+        y = torch.zeros((csr.n_rows, f), dtype=torch.float32, device=x.device)
+        return y if z is None else y.add_(z, alpha=beta)
     y = torch.empty((csr.n_rows, f), dtype=torch.float32, device=x.device)
     zp, ldz = None, 0
     if z is not None:
         z, ldz = _rows(z)
-        if tuple(z.shape) != (csr.n_rows, f):
-            raise ValueError(f"z has shape {tuple(z.shape)}, expected {(csr.n_rows, f)}")
         zp = ptr(z)
     with torch.cuda.device(x.device):
         check(_cabi.lib().pygsd_spmm_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(val), ptr(x), ldx, ptr(y),
@@ -182,6 +185,10 @@ def _spmm2_raw(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, z
     if xa.size(0) != csr.n_cols:
         raise ValueError(f"x has {xa.size(0)} rows, operator expects {csr.n_cols}")
     f = xa.size(1)
+    if csr.nnz == 0 or f == 0 or csr.n_rows == 0:
+        ya = torch.zeros((csr.n_rows, f), dtype=torch.float32, device=xa.device)
+        yb = torch.zeros_like(ya)
+        return (ya, yb) if za is None else (ya.add_(za, alpha=beta), yb.add_(zb, alpha=beta))
     ya = torch.empty((csr.n_rows, f), dtype=torch.float32, device=xa.device)
     yb = torch.empty_like(ya)
     zap = zbp = None

@@ -282,3 +282,49 @@ def test_fullsize_linearity_and_adjoint():
     ones = torch.ones(n, 4, device=d)
     rowsum = torch.zeros(n, device=d, dtype=torch.float64).index_add_(0, ei[1], w.double())
     close(spmm(pat, ones, w)[:, 0], rowsum.float(), 2e-5)
+
+
+# ------------------------------------------------------------------ fused MFMA dense stage
+@pytest.mark.parametrize("f_in,f_out,k1", [(16, 16, 1), (32, 48, 2), (48, 32, 3), (64, 64, 2), (64, 64, 4),
+                                            (64, 128, 2), (128, 64, 2), (128, 128, 2), (16, 64, 2)])
+@pytest.mark.parametrize("n", [1, 37, 1000])
+def test_dense_stage_matches_reference_formula(f_in, f_out, k1, n):
+    """out_real = sum_k (A_k - B_k) W_k + b, out_imag = sum_k (A_k + B_k) W_k + b and its gradients,
+    evaluated the reference's way (four matmul chains, then -, +, += bias; MagNetConv.py:189-247) in
+    float64 on the CPU.  Asymmetric random W catches row/column swaps of the MFMA fragments."""
+    from pytorch_geometric_signed_directed_amd.dense import dense_bwd_raw, dense_fwd_raw, dense_supported
+    assert dense_supported(f_in, f_out, k1)
+    g = torch.Generator().manual_seed(1000 * f_in + 10 * f_out + k1 + n)
+    a = [torch.randn(n, f_in, generator=g) for _ in range(k1)]
+    b = [torch.randn(n, f_in, generator=g) for _ in range(k1)]
+    w = torch.randn(k1, f_in, f_out, generator=g) * 0.3
+    bias = torch.randn(f_out, generator=g)
+    gr, gi = torch.randn(n, f_out, generator=g), torch.randn(n, f_out, generator=g)
+    # reference formula in float64
+    ad = [t.double().requires_grad_() for t in a]
+    bd = [t.double().requires_grad_() for t in b]
+    wd, bbd = w.double().requires_grad_(), bias.double().requires_grad_()
+    rr = sum(ad[k] @ wd[k] for k in range(k1))
+    ii = sum(bd[k] @ wd[k] for k in range(k1))
+    want_r, want_i = rr - ii + bbd, rr + ii + bbd
+    ((want_r * gr.double()).sum() + (want_i * gi.double()).sum()).backward()
+    d = dev()
+    o_r, o_i = dense_fwd_raw([t.to(d) for t in a], [t.to(d) for t in b], w.to(d), bias.to(d))
+    close(o_r, want_r)
+    close(o_i, want_i)
+    da, db, dw, dbias = dense_bwd_raw([t.to(d) for t in a], [t.to(d) for t in b], w.to(d), gr.to(d), gi.to(d))
+    for k in range(k1):
+        close(da[k], ad[k].grad)
+        close(db[k], bd[k].grad)
+    close(dw, wd.grad, 2e-5)
+    close(dbias, bbd.grad, 2e-5)
+    # no-bias forward
+    o_r, o_i = dense_fwd_raw([t.to(d) for t in a], [t.to(d) for t in b], w.to(d), None)
+    close(o_r, want_r - bbd)
+
+
+def test_dense_supported_predicate():
+    from pytorch_geometric_signed_directed_amd.dense import dense_supported
+    assert dense_supported(64, 64, 2) and dense_supported(128, 128, 3) and dense_supported(16, 16, 1)
+    for bad in [(6, 5, 2), (64, 96, 2), (64, 64, 5), (80, 64, 2), (2879, 16, 2)]:
+        assert not dense_supported(*bad)
