@@ -144,7 +144,6 @@ def main():
             xr_loc.grad = xi_loc.grad = None
             o_r, o_i = layer(xr_loc, xi_loc)
             (o_r.sum() + o_i.sum()).backward()
-            layer.allreduce_grads()
 
         def op_nnz():
             return layer.global_nnz
