@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--edges", type=int, default=20000000)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the node-sharded layer even with one rank (exercises the RCCL path on 1 GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,8 +109,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
@@ -119,7 +126,7 @@ def main():
     edge_index, x_real, x_imag, p = build_inputs(n, args.edges, hidden, device)
     e = edge_index.size(1)
     torch.manual_seed(0)
-    if world == 1:
+    if not sharded:
         layer = MagNetConv(hidden, hidden, K=1, q=0.25, trainable_q=False, cached=True).to(device)
         x_real.requires_grad_()
         x_imag.requires_grad_()
