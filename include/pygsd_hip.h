@@ -110,6 +110,59 @@ int pygsd_sort_keys_u64(const uint64_t* keys_in, uint64_t* keys_out, int32_t* pe
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (Signed) magnetic Laplacian build on the device -- utils/directed/get_magnetic_Laplacian.py:47-85,
+ * utils/general/get_magnetic_signed_Laplacian.py:47-90 (called from MagNetConv.__norm__ :100-103 /
+ * MSConv.__norm__ :99-102 on EVERY forward unless cached=True).
+ *   pygsd_maglap_sort  : drop self loops, symmetrise (cat [row,col],[col,row]), stable sort by
+ *                        (row, col), mark duplicate runs; writes the number E_s of distinct entries to
+ *                        the DEVICE int64 *d_num_unique (the caller reads it back to size the outputs --
+ *                        the same host round-trip coalesce's boolean mask costs the reference).
+ *   pygsd_maglap_merge : coalesce(add): per distinct (row, col) in sorted order A_s = sum(w)/2,
+ *                        Theta_arg = sum(+-w), (|w| sums); deg = row sums of A_s (unsigned), of the |w|
+ *                        sums (signed, absolute_degree) or of |A_s| (signed, not absolute_degree).
+ *                        w == NULL means all ones.  Outputs: out_row/out_col int64[E_s], a_sym, theta
+ *                        float[E_s], deg float[n].
+ *   pygsd_maglap_values: off-diagonal values of L: sym != 0: -(D^-1/2 A_s D^-1/2 (.) exp(i 2 pi q Theta_arg))
+ *                        (diagonal is 1); sym == 0: -(A_s (.) exp(...)) (diagonal is deg).
+ * The same workspace (pygsd_maglap_workspace bytes) must be passed, untouched, to sort and merge.
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_maglap_workspace(int64_t n_edges, size_t* bytes);
+int pygsd_maglap_sort(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n,
+                      void* workspace, size_t workspace_bytes, int64_t* d_num_unique, void* stream);
+int pygsd_maglap_merge(const float* w, int64_t n_edges, int32_t n, int32_t is_signed, int32_t absolute_degree,
+                       int64_t num_unique, void* workspace, size_t workspace_bytes,
+                       int64_t* out_row, int64_t* out_col, float* a_sym, float* theta, float* deg,
+                       void* stream);
+int pygsd_maglap_values(const int64_t* out_row, const int64_t* out_col, const float* a_sym,
+                        const float* theta, const float* deg, int64_t num_unique, float q, int32_t sym,
+                        float* off_real, float* off_imag, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * add_remaining_self_loops + degree normalisation: torch_geometric's gcn_norm as called at
+ * nn/directed/DGCNConv.py:75 and conv_norm_rw of nn/general/conv_base.py:12-31.
+ *   pygsd_self_loops_scan : flag non-loop edges, exclusive scan, remember the LAST listed loop of each
+ *                           node (last_loop int32[n], -1 = none); *d_num_kept (device) = #non-loops.
+ *   pygsd_self_loops_emit : out = non-loop edges in order, then n loops (v, v) whose weight is the
+ *                           node's listed loop weight if it had one, else fill_value.  out_w == NULL
+ *                           skips the weights; w == NULL means all ones.
+ *   pygsd_csr_row_sum_f32 : deg[r] = sum of w[perm[slot]] over CSR row r (sequential, COO order).
+ *   pygsd_degree_scale_f32: mode 0: deg^-1/2[row] * w * deg^-1/2[col]; mode 1: deg^-1[row] * w
+ *                           (inf -> 0 as masked_fill_ does).
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_self_loops_workspace(int64_t n_edges, size_t* bytes);
+int pygsd_self_loops_scan(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n,
+                          void* workspace, size_t workspace_bytes, int32_t* last_loop,
+                          int64_t* d_num_kept, void* stream);
+int pygsd_self_loops_emit(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
+                          float fill_value, int64_t num_kept, void* workspace, size_t workspace_bytes,
+                          const int32_t* last_loop, int64_t* out_row, int64_t* out_col, float* out_w,
+                          void* stream);
+int pygsd_csr_row_sum_f32(const int32_t* rowptr, const int32_t* perm, const float* w, int32_t n_rows,
+                          float* out, void* stream);
+int pygsd_degree_scale_f32(const int64_t* row, const int64_t* col, const float* w, const float* deg,
+                           int64_t n_edges, int32_t mode, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Element-wise epilogues of the path.
  * complex ReLU: mask = (real >= 0); out_real = mask*real; out_imag = mask*imag
  *   (nn/directed/complex_relu.py:21-22).  In-place allowed (out == in). */

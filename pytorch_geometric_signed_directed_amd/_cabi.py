@@ -37,6 +37,20 @@ PROTOTYPES = {
     "pygsd_sort_keys_u64_workspace": (c_int32, [c_int64, ctypes.POINTER(c_size_t)]),
     "pygsd_sort_keys_u64": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_size_t,
                                       c_void_p]),
+    "pygsd_maglap_workspace": (c_int32, [c_int64, ctypes.POINTER(c_size_t)]),
+    "pygsd_maglap_sort": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "pygsd_maglap_merge": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int64, c_void_p, c_size_t,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pygsd_maglap_values": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
+                                      c_int32, c_void_p, c_void_p, c_void_p]),
+    "pygsd_self_loops_workspace": (c_int32, [c_int64, ctypes.POINTER(c_size_t)]),
+    "pygsd_self_loops_scan": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_size_t, c_void_p,
+                                        c_void_p, c_void_p]),
+    "pygsd_self_loops_emit": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_int64,
+                                        c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pygsd_csr_row_sum_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "pygsd_degree_scale_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
+                                         c_void_p]),
     "pygsd_complex_relu_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pygsd_complex_relu_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                              c_void_p]),

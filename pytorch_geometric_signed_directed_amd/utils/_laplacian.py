@@ -1,21 +1,22 @@
-"""Device-side build of the (signed) magnetic Laplacian operator -- SURVEY.md 8(a) rows a3/a4.
+"""Device-side build of the (signed) magnetic Laplacian operator -- SURVEY.md 8(a) rows a3/a4 --
+through the HIP pipeline of csrc/laplacian.hip (include/pygsd_hip.h: pygsd_maglap_*).
 
 Follows utils/directed/get_magnetic_Laplacian.py:10-93 and
 utils/general/get_magnetic_signed_Laplacian.py:10-98 of the reference: drop self loops ->
-symmetrise -> coalesce(add) of [w, +-w(, |w|)] -> A_s = sum/2, Theta = 2 pi q (w_uv - w_vu) ->
-degree -> D^-1/2 A_s D^-1/2 (.) exp(i Theta) -> L = I - H (sym) or D - A_s (.) exp(i Theta) (None).
+symmetrise -> coalesce(add) of [w, +-w(, |w|)] -> A_s = sum/2, Theta_arg = w_uv - w_vu -> degree ->
+D^-1/2 A_s D^-1/2 (.) exp(i 2 pi q Theta_arg) -> L = I - H (sym) or D - A_s (.) exp(...) (None).
 
-All arrays stay on the GPU.  Two host round-trips are inherent (the number of surviving
-non-loop entries and the number of distinct symmetrised entries size the outputs), exactly as in
-the reference's boolean-mask / coalesce calls.
+One host round-trip is inherent: the number of distinct symmetrised entries sizes the outputs
+(the reference pays the same for coalesce's boolean mask).
 """
+import ctypes
 import math
 from typing import Optional, Tuple
 
 import torch
 
 from .. import _cabi
-from ..sparse_build import coalesce_sum
+from .._cabi import check, ptr, stream_ptr
 
 Tensor = torch.Tensor
 
@@ -29,42 +30,61 @@ class LaplacianParts:
 
 
 def laplacian_parts(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, signed: bool,
-                    absolute_degree: bool, dtype) -> LaplacianParts:
+                    absolute_degree: bool, dtype=None) -> LaplacianParts:
     _cabi.require_gpu(edge_index, edge_weight)
-    row, col = edge_index[0], edge_index[1]
-    keep = row != col
-    row, col = row[keep], col[keep]
-    if edge_weight is None:
-        w = torch.ones(row.numel(), dtype=dtype or torch.float32, device=edge_index.device)
-    else:
-        w = edge_weight[keep]
-    both = torch.stack([torch.cat([row, col]), torch.cat([col, row])])
-    cols = [torch.cat([w, w]), torch.cat([w, -w])]
-    if signed:
-        cols.append(torch.cat([w.abs(), w.abs()]))
-    index, sums = coalesce_sum(both, torch.stack(cols, dim=1), n)
-    a_sym = sums[:, 0] / 2
-    if not signed:
-        deg_src = a_sym
-    elif absolute_degree:
-        deg_src = sums[:, 2] / 2
-    else:
-        deg_src = a_sym.abs()
-    deg = torch.zeros(n, dtype=a_sym.dtype, device=a_sym.device).index_add_(0, index[0], deg_src)
-    return LaplacianParts(index, a_sym, sums[:, 1], deg, n)
+    if edge_index.dtype != torch.int64:
+        raise TypeError("edge_index must be int64 (torch.long)")
+    dev = edge_index.device
+    row, col = edge_index[0].contiguous(), edge_index[1].contiguous()
+    e = row.numel()
+    w = None
+    if edge_weight is not None:
+        w = edge_weight.detach().reshape(-1).contiguous()
+        if w.dtype != torch.float32:
+            w = w.float()
+        if w.numel() != e:
+            raise ValueError(f"edge_weight has {w.numel()} entries for {e} edges")
+    lib = _cabi.lib()
+    with torch.cuda.device(dev):
+        need = ctypes.c_size_t(0)
+        check(lib.pygsd_maglap_workspace(e, ctypes.byref(need)), "pygsd_maglap_workspace")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        check(lib.pygsd_maglap_sort(ptr(row), ptr(col), e, n, ptr(ws), need.value, ptr(count), stream_ptr()),
+              "pygsd_maglap_sort")
+        es = int(count.item())                      # the one host round-trip
+        index = torch.empty((2, es), dtype=torch.int64, device=dev)
+        a_sym = torch.empty(es, dtype=torch.float32, device=dev)
+        theta = torch.empty(es, dtype=torch.float32, device=dev)
+        deg = torch.empty(n, dtype=torch.float32, device=dev)
+        check(lib.pygsd_maglap_merge(ptr(w), e, n, 1 if signed else 0, 1 if absolute_degree else 0, es, ptr(ws),
+                                     need.value, ptr(index[0]) if es else None, ptr(index[1]) if es else None,
+                                     ptr(a_sym), ptr(theta), ptr(deg), stream_ptr()), "pygsd_maglap_merge")
+    return LaplacianParts(index, a_sym, theta, deg, n)
 
 
 def laplacian_values(parts: LaplacianParts, q, normalization: Optional[str]) -> Tuple[Tensor, Tensor, Tensor]:
-    """(off_real, off_imag, diag) of L; differentiable in q when q is a tensor that requires grad."""
-    row, col = parts.index[0], parts.index[1]
-    phase_arg = (2 * math.pi * q) * parts.theta
-    cos, sin = torch.cos(phase_arg), torch.sin(phase_arg)
-    if normalization is None:
-        mag = parts.a_sym
-        diag = parts.deg
-    else:
-        dis = parts.deg.pow(-0.5)
-        dis = dis.masked_fill(dis == float("inf"), 0)
-        mag = dis[row] * parts.a_sym * dis[col]
-        diag = torch.ones_like(parts.deg)
-    return -(mag * cos), -(mag * sin), diag
+    """(off_real, off_imag, diag) of L.  A float q runs the HIP kernel; a tensor q that requires grad
+    (trainable_q) is evaluated with differentiable element-wise tensor ops on the same ingredients."""
+    sym = normalization is not None
+    diag = torch.ones_like(parts.deg) if sym else parts.deg
+    if isinstance(q, torch.Tensor) and q.requires_grad:
+        row, col = parts.index[0], parts.index[1]
+        phase_arg = (2 * math.pi * q) * parts.theta
+        if sym:
+            dis = parts.deg.pow(-0.5)
+            dis = dis.masked_fill(dis == float("inf"), 0)
+            mag = dis[row] * parts.a_sym * dis[col]
+        else:
+            mag = parts.a_sym
+        return -(mag * torch.cos(phase_arg)), -(mag * torch.sin(phase_arg)), diag
+    qf = float(q.detach().item()) if isinstance(q, torch.Tensor) else float(q)
+    es = parts.a_sym.numel()
+    off_r = torch.empty_like(parts.a_sym)
+    off_i = torch.empty_like(parts.a_sym)
+    if es:
+        with torch.cuda.device(parts.a_sym.device):
+            check(_cabi.lib().pygsd_maglap_values(ptr(parts.index[0]), ptr(parts.index[1]), ptr(parts.a_sym),
+                                                  ptr(parts.theta), ptr(parts.deg), es, qf, 1 if sym else 0,
+                                                  ptr(off_r), ptr(off_i), stream_ptr()), "pygsd_maglap_values")
+    return off_r, off_i, diag
