@@ -297,6 +297,63 @@ def kat_case():
          op_real=npy(layer.cached_result[2]), op_imag=npy(layer.cached_result[3]))
 
 
+# ------------------------------------------------------------------ model-level callers (eval mode)
+def model_case(name, model, args, seed):
+    """Reference model in eval mode (dropout off) on fixed inputs: record state_dict + outputs."""
+    model.eval()
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for prm in model.parameters():               # de-trivialise zero biases / unit weights
+            if prm.dim() == 1 and prm.numel() > 1:
+                prm.add_(torch.rand(prm.shape, generator=g) - 0.5)
+        out = model(*args)
+    outs = out if isinstance(out, tuple) else (out,)
+    arrs = {"sd." + k: npy(v) for k, v in model.state_dict().items()}
+    arrs.update({f"out{i}": npy(o) for i, o in enumerate(outs)})
+    return arrs
+
+
+def models():
+    from torch_geometric_signed_directed.nn import (DIGRAC_node_clustering, DiGCN_Inception_Block_node_classification,
+                                                    DiGCN_node_classification, MagNet_link_prediction,
+                                                    MagNet_node_classification, MSGNN_link_prediction,
+                                                    MSGNN_node_classification, SSSNET_node_clustering)
+    n = 40
+    ei, w = toy_graph(51)
+    eis, ws = toy_graph(52, signed=True)
+    g = torch.Generator().manual_seed(50)
+    x = torch.randn(n, 6, generator=g)
+    xi = torch.randn(n, 6, generator=g)
+    query = torch.randint(0, n - 3, (25, 2), generator=g)
+    torch.manual_seed(60)
+    save("model_magnet_node", edge_index=ei, edge_weight=w, x_real=npy(x), x_imag=npy(xi),
+         **model_case("m", MagNet_node_classification(6, hidden=8, q=0.2, K=2, label_dim=4, activation=True,
+                                                      layer=2, dropout=0.5), (x, xi, t(ei), t(w)), 61))
+    save("model_magnet_link", edge_index=ei, edge_weight=w, x_real=npy(x), x_imag=npy(xi), query=npy(query),
+         **model_case("m", MagNet_link_prediction(6, hidden=8, q=0.25, K=1, label_dim=2, layer=2),
+                      (x, xi, t(ei), query, t(w)), 62))
+    save("model_msgnn_node", edge_index=eis, edge_weight=ws, x_real=npy(x), x_imag=npy(xi),
+         **model_case("m", MSGNN_node_classification(6, hidden=8, q=0.1, K=2, label_dim=3, activation=True,
+                                                     layer=2, dropout=0.3), (x, xi, t(eis), t(ws)), 63))
+    save("model_msgnn_link", edge_index=eis, edge_weight=ws, x_real=npy(x), x_imag=npy(xi), query=npy(query),
+         **model_case("m", MSGNN_link_prediction(6, hidden=8, q=0.1, K=2, label_dim=2, layer=2),
+                      (x, xi, t(eis), query, t(ws)), 64))
+    ei2, w2 = toy_graph(53, e=120)
+    save("model_digcn_node", edge_index=ei, edge_weight=w, x=npy(x),
+         **model_case("m", DiGCN_node_classification(6, 8, 4, 0.5), (x, t(ei), t(w)), 65))
+    save("model_digcn_ib", edge_index=ei, edge_weight=w, edge_index2=ei2, edge_weight2=w2, x=npy(x),
+         **model_case("m", DiGCN_Inception_Block_node_classification(6, 8, 4, 0.5),
+                      (x, (t(ei), t(ei2)), (t(w), t(w2))), 66))
+    save("model_digrac", edge_index=ei, edge_weight=w, x=npy(x),
+         **model_case("m", DIGRAC_node_clustering(6, 8, 3, 0.5, 0.5, 2), (t(ei), t(w), x), 67))
+    ein, wn = toy_graph(54, e=90)
+    for directed in (False, True):
+        save("model_sssnet_" + ("directed" if directed else "undirected"), edge_index_p=ei, edge_weight_p=w,
+             edge_index_n=ein, edge_weight_n=wn, x=npy(x), directed=np.bool_(directed),
+             **model_case("m", SSSNET_node_clustering(6, 8, 3, 0.5, 2, 0.5, directed),
+                          (t(ei), t(w), t(ein), t(wn), x), 68))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -328,6 +385,8 @@ def main():
     sgcn_case("sgcn_first_normemb", 33, True, True)
     relu_case("complex_relu", 41)
     kat_case()
+    print("model-level callers")
+    models()
 
 
 if __name__ == "__main__":

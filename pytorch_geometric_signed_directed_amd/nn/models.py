@@ -1,0 +1,309 @@
+"""Thin restatements of the reference's model classes that are CALLERS of the hot path
+(SURVEY.md 2 #11): stacks of the drop-in conv layers plus dense torch ops.  Same constructor
+signatures, parameter names and forward returns as the reference, so its checkpoints load and its
+example scripts run unchanged; all message passing goes through the HIP layers.
+
+Reference files: nn/directed/MagNet_node_classification.py, MagNet_link_prediction.py,
+DiGCN_node_classification.py, DiGCN_Inception_Block.py, DiGCN_Inception_Block_node_classification.py,
+DIGRAC_node_clustering.py, nn/general/MSGNN.py, nn/signed/SSSNET_node_clustering.py.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import Parameter
+
+from .directed.complex_relu import complex_relu_layer
+from .directed.DiGCNConv import DiGCNConv
+from .directed.DIMPA import DIMPA
+from .directed.MagNetConv import MagNetConv
+from .general.MSConv import MSConv
+from .signed.SIMPA import SIMPA
+
+
+class _MagneticStack(nn.Module):
+    """Chebs (ModuleList of magnetic convs) [+ complex ReLU] shared by the MagNet / MSGNN heads."""
+
+    def _build_stack(self, first, rest, layer, activation, normalization, dropout):
+        self.normalization = normalization
+        self.activation = activation
+        if activation:
+            self.complex_relu = complex_relu_layer()
+        self.Chebs = nn.ModuleList([first] + [rest() for _ in range(1, layer)])
+        self.dropout = dropout
+
+    def _encode(self, real, imag, edge_index, edge_weight):
+        for cheb in self.Chebs:
+            real, imag = cheb(real, imag, edge_index, edge_weight)
+            if self.activation:
+                real, imag = self.complex_relu(real, imag)
+        return real, imag
+
+    def _node_head(self, real, imag):
+        """cat -> dropout -> 1x1 Conv1d over the feature axis -> (z, log-probs [N, C])."""
+        x = torch.cat((real, imag), dim=-1)
+        if self.dropout > 0:
+            x = F.dropout(x, self.dropout, training=self.training)
+        logits = self.Conv(x.t().unsqueeze(0))
+        return x, F.log_softmax(logits, dim=1)[0].t()
+
+    def _link_head(self, real, imag, query_edges):
+        a, b = query_edges[:, 0], query_edges[:, 1]
+        x = torch.cat((real[a], real[b], imag[a], imag[b]), dim=-1)
+        if self.dropout > 0:
+            x = F.dropout(x, self.dropout, training=self.training)
+        return x, F.log_softmax(self.linear(x), dim=1)
+
+
+class MagNet_node_classification(_MagneticStack):
+    """nn/directed/MagNet_node_classification.py:12-92."""
+
+    def __init__(self, num_features: int, hidden: int = 2, q: float = 0.25, K: int = 1, label_dim: int = 2,
+                 activation: bool = False, trainable_q: bool = False, layer: int = 2, dropout: float = False,
+                 normalization: str = 'sym', cached: bool = False):
+        super().__init__()
+        kw = dict(K=K, q=q, trainable_q=trainable_q, normalization=normalization, cached=cached)
+        self._build_stack(MagNetConv(in_channels=num_features, out_channels=hidden, **kw),
+                          lambda: MagNetConv(in_channels=hidden, out_channels=hidden, **kw),
+                          layer, activation, normalization, dropout)
+        self.Conv = nn.Conv1d(2 * hidden, label_dim, kernel_size=1)
+
+    def reset_parameters(self):
+        for cheb in self.Chebs:
+            cheb.reset_parameters()
+        self.Conv.reset_parameters()
+
+    def forward(self, real, imag, edge_index, edge_weight: Optional[torch.Tensor] = None):
+        real, imag = self._encode(real, imag, edge_index, edge_weight)
+        return self._node_head(real, imag)[1]
+
+
+class MagNet_link_prediction(_MagneticStack):
+    """nn/directed/MagNet_link_prediction.py:12-89."""
+
+    def __init__(self, num_features: int, hidden: int = 2, q: float = 0.25, K: int = 1, label_dim: int = 2,
+                 activation: bool = True, trainable_q: bool = False, layer: int = 2, dropout: float = 0.5,
+                 normalization: str = 'sym', cached: bool = False):
+        super().__init__()
+        kw = dict(K=K, q=q, trainable_q=trainable_q, normalization=normalization, cached=cached)
+        self._build_stack(MagNetConv(in_channels=num_features, out_channels=hidden, **kw),
+                          lambda: MagNetConv(in_channels=hidden, out_channels=hidden, **kw),
+                          layer, activation, normalization, dropout)
+        self.linear = nn.Linear(hidden * 4, label_dim)
+
+    def reset_parameters(self):
+        for cheb in self.Chebs:
+            cheb.reset_parameters()
+        self.linear.reset_parameters()
+
+    def forward(self, real, imag, edge_index, query_edges, edge_weight: Optional[torch.Tensor] = None):
+        real, imag = self._encode(real, imag, edge_index, edge_weight)
+        return self._link_head(real, imag, query_edges)[1]
+
+
+def _msgnn_convs(num_features, hidden, K, q, trainable_q, normalization, cached, conv_bias, absolute_degree):
+    # the reference builds the FIRST MSConv without `cached` / `absolute_degree`
+    # (general/MSGNN.py:45-46, :130-131)
+    first = MSConv(in_channels=num_features, out_channels=hidden, K=K, q=q, trainable_q=trainable_q,
+                   normalization=normalization, bias=conv_bias)
+    rest = lambda: MSConv(in_channels=hidden, out_channels=hidden, K=K, q=q, trainable_q=trainable_q,  # noqa: E731
+                          normalization=normalization, bias=conv_bias, cached=cached,
+                          absolute_degree=absolute_degree)
+    return first, rest
+
+
+class MSGNN_link_prediction(_MagneticStack):
+    """nn/general/MSGNN.py:11-91."""
+
+    def __init__(self, num_features: int, hidden: int = 2, q: float = 0.25, K: int = 2, label_dim: int = 2,
+                 activation: bool = True, trainable_q: bool = False, layer: int = 2, dropout: float = 0.5,
+                 normalization: str = 'sym', cached: bool = False, conv_bias: bool = True,
+                 absolute_degree: bool = True):
+        super().__init__()
+        first, rest = _msgnn_convs(num_features, hidden, K, q, trainable_q, normalization, cached, conv_bias,
+                                   absolute_degree)
+        self._build_stack(first, rest, layer, activation, normalization, dropout)
+        self.linear = nn.Linear(hidden * 4, label_dim)
+
+    def reset_parameters(self):
+        for cheb in self.Chebs:
+            cheb.reset_parameters()
+        self.linear.reset_parameters()
+
+    def forward(self, real, imag, edge_index, query_edges, edge_weight: Optional[torch.Tensor] = None):
+        real, imag = self._encode(real, imag, edge_index, edge_weight)
+        x, out = self._link_head(real, imag, query_edges)
+        self.z = x.clone()
+        return out
+
+
+class MSGNN_node_classification(_MagneticStack):
+    """nn/general/MSGNN.py:94-188: returns (normalised z, log-probs, argmax, probs)."""
+
+    def __init__(self, num_features: int, hidden: int = 2, q: float = 0.25, K: int = 2, label_dim: int = 2,
+                 activation: bool = False, trainable_q: bool = False, layer: int = 2, dropout: float = False,
+                 normalization: str = 'sym', cached: bool = False, conv_bias: bool = True,
+                 absolute_degree: bool = True):
+        super().__init__()
+        first, rest = _msgnn_convs(num_features, hidden, K, q, trainable_q, normalization, cached, conv_bias,
+                                   absolute_degree)
+        self._build_stack(first, rest, layer, activation, normalization, dropout)
+        self.Conv = nn.Conv1d(2 * hidden, label_dim, kernel_size=1)
+
+    def reset_parameters(self):
+        for cheb in self.Chebs:
+            cheb.reset_parameters()
+        self.Conv.reset_parameters()
+
+    def forward(self, real, imag, edge_index, edge_weight: Optional[torch.Tensor] = None):
+        real, imag = self._encode(real, imag, edge_index, edge_weight)
+        z, output = self._node_head(real, imag)
+        return F.normalize(z.clone()), output, torch.argmax(output, dim=1), F.softmax(output, dim=1)
+
+
+class DiGCN_node_classification(nn.Module):
+    """nn/directed/DiGCN_node_classification.py:9-46."""
+
+    def __init__(self, num_features: int, hidden: int, label_dim: int, dropout: float = 0.5):
+        super().__init__()
+        self.conv1 = DiGCNConv(num_features, hidden)
+        self.conv2 = DiGCNConv(hidden, label_dim)
+        self.dropout = dropout
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.conv1.reset_parameters()
+        self.conv2.reset_parameters()
+
+    def forward(self, x, edge_index, edge_weight=None):
+        x = F.relu(self.conv1(x, edge_index, edge_weight))
+        x = F.dropout(x, p=self.dropout, training=self.training)
+        return F.log_softmax(self.conv2(x, edge_index, edge_weight), dim=1)
+
+
+class DiGCN_InceptionBlock(nn.Module):
+    """nn/directed/DiGCN_Inception_Block.py:9-47: x0 = Linear(x), x1 / x2 = DiGCNConv on the first- /
+    second-order proximity operators."""
+
+    def __init__(self, in_dim: int, out_dim: int):
+        super().__init__()
+        self.ln = nn.Linear(in_dim, out_dim)
+        self.conv1 = DiGCNConv(in_dim, out_dim)
+        self.conv2 = DiGCNConv(in_dim, out_dim)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.ln.reset_parameters()
+        self.conv1.reset_parameters()
+        self.conv2.reset_parameters()
+
+    def forward(self, x, edge_index, edge_weight, edge_index2, edge_weight2):
+        return self.ln(x), self.conv1(x, edge_index, edge_weight), self.conv2(x, edge_index2, edge_weight2)
+
+
+class DiGCN_Inception_Block_node_classification(nn.Module):
+    """nn/directed/DiGCN_Inception_Block_node_classification.py:9-73: three inception blocks, the three
+    branches summed with dropouts."""
+
+    def __init__(self, num_features: int, hidden: int, label_dim: int, dropout: float = 0.5):
+        super().__init__()
+        self.ib1 = DiGCN_InceptionBlock(num_features, hidden)
+        self.ib2 = DiGCN_InceptionBlock(hidden, hidden)
+        self.ib3 = DiGCN_InceptionBlock(hidden, label_dim)
+        self._dropout = dropout
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for ib in (self.ib1, self.ib2, self.ib3):
+            ib.reset_parameters()
+
+    def forward(self, features, edge_index_tuple, edge_weight_tuple):
+        (ei1, ei2), (ew1, ew2) = edge_index_tuple, edge_weight_tuple
+        drop = lambda t: F.dropout(t, p=self._dropout, training=self.training)  # noqa: E731
+        x = features
+        for depth, ib in enumerate((self.ib1, self.ib2, self.ib3)):
+            x0, x1, x2 = ib(x, ei1, ew1, ei2, ew2)
+            x = drop(x0) + drop(x1) + drop(x2)
+            if depth < 2:
+                x = drop(x)
+        return F.log_softmax(x, dim=1)
+
+
+def _cluster_head(z, w_prob, bias):
+    output = torch.mm(z, w_prob)
+    if bias is not None:
+        output = output + bias
+    return F.normalize(z), F.log_softmax(output, dim=1), torch.argmax(output, dim=1), F.softmax(output, dim=1)
+
+
+class DIGRAC_node_clustering(nn.Module):
+    """nn/directed/DIGRAC_node_clustering.py:11-89."""
+
+    def __init__(self, num_features: int, hidden: int, nclass: int, fill_value: float, dropout: float, hop: int):
+        super().__init__()
+        self._num_clusters = int(nclass)
+        self._w_s0 = Parameter(torch.FloatTensor(num_features, hidden))
+        self._w_s1 = Parameter(torch.FloatTensor(hidden, hidden))
+        self._w_t0 = Parameter(torch.FloatTensor(num_features, hidden))
+        self._w_t1 = Parameter(torch.FloatTensor(hidden, hidden))
+        self._dimpa = DIMPA(hop, fill_value)
+        self._relu = nn.ReLU()
+        self.dropout = nn.Dropout(p=dropout)
+        self._bias = Parameter(torch.FloatTensor(self._num_clusters))
+        self._W_prob = Parameter(torch.FloatTensor(2 * hidden, self._num_clusters))
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for w in (self._w_s0, self._w_s1, self._w_t0, self._w_t1, self._W_prob):
+            nn.init.xavier_uniform_(w, gain=1.414)
+        self._bias.data.fill_(0.0)
+
+    def _mlp(self, x, w0, w1):
+        return torch.mm(self.dropout(self._relu(torch.mm(x, w0))), w1)
+
+    def forward(self, edge_index, edge_weight, features):
+        z = self._dimpa(self._mlp(features, self._w_s0, self._w_s1), self._mlp(features, self._w_t0, self._w_t1),
+                        edge_index, edge_weight)
+        return _cluster_head(z, self._W_prob, self._bias)
+
+
+class SSSNET_node_clustering(nn.Module):
+    """nn/signed/SSSNET_node_clustering.py:11-160."""
+
+    def __init__(self, nfeat: int, hidden: int, nclass: int, dropout: float, hop: int, fill_value: float,
+                 directed: bool = False, bias: bool = True):
+        super().__init__()
+        self._num_clusters = int(nclass)
+        self._simpa = SIMPA(hop, fill_value, directed)
+        if bias:
+            self._bias = Parameter(torch.FloatTensor(self._num_clusters))
+        else:
+            self.register_parameter('_bias', None)
+        self._relu = nn.ReLU()
+        self._dropout = nn.Dropout(p=dropout)
+        self._undirected = not directed
+        self._streams = ("p", "n") if self._undirected else ("sp", "sn", "tp", "tn")
+        for s in self._streams:
+            setattr(self, f"_w_{s}0", Parameter(torch.FloatTensor(nfeat, hidden)))
+            setattr(self, f"_w_{s}1", Parameter(torch.FloatTensor(hidden, hidden)))
+        self._W_prob = Parameter(torch.FloatTensor(len(self._streams) * hidden, self._num_clusters))
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for s in self._streams:
+            nn.init.xavier_uniform_(getattr(self, f"_w_{s}0"), gain=1.414)
+            nn.init.xavier_uniform_(getattr(self, f"_w_{s}1"), gain=1.414)
+        if self._bias is not None:
+            self._bias.data.fill_(0.0)
+        nn.init.xavier_uniform_(self._W_prob, gain=1.414)
+
+    _reset_parameters_undirected = _reset_parameters
+    _reset_parameters_directed = _reset_parameters
+
+    def forward(self, edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, features
+                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        xs = [torch.mm(self._dropout(self._relu(torch.mm(features, getattr(self, f"_w_{s}0")))),
+                       getattr(self, f"_w_{s}1")) for s in self._streams]
+        z = self._simpa(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, *xs)
+        return _cluster_head(z, self._W_prob, self._bias)
