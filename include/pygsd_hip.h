@@ -64,6 +64,18 @@ int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* v
                        float alpha, float beta, int32_t mean,
                        void* stream);
 
+/* bf16-storage variant (BASELINE config "DiGCN_Inception_Block ... bf16"): X, Y, Z are bf16 row-major
+ * (n_feat and the row strides multiples of 8, 16-byte aligned), edge values and accumulation fp32,
+ * the result rounded to nearest-even bf16.  The reference has no reduced-precision path; parity is
+ * defined against the fp32 oracle evaluated on the bf16-rounded inputs. */
+int pygsd_spmm_csr_bf16(const int32_t* rowptr, const int32_t* col, const float* val,
+                        const void* X, int64_t ldx,
+                        void* Y, int64_t ldy,
+                        const void* Z, int64_t ldz,
+                        int32_t n_rows, int32_t n_feat,
+                        float alpha, float beta, int32_t mean,
+                        void* stream);
+
 /* Two operators sharing ONE sparsity pattern, two inputs, two outputs, one traversal:
  *   Ya = alpha * sum val_a[e] * Xa[col[e]] + beta * Za ;  Yb likewise with val_b / Xb / Zb.
  * This is the complex Hermitian (magnetic) Laplacian product of MagNetConv / MSConv: the real

@@ -25,6 +25,9 @@ PROTOTYPES = {
     "pygsd_spmm_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                      c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_int32,
                                      c_void_p]),
+    "pygsd_spmm_csr_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                      c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_int32,
+                                      c_void_p]),
     "pygsd_spmm2_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                       c_int32, c_float, c_float, c_void_p]),

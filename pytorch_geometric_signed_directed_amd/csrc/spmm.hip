@@ -227,6 +227,130 @@ int launch_spmm(const SpmmArgs& a, hipStream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16-storage SpMM (BASELINE config C5: DiGCN inception blocks in bf16): X / Z / Y are bf16 in HBM
+// (half the gather bytes), edge values and accumulation stay fp32.  Same mapping as the fp32
+// kernel with 8 features per lane: LPR = F/8 lanes per gathered row (F = 64 -> 8 lanes x 16 B =
+// 128 B), NPW = 64/LPR neighbours per wave-wide load.
+// ------------------------------------------------------------------------------------------
+struct SpmmBf16Args {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const float* val;
+    const uint16_t* x;
+    uint16_t* y;
+    const uint16_t* z;
+    int64_t ldx, ldy, ldz;
+    int32_t n_rows, n_feat;
+    float alpha, beta;
+    int32_t mean;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;                   // round to nearest even
+}
+__device__ __forceinline__ void unpack8(const uint4& q, float (&v)[8])
+{
+    v[0] = bf16_to_f32(q.x & 0xffffu); v[1] = bf16_to_f32(q.x >> 16);
+    v[2] = bf16_to_f32(q.y & 0xffffu); v[3] = bf16_to_f32(q.y >> 16);
+    v[4] = bf16_to_f32(q.z & 0xffffu); v[5] = bf16_to_f32(q.z >> 16);
+    v[6] = bf16_to_f32(q.w & 0xffffu); v[7] = bf16_to_f32(q.w >> 16);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_bf16_kernel(SpmmBf16Args p)
+{
+    constexpr int NPW = 64 / LPR;
+    constexpr int UNROLL = 4;
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(
+        static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+    if (row >= p.n_rows) return;
+    const int sub = lane / LPR;
+    const int fl = static_cast<int>(blockIdx.y) * (LPR * 8) + (lane % LPR) * 8;
+    const bool fact = fl < p.n_feat;
+    const int beg = p.rowptr[row];
+    const int end = p.rowptr[row + 1];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint16_t* xb = p.x + fl;
+    for (int base = beg; base < end; base += 64) {
+        const int cnt = (end - base) < 64 ? (end - base) : 64;
+        int c = 0;
+        float w = 0.f;
+        if (lane < cnt) {
+            c = p.col[base + lane];
+            w = p.val ? p.val[base + lane] : 1.f;
+        }
+        for (int u = 0; u < cnt; u += NPW * UNROLL) {
+            uint4 g[UNROLL];
+            float sc[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const int idx = u + k * NPW + sub;
+                const bool ok = fact && idx < cnt;
+                const int cj = __shfl(c, idx & 63);
+                const float t = __shfl(w, idx & 63);
+                sc[k] = ok ? t : 0.f;
+                g[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) g[k] = *reinterpret_cast<const uint4*>(xb + static_cast<int64_t>(cj) * p.ldx);
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                float v[8];
+                unpack8(g[k], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(sc[k], v[j], acc[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off);
+    if (sub == 0 && fact) {
+        const int deg = end - beg;
+        const float d = p.mean ? static_cast<float>(deg > 1 ? deg : 1) : 1.f;
+        float zz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.z) unpack8(*reinterpret_cast<const uint4*>(p.z + static_cast<int64_t>(row) * p.ldz + fl), zz);
+        uint32_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float r = p.mean ? acc[j] / d : acc[j];
+            r = fmaf(p.beta, zz[j], r * p.alpha);
+            o[j] = f32_to_bf16(r);
+        }
+        uint4 q = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+        *reinterpret_cast<uint4*>(p.y + static_cast<int64_t>(row) * p.ldy + fl) = q;
+    }
+}
+
+int launch_spmm_bf16(const SpmmBf16Args& a, hipStream_t stream)
+{
+    const dim3 block(kWavesPerBlock * 64);
+    const unsigned gx = (static_cast<unsigned>(a.n_rows) + kWavesPerBlock - 1) / kWavesPerBlock;
+    ProfScope prof(PYGSD_K_SPMM, stream);
+    const int oct = a.n_feat / 8;
+    if (oct <= 2) {
+        hipLaunchKernelGGL(spmm_vec_bf16_kernel<2>, dim3(gx), block, 0, stream, a);
+    } else if (oct <= 4) {
+        hipLaunchKernelGGL(spmm_vec_bf16_kernel<4>, dim3(gx), block, 0, stream, a);
+    } else if (oct <= 8) {
+        hipLaunchKernelGGL(spmm_vec_bf16_kernel<8>, dim3(gx), block, 0, stream, a);
+    } else if (oct <= 16) {
+        hipLaunchKernelGGL(spmm_vec_bf16_kernel<16>, dim3(gx), block, 0, stream, a);
+    } else if (oct <= 32) {
+        hipLaunchKernelGGL(spmm_vec_bf16_kernel<32>, dim3(gx), block, 0, stream, a);
+    } else {
+        const unsigned gy = (static_cast<unsigned>(oct) + 63) / 64;
+        hipLaunchKernelGGL(spmm_vec_bf16_kernel<64>, dim3(gx, gy), block, 0, stream, a);
+    }
+    return check_launch("spmm_vec_bf16_kernel");
+}
+
+// ------------------------------------------------------------------------------------------
 // SDDMM: out[e] = <A[ia[e]], B[ib[e]]>; 16 lanes per edge, 4 edges per wavefront.
 // ------------------------------------------------------------------------------------------
 template <bool VEC>
@@ -278,6 +402,24 @@ extern "C" int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, con
     SpmmArgs a{rowptr, col, val, nullptr, X, nullptr, Y, nullptr, Z, nullptr,
                ldx, ldy, ldz, n_rows, n_feat, alpha, beta, mean};
     return launch_spmm<false>(a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pygsd_spmm_csr_bf16(const int32_t* rowptr, const int32_t* col, const float* val,
+                                   const void* X, int64_t ldx, void* Y, int64_t ldy, const void* Z,
+                                   int64_t ldz, int32_t n_rows, int32_t n_feat, float alpha, float beta,
+                                   int32_t mean, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_spmm_csr_bf16: negative size");
+    if (n_rows == 0 || n_feat == 0) return 0;
+    PYGSD_REQUIRE(rowptr && col && X && Y, "pygsd_spmm_csr_bf16: null pointer");
+    PYGSD_REQUIRE(n_feat % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (!Z || ldz % 8 == 0),
+                  "pygsd_spmm_csr_bf16: n_feat and row strides must be multiples of 8 (16-byte rows)");
+    PYGSD_REQUIRE(aligned16(X) && aligned16(Y) && (!Z || aligned16(Z)), "pygsd_spmm_csr_bf16: pointers must be 16-byte aligned");
+    PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat),
+                  "pygsd_spmm_csr_bf16: row stride smaller than n_feat");
+    SpmmBf16Args a{rowptr, col, val, static_cast<const uint16_t*>(X), static_cast<uint16_t*>(Y),
+                   static_cast<const uint16_t*>(Z), ldx, ldy, ldz, n_rows, n_feat, alpha, beta, mean};
+    return launch_spmm_bf16(a, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int pygsd_spmm2_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val_a,

@@ -31,8 +31,8 @@ def _rows(t: Tensor) -> Tuple[Tensor, int]:
     """Return (tensor with unit inner stride, row stride in elements)."""
     if t.dim() != 2:
         raise ValueError(f"expected a [N, F] feature matrix, got shape {tuple(t.shape)}")
-    if t.dtype != torch.float32:
-        raise TypeError(f"the HIP path computes in float32; got {t.dtype}")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"the HIP path stores features as float32 or bfloat16 (fp32 accumulate); got {t.dtype}")
     if t.size(1) > 0 and (t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1))):
         t = t.contiguous()
     ld = t.stride(0) if t.size(0) > 1 else max(t.size(1), 1)
@@ -148,17 +148,43 @@ class Pattern:
 # ------------------------------------------------------------------------------------------------
 # raw launches
 # ------------------------------------------------------------------------------------------------
+def _spmm_bf16_raw(csr: CSR, val: Optional[Tensor], x: Tensor, ldx: int, z: Optional[Tensor], alpha: float,
+                   beta: float, mean: bool) -> Tensor:
+    """bf16-storage SpMM (fp32 values / accumulation).  Shapes the 16-byte-row kernel cannot address
+    are widened to fp32, run through the fp32 kernel and rounded back -- still the HIP path."""
+    f = x.size(1)
+    ok = f % 8 == 0 and ldx % 8 == 0 and x.data_ptr() % 16 == 0
+    zp, ldz = None, 0
+    if z is not None:
+        z, ldz = _rows(z.to(torch.bfloat16))
+        ok = ok and ldz % 8 == 0 and z.data_ptr() % 16 == 0
+        zp = ptr(z)
+    if not ok:
+        y32 = _spmm_raw(csr, val, x.float(), None if z is None else z.float(), alpha, beta, mean)
+        return y32.to(torch.bfloat16)
+    y = torch.empty((csr.n_rows, f), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_cabi.lib().pygsd_spmm_csr_bf16(ptr(csr.rowptr), ptr(csr.col), ptr(val), ptr(x), ldx, ptr(y), f, zp,
+                                              ldz, csr.n_rows, f, float(alpha), float(beta), 1 if mean else 0,
+                                              stream_ptr()), "pygsd_spmm_csr_bf16")
+    return y
+
+
 def _spmm_raw(csr: CSR, val: Optional[Tensor], x: Tensor, z: Optional[Tensor], alpha: float, beta: float,
               mean: bool) -> Tensor:
     _cabi.require_gpu(x, z, val)
     x, ldx = _rows(x)
+    if x.dtype == torch.bfloat16 and csr.nnz > 0 and x.size(1) > 0 and csr.n_rows > 0:
+        if x.size(0) != csr.n_cols:
+            raise ValueError(f"x has {x.size(0)} rows, operator expects {csr.n_cols}")
+        return _spmm_bf16_raw(csr, val, x, ldx, z, alpha, beta, mean)
     if x.size(0) != csr.n_cols:
         raise ValueError(f"x has {x.size(0)} rows, operator expects {csr.n_cols}")
     f = x.size(1)
     if z is not None and tuple(z.shape) != (csr.n_rows, f):
         raise ValueError(f"z has shape {tuple(z.shape)}, expected {(csr.n_rows, f)}")
     if csr.nnz == 0 or f == 0 or csr.n_rows == 0:  # edgeless operator: nothing to gather
-        y = torch.zeros((csr.n_rows, f), dtype=torch.float32, device=x.device)
+        y = torch.zeros((csr.n_rows, f), dtype=x.dtype, device=x.device)
         return y if z is None else y.add_(z, alpha=beta)
     y = torch.empty((csr.n_rows, f), dtype=torch.float32, device=x.device)
     zp, ldz = None, 0
@@ -211,8 +237,8 @@ def _spmm2_raw(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, z
 def _sddmm_raw(ia: Tensor, ib: Tensor, a: Tensor, b: Tensor) -> Tensor:
     """out[e] = <a[ia[e]], b[ib[e]]>."""
     _cabi.require_gpu(ia, ib, a, b)
-    a, lda = _rows(a)
-    b, ldb = _rows(b)
+    a, lda = _rows(a.float())
+    b, ldb = _rows(b.float())
     out = torch.empty(ia.numel(), dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
         check(_cabi.lib().pygsd_sddmm_coo_f32(ptr(ia), ptr(ib), ia.numel(), ptr(a), lda, ptr(b), ldb,
@@ -253,7 +279,7 @@ class _Spmm(torch.autograd.Function):
                 gw = gw * pat.mean_values()
             if alpha != 1.0:
                 gw = gw * alpha
-            gw = gw.view_as(w)
+            gw = gw.view_as(w).to(w.dtype)
         if ctx.needs_input_grad[2]:
             gz = gy * ctx.beta
         return gx, gw, gz, None, None, None, None

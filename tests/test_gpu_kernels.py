@@ -408,3 +408,49 @@ def test_self_loops_and_norms_match_oracle(weighted):
         wi, ww = R.conv_norm_rw(ei, w, n, fill)
         assert torch.equal(gi.cpu(), wi)
         close(gw, ww, 1e-6)
+
+
+# ------------------------------------------------------------------ bf16 storage (BASELINE config C5)
+@pytest.mark.parametrize("f", [8, 16, 64, 128, 256, 520, 20])
+def test_spmm_bf16_vs_oracle_on_rounded_inputs(f):
+    """Parity for the bf16-storage SpMM is defined against the fp32 oracle evaluated on the
+    bf16-ROUNDED inputs; the only extra error is the final bf16 rounding of the
+    result (relative 2^-8) on top of the 1e-5 accumulation bar."""
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
+    n, nnz = 300, 6000
+    ei = rand_graph(n, n, nnz, seed=f, long_row=150, empty_tail=3)
+    g = torch.Generator().manual_seed(f)
+    x = torch.randn(n, f, generator=g).to(torch.bfloat16)
+    z = torch.randn(n, f, generator=g).to(torch.bfloat16)
+    w = torch.rand(nnz, generator=g)
+    want = 2.0 * R.propagate(x.float(), ei, w, n) - z.float()
+    d = dev()
+    got = spmm(Pattern(ei.to(d), n, n), x.to(d), w.to(d), z=z.to(d), alpha=2.0, beta=-1.0)
+    assert got.dtype == torch.bfloat16
+    err = (got.float().cpu() - want).abs()
+    bound = want.abs() * 2.0 ** -8 + 1e-5 * max(1.0, float(want.abs().max()))
+    assert bool((err <= bound).all()), float((err - bound).max())
+    # mean aggregation, no values
+    want = R.propagate(x.float(), ei, None, n, reduce="mean")
+    got = spmm(Pattern(ei.to(d), n, n), x.to(d), None, reduce="mean").float().cpu()
+    assert bool(((got - want).abs() <= want.abs() * 2.0 ** -8 + 1e-5).all())
+
+
+def test_digcn_conv_bf16_layer():
+    from pytorch_geometric_signed_directed_amd.nn import DiGCNConv
+    n, e, fi, fo = 500, 8000, 64, 64
+    g = torch.Generator().manual_seed(9)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    w = torch.rand(e, generator=g) / 16
+    x = torch.randn(n, fi, generator=g)
+    torch.manual_seed(9)
+    layer = DiGCNConv(fi, fo)
+    wt, bs = layer.weight.detach().clone(), layer.bias.detach().clone()
+    # oracle on bf16-rounded operands, bf16 rounding after the dense product as the layer does
+    h = (x.to(torch.bfloat16).float() @ wt.to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    want = R.propagate(h, ei, w, n) + bs.to(torch.bfloat16).float()
+    d = dev()
+    out = layer.to(d).to(torch.bfloat16)(x.to(d).to(torch.bfloat16), ei.to(d), w.to(d))
+    assert out.dtype == torch.bfloat16
+    err = (out.float().cpu() - want).abs()
+    assert bool((err <= want.abs() * 2.0 ** -7 + 2e-2).all()), float(err.max())

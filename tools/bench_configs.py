@@ -1,0 +1,162 @@
+"""Measurement helper (GPU box): the other BASELINE.json configs on ONE MI355X -- they are parity-test
+sizes, not bench.py lines, but each gets a timing and the achieved algorithmic GB/s of its SpMM kernel
+(SURVEY.md 8(d) byte model) so DESIGN.md can quote them.  Writes gpurun_out/configs.json."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.getcwd())
+from pytorch_geometric_signed_directed_amd import _cabi, graphs  # noqa: E402
+from pytorch_geometric_signed_directed_amd.nn import (Conv_Base, DiGCN_InceptionBlock, MagNetConv, MSConv,  # noqa: E402
+                                                      SGCNConv, SIMPA)
+
+dev = torch.device("cuda:0")
+out = {}
+
+
+def timed(step, iters=10, warm=3):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    _cabi.prof_reset(); _cabi.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    _cabi.prof_enable(False)
+    prof = {k: _cabi.prof_collect(k) for k in ("spmm", "spmm2", "dense", "build")}
+    _cabi.prof_reset()
+    return ms, {k: {"launches_per_step": n / iters, "ms_per_launch": (t / n if n else 0.0)} for k, (n, t) in prof.items()}
+
+
+def spmm_bytes(nnz, n, f, s=4, val=True):
+    return nnz * (4 + (4 if val else 0) + f * s) + n * f * s + 4 * (n + 1)
+
+
+def magnetic(name, cls, n, e, h, K, signed, **kw):
+    ei_np, _, _ = graphs.dsbm_for_edges(n, e, seed=1)
+    ei = torch.from_numpy(ei_np).to(dev)
+    w = None
+    if signed:
+        g = torch.Generator().manual_seed(1)
+        w = (torch.randint(0, 2, (ei.size(1),), generator=g) * 2 - 1).float().to(dev)   # SDSBM-style signs
+    g = torch.Generator().manual_seed(0)
+    xr = torch.randn(n, h, generator=g).to(dev).requires_grad_()
+    xi = torch.randn(n, h, generator=g).to(dev).requires_grad_()
+    torch.manual_seed(0)
+    layer = cls(h, h, K, 0.25, False, cached=True, **kw).to(dev)
+
+    def step():
+        layer.zero_grad(set_to_none=True); xr.grad = xi.grad = None
+        o = layer(xr, xi, ei, w)
+        (o[0].sum() + o[1].sum()).backward()
+    ms, prof = timed(step)
+    nnz = layer._operator.pattern.nnz
+    b = spmm_bytes(nnz, n, h) + spmm_bytes(nnz - n, n, h)
+    k = prof["spmm2"]
+    out[name] = {"nodes": n, "edges": int(ei.size(1)), "hidden": h, "K": K, "ms_per_step": ms,
+                 "edges_per_s": ei.size(1) / ms * 1e3, "operator_nnz": nnz, "kernels": prof,
+                 "spmm2_alg_GBps": b / k["ms_per_launch"] / 1e6 if k["ms_per_launch"] else None}
+    # reference default: cached=False, operator rebuilt on every forward
+    layer_u = cls(h, h, K, 0.25, False, cached=False, **kw).to(dev)
+    layer_u.load_state_dict(layer.state_dict())
+
+    def step_u():
+        layer_u.zero_grad(set_to_none=True); xr.grad = xi.grad = None
+        o = layer_u(xr, xi, ei, w)
+        (o[0].sum() + o[1].sum()).backward()
+    ms_u, prof_u = timed(step_u, iters=5, warm=2)
+    out[name]["uncached_ms_per_step"] = ms_u
+    out[name]["uncached_build_ms"] = prof_u["build"]["launches_per_step"] * prof_u["build"]["ms_per_launch"]
+    print(name, json.dumps(out[name]), flush=True)
+    del layer, layer_u, xr, xi, ei
+    torch.cuda.empty_cache()
+
+
+def signed_c3(n=500000, entries=10000000, h=64):
+    p = (entries / 2) / (n * (n - 1) / 2)
+    ei_np, sign, _ = graphs.ssbm(n, 5, p, 0.1, 2.0, seed=2)
+    ei, sign = torch.from_numpy(ei_np).to(dev), torch.from_numpy(sign).to(dev)
+    pos, neg = ei[:, sign > 0].contiguous(), ei[:, sign < 0].contiguous()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, h, generator=g).to(dev).requires_grad_()
+    torch.manual_seed(0)
+    conv = SGCNConv(h, h // 2, first_aggr=True).to(dev)
+
+    def step():
+        conv.zero_grad(set_to_none=True); x.grad = None
+        conv(x, pos, neg).sum().backward()
+    ms, prof = timed(step)
+    b = spmm_bytes(pos.size(1), n, h, val=False) + spmm_bytes(neg.size(1), n, h, val=False)
+    k = prof["spmm"]
+    out["C3_sgcnconv_first"] = {"nodes": n, "pos_entries": int(pos.size(1)), "neg_entries": int(neg.size(1)),
+                                "hidden": h, "ms_per_step": ms, "entries_per_s": ei.size(1) / ms * 1e3, "kernels": prof,
+                                "spmm_alg_GBps_fwd_pair": b / (2 * k["ms_per_launch"]) / 1e6 * 2 / 2 if k["ms_per_launch"] else None}
+    print("C3_sgcnconv_first", json.dumps(out["C3_sgcnconv_first"]), flush=True)
+    simpa = SIMPA(2, 0.5).to(dev)
+    wp = torch.ones(pos.size(1), device=dev)
+    wn = torch.ones(neg.size(1), device=dev)
+    xp = torch.randn(n, h, generator=g).to(dev).requires_grad_()
+    xn = torch.randn(n, h, generator=g).to(dev).requires_grad_()
+
+    def step2():
+        simpa.zero_grad(set_to_none=True); xp.grad = xn.grad = None
+        simpa(pos, wp, neg, wn, xp, xn).sum().backward()
+    ms, prof = timed(step2)
+    out["C3_simpa_hop2"] = {"nodes": n, "hidden": h, "ms_per_step": ms, "entries_per_s": ei.size(1) / ms * 1e3,
+                            "kernels": prof, "note": "7 SpMM fwd + 7 bwd (5 on A_p, 2 on A_n) per step"}
+    print("C3_simpa_hop2", json.dumps(out["C3_simpa_hop2"]), flush=True)
+    torch.cuda.empty_cache()
+
+
+def digcn_c5(n=2000000, e=25000000, h=64):
+    ei_np, _, _ = graphs.dsbm_for_edges(n, e, seed=3)
+    src, dst = torch.from_numpy(ei_np).to(dev)
+    loops = torch.arange(n, device=dev)
+    res = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        ops = []
+        for k in range(2):           # two symmetric, positively weighted, sym-normalised operators
+            g = torch.Generator(device="cuda").manual_seed(10 + k)
+            perm = torch.randperm(src.numel(), device=dev, generator=g) if k else torch.arange(src.numel(), device=dev)
+            s, d = src[perm], (dst if k == 0 else dst[torch.randperm(dst.numel(), device=dev, generator=g)])
+            wv = torch.rand(s.numel(), device=dev, generator=g)
+            ei = torch.stack([torch.cat([s, d, loops]), torch.cat([d, s, loops])])
+            w = torch.cat([wv, wv, torch.ones(n, device=dev)])
+            deg = torch.zeros(n, device=dev).index_add_(0, ei[0], w)
+            w = deg[ei[0]].rsqrt() * w * deg[ei[1]].rsqrt()
+            ops.append((ei, w))
+        x = torch.randn(n, h, device=dev).to(dtype).requires_grad_()
+        torch.manual_seed(0)
+        ib = DiGCN_InceptionBlock(h, h).to(dev).to(dtype)
+
+        def step():
+            ib.zero_grad(set_to_none=True); x.grad = None
+            x0, x1, x2 = ib(x, ops[0][0], ops[0][1], ops[1][0], ops[1][1])
+            (x0 + x1 + x2).float().sum().backward()
+        ms, prof = timed(step, iters=5, warm=2)
+        nnz = ops[0][0].size(1)
+        s_el = 2 if dtype == torch.bfloat16 else 4
+        b = spmm_bytes(nnz, n, h, s=s_el)
+        k = prof["spmm"]
+        res[str(dtype).split(".")[-1]] = {"ms_per_block_step": ms, "nnz_per_operator": nnz, "kernels": prof,
+                                          "spmm_alg_GBps": b / k["ms_per_launch"] / 1e6 if k["ms_per_launch"] else None,
+                                          "nnz_per_s": 2 * nnz / ms * 1e3}
+        del ops, x, ib
+        torch.cuda.empty_cache()
+    out["C5_digcn_inception_block_1gpu"] = {"nodes": n, "hidden": h, **res}
+    print("C5", json.dumps(out["C5_digcn_inception_block_1gpu"]), flush=True)
+
+
+magnetic("C2_magnetconv_100k_2M_h64", MagNetConv, 100000, 2000000, 64, 1, False)
+signed_c3()
+magnetic("C4_msconv_1M_20M_h128_K2_1gpu", MSConv, 1000000, 20000000, 128, 2, True)
+magnetic("northstar_magnetconv_1M_20M_h64", MagNetConv, 1000000, 20000000, 64, 1, False)
+digcn_c5()
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/configs.json", "w"), indent=1)
