@@ -111,3 +111,45 @@ class MagneticConvFunction(torch.autograd.Function):
             else:
                 gx_r, gx_i = da[0], db[0]
         return gx_r, gx_i, dw, (dbias if ctx.has_bias else None), None, None, None
+
+
+class _TallLinear(torch.autograd.Function):
+    """y = x @ W (+ b) for a tall x [N, F_in] (N ~ 10^5..10^6, F ~ 10^1..10^2) with library GEMMs.
+    Forward and dX are ordinary GEMMs; the weight gradient dW = x^T g has a reduction dimension of N and
+    only F_in x F_out outputs, which rocBLAS runs on a handful of CUs (measured 1.8 ms at N = 10^6,
+    F = 64).  Here it is a batched split-K: N is cut into 4096-row slabs, one GEMM per slab (bmm), and
+    the [S, F_in, F_out] partials are summed -- every CU gets work, ~10x faster."""
+    SLAB = 4096
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        y = torch.matmul(x, weight)
+        return y if bias is None else y + bias
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.matmul(g, weight.t())
+        if ctx.needs_input_grad[1]:
+            n, slab = x.size(0), _TallLinear.SLAB
+            s = n // slab
+            if s >= 8 and x.is_contiguous():
+                head = s * slab
+                gw = torch.bmm(x[:head].view(s, slab, -1).transpose(1, 2), g[:head].view(s, slab, -1)).sum(0)
+                if head < n:
+                    gw = gw + x[head:].t() @ g[head:]
+            else:
+                gw = x.t() @ g
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+def tall_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+    """x [N, F_in] @ weight [F_in, F_out] (+ bias) with a split-K weight gradient."""
+    return _TallLinear.apply(x, weight, bias)

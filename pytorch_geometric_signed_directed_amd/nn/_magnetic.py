@@ -20,7 +20,7 @@ from torch.nn import Parameter
 
 from .. import _cabi
 from ..message_passing import MessagePassing
-from ..dense import MagneticConvFunction, dense_supported
+from ..dense import MagneticConvFunction, dense_supported, tall_linear
 from ..sparse import Pattern, spmm2
 from ..utils._laplacian import laplacian_parts, laplacian_values
 
@@ -199,16 +199,16 @@ class MagneticChebConv(MessagePassing):
         # do not tile): same HIP SpMMs, dense stage composed from library GEMMs
         # A-chain on (S_r, X_r), B-chain on (S_i, X_i); one fused traversal per Chebyshev order
         t0_r, t0_i = x_real, x_imag
-        acc_a = torch.matmul(t0_r, self.weight[0])
-        acc_b = torch.matmul(t0_i, self.weight[0])
+        acc_a = tall_linear(t0_r, self.weight[0])
+        acc_b = tall_linear(t0_i, self.weight[0])
         if self.weight.size(0) > 1:
             t1_r, t1_i = spmm2(op.pattern, t0_r, t0_i, w_r, w_i)
-            acc_a = torch.addmm(acc_a, t1_r, self.weight[1])
-            acc_b = torch.addmm(acc_b, t1_i, self.weight[1])
+            acc_a = acc_a + tall_linear(t1_r, self.weight[1])
+            acc_b = acc_b + tall_linear(t1_i, self.weight[1])
         for k in range(2, self.weight.size(0)):
             t2_r, t2_i = spmm2(op.pattern, t1_r, t1_i, w_r, w_i, za=t0_r, zb=t0_i, alpha=2.0, beta=-1.0)
-            acc_a = torch.addmm(acc_a, t2_r, self.weight[k])
-            acc_b = torch.addmm(acc_b, t2_i, self.weight[k])
+            acc_a = acc_a + tall_linear(t2_r, self.weight[k])
+            acc_b = acc_b + tall_linear(t2_i, self.weight[k])
             t0_r, t0_i, t1_r, t1_i = t1_r, t1_i, t2_r, t2_i
 
         out_real = acc_a - acc_b

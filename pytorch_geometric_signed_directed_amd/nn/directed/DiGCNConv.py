@@ -5,6 +5,7 @@ from torch.nn import Parameter
 
 from ... import _cabi
 from ...message_passing import MessagePassing
+from ...dense import tall_linear
 from ...sparse import Pattern, spmm
 from .._magnetic import glorot, zeros
 
@@ -37,7 +38,7 @@ class DiGCNConv(MessagePassing):
     def forward(self, x: torch.FloatTensor, edge_index: torch.LongTensor,
                 edge_weight: torch.FloatTensor = None) -> torch.FloatTensor:
         _cabi.require_gpu(x, edge_index, edge_weight)
-        x = torch.matmul(x, self.weight)
+        x = tall_linear(x, self.weight) if x.dim() == 2 else torch.matmul(x, self.weight)
 
         if self.cached and self.cached_result is not None and edge_index.size(1) != self.cached_num_edges:
             raise RuntimeError(

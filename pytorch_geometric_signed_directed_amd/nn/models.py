@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn import Parameter
 
+from ..dense import tall_linear
 from .directed.complex_relu import complex_relu_layer
 from .directed.DiGCNConv import DiGCNConv
 from .directed.DIMPA import DIMPA
@@ -199,7 +200,8 @@ class DiGCN_InceptionBlock(nn.Module):
         self.conv2.reset_parameters()
 
     def forward(self, x, edge_index, edge_weight, edge_index2, edge_weight2):
-        return self.ln(x), self.conv1(x, edge_index, edge_weight), self.conv2(x, edge_index2, edge_weight2)
+        x0 = tall_linear(x, self.ln.weight.t(), self.ln.bias) if x.dim() == 2 else self.ln(x)
+        return x0, self.conv1(x, edge_index, edge_weight), self.conv2(x, edge_index2, edge_weight2)
 
 
 class DiGCN_Inception_Block_node_classification(nn.Module):

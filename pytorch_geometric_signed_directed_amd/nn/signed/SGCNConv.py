@@ -9,6 +9,7 @@ from torch import Tensor
 
 from ... import _cabi
 from ...message_passing import MessagePassing
+from ...dense import tall_linear
 from ...sparse import GLOBAL_PATTERNS, spmm
 
 
@@ -45,16 +46,18 @@ class SGCNConv(MessagePassing):
             raise NotImplementedError("SGCNConv: only the edge_index (Tensor) path exists on the HIP stack")
         _cabi.require_gpu(x[0], x[1], pos_edge_index, neg_edge_index)
         n = x[1].size(0)
+        lin_b = lambda t: tall_linear(t, self.lin_b.weight.t(), self.lin_b.bias)  # noqa: E731
+        lin_u = lambda t: tall_linear(t, self.lin_u.weight.t(), self.lin_u.bias)  # noqa: E731
         if self.first_aggr:
-            out_b = self.lin_b(torch.cat([self._mean_in(x[0], n, pos_edge_index), x[1]], dim=-1))
-            out_u = self.lin_u(torch.cat([self._mean_in(x[0], n, neg_edge_index), x[1]], dim=-1))
+            out_b = lin_b(torch.cat([self._mean_in(x[0], n, pos_edge_index), x[1]], dim=-1))
+            out_u = lin_u(torch.cat([self._mean_in(x[0], n, neg_edge_index), x[1]], dim=-1))
         else:
             f = self.in_dim
             lo, hi = x[0][..., :f], x[0][..., f:]   # column slices: passed by row stride, no copy
-            out_b = self.lin_b(torch.cat([self._mean_in(lo, n, pos_edge_index),
-                                          self._mean_in(hi, n, neg_edge_index), x[1][..., :f]], dim=-1))
-            out_u = self.lin_u(torch.cat([self._mean_in(hi, n, pos_edge_index),
-                                          self._mean_in(lo, n, neg_edge_index), x[1][..., f:]], dim=-1))
+            out_b = lin_b(torch.cat([self._mean_in(lo, n, pos_edge_index),
+                                     self._mean_in(hi, n, neg_edge_index), x[1][..., :f]], dim=-1))
+            out_u = lin_u(torch.cat([self._mean_in(hi, n, pos_edge_index),
+                                     self._mean_in(lo, n, neg_edge_index), x[1][..., f:]], dim=-1))
         out = torch.cat([out_b, out_u], dim=-1)
         if self.norm_emb:
             out = F.normalize(out, p=2, dim=-1)
