@@ -98,6 +98,25 @@ int pygsd_sddmm_coo_f32(const int32_t* ia, const int32_t* ib, int64_t nnz,
                         int32_t n_feat, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Attention aggregate of SDGNN / SiGAT: what torch_geometric.nn.GATConv computes for the reference at
+ * nn/signed/SDGNN.py:35-41,57-64 and nn/signed/SiGAT.py:59-64 (heads handled one at a time by the host).
+ *   pygsd_gat_alpha_csr_f32    : alpha[e] = softmax over CSR row r of leaky_relu(a_src[col[e]] + a_dst[r])
+ *                                (max-shifted exp, denominator + 1e-16), CSR order.  The weighted sum
+ *                                out = sum alpha * h[col] is then pygsd_spmm_csr_f32 with val = alpha.
+ *   pygsd_gat_alpha_bwd_csr_f32: ds[e] = alpha[e] * (<g_r, h_col[e]> - <g_r, out_r>) * lrelu'(s_e), the
+ *                                gradient w.r.t. the pre-activation score s_e = a_src[col] + a_dst[r];
+ *                                written, together with alpha, in COO order through perm (so that
+ *                                d a_src / d a_dst are row sums over the two CSR orientations).
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_gat_alpha_csr_f32(const int32_t* rowptr, const int32_t* col, const float* a_src, const float* a_dst,
+                            int32_t n_rows, float negative_slope, float* alpha, void* stream);
+int pygsd_gat_alpha_bwd_csr_f32(const int32_t* rowptr, const int32_t* col, const int32_t* perm,
+                                const float* a_src, const float* a_dst, float negative_slope,
+                                const float* alpha, const float* h, int64_t ldh, const float* g, int64_t ldg,
+                                const float* out, int64_t ldo, int32_t n_rows, int32_t n_feat,
+                                float* ds_coo, float* alpha_coo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * COO -> CSR (operator build).  Groups the nnz entries by seg[e] (stable: entries of one group
  * keep their COO order, which is the order torch's scatter_add_ sums them in the reference) and
  * emits rowptr[n_seg+1], col[e'] = (int32) other[perm[e']], perm[e'] = original entry id.

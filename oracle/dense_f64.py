@@ -199,3 +199,25 @@ def sgcn_conv(x, pos_ei, neg_ei, lin_b, lin_u, first_aggr, in_dim, norm_emb=Fals
     if norm_emb:
         out = out / np.maximum(np.linalg.norm(out, axis=1, keepdims=True), 1e-12)
     return out
+
+
+def gat_conv(x, edge_index, lin_weight, att_src, att_dst, bias, negative_slope=0.2):
+    """heads = 1 attention aggregate, node by node (no scatter, no segment ops)."""
+    x = np.asarray(x, np.float64)
+    n = x.shape[0]
+    h = x @ np.asarray(lin_weight, np.float64).T
+    a_s = h @ np.asarray(att_src, np.float64).reshape(-1)
+    a_d = h @ np.asarray(att_dst, np.float64).reshape(-1)
+    incoming = [[] for _ in range(n)]
+    for u, v in np.asarray(edge_index).T:
+        if u != v:
+            incoming[v].append(u)
+    out = np.zeros_like(h)
+    for i in range(n):
+        nb = incoming[i] + [i]                     # self loop re-added
+        e = np.array([a_s[j] + a_d[i] for j in nb])
+        e = np.where(e > 0, e, negative_slope * e)
+        w = np.exp(e - e.max())
+        w = w / w.sum()
+        out[i] = (w[:, None] * h[nb]).sum(0)
+    return out if bias is None else out + np.asarray(bias, np.float64)

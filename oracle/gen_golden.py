@@ -297,6 +297,41 @@ def kat_case():
          op_real=npy(layer.cached_result[2]), op_imag=npy(layer.cached_result[3]))
 
 
+# ------------------------------------------------------------------ attention aggregate (SDGNN / SiGAT)
+def gat_cases():
+    from torch_geometric.nn import GATConv          # the shim's restatement of PyG GATConv
+    from torch_geometric_signed_directed.nn.signed.SDGNN import SDRLayer
+    n, f = 40, 6
+    ei, _ = toy_graph(71, weighted=False)
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(n, f, generator=g, requires_grad=True)
+    go = torch.randn(n, 5, generator=g)
+    torch.manual_seed(71)
+    conv = GATConv(f, 5)
+    with torch.no_grad():
+        conv.bias.uniform_(-0.5, 0.5)
+    out = conv(x, t(ei))
+    (out * go).sum().backward()
+    close("gat", npy(out), D.gat_conv(npy(x), ei, npy(conv.lin.weight), npy(conv.att_src), npy(conv.att_dst),
+                                      npy(conv.bias)))
+    save("gat_conv", edge_index=ei, x=npy(x), grad_out=npy(go), out=npy(out), dx=npy(x.grad),
+         **{"sd." + k: npy(v) for k, v in conv.state_dict().items()},
+         **{"d." + k: npy(p.grad) for k, p in conv.named_parameters()})
+    # SDRLayer: the reference's own class over four motif edge lists
+    lists = [t(toy_graph(72 + k, e=60 + 20 * k, weighted=False)[0]) for k in range(4)]
+    x2 = torch.randn(n, f, generator=g, requires_grad=True)
+    torch.manual_seed(72)
+    layer = SDRLayer(f, f, edge_lists=lists)
+    layer.reset_parameters()
+    out2 = layer(x2)
+    go2 = torch.randn(out2.shape, generator=g)
+    (out2 * go2).sum().backward()
+    save("sdr_layer", x=npy(x2), grad_out=npy(go2), out=npy(out2), dx=npy(x2.grad),
+         **{f"edges{k}": npy(e) for k, e in enumerate(lists)},
+         **{"sd." + k: npy(v) for k, v in layer.state_dict().items()},
+         **{"d." + k: npy(p.grad) for k, p in layer.named_parameters()})
+
+
 # ------------------------------------------------------------------ model-level callers (eval mode)
 def model_case(name, model, args, seed):
     """Reference model in eval mode (dropout off) on fixed inputs: record state_dict + outputs."""
@@ -385,6 +420,8 @@ def main():
     sgcn_case("sgcn_first_normemb", 33, True, True)
     relu_case("complex_relu", 41)
     kat_case()
+    print("attention aggregate")
+    gat_cases()
     print("model-level callers")
     models()
 

@@ -61,10 +61,53 @@ class MessagePassing(torch.nn.Module):
         return self.update(out, **{k: kwargs.get(k) for k in self._upd_params})
 
 
-class GATConv(torch.nn.Module):
-    def __init__(self, *a, **k):
-        super().__init__()
-        raise NotImplementedError("GATConv: out of scope for the shim (SURVEY 8(f) rank 1)")
+class GATConv(MessagePassing):
+    """torch_geometric.nn.GATConv restated from its documentation (current single-`lin` layout):
+    x' = lin(x) (no bias); alpha_src = <x', att_src>, alpha_dst = <x', att_dst>; self loops removed and
+    re-added; e_ij = leaky_relu(alpha_src[j] + alpha_dst[i], 0.2); softmax over the incoming edges of i
+    (max-shifted, denominator + 1e-16); out_i = sum_j alpha_ij x'_j (+ bias); heads concatenated."""
+
+    def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, dropout=0.0,
+                 add_self_loops=True, bias=True, **kwargs):
+        kwargs.setdefault('aggr', 'add')
+        super().__init__(node_dim=0, **kwargs)
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
+        self.add_self_loops = add_self_loops
+        self.lin = torch.nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.att_src = torch.nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = torch.nn.Parameter(torch.empty(1, heads, out_channels))
+        if bias:
+            self.bias = torch.nn.Parameter(torch.empty(heads * out_channels if concat else out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        from ..inits import glorot, zeros
+        glorot(self.lin.weight)
+        glorot(self.att_src)
+        glorot(self.att_dst)
+        zeros(self.bias)
+
+    def forward(self, x, edge_index):
+        from ...utils import add_self_loops, remove_self_loops, softmax
+        H, C = self.heads, self.out_channels
+        n = x.size(0)
+        h = self.lin(x).view(-1, H, C)
+        a_src = (h * self.att_src).sum(dim=-1)
+        a_dst = (h * self.att_dst).sum(dim=-1)
+        if self.add_self_loops:
+            edge_index, _ = remove_self_loops(edge_index)
+            edge_index, _ = add_self_loops(edge_index, num_nodes=n)
+        j, i = edge_index[0], edge_index[1]
+        e = torch.nn.functional.leaky_relu(a_src[j] + a_dst[i], self.negative_slope)
+        alpha = softmax(e, i, num_nodes=n)
+        alpha = torch.nn.functional.dropout(alpha, p=self.dropout, training=self.training)
+        msg = alpha.unsqueeze(-1) * h[j]
+        out = torch.zeros(n, H, C, dtype=msg.dtype).index_add_(0, i, msg)
+        out = out.view(-1, H * C) if self.concat else out.mean(dim=1)
+        return out if self.bias is None else out + self.bias
 
 
 class GCNConv(torch.nn.Module):

@@ -364,3 +364,35 @@ def sgcn_conv(x, pos_edge_index, neg_edge_index, lin_b: Tuple[Tensor, Optional[T
                                    dim=-1), *lin_u)
     out = torch.cat([out_b, out_u], dim=-1)
     return F.normalize(out, p=2, dim=-1) if norm_emb else out
+
+
+# --------------------------------------------------------------------------
+# a13: attention aggregate of SDGNN / SiGAT (third-party torch_geometric.nn.GATConv, heads >= 1)
+# --------------------------------------------------------------------------
+def segment_softmax(e: Tensor, index: Tensor, n: int) -> Tensor:
+    """torch_geometric.utils.softmax: per-target max-shifted exp / (segment sum + 1e-16)."""
+    shape = (n,) + tuple(e.shape[1:])
+    idx = index.view((-1,) + (1,) * (e.dim() - 1)).expand_as(e)
+    mx = torch.full(shape, float("-inf"), dtype=e.dtype).scatter_reduce(0, idx, e.detach(), "amax", include_self=True)
+    out = (e - mx.index_select(0, index)).exp()
+    den = torch.zeros(shape, dtype=e.dtype).scatter_add_(0, idx, out) + 1e-16
+    return out / den.index_select(0, index)
+
+
+def gat_conv(x, edge_index, lin_weight, att_src, att_dst, bias, heads=1, concat=True, negative_slope=0.2,
+             add_self_loops=True):
+    """GATConv as SDRLayer calls it (reference nn/signed/SDGNN.py:35-41,57-64; SiGAT.py:59-64)."""
+    import torch.nn.functional as F
+    n = x.size(0)
+    c = lin_weight.size(0) // heads
+    h = F.linear(x, lin_weight).view(-1, heads, c)
+    a_src = (h * att_src).sum(-1)
+    a_dst = (h * att_dst).sum(-1)
+    if add_self_loops:
+        edge_index, _ = drop_self_loops(edge_index, None)
+        edge_index, _ = append_self_loops(edge_index, None, 1.0, n)
+    j, i = edge_index[0], edge_index[1]
+    alpha = segment_softmax(F.leaky_relu(a_src[j] + a_dst[i], negative_slope), i, n)
+    out = scatter_rows(alpha.unsqueeze(-1) * h[j], i, n)
+    out = out.reshape(n, heads * c) if concat else out.mean(dim=1)
+    return out if bias is None else out + bias

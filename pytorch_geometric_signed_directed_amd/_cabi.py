@@ -33,6 +33,11 @@ PROTOTYPES = {
                                       c_int32, c_float, c_float, c_void_p]),
     "pygsd_sddmm_coo_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                       c_int32, c_void_p, c_void_p]),
+    "pygsd_gat_alpha_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p,
+                                          c_void_p]),
+    "pygsd_gat_alpha_bwd_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                              c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
+                                              c_int32, c_void_p, c_void_p, c_void_p]),
     "pygsd_csr_from_coo_workspace": (c_int32, [c_int64, c_int32, ctypes.POINTER(c_size_t)]),
     "pygsd_csr_from_coo": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),

@@ -1,0 +1,136 @@
+// Attention aggregate of SDGNN / SiGAT: the arithmetic the reference reaches
+// through torch_geometric.nn.GATConv (nn/signed/SDGNN.py:35-41,57-64; nn/signed/SiGAT.py:59-64):
+//   e_ij = leaky_relu(a_src[j] + a_dst[i]);  alpha_ij = softmax over the incoming edges of i
+//   (max-shifted, denominator + 1e-16);      out_i = sum_j alpha_ij h_j.
+// Same traversal as the SpMM: one wavefront owns a target row of the by-target CSR.  The softmax
+// coefficients are produced once per (row, edge) into an [nnz] array in CSR order; the weighted sum then
+// IS pygsd_spmm_csr_f32 with those values.  Backward: per edge d_alpha = <g_i, h_j> (an SDDMM), folded
+// with the softmax and leaky-relu derivatives into ds_ij = alpha_ij (d_alpha - <g_i, out_i>) * lrelu'(s_ij).
+#include "common.hpp"
+
+namespace pygsd {
+namespace {
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gat_alpha_kernel(const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col,
+                                                        const float* __restrict__ a_src,
+                                                        const float* __restrict__ a_dst, int32_t n_rows,
+                                                        float slope, float* __restrict__ alpha)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + static_cast<int>(threadIdx.x >> 6));
+    if (row >= n_rows) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    const float ad = a_dst[row];
+    float mx = -INFINITY;
+    for (int e = beg + lane; e < end; e += 64) {
+        const float s = a_src[col[e]] + ad;
+        mx = fmaxf(mx, s > 0.f ? s : slope * s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int e = beg + lane; e < end; e += 64) {
+        const float s = a_src[col[e]] + ad;
+        sum += expf((s > 0.f ? s : slope * s) - mx);
+    }
+    sum = wave_sum(sum) + 1e-16f;
+    for (int e = beg + lane; e < end; e += 64) {
+        const float s = a_src[col[e]] + ad;
+        alpha[e] = expf((s > 0.f ? s : slope * s) - mx) / sum;
+    }
+}
+
+// one 16-lane team per edge (4 edges per wavefront pass); writes ds and alpha in COO order
+__global__ __launch_bounds__(256) void gat_alpha_bwd_kernel(const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col,
+                                                            const int32_t* __restrict__ perm,
+                                                            const float* __restrict__ a_src,
+                                                            const float* __restrict__ a_dst, float slope,
+                                                            const float* __restrict__ alpha,
+                                                            const float* __restrict__ h, int64_t ldh,
+                                                            const float* __restrict__ g, int64_t ldg,
+                                                            const float* __restrict__ out, int64_t ldo,
+                                                            int32_t n_rows, int32_t n_feat,
+                                                            float* __restrict__ ds_coo, float* __restrict__ alpha_coo)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + static_cast<int>(threadIdx.x >> 6));
+    if (row >= n_rows) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    const float* gi = g + static_cast<int64_t>(row) * ldg;
+    const float* oi = out + static_cast<int64_t>(row) * ldo;
+    float rd = 0.f;
+    for (int f = lane; f < n_feat; f += 64) rd = fmaf(gi[f], oi[f], rd);
+    rd = wave_sum(rd);                                   // <g_i, out_i>
+    const float ad = a_dst[row];
+    const int t = lane & 15, team = lane >> 4;
+    for (int e0 = beg; e0 < end; e0 += 4) {
+        const int e = e0 + team;
+        float dot = 0.f;
+        int cj = 0;
+        if (e < end) {
+            cj = col[e];
+            const float* hj = h + static_cast<int64_t>(cj) * ldh;
+            for (int f = t; f < n_feat; f += 16) dot = fmaf(gi[f], hj[f], dot);
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) dot += __shfl_xor(dot, off);
+        if (e < end && t == 0) {
+            const float a = alpha[e];
+            const float s = a_src[cj] + ad;
+            const float ds = a * (dot - rd) * (s > 0.f ? 1.f : slope);
+            const int p = perm[e];
+            ds_coo[p] = ds;
+            alpha_coo[p] = a;
+        }
+    }
+}
+
+}  // namespace
+}  // namespace pygsd
+
+using namespace pygsd;
+
+extern "C" int pygsd_gat_alpha_csr_f32(const int32_t* rowptr, const int32_t* col, const float* a_src,
+                                       const float* a_dst, int32_t n_rows, float negative_slope, float* alpha,
+                                       void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0, "pygsd_gat_alpha_csr_f32: negative size");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(rowptr && a_src && a_dst, "pygsd_gat_alpha_csr_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_SPMM, s);
+    hipLaunchKernelGGL(gat_alpha_kernel, dim3((static_cast<unsigned>(n_rows) + 3) / 4), dim3(256), 0, s, rowptr,
+                       col, a_src, a_dst, n_rows, negative_slope, alpha);
+    return check_launch("gat_alpha_kernel");
+}
+
+extern "C" int pygsd_gat_alpha_bwd_csr_f32(const int32_t* rowptr, const int32_t* col, const int32_t* perm,
+                                           const float* a_src, const float* a_dst, float negative_slope,
+                                           const float* alpha, const float* h, int64_t ldh, const float* g,
+                                           int64_t ldg, const float* out, int64_t ldo, int32_t n_rows,
+                                           int32_t n_feat, float* ds_coo, float* alpha_coo, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_gat_alpha_bwd_csr_f32: negative size");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(rowptr && a_src && a_dst && h && g && out, "pygsd_gat_alpha_bwd_csr_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_SDDMM, s);
+    hipLaunchKernelGGL(gat_alpha_bwd_kernel, dim3((static_cast<unsigned>(n_rows) + 3) / 4), dim3(256), 0, s, rowptr,
+                       col, perm, a_src, a_dst, negative_slope, alpha, h, ldh, g, ldg, out, ldo, n_rows, n_feat,
+                       ds_coo, alpha_coo);
+    return check_launch("gat_alpha_bwd_kernel");
+}

@@ -1,0 +1,153 @@
+"""GATConv + SDRLayer -- the attention aggregate under SDGNN / SiGAT.
+
+The reference builds its signed-directed-relationship layer (nn/signed/SDGNN.py:13-64) and SiGAT's
+aggregators (nn/signed/SiGAT.py:59-64) from `torch_geometric.nn.GATConv` with all defaults.  PyG is not part
+of this stack, so GATConv is restated here (current PyG layout: one bias-free `lin`, `att_src`, `att_dst`
+[1, heads, out], `bias`; state_dict keys att_src, att_dst, bias, lin.weight) over the HIP kernels:
+segment-softmax coefficients (pygsd_gat_alpha_csr_f32), weighted aggregate (pygsd_spmm_csr_f32), and a
+fused SDDMM + softmax/leaky-relu backward (pygsd_gat_alpha_bwd_csr_f32)."""
+import math
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from ... import _cabi
+from ..._cabi import check, ptr, stream_ptr
+from ...sparse import GLOBAL_PATTERNS, Pattern, _rows, _spmm_raw, gather_values
+
+
+def _row_sum(csr, w_coo):
+    out = torch.empty(csr.n_rows, dtype=torch.float32, device=w_coo.device)
+    with torch.cuda.device(w_coo.device):
+        check(_cabi.lib().pygsd_csr_row_sum_f32(ptr(csr.rowptr), ptr(csr.perm), ptr(w_coo), csr.n_rows, ptr(out),
+                                                stream_ptr()), "pygsd_csr_row_sum_f32")
+    return out
+
+
+class _GatAggregate(torch.autograd.Function):
+    """out_i = sum_j softmax_i(leaky_relu(a_src[j] + a_dst[i])) h_j over the pattern's incoming edges."""
+
+    @staticmethod
+    def forward(ctx, h, a_src, a_dst, pat: Pattern, slope: float):
+        _cabi.require_gpu(h, a_src, a_dst)
+        h, _ = _rows(h.float())
+        a_src, a_dst = a_src.float().contiguous(), a_dst.float().contiguous()
+        csr = pat.fwd
+        alpha = torch.empty(csr.nnz, dtype=torch.float32, device=h.device)
+        if csr.nnz:
+            with torch.cuda.device(h.device):
+                check(_cabi.lib().pygsd_gat_alpha_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(a_src), ptr(a_dst),
+                                                          csr.n_rows, float(slope), ptr(alpha), stream_ptr()),
+                      "pygsd_gat_alpha_csr_f32")
+        out = _spmm_raw(csr, alpha if csr.nnz else None, h, None, 1.0, 0.0, False)
+        ctx.pat, ctx.slope = pat, slope
+        ctx.save_for_backward(h, a_src, a_dst, alpha, out)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        h, a_src, a_dst, alpha, out = ctx.saved_tensors
+        pat = ctx.pat
+        fwd, bwd = pat.fwd, pat.bwd
+        g, ldg = _rows(g.contiguous())
+        hh, ldh = _rows(h)
+        oo, ldo = _rows(out)
+        ds = torch.empty(fwd.nnz, dtype=torch.float32, device=h.device)
+        a_coo = torch.empty_like(ds)
+        if fwd.nnz:
+            with torch.cuda.device(h.device):
+                check(_cabi.lib().pygsd_gat_alpha_bwd_csr_f32(ptr(fwd.rowptr), ptr(fwd.col), ptr(fwd.perm), ptr(a_src),
+                                                              ptr(a_dst), float(ctx.slope), ptr(alpha), ptr(hh), ldh,
+                                                              ptr(g), ldg, ptr(oo), ldo, fwd.n_rows, h.size(1),
+                                                              ptr(ds), ptr(a_coo), stream_ptr()),
+                      "pygsd_gat_alpha_bwd_csr_f32")
+        gh = _spmm_raw(bwd, gather_values(a_coo, bwd.perm) if bwd.nnz else None, g, None, 1.0, 0.0, False)
+        return gh, _row_sum(bwd, ds), _row_sum(fwd, ds), None, None
+
+
+class GATConv(nn.Module):
+    r"""Graph attention convolution with torch_geometric.nn.GATConv's default behaviour (heads=1,
+    concat=True, negative_slope=0.2, add_self_loops=True, bias=True).  Dropout on the attention
+    coefficients is not supported on the fused path (the reference uses the default 0)."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
+                 negative_slope: float = 0.2, dropout: float = 0.0, add_self_loops: bool = True,
+                 bias: bool = True, **kwargs):
+        super().__init__()
+        if dropout != 0.0:
+            raise NotImplementedError("GATConv: attention dropout is not on the HIP path")
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
+        self.add_self_loops = add_self_loops
+        self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(heads * out_channels if concat else out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self._loops_memo = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for t in (self.lin.weight, self.att_src, self.att_dst):
+            a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+            t.data.uniform_(-a, a)
+        if self.bias is not None:
+            self.bias.data.fill_(0)
+
+    def _with_self_loops(self, edge_index, n):
+        """remove_self_loops then add_self_loops (pure function of the edge list; memoised on the tensor)."""
+        m = self._loops_memo
+        if m is not None and m[0] is edge_index and m[1] == (edge_index._version, n):
+            return m[2]
+        from ...utils._norm import add_remaining_self_loops
+        out, _ = add_remaining_self_loops(edge_index, None, 1.0, n, with_weights=False)
+        self._loops_memo = (edge_index, (edge_index._version, n), out)
+        return out
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+        _cabi.require_gpu(x, edge_index)
+        n, hds, c = x.size(0), self.heads, self.out_channels
+        h = self.lin(x).view(n, hds, c)
+        a_src = (h * self.att_src).sum(dim=-1)
+        a_dst = (h * self.att_dst).sum(dim=-1)
+        if self.add_self_loops:
+            edge_index = self._with_self_loops(edge_index, n)
+        pat = GLOBAL_PATTERNS.get(edge_index, n, n, "source_to_target")
+        outs = [_GatAggregate.apply(h[:, k], a_src[:, k], a_dst[:, k], pat, self.negative_slope)
+                for k in range(hds)]
+        out = torch.cat(outs, dim=1) if self.concat else torch.stack(outs, dim=1).mean(dim=1)
+        return out if self.bias is None else out + self.bias
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})'
+
+
+class SDRLayer(nn.Module):
+    r"""The signed directed relationship layer of SDGNN (reference nn/signed/SDGNN.py:13-64): one GATConv
+    per motif edge list, concatenated with the input, then Linear-Tanh-Linear."""
+
+    def __init__(self, in_dim: int = 20, out_dim: int = 20, edge_lists: List[torch.Tensor] = [], **kwargs):
+        super().__init__(**kwargs)
+        self.edge_lists = edge_lists
+        self.aggs = []
+        for i in range(len(edge_lists)):
+            self.aggs.append(GATConv(in_dim, out_dim))
+            self.add_module('agg_{}'.format(i), self.aggs[-1])
+        self.mlp_layer = nn.Sequential(nn.Linear(in_dim * (len(edge_lists) + 1), out_dim), nn.Tanh(),
+                                       nn.Linear(out_dim, out_dim))
+
+    def reset_parameters(self):
+        def init_weights(m):
+            if type(m) == nn.Linear:
+                torch.nn.init.kaiming_normal_(m.weight)
+        self.mlp_layer.apply(init_weights)
+        for agg in self.aggs:
+            agg.reset_parameters()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        neigh = [agg(x, edges) for edges, agg in zip(self.edge_lists, self.aggs)]
+        return self.mlp_layer(torch.cat([x] + neigh, 1))

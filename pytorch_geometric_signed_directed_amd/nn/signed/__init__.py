@@ -1,2 +1,3 @@
 from .SGCNConv import SGCNConv  # noqa: F401
 from .SIMPA import SIMPA  # noqa: F401
+from .GATConv import GATConv, SDRLayer  # noqa: F401

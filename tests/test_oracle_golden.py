@@ -162,3 +162,24 @@ def test_complex_relu():
     g = load_golden("complex_relu")
     o_r, o_i = R.complex_relu(g.t("real"), g.t("imag"))
     assert np.array_equal(o_r.numpy(), g["out_real"]) and np.array_equal(o_i.numpy(), g["out_imag"])
+
+
+def test_gat_conv_and_sdr_layer():
+    """Attention aggregate (reference SDRLayer over the restated PyG GATConv) vs the oracle."""
+    g = load_golden("gat_conv")
+    x = g.t("x").requires_grad_()
+    prm = {k[3:]: g.t(k).requires_grad_() for k in g if k.startswith("sd.")}
+    out = R.gat_conv(x, g.t("edge_index"), prm["lin.weight"], prm["att_src"], prm["att_dst"], prm["bias"])
+    assert_close(out, g["out"])
+    (out * g.t("grad_out")).sum().backward()
+    assert_close(x.grad, g["dx"])
+    for k, p in prm.items():
+        assert_close(p.grad, g["d." + k], 2e-6)
+    g = load_golden("sdr_layer")
+    x = g.t("x")
+    neigh = [R.gat_conv(x, g.t(f"edges{k}"), g.t(f"sd.agg_{k}.lin.weight"), g.t(f"sd.agg_{k}.att_src"),
+                        g.t(f"sd.agg_{k}.att_dst"), g.t(f"sd.agg_{k}.bias")) for k in range(4)]
+    hcat = torch.cat([x] + neigh, 1)
+    hid = torch.tanh(torch.nn.functional.linear(hcat, g.t("sd.mlp_layer.0.weight"), g.t("sd.mlp_layer.0.bias")))
+    out = torch.nn.functional.linear(hid, g.t("sd.mlp_layer.2.weight"), g.t("sd.mlp_layer.2.bias"))
+    assert_close(out, g["out"])
