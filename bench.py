@@ -178,6 +178,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launches, kernel_ms = _cabi.prof_collect("spmm2")
+    other = {k: _cabi.prof_collect(k) for k in ("dense", "dense_bwd")}
     _cabi.prof_reset()
 
     if rank == 0:
@@ -221,6 +222,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": int(launches), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
+            "kernel_ms_per_step": {"spmm2": kernel_ms / args.steps,
+                                   **{k: v[1] / args.steps for k, v in other.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hidden)

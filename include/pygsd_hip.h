@@ -241,8 +241,9 @@ enum {
     PYGSD_K_SDDMM = 2,
     PYGSD_K_BUILD = 3,
     PYGSD_K_ELEMENTWISE = 4,
-    PYGSD_K_DENSE = 5,
-    PYGSD_K_COUNT = 6
+    PYGSD_K_DENSE = 5,      /* fused dense forward */
+    PYGSD_K_DENSE_BWD = 6,  /* fused dense backward (+ partial reduction) */
+    PYGSD_K_COUNT = 7
 };
 int pygsd_prof_enable(int32_t on);
 int pygsd_prof_reset(void);

@@ -14,9 +14,9 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpygsd_hip.so")
 _lib = None
 
-K_SPMM, K_SPMM2, K_SDDMM, K_BUILD, K_ELEMENTWISE, K_DENSE = range(6)
+K_SPMM, K_SPMM2, K_SDDMM, K_BUILD, K_ELEMENTWISE, K_DENSE, K_DENSE_BWD = range(7)
 KERNEL_IDS = {"spmm": K_SPMM, "spmm2": K_SPMM2, "sddmm": K_SDDMM, "build": K_BUILD,
-              "elementwise": K_ELEMENTWISE, "dense": K_DENSE}
+              "elementwise": K_ELEMENTWISE, "dense": K_DENSE, "dense_bwd": K_DENSE_BWD}
 
 # name -> (restype, argtypes); must list every symbol include/pygsd_hip.h declares
 PROTOTYPES = {

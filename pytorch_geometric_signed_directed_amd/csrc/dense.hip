@@ -45,7 +45,12 @@ struct DenseFwdArgs {
 };
 
 // grid = (row blocks, ceil(f_out / 64)); block = 256 threads = 4 wavefronts x 16 rows.
-template <int NT>
+// The MFMA is issued TRANSPOSED (A operand = W^T fragment, B operand = activation fragment), so the
+// C/D layout (col = lane & 15, row = 4 (lane >> 4) + reg) hands every lane 4 CONSECUTIVE output features
+// of ONE node row: the epilogue is one float4 store per tile instead of four scalar stores.
+// FIN > 0 fixes f_in at compile time: the feature loop unrolls and all of a Chebyshev term's 16-byte
+// loads are in flight before its first MFMA.
+template <int NT, int FIN>
 __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -53,7 +58,8 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs p)
     const int n0 = static_cast<int>(blockIdx.y) * kChunk;
     constexpr int nc = NT * 16;
     constexpr int ws = nc + kPad;
-    const int wrows = p.k1 * p.f_in;
+    const int f_in = FIN > 0 ? FIN : p.f_in;
+    const int wrows = p.k1 * f_in;
     for (int idx = tid; idx < wrows * nc; idx += 256) {
         const int r = idx / nc, c = idx - r * nc;
         lds[r * ws + c] = p.w[static_cast<int64_t>(r) * p.f_out + n0 + c];
@@ -73,10 +79,11 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs p)
             acc_i[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         for (int k = 0; k < p.k1; ++k) {
-            const float* ap = p.a[k] + static_cast<int64_t>(lrow) * p.f_in + 4 * g;
-            const float* bp = p.b[k] + static_cast<int64_t>(lrow) * p.f_in + 4 * g;
-            const float* wk = lds + (k * p.f_in + 4 * g) * ws + i;
-            for (int t = 0; t < p.f_in; t += 16) {
+            const float* ap = p.a[k] + static_cast<int64_t>(lrow) * f_in + 4 * g;
+            const float* bp = p.b[k] + static_cast<int64_t>(lrow) * f_in + 4 * g;
+            const float* wk = lds + (k * f_in + 4 * g) * ws + i;
+#pragma unroll
+            for (int t = 0; t < f_in; t += 16) {
                 const float4 a = ldg4(ap + t);
                 const float4 b = ldg4(bp + t);
                 const float d[4] = {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w};
@@ -87,25 +94,24 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs p)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const float w = wt[m * ws + nt * 16];
-                        acc_r[nt] = mfma(d[m], w, acc_r[nt]);
-                        acc_i[nt] = mfma(s[m], w, acc_i[nt]);
+                        acc_r[nt] = mfma(w, d[m], acc_r[nt]);   // (W^T)(D^T): rows = out features
+                        acc_i[nt] = mfma(w, s[m], acc_i[nt]);
                     }
                 }
             }
         }
-        // C/D layout of mfma_16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
+        // transposed C/D: lane (i, g), reg r  ->  out[node r0 + i][feature n0 + 16 nt + 4 g + r]
+        if (r0 + i < p.n_rows) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = n0 + nt * 16 + i;
-            const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int orow = r0 + 4 * g + r;
-                if (orow < p.n_rows) {
-                    const int64_t o = static_cast<int64_t>(orow) * p.f_out + col;
-                    p.out_r[o] = acc_r[nt][r] + bv;
-                    p.out_i[o] = acc_i[nt][r] + bv;
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = n0 + nt * 16 + 4 * g;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias) bv = ldg4(p.bias + col);
+                const int64_t o = static_cast<int64_t>(r0 + i) * p.f_out + col;
+                *reinterpret_cast<float4*>(p.out_r + o) =
+                    make_float4(acc_r[nt][0] + bv.x, acc_r[nt][1] + bv.y, acc_r[nt][2] + bv.z, acc_r[nt][3] + bv.w);
+                *reinterpret_cast<float4*>(p.out_i + o) =
+                    make_float4(acc_i[nt][0] + bv.x, acc_i[nt][1] + bv.y, acc_i[nt][2] + bv.z, acc_i[nt][3] + bv.w);
             }
         }
     }
@@ -127,7 +133,7 @@ struct DenseBwdArgs {
 // dA_k[:, chunk ci], dB_k[:, chunk ci] for its rows and one partial of dW_k[chunk ci, :] (+ db when
 // k == 0 and ci == 0).  NTI = f_in-chunk tiles (<= 4), NTO = f_out tiles (<= 8).
 template <int NTI, int NTO>
-__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs p)
+__global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(DenseBwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -164,57 +170,66 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs p)
     for (int tile = static_cast<int>(blockIdx.x) * 4 + (tid >> 6); tile < n_tiles;
          tile += static_cast<int>(gridDim.x) * 4) {
         const int r0 = tile << 4;
-        // ---- phase 1: dA_k, dB_k tile = [P | M] (16 x f_out) . W_k^T (f_out x fc) --------------
-        {
-            const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;
-            const float* grp = p.gr + static_cast<int64_t>(lrow) * p.f_out + 4 * g;
-            const float* gip = p.gi + static_cast<int64_t>(lrow) * p.f_out + 4 * g;
-            f32x4 acc_a[NTI], acc_b[NTI];
+        // ---- all of the tile's loads first (phase-1 float4 rows of G, phase-2 column fragments of
+        //      G / A_k / B_k), so every fetch is in flight before the first MFMA and none of them queues
+        //      behind this tile's dA / dB stores -------------------------------------------------------
+        const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;
+        const float* grp = p.gr + static_cast<int64_t>(lrow) * p.f_out + 4 * g;
+        const float* gip = p.gi + static_cast<int64_t>(lrow) * p.f_out + 4 * g;
+        float4 xg[NTO], yg[NTO];
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) {
+            xg[nt] = ldg4(grp + nt * 16);
+            yg[nt] = ldg4(gip + nt * 16);
+        }
+        float av[4][NTI], bv[4][NTI];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // MFMA step s of phase 2 consumes rows {4 g + s : g = 0..3}; lane (i, g) supplies column i.
+            // A_k / B_k come from HBM: fetched now, consumed after phase 1.
+            const int row = r0 + 4 * g + s;
+            const bool live = row < p.n_rows;
+            const int64_t ro = static_cast<int64_t>(live ? row : 0);
 #pragma unroll
             for (int ft = 0; ft < NTI; ++ft) {
-                acc_a[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc_b[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+                av[s][ft] = live ? ak[ro * p.f_in + c0 + ft * 16 + i] : 0.f;
+                bv[s][ft] = live ? bk[ro * p.f_in + c0 + ft * 16 + i] : 0.f;
             }
+        }
+        // ---- phase 1: dA_k, dB_k tile = [P | M] (16 x f_out) . W_k^T (f_out x fc) --------------------
+        f32x4 acc_a[NTI], acc_b[NTI];
+#pragma unroll
+        for (int ft = 0; ft < NTI; ++ft) {
+            acc_a[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc_b[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        {
             const float* wk = lds + (4 * g) * ws + i;
 #pragma unroll
-            for (int t = 0; t < fo; t += 16) {
-                const float4 x = ldg4(grp + t);
-                const float4 y = ldg4(gip + t);
+            for (int nt = 0; nt < NTO; ++nt) {
+                const float4 x = xg[nt], y = yg[nt];
                 const float pp[4] = {x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w};
                 const float mm[4] = {y.x - x.x, y.y - x.y, y.z - x.z, y.w - x.w};
-                const float* wt = wk + t * ws;
+                const float* wt = wk + nt * 16 * ws;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
 #pragma unroll
                     for (int ft = 0; ft < NTI; ++ft) {
                         const float w = wt[m * ws + ft * 16];
-                        acc_a[ft] = mfma(pp[m], w, acc_a[ft]);
-                        acc_b[ft] = mfma(mm[m], w, acc_b[ft]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int ft = 0; ft < NTI; ++ft) {
-                const int col = c0 + ft * 16 + i;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int orow = r0 + 4 * g + r;
-                    if (orow < p.n_rows) {
-                        const int64_t o = static_cast<int64_t>(orow) * p.f_in + col;
-                        dak[o] = acc_a[ft][r];
-                        dbk[o] = acc_b[ft][r];
+                        acc_a[ft] = mfma(w, pp[m], acc_a[ft]);   // transposed issue, see dense_fwd_kernel
+                        acc_b[ft] = mfma(w, mm[m], acc_b[ft]);
                     }
                 }
             }
         }
-        // ---- phase 2: dW_k[chunk, :] += A_tile^T P + B_tile^T M  (reduction over the 16 rows) ----
-        // MFMA step s consumes rows {4 g + s : g = 0..3}; lane (i, g) supplies column i of that row.
+        // ---- phase 2: dW_k[chunk, :] += A_tile^T P + B_tile^T M  (reduction over the 16 rows) ----------
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            // column fragments of G for these rows: L1 / L2 hits (the same lines were read for phase 1)
             const int row = r0 + 4 * g + s;
             const bool live = row < p.n_rows;
             const int64_t ro = static_cast<int64_t>(live ? row : 0);
-            float pb[NTO], mb[NTO], av[NTI], bv[NTI];
+            float pb[NTO], mb[NTO];
 #pragma unroll
             for (int nt = 0; nt < NTO; ++nt) {
                 const float x = live ? p.gr[ro * p.f_out + nt * 16 + i] : 0.f;
@@ -222,21 +237,28 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs p)
                 pb[nt] = x + y;
                 mb[nt] = y - x;
             }
-#pragma unroll
-            for (int ft = 0; ft < NTI; ++ft) {
-                av[ft] = live ? ak[ro * p.f_in + c0 + ft * 16 + i] : 0.f;
-                bv[ft] = live ? bk[ro * p.f_in + c0 + ft * 16 + i] : 0.f;
-            }
+            // two sweeps, so that consecutive MFMAs never hit the same accumulator (40-cycle dependent
+            // latency vs 32-cycle issue)
 #pragma unroll
             for (int ft = 0; ft < NTI; ++ft)
 #pragma unroll
-                for (int nt = 0; nt < NTO; ++nt) {
-                    acc_w[ft][nt] = mfma(av[ft], pb[nt], acc_w[ft][nt]);
-                    acc_w[ft][nt] = mfma(bv[ft], mb[nt], acc_w[ft][nt]);
-                }
+                for (int nt = 0; nt < NTO; ++nt) acc_w[ft][nt] = mfma(av[s][ft], pb[nt], acc_w[ft][nt]);
+#pragma unroll
+            for (int ft = 0; ft < NTI; ++ft)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) acc_w[ft][nt] = mfma(bv[s][ft], mb[nt], acc_w[ft][nt]);
             if (do_bias) {
 #pragma unroll
                 for (int nt = 0; nt < NTO; ++nt) acc_bias[nt] += pb[nt];
+            }
+        }
+        // ---- stores last -----------------------------------------------------------------------------
+        if (r0 + i < p.n_rows) {
+#pragma unroll
+            for (int ft = 0; ft < NTI; ++ft) {
+                const int64_t o = static_cast<int64_t>(r0 + i) * p.f_in + c0 + ft * 16 + 4 * g;
+                *reinterpret_cast<float4*>(dak + o) = make_float4(acc_a[ft][0], acc_a[ft][1], acc_a[ft][2], acc_a[ft][3]);
+                *reinterpret_cast<float4*>(dbk + o) = make_float4(acc_b[ft][0], acc_b[ft][1], acc_b[ft][2], acc_b[ft][3]);
             }
         }
     }
@@ -313,14 +335,22 @@ int set_lds(Kern kern, size_t bytes)
     return 0;
 }
 
+template <int NT, int FIN>
+int launch_fwd_fin(const DenseFwdArgs& a, unsigned gy, size_t lds_bytes, hipStream_t s)
+{
+    if (int rc = set_lds(dense_fwd_kernel<NT, FIN>, lds_bytes)) return rc;
+    hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN>), dim3(row_blocks(a.n_rows, 2048), gy), dim3(256), lds_bytes, s, a);
+    return check_launch("dense_fwd_kernel");
+}
+
 template <int NT>
 int launch_fwd(const DenseFwdArgs& a, unsigned gy, hipStream_t s)
 {
     const size_t lds_bytes = static_cast<size_t>(a.k1) * a.f_in * (NT * 16 + kPad) * sizeof(float);
     PYGSD_REQUIRE(lds_bytes <= 160 * 1024 - 1024, "pygsd_magnetic_dense_fwd_f32: W slice needs %zu B of LDS", lds_bytes);
-    if (int rc = set_lds(dense_fwd_kernel<NT>, lds_bytes)) return rc;
-    hipLaunchKernelGGL(dense_fwd_kernel<NT>, dim3(row_blocks(a.n_rows, 2048), gy), dim3(256), lds_bytes, s, a);
-    return check_launch("dense_fwd_kernel");
+    if (a.f_in == 64) return launch_fwd_fin<NT, 64>(a, gy, lds_bytes, s);
+    if (a.f_in == 128) return launch_fwd_fin<NT, 128>(a, gy, lds_bytes, s);
+    return launch_fwd_fin<NT, 0>(a, gy, lds_bytes, s);
 }
 
 template <int NTI, int NTO>
@@ -432,7 +462,7 @@ extern "C" int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* 
     args.gr = g_real; args.gi = g_imag; args.w = w; args.partial = static_cast<float*>(workspace);
     args.n_rows = n_rows; args.f_in = f_in; args.f_out = f_out; args.k1 = k1;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    ProfScope prof(PYGSD_K_DENSE, s);
+    ProfScope prof(PYGSD_K_DENSE_BWD, s);
     const unsigned gx = row_blocks(n_rows, 256);
     const unsigned gz = (static_cast<unsigned>(f_in) + kChunk - 1) / kChunk;
     int rc;

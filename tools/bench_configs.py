@@ -29,7 +29,7 @@ def timed(step, iters=10, warm=3):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
     _cabi.prof_enable(False)
-    prof = {k: _cabi.prof_collect(k) for k in ("spmm", "spmm2", "dense", "build")}
+    prof = {k: _cabi.prof_collect(k) for k in ("spmm", "spmm2", "dense", "dense_bwd", "build")}
     _cabi.prof_reset()
     return ms, {k: {"launches_per_step": n / iters, "ms_per_launch": (t / n if n else 0.0)} for k, (n, t) in prof.items()}
 
