@@ -107,3 +107,40 @@ def test_model_trains_one_step():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0]
+
+
+def test_train_step_captures_into_a_hipgraph():
+    """The C-ABI kernels are plain stream launches, so a whole cached-operator train step can be captured
+    by torch.cuda.graphs (hipStreamBeginCapture) and replayed: replay must reproduce the eager result."""
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    g = load_golden("model_magnet_node")
+    torch.manual_seed(0)
+    layer = MagNetConv(6, 16, 2, 0.25, False, cached=True).to(D)
+    xr, xi = g.t("x_real", D), g.t("x_imag", D)
+    ei, w = g.t("edge_index", D), g.t("edge_weight", D)
+    a, b = xr.clone().requires_grad_(), xi.clone().requires_grad_()
+
+    def step():
+        layer.zero_grad(set_to_none=False)
+        if a.grad is not None:
+            a.grad.zero_()
+        o = layer(a, b, ei, w)
+        (o[0].square().sum() + o[1].sum()).backward()
+        return o
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    want_o = [t.detach().clone() for t in step()]
+    want_g = layer.weight.grad.detach().clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_o = step()
+    layer.weight.grad.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_o[0], want_o[0]) and torch.equal(static_o[1], want_o[1])
+    assert torch.equal(layer.weight.grad, want_g)
