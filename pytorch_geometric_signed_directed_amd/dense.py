@@ -24,6 +24,9 @@ def _ptr_array(ts: Sequence[Tensor]):
 def dense_fwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, bias: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
     """out_real = sum_k (a_k - b_k) W_k + bias ; out_imag = sum_k (a_k + b_k) W_k + bias."""
     k1, f_in, f_out = weight.shape
+    for t in list(a) + list(b) + [weight]:
+        if t.dtype != torch.float32:
+            raise TypeError(f"the fused dense stage computes in float32; got {t.dtype}")
     a = [t.contiguous() for t in a]
     b = [t.contiguous() for t in b]
     n = a[0].size(0)

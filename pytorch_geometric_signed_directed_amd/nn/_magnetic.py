@@ -153,6 +153,8 @@ class MagneticChebConv(MessagePassing):
 
     def forward(self, x_real, x_imag, edge_index, edge_weight=None, lambda_max=None):
         _cabi.require_gpu(x_real, x_imag, edge_index, edge_weight)
+        if x_real.dtype != torch.float32 or x_imag.dtype != torch.float32:
+            raise TypeError(f"{type(self).__name__} computes in float32 on the HIP path; got {x_real.dtype}")
         if self.trainable_q:
             self.q = Parameter(torch.clamp(self.q, 0, 0.25))
 

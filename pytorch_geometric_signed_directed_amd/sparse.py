@@ -201,6 +201,9 @@ def _spmm_raw(csr: CSR, val: Optional[Tensor], x: Tensor, z: Optional[Tensor], a
 def _spmm2_raw(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, za: Optional[Tensor],
                zb: Optional[Tensor], alpha: float, beta: float) -> Tuple[Tensor, Tensor]:
     _cabi.require_gpu(xa, xb, za, zb, val_a, val_b)
+    for t in (xa, xb, za, zb):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError(f"the dual-operator SpMM computes in float32; got {t.dtype}")
     if xa.shape != xb.shape:
         raise ValueError("spmm2: the two inputs must have the same shape")
     xa, lda = _rows(xa)
