@@ -138,7 +138,7 @@ def main():
             (o_r.sum() + o_i.sum()).backward()
 
         def op_nnz():
-            return layer._operator.pattern.nnz
+            return layer._operator.nnz
     else:
         from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv
         layer = ShardedMagNetConv(hidden, hidden, K=1, q=0.25, num_nodes=n, edge_index=edge_index,

@@ -152,9 +152,13 @@ int pygsd_sort_keys_u64(const uint64_t* keys_in, uint64_t* keys_out, int32_t* pe
  *                        Theta_arg = sum(+-w), (|w| sums); deg = row sums of A_s (unsigned), of the |w|
  *                        sums (signed, absolute_degree) or of |A_s| (signed, not absolute_degree).
  *                        w == NULL means all ones.  Outputs: out_row/out_col int64[E_s], a_sym, theta
- *                        float[E_s], deg float[n].
+ *                        float[E_s], deg float[n], off_ptr int32[n+1] (first sorted entry of each row).
  *   pygsd_maglap_values: off-diagonal values of L: sym != 0: -(D^-1/2 A_s D^-1/2 (.) exp(i 2 pi q Theta_arg))
  *                        (diagonal is 1); sym == 0: -(A_s (.) exp(...)) (diagonal is deg).
+ *   pygsd_maglap_assemble_csr: compute layout of the scaled operator: ONE int32 CSR (rowptr[n+1],
+ *                        col[E_s+n]) over the symmetric pattern incl. the diagonal, shared by both
+ *                        orientations, with vb_* = S[row, col] (backward / by-source product) and
+ *                        vf_* = S[col, row] (forward / by-target product) -- no further sorts or gathers.
  * The same workspace (pygsd_maglap_workspace bytes) must be passed, untouched, to sort and merge.
  * ------------------------------------------------------------------------------------------- */
 int pygsd_maglap_workspace(int64_t n_edges, size_t* bytes);
@@ -163,7 +167,11 @@ int pygsd_maglap_sort(const int64_t* row, const int64_t* col, int64_t n_edges, i
 int pygsd_maglap_merge(const float* w, int64_t n_edges, int32_t n, int32_t is_signed, int32_t absolute_degree,
                        int64_t num_unique, void* workspace, size_t workspace_bytes,
                        int64_t* out_row, int64_t* out_col, float* a_sym, float* theta, float* deg,
-                       void* stream);
+                       int32_t* off_ptr, void* stream);
+int pygsd_maglap_assemble_csr(const int64_t* out_row, const int64_t* out_col, const float* off_real,
+                              const float* off_imag, const float* diag_real, const int32_t* off_ptr,
+                              int64_t num_unique, int32_t n, int32_t* rowptr, int32_t* col,
+                              float* vb_real, float* vb_imag, float* vf_real, float* vf_imag, void* stream);
 int pygsd_maglap_values(const int64_t* out_row, const int64_t* out_col, const float* a_sym,
                         const float* theta, const float* deg, int64_t num_unique, float q, int32_t sym,
                         float* off_real, float* off_imag, void* stream);

@@ -96,20 +96,74 @@ __global__ void merge_runs(const uint64_t* __restrict__ keys, const uint32_t* __
     }
 }
 
+// off_ptr[r] = first sorted entry whose row is >= r (r = 0 .. n): entry i starts every row in
+// (row[i-1], row[i]]; the virtual entry i = es closes the remaining rows.  Coalesced, no search.
+__global__ void row_starts(const int64_t* __restrict__ out_row, int64_t es, int32_t n,
+                           int32_t* __restrict__ off_ptr)
+{
+    GRID_STRIDE(i, es + 1)
+    {
+        const int64_t prev = i == 0 ? -1 : out_row[i - 1];
+        const int64_t cur = i == es ? n : out_row[i];
+        for (int64_t r = prev + 1; r <= cur; ++r) off_ptr[r] = static_cast<int32_t>(i);
+    }
+}
+
 // deg[r] = sum over the (row-sorted) entries of row r, sequential in sorted order
-__global__ void row_degree(const int64_t* __restrict__ out_row, const float* __restrict__ src, int64_t es,
-                           int32_t n, int32_t use_abs, float* __restrict__ deg)
+__global__ void row_degree(const int32_t* __restrict__ off_ptr, const float* __restrict__ src, int32_t n,
+                           int32_t use_abs, float* __restrict__ deg)
 {
     GRID_STRIDE(r, n)
     {
-        int64_t lo = 0, hi = es;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (out_row[mid] < r) lo = mid + 1; else hi = mid;
-        }
         float d = 0.f;
-        for (int64_t j = lo; j < es && out_row[j] == r; ++j) d = d + (use_abs ? fabsf(src[j]) : src[j]);
+        for (int32_t j = off_ptr[r]; j < off_ptr[r + 1]; ++j) d = d + (use_abs ? fabsf(src[j]) : src[j]);
         deg[r] = d;
+    }
+}
+
+// Compute layout of the magnetic operator: ONE int32 CSR over the symmetric pattern (off-diagonals + the
+// diagonal, columns ascending inside a row) shared by both orientations, with the values of
+// S[row, col] (by-source / backward product) and of the mirrored entry S[col, row] (by-target / forward
+// product) side by side.  Replaces two radix sorts + six gathers of the generic COO -> CSR route.
+__global__ void assemble_csr(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                             const float* __restrict__ off_re, const float* __restrict__ off_im,
+                             const float* __restrict__ diag_re, const int32_t* __restrict__ off_ptr, int64_t es,
+                             int32_t n, int32_t* __restrict__ rowptr, int32_t* __restrict__ ccol,
+                             float* __restrict__ vb_re, float* __restrict__ vb_im, float* __restrict__ vf_re,
+                             float* __restrict__ vf_im)
+{
+    GRID_STRIDE(t, es + n)
+    {
+        if (t < es) {
+            const int32_t r = static_cast<int32_t>(row[t]), c = static_cast<int32_t>(col[t]);
+            const int64_t slot = t + r + (c > r ? 1 : 0);
+            int32_t lo = off_ptr[c], hi = off_ptr[c + 1];      // mirror (c, r): search row c for column r
+            while (lo < hi) {
+                const int32_t mid = (lo + hi) >> 1;
+                if (col[mid] < r) lo = mid + 1; else hi = mid;
+            }
+            ccol[slot] = c;
+            vb_re[slot] = off_re[t];
+            vb_im[slot] = off_im[t];
+            vf_re[slot] = off_re[lo];
+            vf_im[slot] = off_im[lo];
+        } else {
+            const int32_t r = static_cast<int32_t>(t - es);
+            int32_t lo = off_ptr[r], hi = off_ptr[r + 1];
+            const int32_t beg = lo;
+            while (lo < hi) {
+                const int32_t mid = (lo + hi) >> 1;
+                if (col[mid] < r) lo = mid + 1; else hi = mid;
+            }
+            const int64_t slot = static_cast<int64_t>(beg) + r + (lo - beg);
+            ccol[slot] = r;
+            vb_re[slot] = diag_re[r];
+            vf_re[slot] = diag_re[r];
+            vb_im[slot] = 0.f;
+            vf_im[slot] = 0.f;
+            rowptr[r] = beg + r;
+            if (r == n - 1) rowptr[n] = static_cast<int32_t>(es + n);
+        }
     }
 }
 
@@ -333,16 +387,20 @@ extern "C" int pygsd_maglap_sort(const int64_t* row, const int64_t* col, int64_t
 extern "C" int pygsd_maglap_merge(const float* w, int64_t n_edges, int32_t n, int32_t is_signed,
                                   int32_t absolute_degree, int64_t num_unique, void* workspace,
                                   size_t workspace_bytes, int64_t* out_row, int64_t* out_col, float* a_sym,
-                                  float* theta, float* deg, void* stream)
+                                  float* theta, float* deg, int32_t* off_ptr, void* stream)
 {
     PYGSD_REQUIRE(n_edges >= 0 && n >= 0 && num_unique >= 0, "pygsd_maglap_merge: negative size");
+    PYGSD_REQUIRE(off_ptr, "pygsd_maglap_merge: null off_ptr");
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_BUILD, s);
     if (n > 0) {
         PYGSD_REQUIRE(deg, "pygsd_maglap_merge: null deg");
         PYGSD_HIP_TRY(hipMemsetAsync(deg, 0, sizeof(float) * static_cast<size_t>(n), s));
     }
-    if (n_edges == 0 || num_unique == 0) return 0;
+    if (n_edges == 0 || num_unique == 0) {
+        PYGSD_HIP_TRY(hipMemsetAsync(off_ptr, 0, sizeof(int32_t) * (static_cast<size_t>(n) + 1), s));
+        return 0;
+    }
     PYGSD_REQUIRE(workspace && out_row && out_col && a_sym && theta, "pygsd_maglap_merge: null pointer");
     LapWs l;
     if (int rc = lap_layout(n_edges, &l)) return rc;
@@ -356,10 +414,35 @@ extern "C" int pygsd_maglap_merge(const float* w, int64_t n_edges, int32_t n, in
                        reinterpret_cast<uint32_t*>(base + l.flags), reinterpret_cast<uint32_t*>(base + l.seg), m,
                        n_edges, static_cast<uint64_t>(n), w, out_row, out_col, a_sym, theta, a_abs);
     if (int rc = check_launch("merge_runs")) return rc;
+    hipLaunchKernelGGL(row_starts, dim3(grid_for(num_unique + 1)), dim3(kBlock), 0, s, out_row, num_unique, n, off_ptr);
+    if (int rc = check_launch("row_starts")) return rc;
     const float* src = a_abs ? a_abs : a_sym;
     const int use_abs = (is_signed && !absolute_degree) ? 1 : 0;
-    hipLaunchKernelGGL(row_degree, dim3(grid_for(n)), dim3(kBlock), 0, s, out_row, src, num_unique, n, use_abs, deg);
+    hipLaunchKernelGGL(row_degree, dim3(grid_for(n)), dim3(kBlock), 0, s, off_ptr, src, n, use_abs, deg);
     return check_launch("row_degree");
+}
+
+extern "C" int pygsd_maglap_assemble_csr(const int64_t* out_row, const int64_t* out_col, const float* off_real,
+                                         const float* off_imag, const float* diag_real, const int32_t* off_ptr,
+                                         int64_t num_unique, int32_t n, int32_t* rowptr, int32_t* col,
+                                         float* vb_real, float* vb_imag, float* vf_real, float* vf_imag,
+                                         void* stream)
+{
+    PYGSD_REQUIRE(num_unique >= 0 && n >= 0 && num_unique + n < (int64_t(1) << 31),
+                  "pygsd_maglap_assemble_csr: size out of int32 range");
+    PYGSD_REQUIRE(rowptr, "pygsd_maglap_assemble_csr: null rowptr");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_BUILD, s);
+    if (n == 0) {
+        PYGSD_HIP_TRY(hipMemsetAsync(rowptr, 0, sizeof(int32_t), s));
+        return 0;
+    }
+    PYGSD_REQUIRE(diag_real && off_ptr && col && vb_real && vb_imag && vf_real && vf_imag &&
+                      (num_unique == 0 || (out_row && out_col && off_real && off_imag)),
+                  "pygsd_maglap_assemble_csr: null pointer");
+    hipLaunchKernelGGL(assemble_csr, dim3(grid_for(num_unique + n)), dim3(kBlock), 0, s, out_row, out_col, off_real,
+                       off_imag, diag_real, off_ptr, num_unique, n, rowptr, col, vb_real, vb_imag, vf_real, vf_imag);
+    return check_launch("assemble_csr");
 }
 
 extern "C" int pygsd_maglap_values(const int64_t* out_row, const int64_t* out_col, const float* a_sym,

@@ -8,7 +8,7 @@ import torch
 
 from . import _cabi
 from ._cabi import check, ptr, stream_ptr
-from .sparse import Pattern, _spmm2_raw
+from .sparse import _spmm2_raw
 
 Tensor = torch.Tensor
 
@@ -67,29 +67,53 @@ def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor,
     return da, db, dw, dbias
 
 
+class FixedSpmm2(torch.autograd.Function):
+    """(ya, yb) = alpha * (S_r^T-chain step on xa, S_i^T-chain step on xb) + beta * (za, zb) for an operator
+    whose values carry no gradient: forward on the by-target values, backward on the by-source values of
+    the shared CSR."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, za, zb, op, alpha: float, beta: float):
+        ya, yb = _spmm2_raw(op.csr, op.values_fwd[0], op.values_fwd[1], xa, xb, za, zb, alpha, beta)
+        ctx.op, ctx.alpha, ctx.beta = op, alpha, beta
+        return ya, yb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ga, gb):
+        op = ctx.op
+        gxa = gxb = gza = gzb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gxa, gxb = _spmm2_raw(op.csr, op.values_bwd[0], op.values_bwd[1], ga.contiguous(), gb.contiguous(),
+                                  None, None, ctx.alpha, 0.0)
+        if ctx.needs_input_grad[2]:
+            gza = ga * ctx.beta
+        if ctx.needs_input_grad[3]:
+            gzb = gb * ctx.beta
+        return gxa, gxb, gza, gzb, None, None, None
+
+
 class MagneticConvFunction(torch.autograd.Function):
     """One autograd node for a whole MagNetConv / MSConv layer with fixed operator values:
     K fused dual-value SpMMs (Chebyshev recurrence in the kernel epilogue) + one fused MFMA dense
-    pass forward; one fused MFMA dense pass + K SpMMs over the by-source CSR backward (the adjoint
+    pass forward; one fused MFMA dense pass + K SpMMs over the by-source values backward (the adjoint
     recurrence gT_{k-1} += 2 S^T gT_k, gT_{k-2} -= gT_k and the final gX = gT_0 + S^T gT_1 ride on
     the SpMM's beta*Z epilogue)."""
 
     @staticmethod
-    def forward(ctx, x_real, x_imag, weight, bias, pattern: Pattern, values_real, values_imag):
+    def forward(ctx, x_real, x_imag, weight, bias, op):
         k1 = weight.size(0)
-        fwd = pattern.fwd
-        vr, vi = pattern.values_for(values_real, "fwd"), pattern.values_for(values_imag, "fwd")
+        csr, (vr, vi) = op.csr, op.values_fwd
         ta, tb = [x_real.contiguous()], [x_imag.contiguous()]
         for k in range(1, k1):
             if k == 1:
-                ya, yb = _spmm2_raw(fwd, vr, vi, ta[0], tb[0], None, None, 1.0, 0.0)
+                ya, yb = _spmm2_raw(csr, vr, vi, ta[0], tb[0], None, None, 1.0, 0.0)
             else:
-                ya, yb = _spmm2_raw(fwd, vr, vi, ta[k - 1], tb[k - 1], ta[k - 2], tb[k - 2], 2.0, -1.0)
+                ya, yb = _spmm2_raw(csr, vr, vi, ta[k - 1], tb[k - 1], ta[k - 2], tb[k - 2], 2.0, -1.0)
             ta.append(ya)
             tb.append(yb)
         out_r, out_i = dense_fwd_raw(ta, tb, weight, bias)
-        ctx.pattern, ctx.k1, ctx.has_bias = pattern, k1, bias is not None
-        ctx.values = (values_real, values_imag)
+        ctx.op, ctx.k1, ctx.has_bias = op, k1, bias is not None
         ctx.save_for_backward(weight, *ta, *tb)
         return out_r, out_i
 
@@ -102,18 +126,16 @@ class MagneticConvFunction(torch.autograd.Function):
         da, db, dw, dbias = dense_bwd_raw(ta, tb, weight, g_r, g_i)
         gx_r = gx_i = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            pat = ctx.pattern
-            bwd = pat.bwd
-            vr, vi = pat.values_for(ctx.values[0], "bwd"), pat.values_for(ctx.values[1], "bwd")
+            csr, (vr, vi) = ctx.op.csr, ctx.op.values_bwd
             for k in range(k1 - 1, 1, -1):
-                da[k - 1], db[k - 1] = _spmm2_raw(bwd, vr, vi, da[k], db[k], da[k - 1], db[k - 1], 2.0, 1.0)
+                da[k - 1], db[k - 1] = _spmm2_raw(csr, vr, vi, da[k], db[k], da[k - 1], db[k - 1], 2.0, 1.0)
                 da[k - 2].sub_(da[k])
                 db[k - 2].sub_(db[k])
             if k1 > 1:
-                gx_r, gx_i = _spmm2_raw(bwd, vr, vi, da[1], db[1], da[0], db[0], 1.0, 1.0)
+                gx_r, gx_i = _spmm2_raw(csr, vr, vi, da[1], db[1], da[0], db[0], 1.0, 1.0)
             else:
                 gx_r, gx_i = da[0], db[0]
-        return gx_r, gx_i, dw, (dbias if ctx.has_bias else None), None, None, None
+        return gx_r, gx_i, dw, (dbias if ctx.has_bias else None), None
 
 
 class _TallLinear(torch.autograd.Function):

@@ -20,9 +20,9 @@ from torch.nn import Parameter
 
 from .. import _cabi
 from ..message_passing import MessagePassing
-from ..dense import MagneticConvFunction, dense_supported, tall_linear
+from ..dense import FixedSpmm2, MagneticConvFunction, dense_supported, tall_linear
 from ..sparse import Pattern, spmm2
-from ..utils._laplacian import laplacian_parts, laplacian_values
+from ..utils._laplacian import assemble_operator_csr, laplacian_parts, laplacian_values
 
 Tensor = torch.Tensor
 
@@ -39,14 +39,38 @@ def zeros(t: Optional[Tensor]):
 
 
 class MagneticOperator:
-    """The scaled operator 2L/lambda_max - I in HBM: one Pattern + real / imaginary value arrays
-    (COO order: E_s off-diagonals sorted by (row, col), then the N diagonal entries)."""
+    """The scaled operator 2L/lambda_max - I in HBM.
 
-    def __init__(self, pattern, values_real, values_imag, off_index, off_real, off_imag, diag_scaled, n):
-        self.pattern, self.values_real, self.values_imag = pattern, values_real, values_imag
+    Compute layout (built by pygsd_maglap_assemble_csr, no sorts): ONE int32 CSR over the symmetric
+    pattern (E_s off-diagonals + the N diagonal entries, columns ascending) shared by the forward
+    (by-target) and backward (by-source) products, with the real / imaginary values of each orientation.
+    The COO view (off-diagonals sorted by (row, col), then the diagonal) is kept for the reference-format
+    tuple and for the generic autograd path (trainable q)."""
+
+    def __init__(self, csr, values_fwd, values_bwd, off_index, off_real, off_imag, diag_scaled, n):
+        self.csr, self.values_fwd, self.values_bwd = csr, values_fwd, values_bwd
         self._off_index, self._off_real, self._off_imag = off_index, off_real, off_imag
         self._diag_scaled, self.n = diag_scaled, n
+        self.nnz = int(off_real.numel()) + n
         self._ref_format = None
+        self._coo = None
+        self._pattern = None
+
+    def coo(self):
+        """(edge_index [2, E_s + N], values_real, values_imag) with the two reference self-loop sets folded."""
+        if self._coo is None:
+            loops = torch.arange(self.n, dtype=torch.long, device=self._off_index.device).unsqueeze(0).repeat(2, 1)
+            self._coo = (torch.cat([self._off_index, loops], dim=1),
+                         torch.cat([self._off_real, self._diag_scaled - 1.0]),
+                         torch.cat([self._off_imag, torch.zeros_like(self._diag_scaled)]))
+        return self._coo
+
+    @property
+    def pattern(self):
+        """Generic COO-based pattern (both CSR orientations by stable sort) -- only built on demand."""
+        if self._pattern is None:
+            self._pattern = Pattern(self.coo()[0], self.n, self.n, "source_to_target")
+        return self._pattern
 
     def reference_format(self):
         """(edge_index_real, edge_index_imag, norm_real, norm_imag) exactly as
@@ -119,13 +143,10 @@ class MagneticChebConv(MessagePassing):
         off_i = off_i.masked_fill(off_i == float("inf"), 0)
         diag_s = (2.0 * diag) / lam
         diag_s = diag_s.masked_fill(diag_s == float("inf"), 0)
-        loops = torch.arange(num_nodes, dtype=torch.long, device=edge_index.device).unsqueeze(0).repeat(2, 1)
-        index = torch.cat([parts.index, loops], dim=1)
-        values_real = torch.cat([off_r, diag_s - 1.0])
-        values_imag = torch.cat([off_i, torch.zeros_like(diag_s)])
-        pattern = Pattern(index, num_nodes, num_nodes, "source_to_target")
-        return MagneticOperator(pattern, values_real, values_imag, parts.index, off_r, off_i, diag_s,
-                                num_nodes)
+        csr = vf = vb = None
+        if not (off_r.requires_grad or off_i.requires_grad):
+            csr, vf, vb = assemble_operator_csr(parts, off_r, off_i, diag_s - 1.0)
+        return MagneticOperator(csr, vf, vb, parts.index, off_r, off_i, diag_s, num_nodes)
 
     def __norm__(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype=None):
         """Reference-format operator (MagNetConv.py:78-120): edge_index_real, edge_index_imag,
@@ -190,25 +211,30 @@ class MagneticChebConv(MessagePassing):
                                                   self.q, self.normalization, lambda_max, x_real.dtype)
 
         op = self._operator
-        w_r, w_i = op.values_real, op.values_imag
-        fused = (not (w_r.requires_grad or w_i.requires_grad) and x_real.dim() == 2
-                 and x_real.dtype == torch.float32
-                 and dense_supported(self.in_channels, self.out_channels, self.weight.size(0)))
-        if fused:
+        fixed = op.csr is not None            # operator values carry no gradient (q not trainable)
+        if fixed and x_real.dim() == 2 and dense_supported(self.in_channels, self.out_channels, self.weight.size(0)):
             # whole layer as one autograd node: K dual SpMMs + one MFMA dense pass each way
-            return MagneticConvFunction.apply(x_real, x_imag, self.weight, self.bias, op.pattern, w_r, w_i)
+            return MagneticConvFunction.apply(x_real, x_imag, self.weight, self.bias, op)
         # general path (trainable q -> edge-value gradients through SDDMM; shapes the MFMA kernels
         # do not tile): same HIP SpMMs, dense stage composed from library GEMMs
+        if fixed:
+            def prop(xa, xb, za=None, zb=None, alpha=1.0, beta=0.0):
+                return FixedSpmm2.apply(xa, xb, za, zb, op, alpha, beta)
+        else:
+            _, w_r, w_i = op.coo()
+
+            def prop(xa, xb, za=None, zb=None, alpha=1.0, beta=0.0):
+                return spmm2(op.pattern, xa, xb, w_r, w_i, za=za, zb=zb, alpha=alpha, beta=beta)
         # A-chain on (S_r, X_r), B-chain on (S_i, X_i); one fused traversal per Chebyshev order
         t0_r, t0_i = x_real, x_imag
         acc_a = tall_linear(t0_r, self.weight[0])
         acc_b = tall_linear(t0_i, self.weight[0])
         if self.weight.size(0) > 1:
-            t1_r, t1_i = spmm2(op.pattern, t0_r, t0_i, w_r, w_i)
+            t1_r, t1_i = prop(t0_r, t0_i)
             acc_a = acc_a + tall_linear(t1_r, self.weight[1])
             acc_b = acc_b + tall_linear(t1_i, self.weight[1])
         for k in range(2, self.weight.size(0)):
-            t2_r, t2_i = spmm2(op.pattern, t1_r, t1_i, w_r, w_i, za=t0_r, zb=t0_i, alpha=2.0, beta=-1.0)
+            t2_r, t2_i = prop(t1_r, t1_i, t0_r, t0_i, 2.0, -1.0)
             acc_a = acc_a + tall_linear(t2_r, self.weight[k])
             acc_b = acc_b + tall_linear(t2_i, self.weight[k])
             t0_r, t0_i, t1_r, t1_i = t1_r, t1_i, t2_r, t2_i

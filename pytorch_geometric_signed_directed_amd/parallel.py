@@ -162,14 +162,13 @@ class ShardedMagNetConv(torch.nn.Module):
         op = proto._build_operator(edge_index.to(device), self.plan.n_total,
                                    None if edge_weight is None else edge_weight.to(device), q, normalization,
                                    lam, torch.float32)
-        coo = torch.stack([op.pattern._gather, op.pattern._scatter])      # row 0 = source, row 1 = target
+        coo, vr, vi = op.coo()                                            # row 0 = source, row 1 = target
         self.global_nnz = int(coo.size(1)) - (self.plan.n_total - num_nodes)
         n_tot, n_pad = self.plan.n_total, self.plan.n_pad
         keep_t, sub_t = self.plan.local_entries(coo, by=1)   # forward: rows = my targets, cols = sources
         self._fwd_csr = csr_from_coo(sub_t[1], sub_t[0], n_pad, n_tot)
         keep_s, sub_s = self.plan.local_entries(coo, by=0)   # backward: rows = my sources, cols = targets
         self._bwd_csr = csr_from_coo(sub_s[0], sub_s[1], n_pad, n_tot)
-        vr, vi = op.values_real, op.values_imag
         self._fwd_vals = (gather_values(vr[keep_t], self._fwd_csr.perm), gather_values(vi[keep_t], self._fwd_csr.perm))
         self._bwd_vals = (gather_values(vr[keep_s], self._bwd_csr.perm), gather_values(vi[keep_s], self._bwd_csr.perm))
         self.local_nnz = int(keep_t.numel())

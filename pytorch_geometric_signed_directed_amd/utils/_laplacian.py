@@ -23,10 +23,11 @@ Tensor = torch.Tensor
 
 class LaplacianParts:
     """Symmetrised pattern + the ingredients of the operator values (all COO, sorted by (row, col))."""
-    __slots__ = ("index", "a_sym", "theta", "deg", "n")
+    __slots__ = ("index", "a_sym", "theta", "deg", "n", "off_ptr")
 
-    def __init__(self, index, a_sym, theta, deg, n):
+    def __init__(self, index, a_sym, theta, deg, n, off_ptr):
         self.index, self.a_sym, self.theta, self.deg, self.n = index, a_sym, theta, deg, n
+        self.off_ptr = off_ptr          # int32 [n + 1]: first sorted entry of each row
 
 
 def laplacian_parts(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, signed: bool,
@@ -57,10 +58,35 @@ def laplacian_parts(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, s
         a_sym = torch.empty(es, dtype=torch.float32, device=dev)
         theta = torch.empty(es, dtype=torch.float32, device=dev)
         deg = torch.empty(n, dtype=torch.float32, device=dev)
+        off_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         check(lib.pygsd_maglap_merge(ptr(w), e, n, 1 if signed else 0, 1 if absolute_degree else 0, es, ptr(ws),
                                      need.value, ptr(index[0]) if es else None, ptr(index[1]) if es else None,
-                                     ptr(a_sym), ptr(theta), ptr(deg), stream_ptr()), "pygsd_maglap_merge")
-    return LaplacianParts(index, a_sym, theta, deg, n)
+                                     ptr(a_sym), ptr(theta), ptr(deg), ptr(off_ptr), stream_ptr()),
+              "pygsd_maglap_merge")
+    return LaplacianParts(index, a_sym, theta, deg, n, off_ptr)
+
+
+def assemble_operator_csr(parts: LaplacianParts, off_real: Tensor, off_imag: Tensor, diag_real: Tensor):
+    """Compute layout of an operator given on the symmetrised pattern: one shared int32 CSR (diagonal
+    merged in, columns ascending) + the values for the by-source (backward) and by-target (forward)
+    products.  Returns (CSR, (vf_real, vf_imag), (vb_real, vb_imag))."""
+    from ..sparse import CSR
+    n, es = parts.n, parts.a_sym.numel()
+    dev = diag_real.device
+    nnz = es + n
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    vals = torch.empty((4, max(nnz, 1)), dtype=torch.float32, device=dev)
+    off_real, off_imag = off_real.detach().contiguous(), off_imag.detach().contiguous()
+    diag_real = diag_real.detach().contiguous()
+    with torch.cuda.device(dev):
+        check(_cabi.lib().pygsd_maglap_assemble_csr(ptr(parts.index[0]) if es else None,
+                                                    ptr(parts.index[1]) if es else None, ptr(off_real), ptr(off_imag),
+                                                    ptr(diag_real), ptr(parts.off_ptr), es, n, ptr(rowptr), ptr(col),
+                                                    ptr(vals[0]), ptr(vals[1]), ptr(vals[2]), ptr(vals[3]),
+                                                    stream_ptr()), "pygsd_maglap_assemble_csr")
+    csr = CSR(n, n, nnz, rowptr, col, None)
+    return csr, (vals[2, :nnz], vals[3, :nnz]), (vals[0, :nnz], vals[1, :nnz])
 
 
 def laplacian_values(parts: LaplacianParts, q, normalization: Optional[str]) -> Tuple[Tensor, Tensor, Tensor]:

@@ -56,7 +56,7 @@ def magnetic(name, cls, n, e, h, K, signed, **kw):
         o = layer(xr, xi, ei, w)
         (o[0].sum() + o[1].sum()).backward()
     ms, prof = timed(step)
-    nnz = layer._operator.pattern.nnz
+    nnz = layer._operator.nnz
     b = spmm_bytes(nnz, n, h) + spmm_bytes(nnz - n, n, h)
     k = prof["spmm2"]
     out[name] = {"nodes": n, "edges": int(ei.size(1)), "hidden": h, "K": K, "ms_per_step": ms,
