@@ -155,10 +155,16 @@ int pygsd_sort_keys_u64(const uint64_t* keys_in, uint64_t* keys_out, int32_t* pe
  *                        float[E_s], deg float[n], off_ptr int32[n+1] (first sorted entry of each row).
  *   pygsd_maglap_values: off-diagonal values of L: sym != 0: -(D^-1/2 A_s D^-1/2 (.) exp(i 2 pi q Theta_arg))
  *                        (diagonal is 1); sym == 0: -(A_s (.) exp(...)) (diagonal is deg).
- *   pygsd_maglap_assemble_csr: compute layout of the scaled operator: ONE int32 CSR (rowptr[n+1],
- *                        col[E_s+n]) over the symmetric pattern incl. the diagonal, shared by both
- *                        orientations, with vb_* = S[row, col] (backward / by-source product) and
- *                        vf_* = S[col, row] (forward / by-target product) -- no further sorts or gathers.
+ *                        mir_real / mir_imag (optional, both or neither): the value of the MIRRORED entry
+ *                        (col, row) -- the operator is Hermitian, so it is the same magnitude multiplied in
+ *                        the mirrored entry's own row/col order with the conjugate phase.
+ *   pygsd_maglap_assemble_csr: compute layout of the scaled operator S = 2 L / lambda_max - I: ONE int32
+ *                        CSR (rowptr[n+1], col[E_s+n]) over the symmetric pattern incl. the diagonal
+ *                        (columns ascending), shared by both orientations, with vb_* = S[row, col]
+ *                        (backward / by-source product) and vf_* = S[col, row] (forward / by-target
+ *                        product); v = (2 x) / lambda_max with +inf -> 0 (MagNetConv.py:106-107,115-116),
+ *                        diagonal = (2 diag) / lambda_max + diag_shift (the folded -1 self loops, :108-112).
+ *                        No further sorts or gathers.
  * The same workspace (pygsd_maglap_workspace bytes) must be passed, untouched, to sort and merge.
  * ------------------------------------------------------------------------------------------- */
 int pygsd_maglap_workspace(int64_t n_edges, size_t* bytes);
@@ -169,12 +175,13 @@ int pygsd_maglap_merge(const float* w, int64_t n_edges, int32_t n, int32_t is_si
                        int64_t* out_row, int64_t* out_col, float* a_sym, float* theta, float* deg,
                        int32_t* off_ptr, void* stream);
 int pygsd_maglap_assemble_csr(const int64_t* out_row, const int64_t* out_col, const float* off_real,
-                              const float* off_imag, const float* diag_real, const int32_t* off_ptr,
-                              int64_t num_unique, int32_t n, int32_t* rowptr, int32_t* col,
+                              const float* off_imag, const float* mir_real, const float* mir_imag,
+                              const float* diag, const int32_t* off_ptr, int64_t num_unique, int32_t n,
+                              float lambda_max, float diag_shift, int32_t* rowptr, int32_t* col,
                               float* vb_real, float* vb_imag, float* vf_real, float* vf_imag, void* stream);
 int pygsd_maglap_values(const int64_t* out_row, const int64_t* out_col, const float* a_sym,
                         const float* theta, const float* deg, int64_t num_unique, float q, int32_t sym,
-                        float* off_real, float* off_imag, void* stream);
+                        float* off_real, float* off_imag, float* mir_real, float* mir_imag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * add_remaining_self_loops + degree normalisation: torch_geometric's gcn_norm as called at

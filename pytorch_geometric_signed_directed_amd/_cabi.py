@@ -49,11 +49,11 @@ PROTOTYPES = {
     "pygsd_maglap_sort": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
     "pygsd_maglap_merge": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int64, c_void_p, c_size_t,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "pygsd_maglap_assemble_csr": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                            c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_void_p]),
+    "pygsd_maglap_assemble_csr": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_maglap_values": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
-                                      c_int32, c_void_p, c_void_p, c_void_p]),
+                                      c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_self_loops_workspace": (c_int32, [c_int64, ctypes.POINTER(c_size_t)]),
     "pygsd_self_loops_scan": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_size_t, c_void_p,
                                         c_void_p, c_void_p]),

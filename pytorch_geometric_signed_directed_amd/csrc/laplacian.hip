@@ -124,41 +124,47 @@ __global__ void row_degree(const int32_t* __restrict__ off_ptr, const float* __r
 // Compute layout of the magnetic operator: ONE int32 CSR over the symmetric pattern (off-diagonals + the
 // diagonal, columns ascending inside a row) shared by both orientations, with the values of
 // S[row, col] (by-source / backward product) and of the mirrored entry S[col, row] (by-target / forward
-// product) side by side.  Replaces two radix sorts + six gathers of the generic COO -> CSR route.
+// product) side by side.  The mirror values are evaluated by lap_values (the operator is Hermitian:
+// same |.|, conjugate phase, multiplied in the mirrored entry's own order), so there is no lookup.
+// Scaling S = 2 L / lambda_max - I is folded in: v = (2 x) / lam with +inf -> 0 (masked_fill_), diag - 1.
+// Replaces two radix sorts + six gathers of the generic COO -> CSR route.
+__device__ __forceinline__ float scale_lam(float x, float lam)
+{
+    const float v = (2.0f * x) / lam;
+    return v == INFINITY ? 0.f : v;
+}
+
 __global__ void assemble_csr(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
                              const float* __restrict__ off_re, const float* __restrict__ off_im,
-                             const float* __restrict__ diag_re, const int32_t* __restrict__ off_ptr, int64_t es,
-                             int32_t n, int32_t* __restrict__ rowptr, int32_t* __restrict__ ccol,
-                             float* __restrict__ vb_re, float* __restrict__ vb_im, float* __restrict__ vf_re,
-                             float* __restrict__ vf_im)
+                             const float* __restrict__ mir_re, const float* __restrict__ mir_im,
+                             const float* __restrict__ diag, const int32_t* __restrict__ off_ptr, int64_t es,
+                             int32_t n, float lam, float diag_shift, int32_t* __restrict__ rowptr,
+                             int32_t* __restrict__ ccol, float* __restrict__ vb_re, float* __restrict__ vb_im,
+                             float* __restrict__ vf_re, float* __restrict__ vf_im)
 {
     GRID_STRIDE(t, es + n)
     {
         if (t < es) {
             const int32_t r = static_cast<int32_t>(row[t]), c = static_cast<int32_t>(col[t]);
             const int64_t slot = t + r + (c > r ? 1 : 0);
-            int32_t lo = off_ptr[c], hi = off_ptr[c + 1];      // mirror (c, r): search row c for column r
-            while (lo < hi) {
-                const int32_t mid = (lo + hi) >> 1;
-                if (col[mid] < r) lo = mid + 1; else hi = mid;
-            }
             ccol[slot] = c;
-            vb_re[slot] = off_re[t];
-            vb_im[slot] = off_im[t];
-            vf_re[slot] = off_re[lo];
-            vf_im[slot] = off_im[lo];
+            vb_re[slot] = scale_lam(off_re[t], lam);
+            vb_im[slot] = scale_lam(off_im[t], lam);
+            vf_re[slot] = scale_lam(mir_re[t], lam);
+            vf_im[slot] = scale_lam(mir_im[t], lam);
         } else {
             const int32_t r = static_cast<int32_t>(t - es);
             int32_t lo = off_ptr[r], hi = off_ptr[r + 1];
             const int32_t beg = lo;
-            while (lo < hi) {
+            while (lo < hi) {                                   // #off-diagonals of row r left of the diagonal
                 const int32_t mid = (lo + hi) >> 1;
                 if (col[mid] < r) lo = mid + 1; else hi = mid;
             }
             const int64_t slot = static_cast<int64_t>(beg) + r + (lo - beg);
+            const float d = scale_lam(diag[r], lam) + diag_shift;
             ccol[slot] = r;
-            vb_re[slot] = diag_re[r];
-            vf_re[slot] = diag_re[r];
+            vb_re[slot] = d;
+            vf_re[slot] = d;
             vb_im[slot] = 0.f;
             vf_im[slot] = 0.f;
             rowptr[r] = beg + r;
@@ -173,22 +179,28 @@ __global__ void assemble_csr(const int64_t* __restrict__ row, const int64_t* __r
 __global__ void lap_values(const int64_t* __restrict__ out_row, const int64_t* __restrict__ out_col,
                            const float* __restrict__ a_sym, const float* __restrict__ theta,
                            const float* __restrict__ deg, int64_t es, float two_pi_q, int32_t sym,
-                           float* __restrict__ off_re, float* __restrict__ off_im)
+                           float* __restrict__ off_re, float* __restrict__ off_im,
+                           float* __restrict__ mir_re, float* __restrict__ mir_im)
 {
     GRID_STRIDE(i, es)
     {
         const float ph = two_pi_q * theta[i];
         float sn, cs;
         sincosf(ph, &sn, &cs);
-        float mag = a_sym[i];
+        float mag = a_sym[i], mmag = a_sym[i];
         if (sym) {
             const float dr = deg[out_row[i]], dc = deg[out_col[i]];
             const float ir = dr == 0.f ? 0.f : powf(dr, -0.5f);
             const float ic = dc == 0.f ? 0.f : powf(dc, -0.5f);
-            mag = ir * mag * ic;
+            mag = ir * mag * ic;      // entry (row, col): deg^-1/2[row] * A_s * deg^-1/2[col]
+            mmag = ic * mmag * ir;    // mirrored entry (col, row), multiplied in ITS row/col order
         }
         off_re[i] = -(mag * cs);
         off_im[i] = -(mag * sn);
+        if (mir_re) {                 // Hermitian mirror: A_s symmetric, Theta antisymmetric
+            mir_re[i] = -(mmag * cs);
+            mir_im[i] = mmag * sn;    // -(mmag * sin(-ph))
+        }
     }
 }
 
@@ -423,10 +435,11 @@ extern "C" int pygsd_maglap_merge(const float* w, int64_t n_edges, int32_t n, in
 }
 
 extern "C" int pygsd_maglap_assemble_csr(const int64_t* out_row, const int64_t* out_col, const float* off_real,
-                                         const float* off_imag, const float* diag_real, const int32_t* off_ptr,
-                                         int64_t num_unique, int32_t n, int32_t* rowptr, int32_t* col,
-                                         float* vb_real, float* vb_imag, float* vf_real, float* vf_imag,
-                                         void* stream)
+                                         const float* off_imag, const float* mir_real, const float* mir_imag,
+                                         const float* diag, const int32_t* off_ptr, int64_t num_unique,
+                                         int32_t n, float lambda_max, float diag_shift, int32_t* rowptr,
+                                         int32_t* col, float* vb_real, float* vb_imag, float* vf_real,
+                                         float* vf_imag, void* stream)
 {
     PYGSD_REQUIRE(num_unique >= 0 && n >= 0 && num_unique + n < (int64_t(1) << 31),
                   "pygsd_maglap_assemble_csr: size out of int32 range");
@@ -437,27 +450,30 @@ extern "C" int pygsd_maglap_assemble_csr(const int64_t* out_row, const int64_t* 
         PYGSD_HIP_TRY(hipMemsetAsync(rowptr, 0, sizeof(int32_t), s));
         return 0;
     }
-    PYGSD_REQUIRE(diag_real && off_ptr && col && vb_real && vb_imag && vf_real && vf_imag &&
-                      (num_unique == 0 || (out_row && out_col && off_real && off_imag)),
+    PYGSD_REQUIRE(diag && off_ptr && col && vb_real && vb_imag && vf_real && vf_imag &&
+                      (num_unique == 0 || (out_row && out_col && off_real && off_imag && mir_real && mir_imag)),
                   "pygsd_maglap_assemble_csr: null pointer");
     hipLaunchKernelGGL(assemble_csr, dim3(grid_for(num_unique + n)), dim3(kBlock), 0, s, out_row, out_col, off_real,
-                       off_imag, diag_real, off_ptr, num_unique, n, rowptr, col, vb_real, vb_imag, vf_real, vf_imag);
+                       off_imag, mir_real, mir_imag, diag, off_ptr, num_unique, n, lambda_max, diag_shift, rowptr, col,
+                       vb_real, vb_imag, vf_real, vf_imag);
     return check_launch("assemble_csr");
 }
 
 extern "C" int pygsd_maglap_values(const int64_t* out_row, const int64_t* out_col, const float* a_sym,
                                    const float* theta, const float* deg, int64_t num_unique, float q,
-                                   int32_t sym, float* off_real, float* off_imag, void* stream)
+                                   int32_t sym, float* off_real, float* off_imag, float* mir_real,
+                                   float* mir_imag, void* stream)
 {
     PYGSD_REQUIRE(num_unique >= 0, "pygsd_maglap_values: negative size");
     if (num_unique == 0) return 0;
     PYGSD_REQUIRE(out_row && out_col && a_sym && theta && deg && off_real && off_imag, "pygsd_maglap_values: null pointer");
+    PYGSD_REQUIRE((mir_real == nullptr) == (mir_imag == nullptr), "pygsd_maglap_values: mirror outputs must be given together");
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_BUILD, s);
     // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64
     const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * static_cast<double>(q));
     hipLaunchKernelGGL(lap_values, dim3(grid_for(num_unique)), dim3(kBlock), 0, s, out_row, out_col, a_sym, theta,
-                       deg, num_unique, two_pi_q, sym, off_real, off_imag);
+                       deg, num_unique, two_pi_q, sym, off_real, off_imag, mir_real, mir_imag);
     return check_launch("lap_values");
 }
 

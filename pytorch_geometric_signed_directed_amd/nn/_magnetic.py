@@ -47,22 +47,33 @@ class MagneticOperator:
     The COO view (off-diagonals sorted by (row, col), then the diagonal) is kept for the reference-format
     tuple and for the generic autograd path (trainable q)."""
 
-    def __init__(self, csr, values_fwd, values_bwd, off_index, off_real, off_imag, diag_scaled, n):
+    def __init__(self, csr, values_fwd, values_bwd, off_index, off_real, off_imag, diag, lambda_max, n):
         self.csr, self.values_fwd, self.values_bwd = csr, values_fwd, values_bwd
-        self._off_index, self._off_real, self._off_imag = off_index, off_real, off_imag
-        self._diag_scaled, self.n = diag_scaled, n
+        # un-scaled Laplacian entries; the COO views below apply 2 x / lambda_max lazily
+        self._off_index, self._off_real, self._off_imag, self._diag = off_index, off_real, off_imag, diag
+        self._lambda_max, self.n = lambda_max, n
         self.nnz = int(off_real.numel()) + n
+        self._scaled_cache = None
         self._ref_format = None
         self._coo = None
         self._pattern = None
 
+    def _scaled(self):
+        """(off_real, off_imag, diag) * 2 / lambda_max with +inf -> 0 (MagNetConv.py:106-107,115-116)."""
+        if self._scaled_cache is None:
+            def sc(t):
+                v = (2.0 * t) / self._lambda_max
+                return v.masked_fill(v == float("inf"), 0)
+            self._scaled_cache = (sc(self._off_real), sc(self._off_imag), sc(self._diag))
+        return self._scaled_cache
+
     def coo(self):
         """(edge_index [2, E_s + N], values_real, values_imag) with the two reference self-loop sets folded."""
         if self._coo is None:
+            off_r, off_i, diag_s = self._scaled()
             loops = torch.arange(self.n, dtype=torch.long, device=self._off_index.device).unsqueeze(0).repeat(2, 1)
-            self._coo = (torch.cat([self._off_index, loops], dim=1),
-                         torch.cat([self._off_real, self._diag_scaled - 1.0]),
-                         torch.cat([self._off_imag, torch.zeros_like(self._diag_scaled)]))
+            self._coo = (torch.cat([self._off_index, loops], dim=1), torch.cat([off_r, diag_s - 1.0]),
+                         torch.cat([off_i, torch.zeros_like(diag_s)]))
         return self._coo
 
     @property
@@ -80,9 +91,9 @@ class MagneticOperator:
             loops = torch.arange(self.n, dtype=torch.long, device=dev).unsqueeze(0).repeat(2, 1)
             ei_imag = torch.cat([self._off_index, loops], dim=1)
             ei_real = torch.cat([ei_imag, loops], dim=1)
-            norm_real = torch.cat([self._off_real, self._diag_scaled,
-                                   self._off_real.new_full((self.n,), -1.0)])
-            norm_imag = torch.cat([self._off_imag, self._off_imag.new_zeros(self.n)])
+            off_r, off_i, diag_s = self._scaled()
+            norm_real = torch.cat([off_r, diag_s, off_r.new_full((self.n,), -1.0)])
+            norm_imag = torch.cat([off_i, off_i.new_zeros(self.n)])
             self._ref_format = (ei_real, ei_imag, norm_real, norm_imag)
         return self._ref_format
 
@@ -135,18 +146,12 @@ class MagneticChebConv(MessagePassing):
 
     def _build_operator(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype):
         parts = laplacian_parts(edge_index, edge_weight, num_nodes, dtype=dtype, **self._laplacian_kwargs())
-        off_r, off_i, diag = laplacian_values(parts, q, normalization)
-        lam = lambda_max
-        off_r = (2.0 * off_r) / lam
-        off_r = off_r.masked_fill(off_r == float("inf"), 0)
-        off_i = (2.0 * off_i) / lam
-        off_i = off_i.masked_fill(off_i == float("inf"), 0)
-        diag_s = (2.0 * diag) / lam
-        diag_s = diag_s.masked_fill(diag_s == float("inf"), 0)
-        csr = vf = vb = None
-        if not (off_r.requires_grad or off_i.requires_grad):
-            csr, vf, vb = assemble_operator_csr(parts, off_r, off_i, diag_s - 1.0)
-        return MagneticOperator(csr, vf, vb, parts.index, off_r, off_i, diag_s, num_nodes)
+        if isinstance(q, torch.Tensor) and q.requires_grad:      # trainable q: generic differentiable route
+            off_r, off_i, diag = laplacian_values(parts, q, normalization)
+            return MagneticOperator(None, None, None, parts.index, off_r, off_i, diag, lambda_max, num_nodes)
+        off_r, off_i, diag, mir_r, mir_i = laplacian_values(parts, q, normalization, mirror=True)
+        csr, vf, vb = assemble_operator_csr(parts, off_r, off_i, mir_r, mir_i, diag, float(lambda_max), -1.0)
+        return MagneticOperator(csr, vf, vb, parts.index, off_r, off_i, diag, lambda_max, num_nodes)
 
     def __norm__(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype=None):
         """Reference-format operator (MagNetConv.py:78-120): edge_index_real, edge_index_imag,

@@ -66,35 +66,38 @@ def laplacian_parts(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, s
     return LaplacianParts(index, a_sym, theta, deg, n, off_ptr)
 
 
-def assemble_operator_csr(parts: LaplacianParts, off_real: Tensor, off_imag: Tensor, diag_real: Tensor):
-    """Compute layout of an operator given on the symmetrised pattern: one shared int32 CSR (diagonal
-    merged in, columns ascending) + the values for the by-source (backward) and by-target (forward)
-    products.  Returns (CSR, (vf_real, vf_imag), (vb_real, vb_imag))."""
+def assemble_operator_csr(parts: LaplacianParts, off_real: Tensor, off_imag: Tensor, mir_real: Tensor,
+                          mir_imag: Tensor, diag: Tensor, lambda_max: float, diag_shift: float = -1.0):
+    """Compute layout of the scaled operator 2 L / lambda_max + diag_shift I on the symmetrised pattern:
+    one shared int32 CSR (diagonal merged in, columns ascending) + the values for the by-target (forward)
+    and by-source (backward) products.  Returns (CSR, (vf_real, vf_imag), (vb_real, vb_imag))."""
     from ..sparse import CSR
     n, es = parts.n, parts.a_sym.numel()
-    dev = diag_real.device
+    dev = diag.device
     nnz = es + n
     rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
     col = torch.empty(nnz, dtype=torch.int32, device=dev)
     vals = torch.empty((4, max(nnz, 1)), dtype=torch.float32, device=dev)
-    off_real, off_imag = off_real.detach().contiguous(), off_imag.detach().contiguous()
-    diag_real = diag_real.detach().contiguous()
     with torch.cuda.device(dev):
         check(_cabi.lib().pygsd_maglap_assemble_csr(ptr(parts.index[0]) if es else None,
                                                     ptr(parts.index[1]) if es else None, ptr(off_real), ptr(off_imag),
-                                                    ptr(diag_real), ptr(parts.off_ptr), es, n, ptr(rowptr), ptr(col),
+                                                    ptr(mir_real), ptr(mir_imag), ptr(diag), ptr(parts.off_ptr), es, n,
+                                                    float(lambda_max), float(diag_shift), ptr(rowptr), ptr(col),
                                                     ptr(vals[0]), ptr(vals[1]), ptr(vals[2]), ptr(vals[3]),
                                                     stream_ptr()), "pygsd_maglap_assemble_csr")
     csr = CSR(n, n, nnz, rowptr, col, None)
     return csr, (vals[2, :nnz], vals[3, :nnz]), (vals[0, :nnz], vals[1, :nnz])
 
 
-def laplacian_values(parts: LaplacianParts, q, normalization: Optional[str]) -> Tuple[Tensor, Tensor, Tensor]:
-    """(off_real, off_imag, diag) of L.  A float q runs the HIP kernel; a tensor q that requires grad
-    (trainable_q) is evaluated with differentiable element-wise tensor ops on the same ingredients."""
+def laplacian_values(parts: LaplacianParts, q, normalization: Optional[str], mirror: bool = False):
+    """(off_real, off_imag, diag) of L [+ (mir_real, mir_imag): the values of the mirrored entries].
+    A float q runs the HIP kernel; a tensor q that requires grad (trainable_q) is evaluated with
+    differentiable element-wise tensor ops on the same ingredients (no mirror values there)."""
     sym = normalization is not None
     diag = torch.ones_like(parts.deg) if sym else parts.deg
     if isinstance(q, torch.Tensor) and q.requires_grad:
+        if mirror:
+            raise ValueError("mirror values are only produced for a fixed q")
         row, col = parts.index[0], parts.index[1]
         phase_arg = (2 * math.pi * q) * parts.theta
         if sym:
@@ -108,9 +111,14 @@ def laplacian_values(parts: LaplacianParts, q, normalization: Optional[str]) -> 
     es = parts.a_sym.numel()
     off_r = torch.empty_like(parts.a_sym)
     off_i = torch.empty_like(parts.a_sym)
+    mir_r = torch.empty_like(parts.a_sym) if mirror else None
+    mir_i = torch.empty_like(parts.a_sym) if mirror else None
     if es:
         with torch.cuda.device(parts.a_sym.device):
             check(_cabi.lib().pygsd_maglap_values(ptr(parts.index[0]), ptr(parts.index[1]), ptr(parts.a_sym),
                                                   ptr(parts.theta), ptr(parts.deg), es, qf, 1 if sym else 0,
-                                                  ptr(off_r), ptr(off_i), stream_ptr()), "pygsd_maglap_values")
+                                                  ptr(off_r), ptr(off_i), ptr(mir_r), ptr(mir_i), stream_ptr()),
+                  "pygsd_maglap_values")
+    if mirror:
+        return off_r, off_i, diag, mir_r, mir_i
     return off_r, off_i, diag
