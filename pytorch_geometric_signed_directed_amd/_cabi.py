@@ -90,10 +90,15 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(_LIB_PATH):
-        raise RuntimeError(
-            f"pytorch_geometric_signed_directed_amd: HIP library not built ({_LIB_PATH} is missing). "
-            "Run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root. "
-            "There is no CPU fallback for this path.")
+        # a source-only checkout: compile in-tree once (hipcc, gfx950); never fall back to anything else
+        try:
+            from .build import build_library
+            build_library()
+        except Exception as exc:  # noqa: BLE001
+            raise RuntimeError(
+                f"pytorch_geometric_signed_directed_amd: HIP library not built ({_LIB_PATH} is missing) and "
+                f"building it failed ({exc}). Run `python -c 'import __graft_entry__ as g; g.build()'` at the "
+                "repo root. There is no CPU fallback for this path.") from exc
     handle = ctypes.CDLL(_LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
