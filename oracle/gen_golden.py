@@ -332,6 +332,36 @@ def gat_cases():
          **{"d." + k: npy(p.grad) for k, p in layer.named_parameters()})
 
 
+# ------------------------------------------------------------------ SSSNET cut objectives (8(f) rank 4)
+def loss_case():
+    import scipy.sparse as sp
+    from torch_geometric_signed_directed.utils.signed import (Prob_Balanced_Normalized_Loss,
+                                                              Prob_Balanced_Ratio_Loss, Unhappy_Ratio)
+    n, k = 40, 4
+    eis, ws = toy_graph(81, signed=True)
+    a = sp.coo_matrix((ws, (eis[0], eis[1])), shape=(n, n)).tocsr()
+    a_p, a_n = a.maximum(0), (-a).maximum(0)
+    a_p.eliminate_zeros()
+    a_n.eliminate_zeros()
+    g = torch.Generator().manual_seed(81)
+    prob = torch.softmax(torch.randn(n, k, generator=g), dim=1).requires_grad_()
+    out = {}
+    for name, cls in (("normalized", Prob_Balanced_Normalized_Loss), ("ratio", Prob_Balanced_Ratio_Loss),
+                      ("unhappy", Unhappy_Ratio)):
+        prob.grad = None
+        val = cls(a_p, a_n)(prob)
+        val.sum().backward()
+        out["loss_" + name] = npy(val)
+        out["dprob_" + name] = npy(prob.grad)
+    # dense float64 check of the normalized loss
+    ap, an = a_p.toarray().astype(np.float64), a_n.toarray().astype(np.float64)
+    dp, dn = np.diag(ap.sum(1)), np.diag(an.sum(1))
+    m, dbar, p = dp - (ap - an), dp + dn, npy(prob).astype(np.float64)
+    want = sum(p[:, j] @ m @ p[:, j] / (p[:, j] @ dbar @ p[:, j] + 1e-6) for j in range(k))
+    close("loss_normalized", out["loss_normalized"], np.array([want]))
+    save("sssnet_losses", edge_index=eis, edge_weight=ws, prob=npy(prob), **out)
+
+
 # ------------------------------------------------------------------ model-level callers (eval mode)
 def model_case(name, model, args, seed):
     """Reference model in eval mode (dropout off) on fixed inputs: record state_dict + outputs."""
@@ -422,6 +452,8 @@ def main():
     kat_case()
     print("attention aggregate")
     gat_cases()
+    print("SSSNET cut objectives")
+    loss_case()
     print("model-level callers")
     models()
 

@@ -392,3 +392,23 @@ def test_northstar_size_fused_vs_composed_paths():
             want = 0.75 * (fx[k] - f0[k]) - 1.5 * (fy[k] - f0[k])
             got = fm[k] - f0[k]
             assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_sssnet_cut_objectives_match_reference():
+    """the per-cluster sparse mat-vecs of SSSNET's losses as one HIP SpMM."""
+    import scipy.sparse as sp
+    from pytorch_geometric_signed_directed_amd.utils import (Prob_Balanced_Normalized_Loss, Prob_Balanced_Ratio_Loss,
+                                                             Unhappy_Ratio)
+    g = load_golden("sssnet_losses")
+    ei, w = g["edge_index"], g["edge_weight"]
+    a = sp.coo_matrix((w, (ei[0], ei[1])), shape=(40, 40)).tocsr()
+    a_p, a_n = a.maximum(0), (-a).maximum(0)
+    a_p.eliminate_zeros()
+    a_n.eliminate_zeros()
+    for name, cls in (("normalized", Prob_Balanced_Normalized_Loss), ("ratio", Prob_Balanced_Ratio_Loss),
+                      ("unhappy", Unhappy_Ratio)):
+        prob = g.t("prob", D).requires_grad_()
+        val = cls(a_p, a_n)(prob)
+        close(val, g["loss_" + name])
+        val.sum().backward()
+        close(prob.grad, g["dprob_" + name], 2e-5)
