@@ -431,6 +431,9 @@ def main():
     magnet_case("msconv_k1_sym_abs", 6, 1, "sym", True, signed=True)
     magnet_case("msconv_k2_sym_noabs", 7, 2, "sym", True, signed=True, absolute_degree=False)
     magnet_case("msconv_k2_none_abs", 8, 2, None, True, signed=True, q=0.15)
+    magnet_case("magnet_k1_sym_wide", 9, 1, "sym", True, fin=16, fout=4)
+    magnet_case("magnet_k3_sym_wide", 10, 3, "sym", True, fin=16, fout=4, q=0.2)
+    magnet_case("msconv_k2_sym_wide", 19, 2, "sym", True, signed=True, fin=12, fout=5)
     print("DiGCNConv / DGCNConv / Conv_Base")
     digcn_case("digcn_bias", 11)
     digcn_case("digcn_nobias", 12, bias=False)
