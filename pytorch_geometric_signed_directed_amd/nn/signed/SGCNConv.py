@@ -38,6 +38,21 @@ class SGCNConv(MessagePassing):
         pat = GLOBAL_PATTERNS.get(edge_index, x_src.size(0), n_dst, self.flow)
         return spmm(pat, x_src, None, reduce=self.aggr)
 
+    def _branch(self, lin, aggregated, own, n):
+        """lin(cat([mean_in(x_1), ..., own])).  The Linear is applied block-wise; when it narrows the
+        features (in_dim > out_dim) each block is multiplied BEFORE its mean aggregation --
+        mean_in(x) W = mean_in(x W) -- so the segment-mean SpMM runs at width out_dim
+        (reference order: aggregate, concatenate, then Linear; SGCNConv.py:101-119)."""
+        f = self.in_dim
+        w = lin.weight                                  # [out_dim, (len(aggregated) + 1) * in_dim]
+        if self.in_dim > self.out_dim:
+            out = tall_linear(own, w[:, len(aggregated) * f:].t(), lin.bias)
+            for k, (feat, ei) in enumerate(aggregated):
+                out = out + self._mean_in(tall_linear(feat, w[:, k * f:(k + 1) * f].t()), n, ei)
+            return out
+        parts = [self._mean_in(feat, n, ei) for feat, ei in aggregated] + [own]
+        return tall_linear(torch.cat(parts, dim=-1), w.t(), lin.bias)
+
     def forward(self, x: Union[Tensor, Tuple[Tensor, Tensor]], pos_edge_index: Tensor,
                 neg_edge_index: Tensor) -> Tensor:
         if isinstance(x, Tensor):
@@ -46,18 +61,14 @@ class SGCNConv(MessagePassing):
             raise NotImplementedError("SGCNConv: only the edge_index (Tensor) path exists on the HIP stack")
         _cabi.require_gpu(x[0], x[1], pos_edge_index, neg_edge_index)
         n = x[1].size(0)
-        lin_b = lambda t: tall_linear(t, self.lin_b.weight.t(), self.lin_b.bias)  # noqa: E731
-        lin_u = lambda t: tall_linear(t, self.lin_u.weight.t(), self.lin_u.bias)  # noqa: E731
         if self.first_aggr:
-            out_b = lin_b(torch.cat([self._mean_in(x[0], n, pos_edge_index), x[1]], dim=-1))
-            out_u = lin_u(torch.cat([self._mean_in(x[0], n, neg_edge_index), x[1]], dim=-1))
+            out_b = self._branch(self.lin_b, [(x[0], pos_edge_index)], x[1], n)
+            out_u = self._branch(self.lin_u, [(x[0], neg_edge_index)], x[1], n)
         else:
             f = self.in_dim
             lo, hi = x[0][..., :f], x[0][..., f:]   # column slices: passed by row stride, no copy
-            out_b = lin_b(torch.cat([self._mean_in(lo, n, pos_edge_index),
-                                     self._mean_in(hi, n, neg_edge_index), x[1][..., :f]], dim=-1))
-            out_u = lin_u(torch.cat([self._mean_in(hi, n, pos_edge_index),
-                                     self._mean_in(lo, n, neg_edge_index), x[1][..., f:]], dim=-1))
+            out_b = self._branch(self.lin_b, [(lo, pos_edge_index), (hi, neg_edge_index)], x[1][..., :f], n)
+            out_u = self._branch(self.lin_u, [(hi, pos_edge_index), (lo, neg_edge_index)], x[1][..., f:], n)
         out = torch.cat([out_b, out_u], dim=-1)
         if self.norm_emb:
             out = F.normalize(out, p=2, dim=-1)
