@@ -79,6 +79,96 @@ def pack_pair(a: Tensor, b: Tensor) -> Tensor:
     return torch.cat([a, b], dim=1)
 
 
+class _ShardedSpmmFn(torch.autograd.Function):
+    """y_local = S[my target rows, :] x  with x gathered from all ranks; backward
+    dx_local = S^T[my source rows, :] dy with dy gathered.  fp32 or bf16 storage (bf16 halves the
+    exchanged bytes as well as the gathered ones)."""
+
+    @staticmethod
+    def forward(ctx, x_local, op):
+        from .sparse import _spmm_raw
+        full = all_gather_rows(x_local, op.group)
+        ctx.op = op
+        return _spmm_raw(op.fwd_csr, op.fwd_val, full, None, 1.0, 0.0, op.mean)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_local):
+        from .sparse import _spmm_raw
+        op = ctx.op
+        full = all_gather_rows(g_local.contiguous(), op.group)
+        return _spmm_raw(op.bwd_csr, op.bwd_val, full, None, 1.0, 0.0, False), None
+
+
+class ShardedOperator:
+    """A COO operator out[scatter] += w * x[gather] sharded by node range: this rank keeps the by-target
+    rows of its nodes (forward) and the by-source rows of its nodes (backward), both with GLOBAL column ids
+    into the all-gathered feature matrix.  `apply(x_local)` is differentiable w.r.t. x_local."""
+
+    def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, group=None,
+                 flow: str = "source_to_target", reduce: str = "add"):
+        from .sparse import csr_from_coo, gather_values
+        self.group = group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self.plan = plan = ShardPlan(num_nodes, world, rank)
+        g, s = (0, 1) if flow == "source_to_target" else (1, 0)
+        coo = torch.stack([edge_index[g], edge_index[s]])            # row 0 = gather (source), row 1 = scatter
+        self.mean = reduce == "mean"
+        keep_t, sub_t = plan.local_entries(coo, by=1)
+        self.fwd_csr = csr_from_coo(sub_t[1], sub_t[0], plan.n_pad, plan.n_total)
+        keep_s, sub_s = plan.local_entries(coo, by=0)
+        self.bwd_csr = csr_from_coo(sub_s[0], sub_s[1], plan.n_pad, plan.n_total)
+        w = edge_weight
+        if self.mean:                                                  # backward of mean: 1 / in-degree per entry
+            deg = torch.zeros(plan.n_total, dtype=torch.float32, device=coo.device).index_add_(
+                0, coo[1], torch.ones(coo.size(1), dtype=torch.float32, device=coo.device)).clamp(min=1)
+            inv = (1.0 / deg)[coo[1]]
+            wb = inv if w is None else w.float() * inv
+        else:
+            wb = w
+        self.fwd_val = None if w is None else gather_values(w[keep_t], self.fwd_csr.perm)
+        self.bwd_val = None if wb is None else gather_values(wb[keep_s], self.bwd_csr.perm)
+        self.local_nnz = int(keep_t.numel())
+
+    def apply(self, x_local: Tensor) -> Tensor:
+        return _ShardedSpmmFn.apply(x_local, self)
+
+
+class ShardedDiGCNConv(torch.nn.Module):
+    """DiGCNConv (out = S^T (x W) + b, reference nn/directed/DiGCNConv.py:54-94) over a node-range-sharded
+    graph; fp32 or bf16 (`.to(torch.bfloat16)`: BASELINE config "DiGCN_Inception_Block ... bf16, 8xMI355X").
+    Parameters are replicated; their gradients are all-reduced by hooks during backward."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_nodes: int, edge_index: Tensor,
+                 edge_weight: Tensor, bias: bool = True, device=None, group=None):
+        super().__init__()
+        from .nn import DiGCNConv
+        proto = DiGCNConv(in_channels, out_channels, bias=bias)
+        self.weight, self.bias = proto.weight, proto.bias
+        self.in_channels, self.out_channels = in_channels, out_channels
+        device = device or edge_index.device
+        self.to(device)
+        if edge_weight is None:
+            raise RuntimeError('Normalized adj matrix cannot be None. Please obtain the adj matrix in preprocessing.')
+        self.op = ShardedOperator(edge_index.to(device), edge_weight.to(device), num_nodes, group)
+        self.plan, self.group = self.op.plan, group
+        for prm in self.parameters():
+            prm.register_hook(self._allreduce)
+
+    def _allreduce(self, grad):
+        grad = grad.contiguous()
+        dist.all_reduce(grad, group=self.group)
+        return grad
+
+    def shard_rows(self, x: Tensor) -> Tensor:
+        return self.plan.shard_rows(x)
+
+    def forward(self, x_local: Tensor) -> Tensor:
+        from .dense import tall_linear
+        out = self.op.apply(tall_linear(x_local, self.weight))
+        return out if self.bias is None else out + self.bias
+
+
 class _ShardedMagneticFn(torch.autograd.Function):
     """Forward / backward of one node-sharded MagNetConv layer (local rows only)."""
 

@@ -69,3 +69,54 @@ def test_sharded_layer_matches_oracle(world, n, k, f):
     mp.spawn(_worker, args=(world, _free_port(), n, k, f, ret), nprocs=world, join=True)
     assert len(ret) == world
     assert max(ret.values()) <= 1e-5, dict(ret)
+
+
+def _digcn_worker(rank, world, port, n, f, dtype_name, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref_layers as R
+        from pytorch_geometric_signed_directed_amd.parallel import ShardedDiGCNConv, all_gather_rows
+        dev = torch.device("cuda:0")
+        dtype = getattr(torch, dtype_name)
+        g = torch.Generator().manual_seed(5)
+        e = 12 * n
+        ei = torch.randint(0, n, (2, e), generator=g)
+        w = torch.rand(e, generator=g) / 8
+        x = torch.randn(n, f, generator=g)
+        go = torch.randn(n, f, generator=g)
+        torch.manual_seed(13)
+        layer = ShardedDiGCNConv(f, f, n, ei.to(dev), w.to(dev), device=dev)
+        with torch.no_grad():
+            layer.bias.uniform_(-0.5, 0.5)
+            dist.broadcast(layer.bias.data, 0)
+        wt, bs = layer.weight.detach().cpu().clone(), layer.bias.detach().cpu().clone()
+        layer.to(dtype)
+        a = layer.shard_rows(x.to(dev)).to(dtype).requires_grad_()
+        out = layer(a)
+        (out.float() * layer.shard_rows(go.to(dev))).sum().backward()
+        got = [layer.plan.unshard_rows(all_gather_rows(t.detach().float().contiguous())).cpu() for t in (out, a.grad)]
+        # oracle (fp32 on inputs rounded to the storage dtype)
+        rnd = (lambda t: t.to(dtype).float())
+        xo, wo = rnd(x).requires_grad_(), rnd(wt).requires_grad_()
+        want = R.digcn_conv(xo, ei, w, wo, rnd(bs))
+        (want * go).sum().backward()
+        tol = 1e-5 if dtype is torch.float32 else 3e-2
+        worst = 0.0
+        for x1, y1 in zip(got, (want.detach(), xo.grad)):
+            worst = max(worst, float((x1 - y1).abs().max()) / max(1.0, float(y1.abs().max())))
+        worst = max(worst, float((layer.weight.grad.float().cpu() - wo.grad).abs().max()) /
+                    max(1.0, float(wo.grad.abs().max())))
+        ret[rank] = worst / tol
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,f,dtype_name", [(2, 1001, 64, "float32"), (3, 600, 16, "float32"),
+                                                   (2, 1000, 64, "bfloat16")])
+def test_sharded_digcn_matches_oracle(world, n, f, dtype_name):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_digcn_worker, args=(world, _free_port(), n, f, dtype_name, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    assert max(ret.values()) <= 1.0, dict(ret)
