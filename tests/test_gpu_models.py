@@ -144,3 +144,49 @@ def test_train_step_captures_into_a_hipgraph():
     torch.cuda.synchronize()
     assert torch.equal(static_o[0], want_o[0]) and torch.equal(static_o[1], want_o[1])
     assert torch.equal(layer.weight.grad, want_g)
+
+
+def test_training_trajectory_matches_the_oracle_model():
+    """Five Adam steps of MagNet_node_classification (2 layers, h=16 -> the fused MFMA path, K=2,
+    complex ReLU) on the GPU against the same model assembled from the ORACLE's reference op sequence on
+    the CPU, same initial weights: the loss curves must track each other (fp32 drift only)."""
+    from oracle import ref_layers as R
+    from pytorch_geometric_signed_directed_amd.nn import MagNet_node_classification
+    g = torch.Generator().manual_seed(21)
+    n, e, f, h, c = 3000, 40000, 32, 16, 5
+    ei = torch.randint(0, n, (2, e), generator=g)
+    w = torch.rand(e, generator=g) + 0.5
+    x = torch.randn(n, f, generator=g)
+    y = torch.randint(0, c, (n,), generator=g)
+    torch.manual_seed(21)
+    model = MagNet_node_classification(f, hidden=h, K=2, label_dim=c, activation=True, layer=2, dropout=0.0, cached=True)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    # oracle model: explicit parameter tensors + reference op sequence
+    prm = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0)
+
+    def oracle_forward():
+        re, im = x, x
+        for layer in range(2):
+            re, im = R.magnet_conv(re, im, op, prm[f"Chebs.{layer}.weight"], prm[f"Chebs.{layer}.bias"], duplicate=False)
+            re, im = R.complex_relu(re, im)
+        z = torch.cat([re, im], dim=-1)
+        logits = torch.nn.functional.conv1d(z.t().unsqueeze(0), prm["Conv.weight"], prm["Conv.bias"])
+        return torch.log_softmax(logits, dim=1)[0].t()
+
+    opt_o = torch.optim.Adam(list(prm.values()), lr=0.01)
+    model.to(D)
+    opt_g = torch.optim.Adam(model.parameters(), lr=0.01)
+    xd, eid, wd, yd = x.to(D), ei.to(D), w.to(D), y.to(D)
+    for step in range(5):
+        opt_o.zero_grad()
+        lo = torch.nn.functional.nll_loss(oracle_forward(), y)
+        lo.backward()
+        opt_o.step()
+        opt_g.zero_grad()
+        lg = torch.nn.functional.nll_loss(model(xd, xd, eid, wd), yd)
+        lg.backward()
+        opt_g.step()
+        assert abs(float(lg) - float(lo)) <= 2e-4 * max(1.0, abs(float(lo))), (step, float(lg), float(lo))
+    with torch.no_grad():
+        close(model(xd, xd, eid, wd), oracle_forward().detach().numpy(), 5e-4)
