@@ -1,6 +1,7 @@
-"""Device coalesce (sort by (row, col), merge duplicates by summation): the
-torch_geometric.utils.coalesce step of the operator build
-(reference utils/directed/get_magnetic_Laplacian.py:60)."""
+"""Host wrapper of the stand-alone device key sort (pygsd_sort_keys_u64): a stable radix sort of 64-bit
+keys with the permutation, the primitive under torch_geometric.utils.coalesce
+(reference utils/directed/get_magnetic_Laplacian.py:60).  The Laplacian build fuses its own sort
+(pygsd_maglap_sort); this entry point is kept for callers that coalesce other COO data."""
 import ctypes
 from typing import Tuple
 
@@ -29,22 +30,3 @@ def sort_keys(keys: Tensor, key_bits: int) -> Tuple[Tensor, Tensor]:
         check(lib.pygsd_sort_keys_u64(ptr(keys), ptr(out), ptr(perm), n, int(key_bits), ptr(ws), need.value,
                                       stream_ptr()), "pygsd_sort_keys_u64")
     return out, perm
-
-
-def coalesce_sum(index: Tensor, attr: Tensor, n: int) -> Tuple[Tensor, Tensor]:
-    """index [2, M] int64, attr [M, C] -> (unique index sorted by (row, col), summed attr)."""
-    m = index.size(1)
-    if m == 0:
-        return index, attr
-    key = index[0] * n + index[1]
-    bits = max(1, int(n * n - 1).bit_length()) if n > 1 else 1
-    skey, perm = sort_keys(key, bits)
-    perm = perm.long()
-    head = torch.ones(m, dtype=torch.bool, device=index.device)
-    head[1:] = skey[1:] != skey[:-1]
-    seg = head.long().cumsum(0) - 1
-    ukey = skey[head]
-    out_index = torch.stack([ukey // n, ukey % n])
-    sums = torch.zeros((ukey.numel(), attr.size(1)), dtype=attr.dtype, device=attr.device)
-    sums.index_add_(0, seg, attr[perm])
-    return out_index, sums

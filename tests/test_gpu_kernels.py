@@ -69,18 +69,6 @@ def test_sort_keys_exact_and_stable(n, bits, seed):
     assert torch.equal(perm.cpu().long(), want.indices)
 
 
-def test_coalesce_matches_oracle():
-    from pytorch_geometric_signed_directed_amd.sparse_build import coalesce_sum
-    g = torch.Generator().manual_seed(5)
-    n = 300
-    ei = torch.randint(0, n, (2, 5000), generator=g)
-    attr = torch.randn(5000, 3, generator=g)
-    got_i, got_a = coalesce_sum(ei.to(dev()), attr.to(dev()), n)
-    want_i, want_a = R.coalesce_add(ei, attr, n)
-    assert torch.equal(got_i.cpu(), want_i)
-    close(got_a, want_a, 1e-6)
-
-
 def test_complex_relu_bit_exact():
     from pytorch_geometric_signed_directed_amd.nn import complex_relu_layer
     g = torch.Generator().manual_seed(6)
