@@ -412,3 +412,35 @@ def test_sssnet_cut_objectives_match_reference():
         close(val, g["loss_" + name])
         val.sum().backward()
         close(prob.grad, g["dprob_" + name], 2e-5)
+
+
+def test_api_corners_match_oracle():
+    """Less-travelled arguments of the drop-in surface: __norm__, return_lambda_max, normalize=False,
+    add_self_loops=False, edge_weight=None."""
+    from pytorch_geometric_signed_directed_amd.nn import Conv_Base, DGCNConv, MagNetConv
+    from pytorch_geometric_signed_directed_amd.utils import get_magnetic_Laplacian, get_magnetic_signed_Laplacian
+    g = load_golden("magnet_k2_none_w")
+    ei, w = g.t("edge_index", D), g.t("edge_weight", D)
+    # largest eigenvalue by eigsh, as the reference computes it
+    _, _, _, lam = get_magnetic_Laplacian(ei, w, None, None, 40, float(g["q"]), return_lambda_max=True)
+    assert abs(lam - float(g["lambda_max"])) <= 1e-4 * float(g["lambda_max"])
+    gs = load_golden("msconv_k2_none_abs")
+    _, _, _, lam = get_magnetic_signed_Laplacian(gs.t("edge_index", D), gs.t("edge_weight", D), None, None, 40,
+                                                 float(gs["q"]), return_lambda_max=True, absolute_degree=True)
+    assert abs(lam - float(gs["lambda_max"])) <= 1e-4 * float(gs["lambda_max"])
+    # __norm__ returns the reference's 4-tuple
+    layer = MagNetConv(6, 5, 2, float(g["q"]), False, normalization=None)
+    got = layer.__norm__(ei, 40, w, float(g["q"]), None, float(g["lambda_max"]), dtype=torch.float32)
+    assert got[0].cpu().tolist() == g["op_index_real"].tolist() and got[1].cpu().tolist() == g["op_index_imag"].tolist()
+    close(got[2], g["op_real"], 1e-6)
+    close(got[3], g["op_imag"], 1e-6)
+    # un-normalised / loop-free aggregation paths
+    x = g.t("x_real", D)
+    xc = g.t("x_real")
+    eic, wc = g.t("edge_index"), g.t("edge_weight")
+    close(DGCNConv(normalize=False)(x, ei, w), R.propagate(xc, eic, wc, 40))
+    close(DGCNConv(normalize=False)(x, ei, None), R.propagate(xc, eic, None, 40))
+    close(DGCNConv(add_self_loops=False)(x, ei, None), R.dgcn_conv(xc, eic, None, False, False))
+    close(Conv_Base(0.3, add_self_loops=False)(x, ei, w), R.conv_base(xc, eic, wc, 0.3, add_self_loops=False))
+    close(Conv_Base(normalize=False)(x, ei, w), R.propagate(xc, eic, wc, 40, flow="target_to_source"))
+    close(Conv_Base(0.5)(x, ei, None), R.conv_base(xc, eic, None, 0.5))
