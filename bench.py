@@ -106,6 +106,8 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    if os.environ.get("PYGSD_BENCH_SHARE_GPU") == "1":   # test hook: all ranks on cuda:0 (needs the gloo backend)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -117,7 +119,11 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("PYGSD_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from pytorch_geometric_signed_directed_amd import _cabi
     from pytorch_geometric_signed_directed_amd.nn import MagNetConv
