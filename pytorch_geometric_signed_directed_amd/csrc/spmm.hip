@@ -103,9 +103,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_kernel(SpmmArgs 
         int c = 0;
         float wa = 0.f, wb = 0.f;
         if (lane < cnt) {
-            c = p.col[base + lane];
-            wa = p.va ? p.va[base + lane] : 1.f;
-            if (DUAL) wb = p.vb[base + lane];
+            // the CSR streams are read exactly once: non-temporal, so they do not evict gathered X rows
+            c = __builtin_nontemporal_load(p.col + base + lane);
+            wa = p.va ? __builtin_nontemporal_load(p.va + base + lane) : 1.f;
+            if (DUAL) wb = __builtin_nontemporal_load(p.vb + base + lane);
         }
         for (int u = 0; u < cnt; u += NPW * UNROLL) {
             float4 ga[UNROLL];
