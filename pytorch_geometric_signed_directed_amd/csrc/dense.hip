@@ -132,7 +132,12 @@ struct DenseBwdArgs {
 // grid = (row blocks, k1, ceil(f_in / 64)); block = 256 threads.  Block (x, k, ci) produces
 // dA_k[:, chunk ci], dB_k[:, chunk ci] for its rows and one partial of dW_k[chunk ci, :] (+ db when
 // k == 0 and ci == 0).  NTI = f_in-chunk tiles (<= 4), NTO = f_out tiles (<= 8).
-template <int NTI, int NTO>
+//
+// XPOSE (f_out <= 64): every global load is a 16-byte row load; the column fragments phase 2 needs
+// (rows in the MFMA k-slot, features across the 16 lanes) are produced by a round trip through a
+// wavefront-private LDS region (ds_write_b128 of the row fragments, ds_read_b32 of the column fragments,
+// both conflict-free at a +4-float row pad) instead of 64 scalar global loads per tile.
+template <int NTI, int NTO, bool XPOSE>
 __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(DenseBwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -151,6 +156,8 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
     __syncthreads();
 
     const int lane = tid & 63, i = lane & 15, g = lane >> 4;
+    constexpr int rs = (fo > fc ? fo : fc) + kPad;                 // row stride of the staging region
+    float* stage = lds + fo * ws + (tid >> 6) * (2 * 16 * rs);    // wavefront-private: [2][16][rs]
     const bool do_bias = (k == 0) && (blockIdx.z == 0);
     const float* ak = p.a[k];
     const float* bk = p.b[k];
@@ -173,7 +180,8 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
         // ---- all of the tile's loads first (phase-1 float4 rows of G, phase-2 column fragments of
         //      G / A_k / B_k), so every fetch is in flight before the first MFMA and none of them queues
         //      behind this tile's dA / dB stores -------------------------------------------------------
-        const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;
+        const bool lrow_live = r0 + i < p.n_rows;
+        const int lrow = lrow_live ? r0 + i : p.n_rows - 1;
         const float* grp = p.gr + static_cast<int64_t>(lrow) * p.f_out + 4 * g;
         const float* gip = p.gi + static_cast<int64_t>(lrow) * p.f_out + 4 * g;
         float4 xg[NTO], yg[NTO];
@@ -181,19 +189,52 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
         for (int nt = 0; nt < NTO; ++nt) {
             xg[nt] = ldg4(grp + nt * 16);
             yg[nt] = ldg4(gip + nt * 16);
+            if (XPOSE && !lrow_live) {          // rows past the end must contribute nothing to dW
+                xg[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+                yg[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         float av[4][NTI], bv[4][NTI];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            // MFMA step s of phase 2 consumes rows {4 g + s : g = 0..3}; lane (i, g) supplies column i.
-            // A_k / B_k come from HBM: fetched now, consumed after phase 1.
-            const int row = r0 + 4 * g + s;
-            const bool live = row < p.n_rows;
-            const int64_t ro = static_cast<int64_t>(live ? row : 0);
+        if (XPOSE) {
+            // A_k / B_k rows as float4, then LDS round trip into column fragments
+            const float* arow = ak + static_cast<int64_t>(lrow) * p.f_in + c0 + 4 * g;
+            const float* brow = bk + static_cast<int64_t>(lrow) * p.f_in + c0 + 4 * g;
 #pragma unroll
             for (int ft = 0; ft < NTI; ++ft) {
-                av[s][ft] = live ? ak[ro * p.f_in + c0 + ft * 16 + i] : 0.f;
-                bv[s][ft] = live ? bk[ro * p.f_in + c0 + ft * 16 + i] : 0.f;
+                float4 a4 = ldg4(arow + ft * 16), b4 = ldg4(brow + ft * 16);
+                if (!lrow_live) {
+                    a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                *reinterpret_cast<float4*>(stage + i * rs + ft * 16 + 4 * g) = a4;
+                *reinterpret_cast<float4*>(stage + 16 * rs + i * rs + ft * 16 + 4 * g) = b4;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ft = 0; ft < NTI; ++ft) {
+                    av[s][ft] = stage[(4 * g + s) * rs + ft * 16 + i];
+                    bv[s][ft] = stage[16 * rs + (4 * g + s) * rs + ft * 16 + i];
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                // MFMA step s of phase 2 consumes rows {4 g + s : g = 0..3}; lane (i, g) supplies column i.
+                // A_k / B_k come from HBM: fetched now, consumed after phase 1.
+                const int row = r0 + 4 * g + s;
+                const bool live = row < p.n_rows;
+                const int64_t ro = static_cast<int64_t>(live ? row : 0);
+#pragma unroll
+                for (int ft = 0; ft < NTI; ++ft) {
+                    av[s][ft] = live ? ak[ro * p.f_in + c0 + ft * 16 + i] : 0.f;
+                    bv[s][ft] = live ? bk[ro * p.f_in + c0 + ft * 16 + i] : 0.f;
+                }
             }
         }
         // ---- phase 1: dA_k, dB_k tile = [P | M] (16 x f_out) . W_k^T (f_out x fc) --------------------
@@ -210,6 +251,11 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
                 const float4 x = xg[nt], y = yg[nt];
                 const float pp[4] = {x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w};
                 const float mm[4] = {y.x - x.x, y.y - x.y, y.z - x.z, y.w - x.w};
+                if (XPOSE) {   // P / M row fragments -> staging region (A / B fragments were consumed above)
+                    *reinterpret_cast<float4*>(stage + i * rs + nt * 16 + 4 * g) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                    *reinterpret_cast<float4*>(stage + 16 * rs + i * rs + nt * 16 + 4 * g) =
+                        make_float4(mm[0], mm[1], mm[2], mm[3]);
+                }
                 const float* wt = wk + nt * 16 * ws;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -223,19 +269,32 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
             }
         }
         // ---- phase 2: dW_k[chunk, :] += A_tile^T P + B_tile^T M  (reduction over the 16 rows) ----------
+        if (XPOSE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            // column fragments of G for these rows: L1 / L2 hits (the same lines were read for phase 1)
-            const int row = r0 + 4 * g + s;
-            const bool live = row < p.n_rows;
-            const int64_t ro = static_cast<int64_t>(live ? row : 0);
             float pb[NTO], mb[NTO];
+            if (XPOSE) {
 #pragma unroll
-            for (int nt = 0; nt < NTO; ++nt) {
-                const float x = live ? p.gr[ro * p.f_out + nt * 16 + i] : 0.f;
-                const float y = live ? p.gi[ro * p.f_out + nt * 16 + i] : 0.f;
-                pb[nt] = x + y;
-                mb[nt] = y - x;
+                for (int nt = 0; nt < NTO; ++nt) {
+                    pb[nt] = stage[(4 * g + s) * rs + nt * 16 + i];
+                    mb[nt] = stage[16 * rs + (4 * g + s) * rs + nt * 16 + i];
+                }
+            } else {
+                // column fragments of G for these rows: L1 / L2 hits (the same lines were read for phase 1)
+                const int row = r0 + 4 * g + s;
+                const bool live = row < p.n_rows;
+                const int64_t ro = static_cast<int64_t>(live ? row : 0);
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    const float x = live ? p.gr[ro * p.f_out + nt * 16 + i] : 0.f;
+                    const float y = live ? p.gi[ro * p.f_out + nt * 16 + i] : 0.f;
+                    pb[nt] = x + y;
+                    mb[nt] = y - x;
+                }
             }
             // two sweeps, so that consecutive MFMAs never hit the same accumulator (40-cycle dependent
             // latency vs 32-cycle issue)
@@ -356,12 +415,14 @@ int launch_fwd(const DenseFwdArgs& a, unsigned gy, hipStream_t s)
 template <int NTI, int NTO>
 int launch_bwd(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
 {
-    size_t lds_floats = static_cast<size_t>(NTO * 16) * (NTI * 16 + kPad);
+    constexpr bool kXpose = true;
+    constexpr size_t rs = (NTO > NTI ? NTO : NTI) * 16 + kPad;
+    size_t lds_floats = static_cast<size_t>(NTO * 16) * (NTI * 16 + kPad) + (kXpose ? 4 * 2 * 16 * rs : 0);
     const size_t red = static_cast<size_t>(NTI * 16) * (NTO * 16) + NTO * 16;
     if (red > lds_floats) lds_floats = red;
     const size_t lds_bytes = lds_floats * sizeof(float);
-    if (int rc = set_lds(dense_bwd_kernel<NTI, NTO>, lds_bytes)) return rc;
-    hipLaunchKernelGGL((dense_bwd_kernel<NTI, NTO>), dim3(gx, a.k1, gz), dim3(256), lds_bytes, s, a);
+    if (int rc = set_lds(dense_bwd_kernel<NTI, NTO, kXpose>, lds_bytes)) return rc;
+    hipLaunchKernelGGL((dense_bwd_kernel<NTI, NTO, kXpose>), dim3(gx, a.k1, gz), dim3(256), lds_bytes, s, a);
     return check_launch("dense_bwd_kernel");
 }
 

@@ -82,7 +82,7 @@ template <int LPR, bool DUAL>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_kernel(SpmmArgs p)
 {
     constexpr int NPW = 64 / LPR;
-    constexpr int UNROLL = DUAL ? 8 : 16;
+    constexpr int UNROLL = (DUAL ? 8 : 16) / (LPR >= 32 ? 2 : 1);   // wider rows: fewer, larger gathers
     const int lane = threadIdx.x & 63;
     // wave-uniform row id -> rowptr is fetched with scalar loads
     const int row = __builtin_amdgcn_readfirstlane(
