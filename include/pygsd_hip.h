@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 1
+#define PYGSD_ABI_VERSION 2
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -55,13 +55,16 @@ const char* pygsd_last_error(void);
  *   (MagNetConv.py:216,222,228,234).
  * The same entry point computes the backward dX = S^T dY when handed the CSR grouped by source.
  * Deterministic: no atomics; the summation order inside a row is fixed by the CSR order.
+ * nnz_hint: total number of CSR entries if the caller knows it (0 = unknown).  Tuning only: rows with
+ * >= 24 entries on average run a variant with deeper gather pipelining, sparser ones a low-register
+ * variant with twice the wavefront occupancy; results are identical.
  * ------------------------------------------------------------------------------------------- */
 int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                        const float* X, int64_t ldx,
                        float* Y, int64_t ldy,
                        const float* Z, int64_t ldz,
                        int32_t n_rows, int32_t n_feat,
-                       float alpha, float beta, int32_t mean,
+                       float alpha, float beta, int32_t mean, int64_t nnz_hint,
                        void* stream);
 
 /* bf16-storage variant (BASELINE config "DiGCN_Inception_Block ... bf16"): X, Y, Z are bf16 row-major
@@ -87,7 +90,7 @@ int pygsd_spmm2_csr_f32(const int32_t* rowptr, const int32_t* col,
                         float* Ya, float* Yb, int64_t ldy,
                         const float* Za, const float* Zb, int64_t ldz,
                         int32_t n_rows, int32_t n_feat,
-                        float alpha, float beta,
+                        float alpha, float beta, int64_t nnz_hint,
                         void* stream);
 
 /* Per-edge gradient of the edge values (SDDMM): out[e] = < A[ia[e], :], B[ib[e], :] >.

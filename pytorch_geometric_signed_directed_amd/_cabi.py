@@ -24,13 +24,13 @@ PROTOTYPES = {
     "pygsd_last_error": (ctypes.c_char_p, []),
     "pygsd_spmm_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                      c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_int32,
-                                     c_void_p]),
+                                     c_int64, c_void_p]),
     "pygsd_spmm_csr_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                       c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_int32,
                                       c_void_p]),
     "pygsd_spmm2_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
-                                      c_int32, c_float, c_float, c_void_p]),
+                                      c_int32, c_float, c_float, c_int64, c_void_p]),
     "pygsd_sddmm_coo_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                       c_int32, c_void_p, c_void_p]),
     "pygsd_gat_alpha_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p,
@@ -77,7 +77,7 @@ PROTOTYPES = {
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def lib_path():

@@ -78,11 +78,56 @@ __device__ __forceinline__ float4 finish(float4 acc, float alpha, float beta, bo
 
 constexpr int kWavesPerBlock = 4;
 
-template <int LPR, bool DUAL>
+// One gather step: UN independent 16-byte row fetches per lane (UN * NPW neighbours per wavefront) are
+// issued before the first FMA.  Entry idx of the row chunk is handed to lane group `sub` through the LDS
+// crossbar; lanes past the end of the chunk (or past F) are predicated off.
+template <int LPR, bool DUAL, int UN>
+__device__ __forceinline__ void gather_step(int u, int cnt, int sub, bool fact, int c, float wa, float wb,
+                                            const float* xa, const float* xb, int64_t ldx, float4& acc_a,
+                                            float4& acc_b)
+{
+    constexpr int NPW = 64 / LPR;
+    float4 ga[UN];
+    float4 gb[UN];
+    float sa[UN];
+    float sb[UN];
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+        const int idx = u + k * NPW + sub;
+        const bool ok = fact && idx < cnt;
+        const int cj = __shfl(c, idx & 63);
+        const float ta = __shfl(wa, idx & 63);
+        sa[k] = ok ? ta : 0.f;
+        ga[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DUAL) {
+            const float tb = __shfl(wb, idx & 63);
+            sb[k] = ok ? tb : 0.f;
+            gb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (ok) {
+            const int64_t off = static_cast<int64_t>(cj) * ldx;
+            ga[k] = ld4(xa + off);
+            if (DUAL) gb[k] = ld4(xb + off);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+        fma4(acc_a, sa[k], ga[k]);
+        if (DUAL) fma4(acc_b, sb[k], gb[k]);
+    }
+}
+
+// DEEP = true : deepest step 16 (8 per operator in the dual kernel) row fetches per lane in flight, ~125
+//               VGPRs, 4 waves/SIMD -- measured best on rows with >= ~24 neighbours (the 40-neighbour
+//               benchmark rows: +1..5 % over the light variant).
+// DEEP = false: deepest step 4, <= 64 VGPRs, 8 waves/SIMD -- low-degree rows (signed SBM parts with 6-15
+//               neighbours) issue few gathers each and need the wavefront count instead (the deep variant
+//               is 1.8x SLOWER there).  The host picks by nnz / n_rows.
+template <int LPR, bool DUAL, bool DEEP>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_kernel(SpmmArgs p)
 {
     constexpr int NPW = 64 / LPR;
-    constexpr int UNROLL = (DUAL ? 8 : 16) / (LPR >= 32 ? 2 : 1);   // wider rows: fewer, larger gathers
+    constexpr int UB = DEEP ? (DUAL ? 8 : 16) / (LPR >= 32 ? 2 : 1) : (DUAL ? 2 : 4);
     const int lane = threadIdx.x & 63;
     // wave-uniform row id -> rowptr is fetched with scalar loads
     const int row = __builtin_amdgcn_readfirstlane(
@@ -109,36 +154,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_kernel(SpmmArgs 
             wa = p.va ? __builtin_nontemporal_load(p.va + base + lane) : 1.f;
             if (DUAL) wb = __builtin_nontemporal_load(p.vb + base + lane);
         }
-        for (int u = 0; u < cnt; u += NPW * UNROLL) {
-            float4 ga[UNROLL];
-            float4 gb[UNROLL];
-            float sa[UNROLL];
-            float sb[UNROLL];
-#pragma unroll
-            for (int k = 0; k < UNROLL; ++k) {
-                const int idx = u + k * NPW + sub;
-                const bool ok = fact && idx < cnt;
-                const int cj = __shfl(c, idx & 63);
-                const float ta = __shfl(wa, idx & 63);
-                sa[k] = ok ? ta : 0.f;
-                ga[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (DUAL) {
-                    const float tb = __shfl(wb, idx & 63);
-                    sb[k] = ok ? tb : 0.f;
-                    gb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                if (ok) {
-                    const int64_t off = static_cast<int64_t>(cj) * p.ldx;
-                    ga[k] = ld4(xa + off);
-                    if (DUAL) gb[k] = ld4(xb + off);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < UNROLL; ++k) {
-                fma4(acc_a, sa[k], ga[k]);
-                if (DUAL) fma4(acc_b, sb[k], gb[k]);
-            }
+        int u = 0;
+        for (; cnt - u >= NPW * UB; u += NPW * UB)
+            gather_step<LPR, DUAL, UB>(u, cnt, sub, fact, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
+        if (UB >= 8 && cnt - u >= NPW * (UB / 2)) {
+            gather_step<LPR, DUAL, (UB >= 8 ? UB / 2 : 1)>(u, cnt, sub, fact, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
+            u += NPW * (UB / 2);
         }
+        if (UB >= 16 && cnt - u >= NPW * (UB / 4)) {
+            gather_step<LPR, DUAL, (UB >= 16 ? UB / 4 : 1)>(u, cnt, sub, fact, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
+            u += NPW * (UB / 4);
+        }
+        for (; u < cnt; u += NPW * 2)
+            gather_step<LPR, DUAL, 2>(u, cnt, sub, fact, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
     }
 
     reduce_groups<LPR>(acc_a);
@@ -194,8 +222,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_scalar_kernel(SpmmAr
     }
 }
 
+template <int LPR, bool DUAL>
+void launch_vec(const SpmmArgs& a, bool deep, dim3 grid, dim3 block, hipStream_t stream)
+{
+    if (deep)
+        hipLaunchKernelGGL((spmm_vec_kernel<LPR, DUAL, true>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((spmm_vec_kernel<LPR, DUAL, false>), grid, block, 0, stream, a);
+}
+
 template <bool DUAL>
-int launch_spmm(const SpmmArgs& a, hipStream_t stream)
+int launch_spmm(const SpmmArgs& a, int64_t nnz_hint, hipStream_t stream)
 {
     if (a.n_rows == 0 || a.n_feat == 0) return 0;
     const dim3 block(kWavesPerBlock * 64);
@@ -213,17 +250,18 @@ int launch_spmm(const SpmmArgs& a, hipStream_t stream)
         return check_launch("spmm_scalar_kernel");
     }
     const int quads = a.n_feat / 4;
+    const bool deep = nnz_hint <= 0 || nnz_hint >= static_cast<int64_t>(24) * a.n_rows;   // avg degree >= 24
     if (quads <= 4) {
-        hipLaunchKernelGGL((spmm_vec_kernel<4, DUAL>), dim3(gx), block, 0, stream, a);
+        launch_vec<4, DUAL>(a, deep, dim3(gx), block, stream);
     } else if (quads <= 8) {
-        hipLaunchKernelGGL((spmm_vec_kernel<8, DUAL>), dim3(gx), block, 0, stream, a);
+        launch_vec<8, DUAL>(a, deep, dim3(gx), block, stream);
     } else if (quads <= 16) {
-        hipLaunchKernelGGL((spmm_vec_kernel<16, DUAL>), dim3(gx), block, 0, stream, a);
+        launch_vec<16, DUAL>(a, deep, dim3(gx), block, stream);
     } else if (quads <= 32) {
-        hipLaunchKernelGGL((spmm_vec_kernel<32, DUAL>), dim3(gx), block, 0, stream, a);
+        launch_vec<32, DUAL>(a, deep, dim3(gx), block, stream);
     } else {
         const unsigned gy = (static_cast<unsigned>(quads) + 63) / 64;
-        hipLaunchKernelGGL((spmm_vec_kernel<64, DUAL>), dim3(gx, gy), block, 0, stream, a);
+        launch_vec<64, DUAL>(a, deep, dim3(gx, gy), block, stream);
     }
     return check_launch("spmm_vec_kernel");
 }
@@ -394,7 +432,7 @@ using namespace pygsd;
 extern "C" int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                                   const float* X, int64_t ldx, float* Y, int64_t ldy,
                                   const float* Z, int64_t ldz, int32_t n_rows, int32_t n_feat,
-                                  float alpha, float beta, int32_t mean, void* stream)
+                                  float alpha, float beta, int32_t mean, int64_t nnz_hint, void* stream)
 {
     PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_spmm_csr_f32: negative size");
     if (n_rows == 0 || n_feat == 0) return 0;
@@ -403,7 +441,7 @@ extern "C" int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, con
                   "pygsd_spmm_csr_f32: row stride smaller than n_feat");
     SpmmArgs a{rowptr, col, val, nullptr, X, nullptr, Y, nullptr, Z, nullptr,
                ldx, ldy, ldz, n_rows, n_feat, alpha, beta, mean};
-    return launch_spmm<false>(a, static_cast<hipStream_t>(stream));
+    return launch_spmm<false>(a, nnz_hint, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int pygsd_spmm_csr_bf16(const int32_t* rowptr, const int32_t* col, const float* val,
@@ -428,7 +466,7 @@ extern "C" int pygsd_spmm2_csr_f32(const int32_t* rowptr, const int32_t* col, co
                                    const float* val_b, const float* Xa, const float* Xb, int64_t ldx,
                                    float* Ya, float* Yb, int64_t ldy, const float* Za,
                                    const float* Zb, int64_t ldz, int32_t n_rows, int32_t n_feat,
-                                   float alpha, float beta, void* stream)
+                                   float alpha, float beta, int64_t nnz_hint, void* stream)
 {
     PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_spmm2_csr_f32: negative size");
     if (n_rows == 0 || n_feat == 0) return 0;
@@ -439,7 +477,7 @@ extern "C" int pygsd_spmm2_csr_f32(const int32_t* rowptr, const int32_t* col, co
                   "pygsd_spmm2_csr_f32: row stride smaller than n_feat");
     SpmmArgs a{rowptr, col, val_a, val_b, Xa, Xb, Ya, Yb, Za, Zb,
                ldx, ldy, ldz, n_rows, n_feat, alpha, beta, 0};
-    return launch_spmm<true>(a, static_cast<hipStream_t>(stream));
+    return launch_spmm<true>(a, nnz_hint, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int pygsd_sddmm_coo_f32(const int32_t* ia, const int32_t* ib, int64_t nnz, const float* A,

@@ -194,7 +194,7 @@ def _spmm_raw(csr: CSR, val: Optional[Tensor], x: Tensor, z: Optional[Tensor], a
     with torch.cuda.device(x.device):
         check(_cabi.lib().pygsd_spmm_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(val), ptr(x), ldx, ptr(y),
                                              max(f, 1), zp, ldz, csr.n_rows, f, float(alpha), float(beta),
-                                             1 if mean else 0, stream_ptr()), "pygsd_spmm_csr_f32")
+                                             1 if mean else 0, csr.nnz, stream_ptr()), "pygsd_spmm_csr_f32")
     return y
 
 
@@ -232,7 +232,7 @@ def _spmm2_raw(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, z
     with torch.cuda.device(xa.device):
         check(_cabi.lib().pygsd_spmm2_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(val_a), ptr(val_b), ptr(xa),
                                               ptr(xb), lda, ptr(ya), ptr(yb), max(f, 1), zap, zbp, ldz,
-                                              csr.n_rows, f, float(alpha), float(beta), stream_ptr()),
+                                              csr.n_rows, f, float(alpha), float(beta), csr.nnz, stream_ptr()),
               "pygsd_spmm2_csr_f32")
     return ya, yb
 
