@@ -3,7 +3,7 @@ aggregation of DIGRAC): 2*hop Conv_Base SpMMs."""
 import torch
 from torch.nn import Parameter
 
-from ..general.conv_base import Conv_Base
+from ..general.conv_base import Conv_Base, flipped_edge_index
 
 
 class DIMPA(torch.nn.Module):
@@ -24,7 +24,7 @@ class DIMPA(torch.nn.Module):
         feat_s = self._w_s[0] * x_s
         feat_t = self._w_t[0] * x_t
         cur_s, cur_t = x_s, x_t
-        edge_index_t = edge_index[[1, 0]]
+        edge_index_t = flipped_edge_index(edge_index)
         for h in range(1, 1 + self._hop):
             cur_s = self.conv_layer(cur_s, edge_index, edge_weight)
             cur_t = self.conv_layer(cur_t, edge_index_t, edge_weight)

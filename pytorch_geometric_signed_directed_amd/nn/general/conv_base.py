@@ -10,6 +10,24 @@ from ...sparse import GLOBAL_PATTERNS, spmm
 from ...utils._norm import conv_norm_rw  # noqa: F401  (re-exported like the reference module)
 
 
+_FLIP_MEMO = []   # (edge_index, version, flipped): SIMPA / DIMPA flip the same edge_index every forward
+
+
+def flipped_edge_index(edge_index: Tensor) -> Tensor:
+    """edge_index[[1, 0]] (reference SIMPA.py:99-100, DIMPA.py:50), memoised on the tensor object and its
+    in-place version so that the normalisation and CSR caches keyed on the flipped tensor keep hitting
+    across forwards instead of re-sorting the graph every step."""
+    for k, (src, ver, out) in enumerate(_FLIP_MEMO):
+        if src is edge_index and ver == edge_index._version:
+            _FLIP_MEMO.append(_FLIP_MEMO.pop(k))
+            return out
+    out = edge_index[[1, 0]]
+    _FLIP_MEMO.append((edge_index, edge_index._version, out))
+    if len(_FLIP_MEMO) > 4:
+        _FLIP_MEMO.pop(0)
+    return out
+
+
 class Conv_Base(MessagePassing):
     edge_weight_arg = "edge_weight"
     _fused_message = True

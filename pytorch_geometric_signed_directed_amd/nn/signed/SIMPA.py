@@ -5,7 +5,7 @@ from typing import Optional
 import torch
 from torch.nn import Parameter
 
-from ..general.conv_base import Conv_Base
+from ..general.conv_base import Conv_Base, flipped_edge_index
 
 
 class SIMPA(torch.nn.Module):
@@ -68,6 +68,7 @@ class SIMPA(torch.nn.Module):
             return torch.cat([fp, fn], dim=1)
         sp, sn = self._stream(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, x_p, x_n,
                               self._w_sp, self._w_sn)
-        tp, tn = self._stream(edge_index_p[[1, 0]], edge_weight_p, edge_index_n[[1, 0]], edge_weight_n,
+        tp, tn = self._stream(flipped_edge_index(edge_index_p), edge_weight_p,
+                              flipped_edge_index(edge_index_n), edge_weight_n,
                               x_pt, x_nt, self._w_tp, self._w_tn)
         return torch.cat([sp, sn, tp, tn], dim=1)
