@@ -442,3 +442,36 @@ def test_digcn_conv_bf16_layer():
     assert out.dtype == torch.bfloat16
     err = (out.float().cpu() - want).abs()
     assert bool((err <= want.abs() * 2.0 ** -7 + 2e-2).all()), float(err.max())
+
+
+def test_spmm_variants_are_bitwise_identical():
+    """The nnz hint only selects a tuning variant (deep gather pipelining vs high occupancy); every lane
+    group accumulates its neighbours in the same order in both, so the outputs are bit-identical."""
+    import ctypes
+    from pytorch_geometric_signed_directed_amd import _cabi
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern
+    d = dev()
+    g = torch.Generator().manual_seed(77)
+    n, nnz, f = 3000, 90000, 64
+    ei = torch.randint(0, n, (2, nnz), generator=g)
+    ei[1, :500] = 11                                   # one long row
+    pat = Pattern(ei.to(d), n, n)
+    csr = pat.fwd
+    xa, xb = torch.randn(n, f, generator=g).to(d), torch.randn(n, f, generator=g).to(d)
+    va = pat.values_for(torch.randn(nnz, generator=g).to(d), "fwd")
+    vb = pat.values_for(torch.randn(nnz, generator=g).to(d), "fwd")
+    lib, P = _cabi.lib(), _cabi.ptr
+    outs = []
+    for hint in (0, 1, 10 ** 9):                       # unknown -> deep, tiny -> light, huge -> deep
+        y1 = torch.empty(n, f, device=d)
+        ya, yb = torch.empty(n, f, device=d), torch.empty(n, f, device=d)
+        _cabi.check(lib.pygsd_spmm_csr_f32(P(csr.rowptr), P(csr.col), P(va), P(xa), f, P(y1), f, None, 0, n, f,
+                                           1.0, 0.0, 0, hint, _cabi.stream_ptr()), "spmm")
+        _cabi.check(lib.pygsd_spmm2_csr_f32(P(csr.rowptr), P(csr.col), P(va), P(vb), P(xa), P(xb), f, P(ya), P(yb),
+                                            f, None, None, 0, n, f, 1.0, 0.0, hint, _cabi.stream_ptr()), "spmm2")
+        outs.append((y1, ya, yb))
+    torch.cuda.synchronize()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+    assert torch.equal(outs[0][0], outs[0][1])        # single == the a-half of the dual kernel
