@@ -362,6 +362,25 @@ def loss_case():
     save("sssnet_losses", edge_index=eis, edge_weight=ws, prob=npy(prob), **out)
 
 
+def imbalance_loss_case():
+    from torch_geometric_signed_directed.utils.directed.prob_imbalance_loss import Prob_Imbalance_Loss
+    n, k = 40, 4
+    ei, w = toy_graph(91)
+    a = torch.sparse_coo_tensor(t(ei), t(w), (n, n)).coalesce()
+    g = torch.Generator().manual_seed(91)
+    out = {}
+    for norm in ("vol_sum", "vol_min", "vol_max", "plain"):
+        for thr in ("sort", "std", "naive"):
+            prob = torch.softmax(torch.randn(n, k, generator=g), dim=1).requires_grad_()
+            val = Prob_Imbalance_Loss(3)(prob, a, k, norm, thr)
+            out[f"prob_{norm}_{thr}"] = npy(prob)
+            out[f"loss_{norm}_{thr}"] = npy(val)
+            if thr == "sort":
+                val.sum().backward()
+                out[f"dprob_{norm}_{thr}"] = npy(prob.grad)
+    save("digrac_imbalance_loss", edge_index=ei, edge_weight=w, **out)
+
+
 # ------------------------------------------------------------------ model-level callers (eval mode)
 def model_case(name, model, args, seed):
     """Reference model in eval mode (dropout off) on fixed inputs: record state_dict + outputs."""
@@ -455,8 +474,9 @@ def main():
     kat_case()
     print("attention aggregate")
     gat_cases()
-    print("SSSNET cut objectives")
+    print("SSSNET cut objectives / DIGRAC imbalance")
     loss_case()
+    imbalance_loss_case()
     print("model-level callers")
     models()
 

@@ -444,3 +444,19 @@ def test_api_corners_match_oracle():
     close(Conv_Base(0.3, add_self_loops=False)(x, ei, w), R.conv_base(xc, eic, wc, 0.3, add_self_loops=False))
     close(Conv_Base(normalize=False)(x, ei, w), R.propagate(xc, eic, wc, 40, flow="target_to_source"))
     close(Conv_Base(0.5)(x, ei, None), R.conv_base(xc, eic, None, 0.5))
+
+
+def test_digrac_imbalance_loss_matches_reference():
+    """the K^2 sparse mat-vecs of DIGRAC's imbalance loss as one HIP SpMM, every
+    normalisation x threshold combination, gradients on the 'sort' branch (the only one that has any)."""
+    from pytorch_geometric_signed_directed_amd.utils import Prob_Imbalance_Loss
+    g = load_golden("digrac_imbalance_loss")
+    a = torch.sparse_coo_tensor(g.t("edge_index", D), g.t("edge_weight", D), (40, 40)).coalesce()
+    for norm in ("vol_sum", "vol_min", "vol_max", "plain"):
+        for thr in ("sort", "std", "naive"):
+            prob = g.t(f"prob_{norm}_{thr}", D).requires_grad_()
+            val = Prob_Imbalance_Loss(3)(prob, a, 4, norm, thr)
+            close(val, g[f"loss_{norm}_{thr}"], 2e-5)
+            if thr == "sort":
+                val.sum().backward()
+                close(prob.grad, g[f"dprob_{norm}_{thr}"], 5e-5)
