@@ -398,6 +398,7 @@ def model_case(name, model, args, seed):
 
 
 def models():
+    from torch_geometric_signed_directed.nn import DGCN_node_classification
     from torch_geometric_signed_directed.nn import (DIGRAC_node_clustering, DiGCN_Inception_Block_node_classification,
                                                     DiGCN_node_classification, MagNet_link_prediction,
                                                     MagNet_node_classification, MSGNN_link_prediction,
@@ -430,6 +431,13 @@ def models():
                       (x, (t(ei), t(ei2)), (t(w), t(w2))), 66))
     save("model_digrac", edge_index=ei, edge_weight=w, x=npy(x),
          **model_case("m", DIGRAC_node_clustering(6, 8, 3, 0.5, 0.5, 2), (t(ei), t(w), x), 67))
+    e_in, w_in = toy_graph(55, e=140)
+    e_out, w_out = toy_graph(56, e=150)
+    for cached in (False, True):
+        save("model_dgcn_" + ("cached" if cached else "uncached"), edge_index=ei, edge_in=e_in, in_w=w_in,
+             edge_out=e_out, out_w=w_out, x=npy(x), cached=np.bool_(cached),
+             **model_case("m", DGCN_node_classification(6, 8, 4, 0.5, improved=True, cached=cached),
+                          (x, t(ei), t(e_in), t(e_out), t(w_in), t(w_out)), 69))
     ein, wn = toy_graph(54, e=90)
     for directed in (False, True):
         save("model_sssnet_" + ("directed" if directed else "undirected"), edge_index_p=ei, edge_weight_p=w,

@@ -1,7 +1,7 @@
 from .directed import *  # noqa: F401,F403
 from .general import *  # noqa: F401,F403
 from .signed import *  # noqa: F401,F403
-from .models import (DIGRAC_node_clustering, DiGCN_Inception_Block_node_classification,  # noqa: F401
+from .models import (DGCN_node_classification, DIGRAC_node_clustering, DiGCN_Inception_Block_node_classification,  # noqa: F401
                      DiGCN_InceptionBlock, DiGCN_node_classification, MagNet_link_prediction,
                      MagNet_node_classification, MSGNN_link_prediction, MSGNN_node_classification,
                      SSSNET_node_clustering)

@@ -16,6 +16,7 @@ from torch.nn import Parameter
 
 from ..dense import tall_linear
 from .directed.complex_relu import complex_relu_layer
+from .directed.DGCNConv import DGCNConv
 from .directed.DiGCNConv import DiGCNConv
 from .directed.DIMPA import DIMPA
 from .directed.MagNetConv import MagNetConv
@@ -230,6 +231,46 @@ class DiGCN_Inception_Block_node_classification(nn.Module):
             if depth < 2:
                 x = drop(x)
         return F.log_softmax(x, dim=1)
+
+
+class DGCN_node_classification(nn.Module):
+    """nn/directed/DGCN_node_classification.py:10-97: ONE shared weight-less DGCNConv applied to the
+    symmetrised, in- and out-proximity operators (so `cached=True` silently reuses the first operator for all
+    three), two Linear stages, a 1x1 Conv1d head."""
+
+    def __init__(self, num_features: int, hidden: int, label_dim: int, dropout: Optional[float] = 0.5,
+                 improved: bool = False, cached: bool = False):
+        super().__init__()
+        self.dropout = dropout
+        self.dgconv = DGCNConv(improved=improved, cached=cached)
+        self.Conv = nn.Conv1d(hidden * 3, label_dim, kernel_size=1)
+        self.lin1 = nn.Linear(num_features, hidden, bias=False)
+        self.lin2 = nn.Linear(hidden * 3, hidden, bias=False)
+        self.bias1 = Parameter(torch.Tensor(1, hidden))
+        self.bias2 = Parameter(torch.Tensor(1, hidden))
+        nn.init.zeros_(self.bias1)
+        nn.init.zeros_(self.bias2)
+
+    def reset_parameters(self):
+        self.lin1.reset_parameters()
+        self.lin2.reset_parameters()
+        nn.init.zeros_(self.bias1)
+        nn.init.zeros_(self.bias2)
+        self.Conv.reset_parameters()
+
+    def _three(self, x, edge_index, edge_in, edge_out, in_w, out_w, bias):
+        parts = [self.dgconv(x, edge_index), self.dgconv(x, edge_in, in_w), self.dgconv(x, edge_out, out_w)]
+        return F.relu(torch.cat([t + bias for t in parts], dim=-1))
+
+    def forward(self, x, edge_index, edge_in, edge_out, in_w=None, out_w=None):
+        x = tall_linear(x, self.lin1.weight.t())
+        x = self._three(x, edge_index, edge_in, edge_out, in_w, out_w, self.bias1)
+        x = tall_linear(x, self.lin2.weight.t())
+        x = self._three(x, edge_index, edge_in, edge_out, in_w, out_w, self.bias2)
+        if self.dropout > 0:
+            x = F.dropout(x, self.dropout, training=self.training)
+        x = self.Conv(x.t().unsqueeze(0))
+        return F.log_softmax(x[0].t(), dim=1)
 
 
 def _cluster_head(z, w_prob, bias):

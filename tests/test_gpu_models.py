@@ -193,3 +193,13 @@ def test_training_trajectory_matches_the_oracle_model():
     with torch.no_grad():
         diff = (model(xd, xd, eid, wd).cpu() - oracle_forward().detach()).abs()
     assert float(diff.mean()) <= 5e-3 and float(diff.median()) <= 5e-3
+
+
+def test_dgcn_model_incl_shared_cached_conv_quirk():
+    from pytorch_geometric_signed_directed_amd.nn import DGCN_node_classification
+    for name in ("model_dgcn_uncached", "model_dgcn_cached"):
+        g = load_golden(name)
+        m = load(DGCN_node_classification(6, 8, 4, 0.5, improved=True, cached=bool(g["cached"])), g)
+        with torch.no_grad():
+            check(m(g.t("x", D), g.t("edge_index", D), g.t("edge_in", D), g.t("edge_out", D), g.t("in_w", D),
+                    g.t("out_w", D)), g)
