@@ -434,8 +434,8 @@ def models():
     e_in, w_in = toy_graph(55, e=140)
     e_out, w_out = toy_graph(56, e=150)
     for cached in (False, True):
-        save("model_dgcn_" + ("cached" if cached else "uncached"), edge_index=ei, edge_in=e_in, in_w=w_in,
-             edge_out=e_out, out_w=w_out, x=npy(x), cached=np.bool_(cached),
+        save("model_dgcn_" + ("cached" if cached else "uncached"), edge_index=ei, edge_in=e_in, w_in=w_in,
+             edge_out=e_out, w_out=w_out, x=npy(x), cached=np.bool_(cached),
              **model_case("m", DGCN_node_classification(6, 8, 4, 0.5, improved=True, cached=cached),
                           (x, t(ei), t(e_in), t(e_out), t(w_in), t(w_out)), 69))
     ein, wn = toy_graph(54, e=90)

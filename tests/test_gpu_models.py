@@ -24,7 +24,7 @@ def load(model, g):
 
 
 def outs(g):
-    return [g[k] for k in sorted(k for k in g if k.startswith("out"))]
+    return [g[k] for k in sorted(k for k in g if k.startswith("out") and k[3:].isdigit())]
 
 
 def check(result, g):
@@ -201,5 +201,5 @@ def test_dgcn_model_incl_shared_cached_conv_quirk():
         g = load_golden(name)
         m = load(DGCN_node_classification(6, 8, 4, 0.5, improved=True, cached=bool(g["cached"])), g)
         with torch.no_grad():
-            check(m(g.t("x", D), g.t("edge_index", D), g.t("edge_in", D), g.t("edge_out", D), g.t("in_w", D),
-                    g.t("out_w", D)), g)
+            check(m(g.t("x", D), g.t("edge_index", D), g.t("edge_in", D), g.t("edge_out", D), g.t("w_in", D),
+                    g.t("w_out", D)), g)
