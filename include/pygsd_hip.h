@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 2
+#define PYGSD_ABI_VERSION 3
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -58,14 +58,34 @@ const char* pygsd_last_error(void);
  * nnz_hint: total number of CSR entries if the caller knows it (0 = unknown).  Tuning only: rows with
  * >= 24 entries on average run a variant with deeper gather pipelining, sparser ones a low-register
  * variant with twice the wavefront occupancy; results are identical.
+ * long_rows (may be NULL): hub rows.  One wavefront owns one output row, so a row with 10^5..10^6 entries
+ * (power-law graphs; the reference's scatter has no such cliff) would serialise the launch.  The caller
+ * lists the rows with MORE than PYGSD_LONG_ROW entries; the row-per-wavefront kernel skips them and a
+ * second pair of kernels reduces them in 4096-entry segments, adding the segment partials in segment
+ * order (deterministic, no atomics; the summation ORDER of a hub row differs from the single-wavefront
+ * order, i.e. results agree to fp32 rounding, not bitwise, with long_rows = NULL).  Rows listed must
+ * really exceed PYGSD_LONG_ROW entries (others would be computed twice, harmlessly); rows above the
+ * threshold that are NOT listed are left unwritten.
  * ------------------------------------------------------------------------------------------- */
+#define PYGSD_LONG_ROW 4096
+typedef struct pygsd_long_rows {
+    const int32_t* rows;      /* device: ids of the rows with > PYGSD_LONG_ROW entries                 */
+    int32_t n_rows;           /* how many                                                             */
+    int32_t max_entries;      /* entries of the longest of them                                       */
+    void* workspace;          /* device scratch, pygsd_spmm_long_rows_workspace() bytes               */
+    int64_t workspace_bytes;
+} pygsd_long_rows;
+
+int pygsd_spmm_long_rows_workspace(int32_t n_long, int32_t max_entries, int32_t n_feat, int32_t dual,
+                                   int64_t* bytes);
+
 int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                        const float* X, int64_t ldx,
                        float* Y, int64_t ldy,
                        const float* Z, int64_t ldz,
                        int32_t n_rows, int32_t n_feat,
                        float alpha, float beta, int32_t mean, int64_t nnz_hint,
-                       void* stream);
+                       const pygsd_long_rows* long_rows, void* stream);
 
 /* bf16-storage variant (BASELINE config "DiGCN_Inception_Block ... bf16"): X, Y, Z are bf16 row-major
  * (n_feat and the row strides multiples of 8, 16-byte aligned), edge values and accumulation fp32,
@@ -91,7 +111,7 @@ int pygsd_spmm2_csr_f32(const int32_t* rowptr, const int32_t* col,
                         const float* Za, const float* Zb, int64_t ldz,
                         int32_t n_rows, int32_t n_feat,
                         float alpha, float beta, int64_t nnz_hint,
-                        void* stream);
+                        const pygsd_long_rows* long_rows, void* stream);
 
 /* Per-edge gradient of the edge values (SDDMM): out[e] = < A[ia[e], :], B[ib[e], :] >.
  * Backward of message() w.r.t. `norm` (needed by trainable_q, MagNetConv.py:58-59,141-142, and by

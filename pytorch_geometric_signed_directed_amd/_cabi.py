@@ -18,19 +18,29 @@ K_SPMM, K_SPMM2, K_SDDMM, K_BUILD, K_ELEMENTWISE, K_DENSE, K_DENSE_BWD = range(7
 KERNEL_IDS = {"spmm": K_SPMM, "spmm2": K_SPMM2, "sddmm": K_SDDMM, "build": K_BUILD,
               "elementwise": K_ELEMENTWISE, "dense": K_DENSE, "dense_bwd": K_DENSE_BWD}
 
+LONG_ROW = 4096  # PYGSD_LONG_ROW
+
+
+class LongRows(ctypes.Structure):
+    """struct pygsd_long_rows (include/pygsd_hip.h)."""
+    _fields_ = [("rows", c_void_p), ("n_rows", c_int32), ("max_entries", c_int32), ("workspace", c_void_p),
+                ("workspace_bytes", c_int64)]
+
+
 # name -> (restype, argtypes); must list every symbol include/pygsd_hip.h declares
 PROTOTYPES = {
     "pygsd_version": (c_int32, []),
     "pygsd_last_error": (ctypes.c_char_p, []),
     "pygsd_spmm_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                      c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_int32,
-                                     c_int64, c_void_p]),
+                                     c_int64, c_void_p, c_void_p]),
+    "pygsd_spmm_long_rows_workspace": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "pygsd_spmm_csr_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                       c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_int32,
                                       c_void_p]),
     "pygsd_spmm2_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
-                                      c_int32, c_float, c_float, c_int64, c_void_p]),
+                                      c_int32, c_float, c_float, c_int64, c_void_p, c_void_p]),
     "pygsd_sddmm_coo_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                       c_int32, c_void_p, c_void_p]),
     "pygsd_gat_alpha_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p,
@@ -77,7 +87,7 @@ PROTOTYPES = {
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def lib_path():

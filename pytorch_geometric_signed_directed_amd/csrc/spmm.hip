@@ -34,6 +34,7 @@ struct SpmmArgs {
     int32_t n_rows, n_feat;
     float alpha, beta;
     int32_t mean;
+    int32_t skip_longer_than;   // > 0: rows with more entries are left to the long-row path
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_kernel(SpmmArgs 
     const bool fact = fl < p.n_feat;
     const int beg = p.rowptr[row];
     const int end = p.rowptr[row + 1];
+    if (p.skip_longer_than > 0 && end - beg > p.skip_longer_than) return;   // hub row: spmm_long_kernel
 
     float4 acc_a = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -180,6 +182,111 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_kernel(SpmmArgs 
         if (DUAL)
             st4(p.yb + yo, finish(acc_b, p.alpha, p.beta, false, deg, p.zb ? p.zb + zo : nullptr));
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Hub rows (power-law tails).  One wavefront per row makes a row with 10^5..10^6 entries the critical path
+// (27 us per 1000 entries: 27 ms for a 1M-entry hub against 0.14 ms for the rest of a 4M-entry operator).
+// Rows longer than PYGSD_LONG_ROW entries are therefore skipped by the main kernel and handled here:
+// block (r, s) reduces segment s (kLongSeg entries, 4 wavefronts x 1024) of long row r into a partial
+// feature row, a second kernel adds the partials IN SEGMENT ORDER and applies the epilogue --
+// deterministic, no atomics.
+// ------------------------------------------------------------------------------------------
+constexpr int kLongSeg = 4096;
+
+template <int LPR, bool DUAL>
+__global__ __launch_bounds__(256) void spmm_long_kernel(SpmmArgs p, const int32_t* __restrict__ long_rows,
+                                                        float* __restrict__ part_a, float* __restrict__ part_b,
+                                                        int n_seg)
+{
+    constexpr int NPW = 64 / LPR;
+    constexpr int UB = (DUAL ? 8 : 16) / (LPR >= 32 ? 2 : 1);
+    __shared__ float4 sm[4][2][LPR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = long_rows[blockIdx.x];
+    const int seg = blockIdx.y;
+    const int sub = lane / LPR;
+    const int fl = static_cast<int>(blockIdx.z) * (LPR * 4) + (lane % LPR) * 4;
+    const bool fact = fl < p.n_feat;
+    const int row_end = p.rowptr[row + 1];
+    if (p.rowptr[row] + seg * kLongSeg >= row_end) return;      // block-uniform: shorter hub than the longest
+    int beg = p.rowptr[row] + seg * kLongSeg + wave * (kLongSeg / 4);
+    int end = beg + kLongSeg / 4;
+    if (end > row_end) end = row_end;
+    float4 acc_a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xa = p.xa + fl;
+    const float* xb = DUAL ? p.xb + fl : nullptr;
+    for (int base = beg; base < end; base += 64) {
+        const int cnt = (end - base) < 64 ? (end - base) : 64;
+        int c = 0;
+        float wa = 0.f, wb = 0.f;
+        if (lane < cnt) {
+            c = __builtin_nontemporal_load(p.col + base + lane);
+            wa = p.va ? __builtin_nontemporal_load(p.va + base + lane) : 1.f;
+            if (DUAL) wb = __builtin_nontemporal_load(p.vb + base + lane);
+        }
+        int u = 0;
+        for (; cnt - u >= NPW * UB; u += NPW * UB)
+            gather_step<LPR, DUAL, UB>(u, cnt, sub, fact, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
+        for (; u < cnt; u += NPW * 2)
+            gather_step<LPR, DUAL, 2>(u, cnt, sub, fact, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
+    }
+    reduce_groups<LPR>(acc_a);
+    if (DUAL) reduce_groups<LPR>(acc_b);
+    if (sub == 0) {
+        sm[wave][0][lane] = acc_a;
+        if (DUAL) sm[wave][1][lane] = acc_b;
+    }
+    __syncthreads();
+    if (wave == 0 && sub == 0 && fact) {
+        const int64_t o = (static_cast<int64_t>(blockIdx.x) * n_seg + seg) * p.n_feat + fl;
+        float4 a = sm[0][0][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 t = sm[w][0][lane];
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        st4(part_a + o, a);
+        if (DUAL) {
+            float4 b = sm[0][1][lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 t = sm[w][1][lane];
+                b.x += t.x; b.y += t.y; b.z += t.z; b.w += t.w;
+            }
+            st4(part_b + o, b);
+        }
+    }
+}
+
+// one thread per (long row, feature quad): add the segment partials in order, apply the epilogue
+template <bool DUAL>
+__global__ __launch_bounds__(256) void spmm_long_finish_kernel(SpmmArgs p, const int32_t* __restrict__ long_rows,
+                                                               int n_long, const float* __restrict__ part_a,
+                                                               const float* __restrict__ part_b, int n_seg)
+{
+    const int quads = p.n_feat / 4;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= static_cast<int64_t>(n_long) * quads) return;
+    const int r = static_cast<int>(t / quads), fl = static_cast<int>(t - static_cast<int64_t>(r) * quads) * 4;
+    const int row = long_rows[r];
+    const int deg = p.rowptr[row + 1] - p.rowptr[row];
+    const int used = (deg + kLongSeg - 1) / kLongSeg;          // segments past the row's end hold zeros
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < used && s < n_seg; ++s) {
+        const int64_t o = (static_cast<int64_t>(r) * n_seg + s) * p.n_feat + fl;
+        const float4 x = ld4(part_a + o);
+        a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        if (DUAL) {
+            const float4 y = ld4(part_b + o);
+            b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+        }
+    }
+    const int64_t yo = static_cast<int64_t>(row) * p.ldy + fl;
+    const int64_t zo = static_cast<int64_t>(row) * p.ldz + fl;
+    st4(p.ya + yo, finish(a, p.alpha, p.beta, p.mean != 0, deg, p.za ? p.za + zo : nullptr));
+    if (DUAL) st4(p.yb + yo, finish(b, p.alpha, p.beta, false, deg, p.zb ? p.zb + zo : nullptr));
 }
 
 // Generic fallback (any F, any alignment): lane <-> feature, neighbours walked sequentially with
@@ -231,8 +338,26 @@ void launch_vec(const SpmmArgs& a, bool deep, dim3 grid, dim3 block, hipStream_t
         hipLaunchKernelGGL((spmm_vec_kernel<LPR, DUAL, false>), grid, block, 0, stream, a);
 }
 
+template <int LPR, bool DUAL>
+void launch_long(const SpmmArgs& a, const pygsd_long_rows& h, int n_seg, unsigned gz, hipStream_t stream)
+{
+    float* part_a = static_cast<float*>(h.workspace);
+    float* part_b = DUAL ? part_a + static_cast<int64_t>(h.n_rows) * n_seg * a.n_feat : nullptr;
+    hipLaunchKernelGGL((spmm_long_kernel<LPR, DUAL>), dim3(h.n_rows, n_seg, gz), dim3(256), 0, stream, a, h.rows,
+                       part_a, part_b, n_seg);
+    const int64_t threads = static_cast<int64_t>(h.n_rows) * (a.n_feat / 4);
+    hipLaunchKernelGGL(spmm_long_finish_kernel<DUAL>, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256),
+                       0, stream, a, h.rows, h.n_rows, part_a, part_b, n_seg);
+}
+
+int64_t long_workspace_bytes(int32_t n_long, int32_t max_entries, int32_t n_feat, bool dual)
+{
+    const int64_t n_seg = (static_cast<int64_t>(max_entries) + kLongSeg - 1) / kLongSeg;
+    return static_cast<int64_t>(n_long) * n_seg * n_feat * static_cast<int64_t>(sizeof(float)) * (dual ? 2 : 1);
+}
+
 template <bool DUAL>
-int launch_spmm(const SpmmArgs& a, int64_t nnz_hint, hipStream_t stream)
+int launch_spmm(SpmmArgs a, int64_t nnz_hint, const pygsd_long_rows* hubs, hipStream_t stream)
 {
     if (a.n_rows == 0 || a.n_feat == 0) return 0;
     const dim3 block(kWavesPerBlock * 64);
@@ -250,6 +375,14 @@ int launch_spmm(const SpmmArgs& a, int64_t nnz_hint, hipStream_t stream)
         return check_launch("spmm_scalar_kernel");
     }
     const int quads = a.n_feat / 4;
+    const bool split = hubs && hubs->n_rows > 0;
+    if (split) {
+        PYGSD_REQUIRE(hubs->rows && hubs->workspace && hubs->max_entries > PYGSD_LONG_ROW,
+                      "pygsd_spmm: long-row descriptor needs rows, workspace and max_entries > PYGSD_LONG_ROW");
+        PYGSD_REQUIRE(hubs->workspace_bytes >= long_workspace_bytes(hubs->n_rows, hubs->max_entries, a.n_feat, DUAL),
+                      "pygsd_spmm: long-row workspace too small (pygsd_spmm_long_rows_workspace)");
+        a.skip_longer_than = PYGSD_LONG_ROW;
+    }
     const bool deep = nnz_hint <= 0 || nnz_hint >= static_cast<int64_t>(24) * a.n_rows;   // avg degree >= 24
     if (quads <= 4) {
         launch_vec<4, DUAL>(a, deep, dim3(gx), block, stream);
@@ -262,6 +395,14 @@ int launch_spmm(const SpmmArgs& a, int64_t nnz_hint, hipStream_t stream)
     } else {
         const unsigned gy = (static_cast<unsigned>(quads) + 63) / 64;
         launch_vec<64, DUAL>(a, deep, dim3(gx, gy), block, stream);
+    }
+    if (split) {
+        const int n_seg = (hubs->max_entries + kLongSeg - 1) / kLongSeg;
+        if (quads <= 4) launch_long<4, DUAL>(a, *hubs, n_seg, 1, stream);
+        else if (quads <= 8) launch_long<8, DUAL>(a, *hubs, n_seg, 1, stream);
+        else if (quads <= 16) launch_long<16, DUAL>(a, *hubs, n_seg, 1, stream);
+        else if (quads <= 32) launch_long<32, DUAL>(a, *hubs, n_seg, 1, stream);
+        else launch_long<64, DUAL>(a, *hubs, n_seg, (static_cast<unsigned>(quads) + 63) / 64, stream);
     }
     return check_launch("spmm_vec_kernel");
 }
@@ -432,7 +573,8 @@ using namespace pygsd;
 extern "C" int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                                   const float* X, int64_t ldx, float* Y, int64_t ldy,
                                   const float* Z, int64_t ldz, int32_t n_rows, int32_t n_feat,
-                                  float alpha, float beta, int32_t mean, int64_t nnz_hint, void* stream)
+                                  float alpha, float beta, int32_t mean, int64_t nnz_hint,
+                                  const pygsd_long_rows* long_rows, void* stream)
 {
     PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_spmm_csr_f32: negative size");
     if (n_rows == 0 || n_feat == 0) return 0;
@@ -440,8 +582,8 @@ extern "C" int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, con
     PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat),
                   "pygsd_spmm_csr_f32: row stride smaller than n_feat");
     SpmmArgs a{rowptr, col, val, nullptr, X, nullptr, Y, nullptr, Z, nullptr,
-               ldx, ldy, ldz, n_rows, n_feat, alpha, beta, mean};
-    return launch_spmm<false>(a, nnz_hint, static_cast<hipStream_t>(stream));
+               ldx, ldy, ldz, n_rows, n_feat, alpha, beta, mean, 0};
+    return launch_spmm<false>(a, nnz_hint, long_rows, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int pygsd_spmm_csr_bf16(const int32_t* rowptr, const int32_t* col, const float* val,
@@ -466,7 +608,8 @@ extern "C" int pygsd_spmm2_csr_f32(const int32_t* rowptr, const int32_t* col, co
                                    const float* val_b, const float* Xa, const float* Xb, int64_t ldx,
                                    float* Ya, float* Yb, int64_t ldy, const float* Za,
                                    const float* Zb, int64_t ldz, int32_t n_rows, int32_t n_feat,
-                                   float alpha, float beta, int64_t nnz_hint, void* stream)
+                                   float alpha, float beta, int64_t nnz_hint,
+                                   const pygsd_long_rows* long_rows, void* stream)
 {
     PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_spmm2_csr_f32: negative size");
     if (n_rows == 0 || n_feat == 0) return 0;
@@ -476,8 +619,17 @@ extern "C" int pygsd_spmm2_csr_f32(const int32_t* rowptr, const int32_t* col, co
     PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Za || ldz >= n_feat),
                   "pygsd_spmm2_csr_f32: row stride smaller than n_feat");
     SpmmArgs a{rowptr, col, val_a, val_b, Xa, Xb, Ya, Yb, Za, Zb,
-               ldx, ldy, ldz, n_rows, n_feat, alpha, beta, 0};
-    return launch_spmm<true>(a, nnz_hint, static_cast<hipStream_t>(stream));
+               ldx, ldy, ldz, n_rows, n_feat, alpha, beta, 0, 0};
+    return launch_spmm<true>(a, nnz_hint, long_rows, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pygsd_spmm_long_rows_workspace(int32_t n_long, int32_t max_entries, int32_t n_feat, int32_t dual,
+                                              int64_t* bytes)
+{
+    PYGSD_REQUIRE(bytes, "pygsd_spmm_long_rows_workspace: null pointer");
+    PYGSD_REQUIRE(n_long >= 0 && max_entries >= 0 && n_feat >= 0, "pygsd_spmm_long_rows_workspace: negative size");
+    *bytes = long_workspace_bytes(n_long, max_entries, n_feat, dual != 0);
+    return 0;
 }
 
 extern "C" int pygsd_sddmm_coo_f32(const int32_t* ia, const int32_t* ib, int64_t nnz, const float* A,

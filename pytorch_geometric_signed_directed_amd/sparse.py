@@ -41,11 +41,39 @@ def _rows(t: Tensor) -> Tuple[Tensor, int]:
 
 class CSR:
     """One orientation of a pattern: int32 rowptr / col / perm on the device."""
-    __slots__ = ("n_rows", "n_cols", "nnz", "rowptr", "col", "perm")
+    __slots__ = ("n_rows", "n_cols", "nnz", "rowptr", "col", "perm", "_hubs")
 
     def __init__(self, n_rows, n_cols, nnz, rowptr, col, perm):
         self.n_rows, self.n_cols, self.nnz = n_rows, n_cols, nnz
         self.rowptr, self.col, self.perm = rowptr, col, perm
+        self._hubs = None
+
+    def hubs(self):
+        """(row ids int32 [n_long], longest row's entry count) of the rows with more than
+        PYGSD_LONG_ROW entries, or None.  Found once per CSR (one device->host read)."""
+        if self._hubs is None:
+            if self.nnz <= _cabi.LONG_ROW or self.n_rows == 0:
+                self._hubs = ()
+            else:
+                deg = self.rowptr[1:] - self.rowptr[:-1]
+                top = int(deg.max())
+                self._hubs = () if top <= _cabi.LONG_ROW else (
+                    torch.nonzero(deg > _cabi.LONG_ROW).flatten().to(torch.int32), top)
+        return self._hubs or None
+
+
+def _long_rows_arg(csr: CSR, n_feat: int, dual: bool):
+    """(pointer-or-None, keepalive) for the long_rows argument of the fp32 SpMM entry points."""
+    hubs = csr.hubs()
+    if hubs is None:
+        return None, None
+    rows, top = hubs
+    need = ctypes.c_int64(0)
+    check(_cabi.lib().pygsd_spmm_long_rows_workspace(rows.numel(), top, n_feat, 1 if dual else 0,
+                                                     ctypes.byref(need)), "pygsd_spmm_long_rows_workspace")
+    ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=rows.device)
+    desc = _cabi.LongRows(ptr(rows), rows.numel(), top, ptr(ws), need.value)
+    return ctypes.byref(desc), (desc, ws)
 
 
 def csr_from_coo(seg: Tensor, other: Tensor, n_seg: int, n_other: int) -> CSR:
@@ -192,9 +220,12 @@ def _spmm_raw(csr: CSR, val: Optional[Tensor], x: Tensor, z: Optional[Tensor], a
         z, ldz = _rows(z)
         zp = ptr(z)
     with torch.cuda.device(x.device):
+        hubs, keep = _long_rows_arg(csr, f, False)
         check(_cabi.lib().pygsd_spmm_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(val), ptr(x), ldx, ptr(y),
                                              max(f, 1), zp, ldz, csr.n_rows, f, float(alpha), float(beta),
-                                             1 if mean else 0, csr.nnz, stream_ptr()), "pygsd_spmm_csr_f32")
+                                             1 if mean else 0, csr.nnz, hubs, stream_ptr()),
+              "pygsd_spmm_csr_f32")
+        del keep
     return y
 
 
@@ -230,10 +261,13 @@ def _spmm2_raw(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, z
             ldz = max(f, 1)
         zap, zbp = ptr(za), ptr(zb)
     with torch.cuda.device(xa.device):
+        hubs, keep = _long_rows_arg(csr, f, True)
         check(_cabi.lib().pygsd_spmm2_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(val_a), ptr(val_b), ptr(xa),
                                               ptr(xb), lda, ptr(ya), ptr(yb), max(f, 1), zap, zbp, ldz,
-                                              csr.n_rows, f, float(alpha), float(beta), csr.nnz, stream_ptr()),
+                                              csr.n_rows, f, float(alpha), float(beta), csr.nnz, hubs,
+                                              stream_ptr()),
               "pygsd_spmm2_csr_f32")
+        del keep
     return ya, yb
 
 

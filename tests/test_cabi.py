@@ -39,9 +39,9 @@ def test_argument_validation_needs_no_gpu():
     """Null / negative arguments are rejected on the host before any launch."""
     from pytorch_geometric_signed_directed_amd import _cabi
     lib = _cabi.lib()
-    rc = lib.pygsd_spmm_csr_f32(None, None, None, None, 0, None, 0, None, 0, 5, 4, 1.0, 0.0, 0, 0, None)
+    rc = lib.pygsd_spmm_csr_f32(None, None, None, None, 0, None, 0, None, 0, 5, 4, 1.0, 0.0, 0, 0, None, None)
     assert rc != 0 and b"null pointer" in lib.pygsd_last_error()
-    rc = lib.pygsd_spmm_csr_f32(None, None, None, None, 0, None, 0, None, 0, -1, 4, 1.0, 0.0, 0, 0, None)
+    rc = lib.pygsd_spmm_csr_f32(None, None, None, None, 0, None, 0, None, 0, -1, 4, 1.0, 0.0, 0, 0, None, None)
     assert rc != 0 and b"negative" in lib.pygsd_last_error()
     with pytest.raises(RuntimeError, match="negative"):
         _cabi.check(rc, "pygsd_spmm_csr_f32")

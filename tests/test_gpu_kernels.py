@@ -466,12 +466,107 @@ def test_spmm_variants_are_bitwise_identical():
         y1 = torch.empty(n, f, device=d)
         ya, yb = torch.empty(n, f, device=d), torch.empty(n, f, device=d)
         _cabi.check(lib.pygsd_spmm_csr_f32(P(csr.rowptr), P(csr.col), P(va), P(xa), f, P(y1), f, None, 0, n, f,
-                                           1.0, 0.0, 0, hint, _cabi.stream_ptr()), "spmm")
+                                           1.0, 0.0, 0, hint, None, _cabi.stream_ptr()), "spmm")
         _cabi.check(lib.pygsd_spmm2_csr_f32(P(csr.rowptr), P(csr.col), P(va), P(vb), P(xa), P(xb), f, P(ya), P(yb),
-                                            f, None, None, 0, n, f, 1.0, 0.0, hint, _cabi.stream_ptr()), "spmm2")
+                                            f, None, None, 0, n, f, 1.0, 0.0, hint, None, _cabi.stream_ptr()), "spmm2")
         outs.append((y1, ya, yb))
     torch.cuda.synchronize()
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
     assert torch.equal(outs[0][0], outs[0][1])        # single == the a-half of the dual kernel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f", [16, 64, 128, 320])
+def test_hub_rows_take_the_segmented_path(f):
+    """Rows with more than PYGSD_LONG_ROW entries (power-law hubs) are reduced in 4096-entry segments by
+    spmm_long_kernel; everything else still goes through the row-per-wavefront kernel.  Checked against
+    a float64 evaluation (sum order differs from the single-wavefront order, so tolerance not bit equality),
+    for add / mean / alpha-beta-Z epilogues, single and dual operator, and for determinism."""
+    from pytorch_geometric_signed_directed_amd import _cabi
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, _spmm_raw, _spmm2_raw
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11 + f)
+    n, base = 2000, 30000
+    hub_sizes = {5: 4097, 77: 150000, 1999: 9000}        # just over the threshold, multi-segment, last row
+    src = [torch.randint(0, n, (base,), generator=g)]
+    dst = [torch.randint(0, n, (base,), generator=g)]
+    for r, k in hub_sizes.items():
+        src.append(torch.randint(0, n, (k,), generator=g))
+        dst.append(torch.full((k,), r, dtype=torch.long))
+    ei = torch.stack([torch.cat(src), torch.cat(dst)])
+    ei = ei[:, torch.randperm(ei.size(1), generator=g)]
+    nnz = ei.size(1)
+    wa, wb = torch.randn(nnz, generator=g), torch.randn(nnz, generator=g)
+    xa, xb = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    za, zb = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    pat = Pattern(ei.to(d), n, n)
+    hubs = pat.fwd.hubs()
+    assert hubs is not None and sorted(hubs[0].tolist()) == sorted(hub_sizes) and hubs[1] >= 150000
+    assert pat.bwd.hubs() is None                        # the transposed orientation has no long row
+
+    def dense(w):
+        a = torch.zeros(n, n, dtype=torch.float64)
+        a.index_put_((ei[1], ei[0]), w.double(), accumulate=True)
+        return a
+
+    A, B = dense(wa), dense(wb)
+    va, vb = pat.values_for(wa.to(d), "fwd"), pat.values_for(wb.to(d), "fwd")
+    scale = (A.abs() @ xa.double().abs()).clamp_min(1.0)  # per-entry magnitude of the summed terms
+
+    def close(got, want, s=scale):
+        err = ((got.double().cpu() - want).abs() / s).max().item()
+        assert err < 2e-6, err
+
+    y = _spmm_raw(pat.fwd, va, xa.to(d), None, 1.0, 0.0, False)
+    close(y, A @ xa.double())
+    assert torch.equal(y, _spmm_raw(pat.fwd, va, xa.to(d), None, 1.0, 0.0, False))        # deterministic
+    y = _spmm_raw(pat.fwd, va, xa.to(d), za.to(d), 2.0, -1.0, False)
+    close(y, 2.0 * (A @ xa.double()) - za.double())
+    cnt = dense(torch.ones(nnz)).sum(1).clamp_min(1.0)
+    y = _spmm_raw(pat.fwd, None, xa.to(d), None, 1.0, 0.0, True)
+    close(y, (dense(torch.ones(nnz)) @ xa.double()) / cnt[:, None], torch.ones(n, f, dtype=torch.float64))
+    ya, yb = _spmm2_raw(pat.fwd, va, vb, xa.to(d), xb.to(d), za.to(d), zb.to(d), 2.0, -1.0)
+    close(ya, 2.0 * (A @ xa.double()) - za.double())
+    close(yb, 2.0 * (B @ xb.double()) - zb.double(), (B.abs() @ xb.double().abs()).clamp_min(1.0))
+    # rows that are not hubs are bit-identical to the plain launch (same kernel, same order)
+    plain = torch.empty(n, f, device=d)
+    lib, P = _cabi.lib(), _cabi.ptr
+    _cabi.check(lib.pygsd_spmm_csr_f32(P(pat.fwd.rowptr), P(pat.fwd.col), P(va), P(xa.to(d)), f, P(plain), f, None, 0,
+                                       n, f, 1.0, 0.0, 0, nnz, None, _cabi.stream_ptr()), "spmm")
+    split = _spmm_raw(pat.fwd, va, xa.to(d), None, 1.0, 0.0, False)
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[list(hub_sizes)] = False
+    assert torch.equal(plain[keep.to(d)], split[keep.to(d)])
+    close(plain, A @ xa.double())
+
+
+@pytest.mark.gpu
+def test_hub_row_gradients_through_the_layer_api():
+    """A hub in the forward orientation (many in-edges) and one in the backward orientation (many
+    out-edges): autograd through spmm() matches the float64 dense product for both."""
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    n, f = 1500, 32
+    src = torch.cat([torch.randint(0, n, (20000,), generator=g), torch.randint(0, n, (6000,), generator=g),
+                     torch.full((7000,), 3, dtype=torch.long)])
+    dst = torch.cat([torch.randint(0, n, (20000,), generator=g), torch.full((6000,), 9, dtype=torch.long),
+                     torch.randint(0, n, (7000,), generator=g)])
+    ei = torch.stack([src, dst])
+    w = torch.rand(ei.size(1), generator=g)
+    x = torch.randn(n, f, generator=g)
+    pat = Pattern(ei.to(d), n, n)
+    assert pat.fwd.hubs() is not None and pat.bwd.hubs() is not None
+    xd = x.to(d).requires_grad_(True)
+    wd = w.to(d).requires_grad_(True)
+    out = spmm(pat, xd, wd)
+    gout = torch.randn(n, f, generator=g)
+    out.backward(gout.to(d))
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A.index_put_((ei[1], ei[0]), w.double(), accumulate=True)
+    assert torch.allclose(out.detach().cpu().double(), A @ x.double(), atol=2e-3, rtol=1e-4)
+    assert torch.allclose(xd.grad.cpu().double(), A.T @ gout.double(), atol=2e-3, rtol=1e-4)
+    gw = (gout.double()[ei[1]] * x.double()[ei[0]]).sum(1)
+    assert torch.allclose(wd.grad.cpu().double(), gw, atol=1e-4, rtol=1e-4)
