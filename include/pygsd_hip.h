@@ -56,8 +56,9 @@ const char* pygsd_last_error(void);
  * The same entry point computes the backward dX = S^T dY when handed the CSR grouped by source.
  * Deterministic: no atomics; the summation order inside a row is fixed by the CSR order.
  * nnz_hint: total number of CSR entries if the caller knows it (0 = unknown).  Tuning only: rows with
- * >= 24 entries on average run a variant with deeper gather pipelining, sparser ones a low-register
- * variant with twice the wavefront occupancy; results are identical.
+ * >= 48 entries on average (>= 28 in the dual-operator kernel) run a variant with deeper gather
+ * pipelining, sparser ones (and unknown) a low-register variant with twice the wavefront occupancy;
+ * results are identical.
  * long_rows (may be NULL): hub rows.  One wavefront owns one output row, so a row with 10^5..10^6 entries
  * (power-law graphs; the reference's scatter has no such cliff) would serialise the launch.  The caller
  * lists the rows with MORE than PYGSD_LONG_ROW entries; the row-per-wavefront kernel skips them and a

@@ -119,8 +119,8 @@ __device__ __forceinline__ void gather_step(int u, int cnt, int sub, bool fact, 
 }
 
 // DEEP = true : deepest step 16 (8 per operator in the dual kernel) row fetches per lane in flight, ~125
-//               VGPRs, 4 waves/SIMD -- measured best on rows with >= ~24 neighbours (the 40-neighbour
-//               benchmark rows: +1..5 % over the light variant).
+//               VGPRs, 4 waves/SIMD -- measured best on rows with >= 28 (dual) / 48 (single) neighbours
+//               (the 41-neighbour benchmark rows of the dual kernel: +1.5 % over the light variant).
 // DEEP = false: deepest step 4, <= 64 VGPRs, 8 waves/SIMD -- low-degree rows (signed SBM parts with 6-15
 //               neighbours) issue few gathers each and need the wavefront count instead (the deep variant
 //               is 1.8x SLOWER there).  The host picks by nnz / n_rows.
@@ -383,7 +383,9 @@ int launch_spmm(SpmmArgs a, int64_t nnz_hint, const pygsd_long_rows* hubs, hipSt
                       "pygsd_spmm: long-row workspace too small (pygsd_spmm_long_rows_workspace)");
         a.skip_longer_than = PYGSD_LONG_ROW;
     }
-    const bool deep = nnz_hint <= 0 || nnz_hint >= static_cast<int64_t>(24) * a.n_rows;   // avg degree >= 24
+    // measured crossover (tools/deep_light_probe.py, F=64, 40M entries): the deep variant wins by 1-4 % from
+    // 28 entries per row (dual) / 48 (single) and loses up to 1.8x below; unknown -> light
+    const bool deep = nnz_hint >= static_cast<int64_t>(DUAL ? 28 : 48) * a.n_rows;
     if (quads <= 4) {
         launch_vec<4, DUAL>(a, deep, dim3(gx), block, stream);
     } else if (quads <= 8) {

@@ -462,7 +462,7 @@ def test_spmm_variants_are_bitwise_identical():
     vb = pat.values_for(torch.randn(nnz, generator=g).to(d), "fwd")
     lib, P = _cabi.lib(), _cabi.ptr
     outs = []
-    for hint in (0, 1, 10 ** 9):                       # unknown -> deep, tiny -> light, huge -> deep
+    for hint in (0, 1, 10 ** 9):                       # unknown -> light, tiny -> light, huge -> deep
         y1 = torch.empty(n, f, device=d)
         ya, yb = torch.empty(n, f, device=d), torch.empty(n, f, device=d)
         _cabi.check(lib.pygsd_spmm_csr_f32(P(csr.rowptr), P(csr.col), P(va), P(xa), f, P(y1), f, None, 0, n, f,
@@ -570,3 +570,32 @@ def test_hub_row_gradients_through_the_layer_api():
     assert torch.allclose(xd.grad.cpu().double(), A.T @ gout.double(), atol=2e-3, rtol=1e-4)
     gw = (gout.double()[ei[1]] * x.double()[ei[0]]).sum(1)
     assert torch.allclose(wd.grad.cpu().double(), gw, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_wide_dual_spmm_column_blocks_match_single_pass(monkeypatch):
+    """_spmm2_raw splits F >= 128 into 64-column passes when the gathered set outgrows the Infinity Cache;
+    forced here on a small graph: same result as one pass (to summation-order rounding), Z epilogue and
+    strided operands included."""
+    from pytorch_geometric_signed_directed_amd import sparse
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, _spmm2_raw
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    n, nnz, f = 3000, 60000, 192
+    ei = torch.randint(0, n, (2, nnz), generator=g)
+    pat = Pattern(ei.to(d), n, n)
+    va = pat.values_for(torch.randn(nnz, generator=g).to(d), "fwd")
+    vb = pat.values_for(torch.randn(nnz, generator=g).to(d), "fwd")
+    packed = torch.randn(n, 2 * f, generator=g).to(d)          # the sharded path hands over column slices
+    xa, xb = packed[:, :f], packed[:, f:]
+    za, zb = torch.randn(n, f, generator=g).to(d), torch.randn(n, f, generator=g).to(d)
+    one = _spmm2_raw(pat.fwd, va, vb, xa, xb, za, zb, 2.0, -1.0)
+    monkeypatch.setattr(sparse, "_COLBLOCK_BYTES", 0)
+    blocked = _spmm2_raw(pat.fwd, va, vb, xa, xb, za, zb, 2.0, -1.0)
+    for a, b in zip(one, blocked):
+        assert torch.allclose(a, b, atol=2e-5, rtol=1e-5)
+    dense = torch.zeros(n, n, dtype=torch.float64)
+    rows = torch.repeat_interleave(torch.arange(n), (pat.fwd.rowptr[1:] - pat.fwd.rowptr[:-1]).cpu().long())
+    dense.index_put_((rows, pat.fwd.col.cpu().long()), va.cpu().double(), accumulate=True)
+    want = 2.0 * (dense @ xa.cpu().double()) - za.cpu().double()
+    assert torch.allclose(blocked[0].cpu().double(), want, atol=1e-4, rtol=1e-5)

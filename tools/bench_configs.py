@@ -61,7 +61,9 @@ def magnetic(name, cls, n, e, h, K, signed, **kw):
     k = prof["spmm2"]
     out[name] = {"nodes": n, "edges": int(ei.size(1)), "hidden": h, "K": K, "ms_per_step": ms,
                  "edges_per_s": ei.size(1) / ms * 1e3, "operator_nnz": nnz, "kernels": prof,
-                 "spmm2_alg_GBps": b / k["ms_per_launch"] / 1e6 if k["ms_per_launch"] else None}
+                 # one logical product may be several column-block launches (F >= 128): price it as a whole
+                 "spmm2_alg_GBps": (b / (k["ms_per_launch"] * k["launches_per_step"] / (2 * K)) / 1e6
+                                    if k["ms_per_launch"] else None)}
     # reference default: cached=False, operator rebuilt on every forward
     layer_u = cls(h, h, K, 0.25, False, cached=False, **kw).to(dev)
     layer_u.load_state_dict(layer.state_dict())
