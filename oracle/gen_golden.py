@@ -438,12 +438,73 @@ def models():
              edge_out=e_out, w_out=w_out, x=npy(x), cached=np.bool_(cached),
              **model_case("m", DGCN_node_classification(6, 8, 4, 0.5, improved=True, cached=cached),
                           (x, t(ei), t(e_in), t(e_out), t(w_in), t(w_out)), 69))
+    from torch_geometric_signed_directed.nn import (DGCN_link_prediction, DiGCN_Inception_Block_link_prediction,
+                                                    DiGCN_link_prediction, SSSNET_link_prediction)
+    save("model_digcn_link", edge_index=ei, edge_weight=w, x=npy(x), query=npy(query),
+         **model_case("m", DiGCN_link_prediction(6, 8, 2, 0.5), (x, t(ei), query, t(w)), 70))
+    save("model_digcn_ib_link", edge_index=ei, edge_weight=w, edge_index2=ei2, edge_weight2=w2, x=npy(x),
+         query=npy(query),
+         **model_case("m", DiGCN_Inception_Block_link_prediction(6, 8, 3, 0.5),
+                      (x, (t(ei), t(ei2)), query, (t(w), t(w2))), 71))
+    save("model_dgcn_link", edge_index=ei, edge_in=e_in, w_in=w_in, edge_out=e_out, w_out=w_out, x=npy(x),
+         query=npy(query),
+         **model_case("m", DGCN_link_prediction(6, 8, 2, 0.5, improved=False, cached=False),
+                      (x, t(ei), t(e_in), t(e_out), query, t(w_in), t(w_out)), 72))
     ein, wn = toy_graph(54, e=90)
+    for directed in (False, True):
+        save("model_sssnet_link_" + ("directed" if directed else "undirected"), edge_index_p=ei, edge_weight_p=w,
+             edge_index_n=ein, edge_weight_n=wn, x=npy(x), query=npy(query), directed=np.bool_(directed),
+             **model_case("m", SSSNET_link_prediction(6, 8, 3, 0.5, 2, 0.5, directed),
+                          (t(ei), t(w), t(ein), t(wn), x, query), 73))
     for directed in (False, True):
         save("model_sssnet_" + ("directed" if directed else "undirected"), edge_index_p=ei, edge_weight_p=w,
              edge_index_n=ein, edge_weight_n=wn, x=npy(x), directed=np.bool_(directed),
              **model_case("m", SSSNET_node_clustering(6, 8, 3, 0.5, 2, 0.5, directed),
                           (t(ei), t(w), t(ein), t(wn), x), 68))
+
+
+def sgcn_model_and_sign_losses():
+    """SGCN.forward (z) with given initial embeddings, and the signed objectives with the random negative
+    draws of PyG replaced by fixed index sets (patched into the reference module), so the arithmetic is pinned."""
+    import torch_geometric_signed_directed.utils.signed.link_sign_loss as L
+    from torch_geometric_signed_directed.nn.signed.SGCN import SGCN
+    from torch_geometric_signed_directed.utils.signed import create_spectral_features
+    n = 40
+    g = torch.Generator().manual_seed(80)
+    pairs = torch.randint(0, n, (2, 150), generator=g)
+    pairs = pairs[:, pairs[0] != pairs[1]]
+    sign = torch.where(torch.rand(pairs.size(1), generator=g) < 0.6, 1, -1)
+    edge_index_s = torch.cat([pairs.t(), sign[:, None]], dim=1)
+    init = torch.randn(n, 6, generator=g)
+    torch.manual_seed(81)
+    model = SGCN(n, edge_index_s, in_dim=6, out_dim=8, layer_num=3, init_emb=init, norm_emb=True)
+    with torch.no_grad():
+        for prm in model.parameters():
+            if prm.dim() == 1 and prm.numel() > 1:
+                prm.add_(torch.rand(prm.shape, generator=g) - 0.5)
+    z = model()
+    pos, neg = model.pos_edge_index, model.neg_edge_index
+    none_ei = torch.randint(0, n, (2, 70), generator=g)
+    k_pos = torch.randint(0, n, (pos.size(1),), generator=g)
+    k_neg = torch.randint(0, n, (neg.size(1),), generator=g)
+    L.negative_sampling = lambda ei, num: none_ei
+    ks = {pos.size(1): k_pos, neg.size(1): k_neg}
+    assert pos.size(1) != neg.size(1)
+    L.structured_negative_sampling = lambda ei, num: (ei[0], ei[1], ks[ei.size(1)])
+    entropy = model.lsp_loss(z, pos, neg)
+    structure = model.structure_loss(z, pos, neg)
+    total = model.loss()
+    close("sgcn.loss", total.detach(), (entropy + model.lamb * structure).detach())
+    torch.manual_seed(82)
+    direction = L.Sign_Direction_Loss(8)
+    arrs = {"sd." + k_: npy(v) for k_, v in model.state_dict().items()}
+    arrs.update({"dir." + k_: npy(v) for k_, v in direction.state_dict().items()})
+    feats = create_spectral_features(pos, neg, n, 5)
+    save("model_sgcn", edge_index_s=npy(edge_index_s), init_emb=npy(init), z=npy(z), none_edge_index=npy(none_ei),
+         k_pos=npy(k_pos), k_neg=npy(k_neg), loss_entropy=npy(entropy), loss_structure=npy(structure),
+         loss_total=npy(total), loss_product=npy(L.Link_Sign_Product_Loss()(z, pos, neg)),
+         loss_product_entropy=npy(L.Sign_Product_Entropy_Loss()(z, pos, neg)),
+         loss_direction=npy(direction(z, pos, neg)), spectral=npy(feats), **arrs)
 
 
 def main():
@@ -487,6 +548,7 @@ def main():
     imbalance_loss_case()
     print("model-level callers")
     models()
+    sgcn_model_and_sign_losses()
 
 
 if __name__ == "__main__":

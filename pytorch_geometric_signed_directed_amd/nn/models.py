@@ -5,7 +5,8 @@ example scripts run unchanged; all message passing goes through the HIP layers.
 
 Reference files: nn/directed/MagNet_node_classification.py, MagNet_link_prediction.py,
 DiGCN_node_classification.py, DiGCN_Inception_Block.py, DiGCN_Inception_Block_node_classification.py,
-DIGRAC_node_clustering.py, nn/general/MSGNN.py, nn/signed/SSSNET_node_clustering.py.
+DIGRAC_node_clustering.py, nn/general/MSGNN.py, nn/signed/SSSNET_node_clustering.py, the *_link_prediction.py
+variants of DGCN / DiGCN / DiGCN_Inception_Block / SSSNET, nn/signed/SGCN.py.
 """
 from typing import Optional, Tuple
 
@@ -21,6 +22,7 @@ from .directed.DiGCNConv import DiGCNConv
 from .directed.DIMPA import DIMPA
 from .directed.MagNetConv import MagNetConv
 from .general.MSConv import MSConv
+from .signed.SGCNConv import SGCNConv
 from .signed.SIMPA import SIMPA
 
 
@@ -350,3 +352,159 @@ class SSSNET_node_clustering(nn.Module):
                        getattr(self, f"_w_{s}1")) for s in self._streams]
         z = self._simpa(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, *xs)
         return _cluster_head(z, self._W_prob, self._bias)
+
+
+# --------------------------------------------------------------------------------------------------
+# link-prediction callers: the same encoders, read out on pairs of node rows
+# --------------------------------------------------------------------------------------------------
+def _pair_rows(x, query_edges):
+    return torch.cat((x[query_edges[:, 0]], x[query_edges[:, 1]]), dim=-1)
+
+
+class DiGCN_link_prediction(nn.Module):
+    """nn/directed/DiGCN_link_prediction.py:9-52."""
+
+    def __init__(self, num_features: int, hidden: int, label_dim: int, dropout: float = 0.5):
+        super().__init__()
+        self.conv1 = DiGCNConv(num_features, hidden)
+        self.conv2 = DiGCNConv(hidden, hidden)
+        self.dropout = dropout
+        self.linear = nn.Linear(hidden * 2, label_dim)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.conv1.reset_parameters()
+        self.conv2.reset_parameters()
+        self.linear.reset_parameters()
+
+    def forward(self, x, edge_index, query_edges, edge_weight=None):
+        x = F.relu(self.conv1(x, edge_index, edge_weight))
+        x = F.dropout(x, p=self.dropout, training=self.training)
+        x = F.dropout(self.conv2(x, edge_index, edge_weight), p=self.dropout, training=self.training)
+        return F.log_softmax(self.linear(_pair_rows(x, query_edges)), dim=1)
+
+
+class DiGCN_Inception_Block_link_prediction(nn.Module):
+    """nn/directed/DiGCN_Inception_Block_link_prediction.py:10-80: three hidden-width inception blocks, a
+    Linear head on the concatenated endpoint rows (argument order features, edge_index_tuple, query_edges,
+    edge_weight_tuple)."""
+
+    def __init__(self, num_features: int, hidden: int, label_dim: int, dropout: float = 0.5):
+        super().__init__()
+        self.ib1 = DiGCN_InceptionBlock(num_features, hidden)
+        self.ib2 = DiGCN_InceptionBlock(hidden, hidden)
+        self.ib3 = DiGCN_InceptionBlock(hidden, hidden)
+        self.linear = nn.Linear(hidden * 2, label_dim)
+        self._dropout = dropout
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for m in (self.ib1, self.ib2, self.ib3, self.linear):
+            m.reset_parameters()
+
+    def forward(self, features, edge_index_tuple, query_edges, edge_weight_tuple):
+        (ei1, ei2), (ew1, ew2) = edge_index_tuple, edge_weight_tuple
+        drop = lambda t: F.dropout(t, p=self._dropout, training=self.training)  # noqa: E731
+        x = features
+        for depth, ib in enumerate((self.ib1, self.ib2, self.ib3)):
+            x0, x1, x2 = ib(x, ei1, ew1, ei2, ew2)
+            x = drop(x0) + drop(x1) + drop(x2)
+            if depth < 2:
+                x = drop(x)
+        return F.log_softmax(self.linear(_pair_rows(x, query_edges)), dim=1)
+
+
+class DGCN_link_prediction(DGCN_node_classification):
+    """nn/directed/DGCN_link_prediction.py:10-96: the DGCN encoder with a Linear(6 * hidden) head on endpoint
+    pairs instead of the Conv1d node head."""
+
+    def __init__(self, num_features: int, hidden: int, label_dim: int, dropout: Optional[float] = None,
+                 improved: bool = False, cached: bool = False):
+        super().__init__(num_features, hidden, label_dim, dropout, improved, cached)
+        del self.Conv
+        self.linear = nn.Linear(hidden * 6, label_dim)
+
+    def reset_parameters(self):
+        self.lin1.reset_parameters()
+        self.lin2.reset_parameters()
+        nn.init.zeros_(self.bias1)
+        nn.init.zeros_(self.bias2)
+        self.linear.reset_parameters()
+
+    def forward(self, x, edge_index, edge_in, edge_out, query_edges, in_w=None, out_w=None):
+        x = tall_linear(x, self.lin1.weight.t())
+        x = self._three(x, edge_index, edge_in, edge_out, in_w, out_w, self.bias1)
+        x = tall_linear(x, self.lin2.weight.t())
+        x = self._three(x, edge_index, edge_in, edge_out, in_w, out_w, self.bias2)
+        x = _pair_rows(x, query_edges)
+        if self.dropout > 0:          # like the reference: dropout=None (its default) raises here
+            x = F.dropout(x, self.dropout, training=self.training)
+        return F.log_softmax(self.linear(x), dim=1)
+
+
+class SSSNET_link_prediction(SSSNET_node_clustering):
+    """nn/signed/SSSNET_link_prediction.py:11-157: SSSNET's SIMPA encoder, `_W_prob` twice as tall and
+    applied to concatenated endpoint embeddings; returns log-probabilities only."""
+
+    def __init__(self, nfeat: int, hidden: int, nclass: int, dropout: float, hop: int, fill_value: float,
+                 directed: bool = False, bias: bool = True):
+        super().__init__(nfeat, hidden, nclass, dropout, hop, fill_value, directed, bias)
+        self._W_prob = Parameter(torch.FloatTensor(2 * len(self._streams) * hidden, self._num_clusters))
+        self._reset_parameters()
+
+    def forward(self, edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, features, query_edges):
+        xs = [torch.mm(self._dropout(self._relu(torch.mm(features, getattr(self, f"_w_{s}0")))),
+                       getattr(self, f"_w_{s}1")) for s in self._streams]
+        z = self._simpa(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, *xs)
+        output = torch.mm(_pair_rows(z, query_edges), self._W_prob)
+        if self._bias is not None:
+            output = output + self._bias
+        return F.log_softmax(output, dim=1)
+
+
+class SGCN(nn.Module):
+    """nn/signed/SGCN.py:11-97: a stack of SGCNConv layers with tanh on stored node embeddings.
+    `edge_index_s` is the reference's [E, 3] (source, target, sign) list; `forward()` takes no arguments and
+    returns the embedding z; `loss()` = link-sign entropy + lamb * structure loss."""
+
+    def __init__(self, node_num: int, edge_index_s: torch.Tensor, in_dim: int = 64, out_dim: int = 64,
+                 layer_num: int = 2, init_emb: Optional[torch.Tensor] = None, init_emb_grad: bool = False,
+                 lamb: float = 5, norm_emb: bool = False, **kwargs):
+        super().__init__(**kwargs)
+        from ..utils.signed import Link_Sign_Entropy_Loss, Sign_Structure_Loss, create_spectral_features
+        self.node_num, self.in_dim, self.out_dim, self.lamb = node_num, in_dim, out_dim, lamb
+        self.device = edge_index_s.device
+        self.pos_edge_index = edge_index_s[edge_index_s[:, 2] > 0][:, :2].t().contiguous()
+        self.neg_edge_index = edge_index_s[edge_index_s[:, 2] < 0][:, :2].t().contiguous()
+        if init_emb is None:
+            init_emb = create_spectral_features(self.pos_edge_index, self.neg_edge_index, node_num, in_dim
+                                                ).to(self.device)
+        self.x = Parameter(init_emb, requires_grad=init_emb_grad)
+        self.conv1 = SGCNConv(in_dim, out_dim // 2, first_aggr=True)
+        self.convs = nn.ModuleList(SGCNConv(out_dim // 2, out_dim // 2, first_aggr=False, norm_emb=norm_emb)
+                                   for _ in range(layer_num - 1))
+        self.lsp_loss = Link_Sign_Entropy_Loss(out_dim)
+        self.structure_loss = Sign_Structure_Loss()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.conv1.reset_parameters()
+        for conv in self.convs:
+            conv.reset_parameters()
+
+    def _apply(self, fn, *args, **kwargs):          # the stored edge lists follow .to(device), like the embeddings
+        out = super()._apply(fn, *args, **kwargs)
+        self.pos_edge_index, self.neg_edge_index = fn(self.pos_edge_index), fn(self.neg_edge_index)
+        self.device = self.x.device
+        return out
+
+    def forward(self) -> torch.Tensor:
+        z = torch.tanh(self.conv1(self.x, self.pos_edge_index, self.neg_edge_index))
+        for conv in self.convs:
+            z = torch.tanh(conv(z, self.pos_edge_index, self.neg_edge_index))
+        return z
+
+    def loss(self) -> torch.Tensor:
+        z = self.forward()
+        return (self.lsp_loss(z, self.pos_edge_index, self.neg_edge_index)
+                + self.lamb * self.structure_loss(z, self.pos_edge_index, self.neg_edge_index))

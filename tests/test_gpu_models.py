@@ -203,3 +203,55 @@ def test_dgcn_model_incl_shared_cached_conv_quirk():
         with torch.no_grad():
             check(m(g.t("x", D), g.t("edge_index", D), g.t("edge_in", D), g.t("edge_out", D), g.t("w_in", D),
                     g.t("w_out", D)), g)
+
+
+def test_link_prediction_models():
+    from pytorch_geometric_signed_directed_amd.nn import (DGCN_link_prediction, DiGCN_Inception_Block_link_prediction,
+                                                          DiGCN_link_prediction, SSSNET_link_prediction)
+    g = load_golden("model_digcn_link")
+    m = load(DiGCN_link_prediction(6, 8, 2, 0.5), g)
+    with torch.no_grad():
+        check(m(g.t("x", D), g.t("edge_index", D), g.t("query", D), g.t("edge_weight", D)), g)
+    g = load_golden("model_digcn_ib_link")
+    m = load(DiGCN_Inception_Block_link_prediction(6, 8, 3, 0.5), g)
+    with torch.no_grad():
+        check(m(g.t("x", D), (g.t("edge_index", D), g.t("edge_index2", D)), g.t("query", D),
+                (g.t("edge_weight", D), g.t("edge_weight2", D))), g)
+    g = load_golden("model_dgcn_link")
+    m = load(DGCN_link_prediction(6, 8, 2, 0.5, improved=False, cached=False), g)
+    with torch.no_grad():
+        check(m(g.t("x", D), g.t("edge_index", D), g.t("edge_in", D), g.t("edge_out", D), g.t("query", D),
+                g.t("w_in", D), g.t("w_out", D)), g)
+    for name in ("model_sssnet_link_undirected", "model_sssnet_link_directed"):
+        g = load_golden(name)
+        m = load(SSSNET_link_prediction(6, 8, 3, 0.5, 2, 0.5, bool(g["directed"])), g)
+        with torch.no_grad():
+            check(m(g.t("edge_index_p", D), g.t("edge_weight_p", D), g.t("edge_index_n", D),
+                    g.t("edge_weight_n", D), g.t("x", D), g.t("query", D)), g)
+
+
+def test_sgcn_model_and_signed_objectives():
+    """SGCN.forward() (3 SGCNConv layers, tanh, normalised embeddings) against the reference's z, and its
+    objectives with the reference's random negative draws replaced by the recorded index sets."""
+    from pytorch_geometric_signed_directed_amd.nn import SGCN
+    from pytorch_geometric_signed_directed_amd.utils.signed import (Link_Sign_Product_Loss, Sign_Direction_Loss,
+                                                                     Sign_Product_Entropy_Loss)
+    g = load_golden("model_sgcn")
+    m = SGCN(40, g.t("edge_index_s"), in_dim=6, out_dim=8, layer_num=3, init_emb=g.t("init_emb"), norm_emb=True)
+    m = load(m, g)
+    assert m.pos_edge_index.is_cuda and m.x.is_cuda
+    z = m()
+    close(z, g["z"])
+    pos, neg = m.pos_edge_index, m.neg_edge_index
+    close(m.lsp_loss(z, pos, neg, g.t("none_edge_index", D)), g["loss_entropy"])
+    st = m.structure_loss
+    close(st.pos_embedding_loss(z, pos, g.t("k_pos", D)) + st.neg_embedding_loss(z, neg, g.t("k_neg", D)),
+          g["loss_structure"])
+    close(Link_Sign_Product_Loss()(z, pos, neg), g["loss_product"])
+    close(Sign_Product_Entropy_Loss()(z, pos, neg), g["loss_product_entropy"])
+    d = Sign_Direction_Loss(8)
+    d.load_state_dict({k[4:]: g.t(k) for k in g if k.startswith("dir.")})
+    close(d.to(D)(z, pos, neg), g["loss_direction"])
+    loss = m.loss()                                   # sampled negatives: finite, differentiable
+    loss.backward()
+    assert torch.isfinite(loss) and m.conv1.lin_b.weight.grad.abs().sum() > 0
