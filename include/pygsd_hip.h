@@ -140,6 +140,16 @@ int pygsd_gat_alpha_bwd_csr_f32(const int32_t* rowptr, const int32_t* col, const
                                 const float* out, int64_t ldo, int32_t n_rows, int32_t n_feat,
                                 float* ds_coo, float* alpha_coo, void* stream);
 
+/* Segment softmax over per-entry logits given in CSR order (one segment = one CSR row), max-shifted with
+ * the + 1e-16 denominator of torch_geometric.utils.softmax: the attention of SNEAConv
+ * (nn/signed/SNEAConv.py:135-146: alpha = softmax(tanh(alpha_func([x_j, x_i])), index)), whose logits mix
+ * two feature sets per edge type and are therefore formed by the caller.
+ * Backward: dlogits = alpha * (dalpha - sum_segment alpha * dalpha). */
+int pygsd_segment_softmax_csr_f32(const int32_t* rowptr, const float* logits, int32_t n_rows, float* alpha,
+                                  void* stream);
+int pygsd_segment_softmax_bwd_csr_f32(const int32_t* rowptr, const float* alpha, const float* dalpha,
+                                      int32_t n_rows, float* dlogits, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * COO -> CSR (operator build).  Groups the nnz entries by seg[e] (stable: entries of one group
  * keep their COO order, which is the order torch's scatter_add_ sums them in the reference) and
@@ -215,7 +225,8 @@ int pygsd_maglap_values(const int64_t* out_row, const int64_t* out_col, const fl
  *   pygsd_self_loops_emit : out = non-loop edges in order, then n loops (v, v) whose weight is the
  *                           node's listed loop weight if it had one, else fill_value.  out_w == NULL
  *                           skips the weights; w == NULL means all ones.
- *   pygsd_csr_row_sum_f32 : deg[r] = sum of w[perm[slot]] over CSR row r (sequential, COO order).
+ *   pygsd_csr_row_sum_f32 : deg[r] = sum of w[perm[slot]] over CSR row r (sequential, COO order); perm == NULL:
+ *                           w is already in CSR order.
  *   pygsd_degree_scale_f32: mode 0: deg^-1/2[row] * w * deg^-1/2[col]; mode 1: deg^-1[row] * w
  *                           (inf -> 0 as masked_fill_ does).
  * ------------------------------------------------------------------------------------------- */

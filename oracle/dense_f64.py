@@ -221,3 +221,47 @@ def gat_conv(x, edge_index, lin_weight, att_src, att_dst, bias, negative_slope=0
         w = w / w.sum()
         out[i] = (w[:, None] * h[nb]).sum(0)
     return out if bias is None else out + np.asarray(bias, np.float64)
+
+
+def snea_conv(x, pos_ei, neg_ei, lin_b, lin_u, alpha_b, alpha_u, first_aggr, in_dim):
+    """SNEAConv node by node (the message is the TARGET's row times the attention coefficient; self loops
+    re-added only up to the largest node id left after loop removal)."""
+    x = np.asarray(x, np.float64)
+    n = x.shape[0]
+    f = lambda t: np.asarray(t, np.float64)  # noqa: E731
+    lin = lambda z, wb: z @ f(wb[0]).T + (0 if wb[1] is None else f(wb[1]))  # noqa: E731
+
+    def incoming(ei, loops):
+        pairs = [(int(u), int(v)) for u, v in np.asarray(ei).T if u != v]
+        top = max([max(p) for p in pairs], default=-1) + 1 if loops else 0
+        inc = [[] for _ in range(n)]
+        for u, v in pairs:
+            inc[v].append(u)
+        for v in range(top):
+            inc[v].append(v)
+        return inc
+
+    def aggregate(inc0, inc1, x1, x2, aw):
+        w, b = f(aw[0]).reshape(-1), float(np.asarray(aw[1]).reshape(-1)[0])
+        out = np.zeros_like(x1)
+        for i in range(n):
+            logits = [np.tanh(np.concatenate([x1[j], x1[i]]) @ w + b) for j in inc0[i]] + \
+                     [np.tanh(np.concatenate([x2[j], x2[i]]) @ w + b) for j in inc1[i]]
+            if not logits:
+                continue
+            e = np.exp(np.array(logits) - max(logits))
+            a = e / e.sum()
+            out[i] = x1[i] * a[:len(inc0[i])].sum() + x2[i] * a[len(inc0[i]):].sum()
+        return out
+
+    none = [[] for _ in range(n)]
+    if first_aggr:
+        hb, hu = lin(x, lin_b), lin(x, lin_u)
+        ob = aggregate(incoming(pos_ei, True), none, hb, hb, alpha_b)
+        ou = aggregate(incoming(neg_ei, True), none, hu, hu, alpha_u)
+    else:
+        hb, hu = x[:, :in_dim], x[:, in_dim:]
+        inc0, inc1 = incoming(pos_ei, True), incoming(neg_ei, False)
+        ob = aggregate(inc0, inc1, lin(hb, lin_b), lin(hu, lin_b), alpha_b)
+        ou = aggregate(inc0, inc1, lin(hu, lin_u), lin(hb, lin_u), alpha_u)
+    return np.concatenate([ob, ou], 1)

@@ -463,6 +463,45 @@ def models():
                           (t(ei), t(w), t(ein), t(wn), x), 68))
 
 
+def snea_cases():
+    """SNEAConv (first / deep aggregation) with input and parameter gradients, and the SNEA model's z."""
+    from torch_geometric_signed_directed.nn.signed.SNEA import SNEA
+    from torch_geometric_signed_directed.nn.signed.SNEAConv import SNEAConv
+    n = 40
+    for name, seed, first in (("snea_first", 91, True), ("snea_deep", 92, False)):
+        g = torch.Generator().manual_seed(seed)
+        pos = torch.randint(0, n - 3, (2, 110), generator=g)          # nodes 37..39: no positive edge, no loop
+        neg = torch.randint(0, n, (2, 70), generator=g)
+        pos[:, :4] = pos[0, :4]                                       # listed self loops (dropped, re-added)
+        in_dim, out_dim = 5, 4
+        x = torch.randn(n, in_dim if first else 2 * in_dim, generator=g, requires_grad=True)
+        torch.manual_seed(seed)
+        conv = SNEAConv(in_dim, out_dim, first)
+        with torch.no_grad():
+            for lin in (conv.lin_b, conv.lin_u, conv.alpha_b, conv.alpha_u):
+                lin.bias.add_(torch.rand(lin.bias.shape, generator=g) - 0.5)
+        out = conv(x, pos, neg)
+        pair = lambda l: (l.weight.detach(), l.bias.detach())  # noqa: E731
+        want = D.snea_conv(x.detach(), pos, neg, pair(conv.lin_b), pair(conv.lin_u), pair(conv.alpha_b),
+                           pair(conv.alpha_u), first, in_dim)
+        close(name, out.detach(), want)
+        gout = torch.randn(out.shape, generator=g)
+        out.backward(gout)
+        arrs = {"sd." + k: npy(v) for k, v in conv.state_dict().items()}
+        arrs.update({"grad." + k: npy(v.grad) for k, v in conv.named_parameters()})
+        save(name, pos=npy(pos), neg=npy(neg), x=npy(x), out=npy(out), gout=npy(gout), dx=npy(x.grad),
+             dense_f64=want, first_aggr=np.bool_(first), **arrs)
+    g = torch.Generator().manual_seed(93)
+    pairs = torch.randint(0, n, (2, 150), generator=g)
+    sign = torch.where(torch.rand(150, generator=g) < 0.6, 1, -1)
+    edge_index_s = torch.cat([pairs.t(), sign[:, None]], dim=1)
+    init = torch.randn(n, 6, generator=g)
+    torch.manual_seed(94)
+    model = SNEA(n, edge_index_s, in_dim=6, out_dim=8, layer_num=3, init_emb=init)
+    save("model_snea", edge_index_s=npy(edge_index_s), init_emb=npy(init), z=npy(model()),
+         **{"sd." + k: npy(v) for k, v in model.state_dict().items()})
+
+
 def sgcn_model_and_sign_losses():
     """SGCN.forward (z) with given initial embeddings, and the signed objectives with the random negative
     draws of PyG replaced by fixed index sets (patched into the reference module), so the arithmetic is pinned."""
@@ -549,6 +588,7 @@ def main():
     print("model-level callers")
     models()
     sgcn_model_and_sign_losses()
+    snea_cases()
 
 
 if __name__ == "__main__":

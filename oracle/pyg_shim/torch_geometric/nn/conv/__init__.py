@@ -26,7 +26,9 @@ class MessagePassing(torch.nn.Module):
         size = [None, None] if size is None else list(size)
         margs = {}
         for name in self._msg_params:
-            if name[-2:] in ('_i', '_j'):
+            if name in ('size_i', 'size_j'):            # PyG special arguments, not gathered tensors
+                margs[name] = None
+            elif name[-2:] in ('_i', '_j'):
                 data = kwargs[name[:-2]]
                 dim = j if name[-2:] == '_j' else i
                 if isinstance(data, (tuple, list)):

@@ -99,10 +99,72 @@ __global__ __launch_bounds__(256) void gat_alpha_bwd_kernel(const int32_t* __res
     }
 }
 
+// Generic segment softmax over per-entry logits already in CSR order (SNEAConv's tanh attention,
+// nn/signed/SNEAConv.py:135-146: alpha = softmax(tanh(lin([x_j, x_i])), index)): max-shifted, denominator
+// + 1e-16 like torch_geometric.utils.softmax.  One wavefront per segment, three coalesced passes.
+__global__ __launch_bounds__(256) void segment_softmax_kernel(const int32_t* __restrict__ rowptr,
+                                                              const float* __restrict__ logits, int32_t n_rows,
+                                                              float* __restrict__ alpha)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + static_cast<int>(threadIdx.x >> 6));
+    if (row >= n_rows) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    float mx = -INFINITY;
+    for (int e = beg + lane; e < end; e += 64) mx = fmaxf(mx, logits[e]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int e = beg + lane; e < end; e += 64) sum += expf(logits[e] - mx);
+    sum = wave_sum(sum) + 1e-16f;
+    for (int e = beg + lane; e < end; e += 64) alpha[e] = expf(logits[e] - mx) / sum;
+}
+
+// d logits = alpha * (d alpha - sum_segment alpha * d alpha)
+__global__ __launch_bounds__(256) void segment_softmax_bwd_kernel(const int32_t* __restrict__ rowptr,
+                                                                  const float* __restrict__ alpha,
+                                                                  const float* __restrict__ dalpha, int32_t n_rows,
+                                                                  float* __restrict__ dlogits)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + static_cast<int>(threadIdx.x >> 6));
+    if (row >= n_rows) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    float dot = 0.f;
+    for (int e = beg + lane; e < end; e += 64) dot = fmaf(alpha[e], dalpha[e], dot);
+    dot = wave_sum(dot);
+    for (int e = beg + lane; e < end; e += 64) dlogits[e] = alpha[e] * (dalpha[e] - dot);
+}
+
 }  // namespace
 }  // namespace pygsd
 
 using namespace pygsd;
+
+extern "C" int pygsd_segment_softmax_csr_f32(const int32_t* rowptr, const float* logits, int32_t n_rows, float* alpha,
+                                             void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0, "pygsd_segment_softmax_csr_f32: negative size");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(rowptr, "pygsd_segment_softmax_csr_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    hipLaunchKernelGGL(segment_softmax_kernel, dim3((static_cast<unsigned>(n_rows) + 3) / 4), dim3(256), 0, s, rowptr,
+                       logits, n_rows, alpha);
+    return check_launch("segment_softmax_kernel");
+}
+
+extern "C" int pygsd_segment_softmax_bwd_csr_f32(const int32_t* rowptr, const float* alpha, const float* dalpha,
+                                                 int32_t n_rows, float* dlogits, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0, "pygsd_segment_softmax_bwd_csr_f32: negative size");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(rowptr, "pygsd_segment_softmax_bwd_csr_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    hipLaunchKernelGGL(segment_softmax_bwd_kernel, dim3((static_cast<unsigned>(n_rows) + 3) / 4), dim3(256), 0, s,
+                       rowptr, alpha, dalpha, n_rows, dlogits);
+    return check_launch("segment_softmax_bwd_kernel");
+}
 
 extern "C" int pygsd_gat_alpha_csr_f32(const int32_t* rowptr, const int32_t* col, const float* a_src,
                                        const float* a_dst, int32_t n_rows, float negative_slope, float* alpha,

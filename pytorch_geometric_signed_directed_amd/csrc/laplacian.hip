@@ -251,14 +251,14 @@ __global__ void append_loops(const float* __restrict__ w, const int32_t* __restr
     }
 }
 
-// deg[r] = sum_{slots of CSR row r} w[perm[slot]]   (sequential: COO order inside the row)
+// deg[r] = sum_{slots of CSR row r} w[perm[slot]]   (sequential: COO order inside the row; perm == NULL: w[slot])
 __global__ void csr_row_sum(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
                             const float* __restrict__ w, int32_t n, float* __restrict__ deg)
 {
     GRID_STRIDE(r, n)
     {
         float d = 0.f;
-        for (int32_t j = rowptr[r]; j < rowptr[r + 1]; ++j) d = d + w[perm[j]];
+        for (int32_t j = rowptr[r]; j < rowptr[r + 1]; ++j) d = d + w[perm ? perm[j] : j];
         deg[r] = d;
     }
 }

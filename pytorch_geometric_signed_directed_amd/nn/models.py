@@ -508,3 +508,27 @@ class SGCN(nn.Module):
         z = self.forward()
         return (self.lsp_loss(z, self.pos_edge_index, self.neg_edge_index)
                 + self.lamb * self.structure_loss(z, self.pos_edge_index, self.neg_edge_index))
+
+
+class SNEA(SGCN):
+    """nn/signed/SNEA.py:13-93: SGCN's scaffold with SNEAConv attention layers, trainable initial embeddings by
+    default, and a final tanh(Linear)."""
+
+    def __init__(self, node_num: int, edge_index_s: torch.Tensor, in_dim: int = 64, out_dim: int = 64,
+                 layer_num: int = 2, init_emb: Optional[torch.Tensor] = None, init_emb_grad: bool = True,
+                 lamb: float = 4):
+        from .signed.SNEAConv import SNEAConv
+        super().__init__(node_num, edge_index_s, in_dim, out_dim, 1, init_emb, init_emb_grad, lamb)
+        self.conv1 = SNEAConv(in_dim, out_dim // 2, first_aggr=True)
+        self.convs = nn.ModuleList(SNEAConv(out_dim // 2, out_dim // 2, first_aggr=False)
+                                   for _ in range(layer_num - 1))
+        self.weight = nn.Linear(out_dim, out_dim)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        super().reset_parameters()
+        if hasattr(self, "weight"):
+            self.weight.reset_parameters()
+
+    def forward(self) -> torch.Tensor:
+        return torch.tanh(self.weight(super().forward()))

@@ -255,3 +255,13 @@ def test_sgcn_model_and_signed_objectives():
     loss = m.loss()                                   # sampled negatives: finite, differentiable
     loss.backward()
     assert torch.isfinite(loss) and m.conv1.lin_b.weight.grad.abs().sum() > 0
+
+
+def test_snea_model():
+    from pytorch_geometric_signed_directed_amd.nn import SNEA
+    g = load_golden("model_snea")
+    m = load(SNEA(40, g.t("edge_index_s"), in_dim=6, out_dim=8, layer_num=3, init_emb=g.t("init_emb")), g)
+    z = m()
+    close(z, g["z"])
+    m.loss().backward()
+    assert m.x.grad is not None and torch.isfinite(m.x.grad).all()        # init_emb_grad defaults to True
