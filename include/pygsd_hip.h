@@ -150,6 +150,24 @@ int pygsd_segment_softmax_csr_f32(const int32_t* rowptr, const float* logits, in
 int pygsd_segment_softmax_bwd_csr_f32(const int32_t* rowptr, const float* alpha, const float* dalpha,
                                       int32_t n_rows, float* dlogits, void* stream);
 
+/* SNEAConv's attention, fused (nn/signed/SNEAConv.py:70-146).  Slot e of target row i has source col[e] and
+ * edge_type[e] in {0: positive edge or self loop, 1: negative edge} (edge_type == NULL: all 0, s1/d1/share1 and
+ * the other type-1 arrays may be NULL).  pre_e = s_t[col[e]] + d_t[i] + bias[0] (bias: device scalar, NULL = 0), alpha = softmax over the row of
+ * tanh(pre) (max-shifted, + 1e-16).  Because the reference's message is the TARGET row times alpha, the
+ * aggregate is out_i = x1_i * share0[i] + x2_i * share1[i] with share_t[i] = sum of alpha over the row's type-t
+ * slots; the caller forms s_t = <x_t, a_src>, d_t = <x_t, a_dst> and that final product.
+ * Backward: from dshare_t it returns dpre per type in CSR order (zero where the slot has the other type;
+ * summing them by source gives ds_t) and dd_t[i] = per-row sums (= the gradient of d_t and, summed, of bias). */
+int pygsd_snea_alpha_csr_f32(const int32_t* rowptr, const int32_t* col, const uint8_t* edge_type,
+                             const float* s0, const float* s1, const float* d0, const float* d1,
+                             const float* bias, int32_t n_rows, float* alpha, float* share0, float* share1,
+                             void* stream);
+int pygsd_snea_alpha_bwd_csr_f32(const int32_t* rowptr, const int32_t* col, const uint8_t* edge_type,
+                                 const float* s0, const float* s1, const float* d0, const float* d1,
+                                 const float* bias, const float* alpha, const float* dshare0,
+                                 const float* dshare1, int32_t n_rows,
+                                 float* dpre0, float* dpre1, float* dd0, float* dd1, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * COO -> CSR (operator build).  Groups the nnz entries by seg[e] (stable: entries of one group
  * keep their COO order, which is the order torch's scatter_add_ sums them in the reference) and

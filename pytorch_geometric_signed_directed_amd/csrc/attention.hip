@@ -135,10 +135,140 @@ __global__ __launch_bounds__(256) void segment_softmax_bwd_kernel(const int32_t*
     for (int e = beg + lane; e < end; e += 64) dlogits[e] = alpha[e] * (dalpha[e] - dot);
 }
 
+// ------------------------------------------------------------------------------------------
+// SNEAConv (nn/signed/SNEAConv.py:135-146), fused.  Per slot e of target row i with source j and edge
+// type p (0: positive / self loop, 1: negative):  pre = s_p[j] + d_p[i] + bias,  alpha = softmax_i(tanh(pre)).
+// The layer's message is the TARGET row times alpha, so all the aggregate needs per row is the share of
+// alpha that went to each type:  share_t[i] = sum_{e in row i, p_e = t} alpha_e.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float snea_logit(int e, int row, const int32_t* col, const uint8_t* ptype,
+                                            const float* s0, const float* s1, const float* d0v, const float* d1v,
+                                            float d0, float d1, float bias, bool& neg)
+{
+    (void)d0v; (void)d1v;
+    neg = ptype && ptype[e] != 0;
+    const int j = col[e];
+    return tanhf((neg ? s1[j] + d1 : s0[j] + d0) + bias);
+}
+
+__global__ __launch_bounds__(256) void snea_alpha_kernel(const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col,
+                                                         const uint8_t* __restrict__ ptype,
+                                                         const float* __restrict__ s0, const float* __restrict__ s1,
+                                                         const float* __restrict__ d0, const float* __restrict__ d1,
+                                                         const float* __restrict__ bias_p, int32_t n_rows,
+                                                         float* __restrict__ alpha,
+                                                         float* __restrict__ share0, float* __restrict__ share1)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + static_cast<int>(threadIdx.x >> 6));
+    if (row >= n_rows) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    const float di0 = d0[row], di1 = ptype ? d1[row] : 0.f;
+    const float bias = bias_p ? bias_p[0] : 0.f;
+    bool neg;
+    float mx = -INFINITY;
+    for (int e = beg + lane; e < end; e += 64)
+        mx = fmaxf(mx, snea_logit(e, row, col, ptype, s0, s1, d0, d1, di0, di1, bias, neg));
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int e = beg + lane; e < end; e += 64)
+        sum += expf(snea_logit(e, row, col, ptype, s0, s1, d0, d1, di0, di1, bias, neg) - mx);
+    sum = wave_sum(sum) + 1e-16f;
+    float a0 = 0.f, a1 = 0.f;
+    for (int e = beg + lane; e < end; e += 64) {
+        const float a = expf(snea_logit(e, row, col, ptype, s0, s1, d0, d1, di0, di1, bias, neg) - mx) / sum;
+        alpha[e] = a;
+        if (neg) a1 += a; else a0 += a;
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) {
+        share0[row] = a0;
+        if (share1) share1[row] = a1;
+    }
+}
+
+// Given d share_t[i]: d alpha_e = d share_{p_e}[i]; softmax and tanh backward give d pre_e, written per type
+// in CSR order (dpre0 / dpre1, zero where the slot has the other type) for the by-source sums, and summed per
+// row into dd0 / dd1 (the gradient of d_p[i]).
+__global__ __launch_bounds__(256) void snea_alpha_bwd_kernel(const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col,
+                                                             const uint8_t* __restrict__ ptype,
+                                                             const float* __restrict__ s0, const float* __restrict__ s1,
+                                                             const float* __restrict__ d0, const float* __restrict__ d1,
+                                                             const float* __restrict__ bias_p,
+                                                             const float* __restrict__ alpha,
+                                                             const float* __restrict__ dshare0,
+                                                             const float* __restrict__ dshare1, int32_t n_rows,
+                                                             float* __restrict__ dpre0, float* __restrict__ dpre1,
+                                                             float* __restrict__ dd0, float* __restrict__ dd1)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + static_cast<int>(threadIdx.x >> 6));
+    if (row >= n_rows) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    const float di0 = d0[row], di1 = ptype ? d1[row] : 0.f;
+    const float g0 = dshare0[row], g1 = ptype ? dshare1[row] : 0.f;
+    const float bias = bias_p ? bias_p[0] : 0.f;
+    float dot = 0.f;
+    for (int e = beg + lane; e < end; e += 64) dot = fmaf(alpha[e], (ptype && ptype[e]) ? g1 : g0, dot);
+    dot = wave_sum(dot);
+    float r0 = 0.f, r1 = 0.f;
+    for (int e = beg + lane; e < end; e += 64) {
+        bool neg;
+        const float t = snea_logit(e, row, col, ptype, s0, s1, d0, d1, di0, di1, bias, neg);
+        const float dp = alpha[e] * ((neg ? g1 : g0) - dot) * (1.f - t * t);
+        dpre0[e] = neg ? 0.f : dp;
+        if (dpre1) dpre1[e] = neg ? dp : 0.f;
+        if (neg) r1 += dp; else r0 += dp;
+    }
+    r0 = wave_sum(r0);
+    r1 = wave_sum(r1);
+    if (lane == 0) {
+        dd0[row] = r0;
+        if (dd1) dd1[row] = r1;
+    }
+}
+
 }  // namespace
 }  // namespace pygsd
 
 using namespace pygsd;
+
+extern "C" int pygsd_snea_alpha_csr_f32(const int32_t* rowptr, const int32_t* col, const uint8_t* edge_type,
+                                        const float* s0, const float* s1, const float* d0, const float* d1,
+                                        const float* bias, int32_t n_rows, float* alpha, float* share0,
+                                        float* share1, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0, "pygsd_snea_alpha_csr_f32: negative size");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(rowptr && s0 && d0 && share0, "pygsd_snea_alpha_csr_f32: null pointer");
+    PYGSD_REQUIRE(!edge_type || (s1 && d1 && share1), "pygsd_snea_alpha_csr_f32: typed edges need s1, d1, share1");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    hipLaunchKernelGGL(snea_alpha_kernel, dim3((static_cast<unsigned>(n_rows) + 3) / 4), dim3(256), 0, s, rowptr, col,
+                       edge_type, s0, s1, d0, d1, bias, n_rows, alpha, share0, share1);
+    return check_launch("snea_alpha_kernel");
+}
+
+extern "C" int pygsd_snea_alpha_bwd_csr_f32(const int32_t* rowptr, const int32_t* col, const uint8_t* edge_type,
+                                            const float* s0, const float* s1, const float* d0, const float* d1,
+                                            const float* bias, const float* alpha, const float* dshare0,
+                                            const float* dshare1, int32_t n_rows, float* dpre0, float* dpre1,
+                                            float* dd0, float* dd1, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0, "pygsd_snea_alpha_bwd_csr_f32: negative size");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(rowptr && s0 && d0 && dshare0 && dd0, "pygsd_snea_alpha_bwd_csr_f32: null pointer");
+    PYGSD_REQUIRE(!edge_type || (s1 && d1 && dshare1 && dpre1 && dd1),
+                  "pygsd_snea_alpha_bwd_csr_f32: typed edges need the type-1 arrays");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    hipLaunchKernelGGL(snea_alpha_bwd_kernel, dim3((static_cast<unsigned>(n_rows) + 3) / 4), dim3(256), 0, s, rowptr,
+                       col, edge_type, s0, s1, d0, d1, bias, alpha, dshare0, dshare1, n_rows, dpre0, dpre1, dd0, dd1);
+    return check_launch("snea_alpha_bwd_kernel");
+}
 
 extern "C" int pygsd_segment_softmax_csr_f32(const int32_t* rowptr, const float* logits, int32_t n_rows, float* alpha,
                                              void* stream)

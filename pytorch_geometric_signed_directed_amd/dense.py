@@ -163,7 +163,8 @@ class _TallLinear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             n, slab = x.size(0), _TallLinear.SLAB
             s = n // slab
-            if s >= 8 and x.is_contiguous():
+            if s >= 8:
+                x = x.contiguous()          # column slices of a wider matrix: one copy beats the skinny GEMM
                 head = s * slab
                 gw = torch.bmm(x[:head].view(s, slab, -1).transpose(1, 2), g[:head].view(s, slab, -1)).sum(0)
                 if head < n:

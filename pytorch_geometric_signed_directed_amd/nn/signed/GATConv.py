@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from ... import _cabi
 from ..._cabi import check, ptr, stream_ptr
+from ...dense import tall_linear
 from ...sparse import GLOBAL_PATTERNS, Pattern, _rows, _spmm_raw, gather_values
 
 
@@ -111,9 +112,13 @@ class GATConv(nn.Module):
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         _cabi.require_gpu(x, edge_index)
         n, hds, c = x.size(0), self.heads, self.out_channels
-        h = self.lin(x).view(n, hds, c)
-        a_src = (h * self.att_src).sum(dim=-1)
-        a_dst = (h * self.att_dst).sum(dim=-1)
+        # h = lin(x) and the attention projections <h_k, att_src_k>, <h_k, att_dst_k> from ONE GEMM: the
+        # projections are 2 * heads extra output columns W_k^T att_k of the linear map
+        wt = self.lin.weight.t()                                        # [in, heads * c]
+        w3 = wt.reshape(wt.size(0), hds, c)
+        y = tall_linear(x, torch.cat([wt, (w3 * self.att_src).sum(-1), (w3 * self.att_dst).sum(-1)], dim=1))
+        h = y[:, :hds * c].view(n, hds, c)
+        a_src, a_dst = y[:, hds * c:hds * c + hds], y[:, hds * c + hds:]
         if self.add_self_loops:
             edge_index = self._with_self_loops(edge_index, n)
         pat = GLOBAL_PATTERNS.get(edge_index, n, n, "source_to_target")

@@ -8,15 +8,18 @@ What the reference's propagate/message computes (verified against it, tests/gold
     so out_i = x1_i * (sum of alpha over type-0 edges) + x2_i * (sum over type-1 edges).
   * self loops: removed, then re-added for nodes 0 .. max id appearing in the remaining edges (add_self_loops
     with num_nodes=None), so trailing nodes without edges get NO loop and a zero output row.
-Device path: per-edge scalars through torch gathers, softmax and the per-type sums through the HIP segment
-kernels (segment.py)."""
+Device path: the per-node projections s_t = <x_t, a_src>, d_t = <x_t, a_dst> and the final row scaling are
+N x F torch ops; everything per EDGE (logits, softmax, per-type shares, and their backward) runs in the fused
+HIP kernels pygsd_snea_alpha_csr_f32 / pygsd_snea_alpha_bwd_csr_f32, the by-source sums of the backward in
+pygsd_csr_row_sum_f32."""
 from typing import Optional
 
 import torch
 import torch.nn as nn
 
 from ... import _cabi
-from ...segment import row_ids, segment_softmax, segment_sum
+from ..._cabi import check, ptr, stream_ptr
+from ...dense import tall_linear
 from ...sparse import Pattern
 
 
@@ -28,13 +31,77 @@ def _loop_free_plus_loops(edge_index: torch.Tensor) -> torch.Tensor:
 
 
 class _Graph:
-    """CSR by target of one combined edge list + per-slot source ids, row ids and type flags."""
+    """One combined edge list grouped by target (forward) and by source (backward of the s_t projections),
+    the per-slot edge type in by-target order, and for every by-source slot its by-target slot."""
 
     def __init__(self, edge_index: torch.Tensor, edge_p: Optional[torch.Tensor], n: int):
-        self.csr = Pattern(edge_index, n, n).fwd
-        self.src = self.csr.col.long()
-        self.rows = row_ids(self.csr)
-        self.p = None if edge_p is None else edge_p[self.csr.perm.long()]
+        pat = Pattern(edge_index, n, n)
+        self.fwd, self.bwd = pat.fwd, pat.bwd
+        nnz = self.fwd.nnz
+        self.etype = None if edge_p is None else edge_p[self.fwd.perm.long()].to(torch.uint8).contiguous()
+        slot_of_edge = torch.empty(nnz, dtype=torch.int32, device=edge_index.device)
+        slot_of_edge[self.fwd.perm.long()] = torch.arange(nnz, dtype=torch.int32, device=edge_index.device)
+        self.bwd_to_fwd = slot_of_edge[self.bwd.perm.long()].contiguous()
+
+
+def _row_sum(rowptr, perm, w, n):
+    out = torch.zeros(n, dtype=torch.float32, device=w.device)
+    if w.numel():
+        with torch.cuda.device(w.device):
+            check(_cabi.lib().pygsd_csr_row_sum_f32(ptr(rowptr), ptr(perm), ptr(w), n, ptr(out), stream_ptr()),
+                  "pygsd_csr_row_sum_f32")
+    return out
+
+
+class _SneaShares(torch.autograd.Function):
+    """(s0, s1, d0, d1, bias) -> (share0, share1): per-row sums of the attention coefficients per edge type."""
+
+    @staticmethod
+    def forward(ctx, s0, s1, d0, d1, bias, g: _Graph):
+        typed = g.etype is not None
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
+        s0, s1, d0, d1, bias = f32(s0), f32(s1) if typed else None, f32(d0), f32(d1) if typed else None, f32(bias)
+        n = g.fwd.n_rows
+        alpha = torch.empty(g.fwd.nnz, dtype=torch.float32, device=s0.device)
+        share0 = torch.zeros(n, dtype=torch.float32, device=s0.device)
+        share1 = torch.zeros(n, dtype=torch.float32, device=s0.device) if typed else None
+        if g.fwd.nnz:
+            with torch.cuda.device(s0.device):
+                check(_cabi.lib().pygsd_snea_alpha_csr_f32(ptr(g.fwd.rowptr), ptr(g.fwd.col), ptr(g.etype), ptr(s0),
+                                                           ptr(s1), ptr(d0), ptr(d1), ptr(bias), n, ptr(alpha),
+                                                           ptr(share0), ptr(share1), stream_ptr()),
+                      "pygsd_snea_alpha_csr_f32")
+        ctx.g, ctx.typed = g, typed
+        ctx.save_for_backward(s0, s1, d0, d1, bias, alpha)
+        if typed:
+            return share0, share1
+        ctx.mark_non_differentiable(z := torch.zeros_like(share0))
+        return share0, z
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g0, g1):
+        s0, s1, d0, d1, bias, alpha = ctx.saved_tensors
+        g, typed = ctx.g, ctx.typed
+        n, nnz = g.fwd.n_rows, g.fwd.nnz
+        dev = alpha.device
+        g0 = g0.float().contiguous()
+        g1 = g1.float().contiguous() if typed else None
+        dpre0 = torch.empty(nnz, dtype=torch.float32, device=dev)
+        dpre1 = torch.empty(nnz, dtype=torch.float32, device=dev) if typed else None
+        dd0 = torch.zeros(n, dtype=torch.float32, device=dev)
+        dd1 = torch.zeros(n, dtype=torch.float32, device=dev) if typed else None
+        if nnz:
+            with torch.cuda.device(dev):
+                check(_cabi.lib().pygsd_snea_alpha_bwd_csr_f32(ptr(g.fwd.rowptr), ptr(g.fwd.col), ptr(g.etype), ptr(s0),
+                                                               ptr(s1), ptr(d0), ptr(d1), ptr(bias), ptr(alpha),
+                                                               ptr(g0), ptr(g1), n, ptr(dpre0), ptr(dpre1), ptr(dd0),
+                                                               ptr(dd1), stream_ptr()),
+                      "pygsd_snea_alpha_bwd_csr_f32")
+        ds0 = _row_sum(g.bwd.rowptr, g.bwd_to_fwd, dpre0, n)
+        ds1 = _row_sum(g.bwd.rowptr, g.bwd_to_fwd, dpre1, n) if typed else None
+        dbias = (dd0.sum() + dd1.sum() if typed else dd0.sum()).reshape(1)
+        return ds0, ds1, dd0, dd1, dbias, None
 
 
 class SNEAConv(nn.Module):
@@ -72,33 +139,36 @@ class SNEAConv(nn.Module):
         self._memo = (pos, neg, key, out)
         return out
 
-    def _aggregate(self, g: _Graph, x1, x2, alpha_func):
-        w = alpha_func.weight[0]
-        a_src, a_dst = w[:self.out_dim], w[self.out_dim:]
-        s, d = x1 @ a_src, x1 @ a_dst
-        if g.p is None:
-            logits = s[g.src] + d[g.rows]
-        else:
-            s2, d2 = x2 @ a_src, x2 @ a_dst
-            logits = torch.where(g.p, s2[g.src], s[g.src]) + torch.where(g.p, d2[g.rows], d[g.rows])
-        alpha = segment_softmax(g.csr, torch.tanh(logits + alpha_func.bias))
-        if g.p is None:
-            return x1 * segment_sum(g.csr, alpha, g.rows).unsqueeze(1)
-        share1 = segment_sum(g.csr, alpha * g.p, g.rows)
-        share0 = segment_sum(g.csr, alpha * (~g.p), g.rows)
+    def _project(self, lin, alpha_func, x):
+        """(lin(x), <lin(x), a_src>, <lin(x), a_dst>) from ONE GEMM: the two attention projections are two
+        extra output columns W^T a of the linear map (rocBLAS' gemv on a 5e5 x 32 operand takes 4.5 ms; as
+        GEMM columns they are free), weight gradient through the split-K tall_linear."""
+        o = self.out_dim
+        a = alpha_func.weight[0].view(2, o).t()                     # [out, 2] = (a_src | a_dst)
+        wt = lin.weight.t()
+        y = tall_linear(x, torch.cat([wt, wt @ a], dim=1),
+                        None if lin.bias is None else torch.cat([lin.bias, lin.bias @ a]))
+        return y[:, :o], y[:, o], y[:, o + 1]
+
+    def _aggregate(self, g: _Graph, lin, alpha_func, h1, h2=None):
+        x1, s0, d0 = self._project(lin, alpha_func, h1)
+        if g.etype is None:
+            share0, _ = _SneaShares.apply(s0, None, d0, None, alpha_func.bias, g)
+            return x1 * share0.unsqueeze(1)
+        x2, s1, d1 = self._project(lin, alpha_func, h2)
+        share0, share1 = _SneaShares.apply(s0, s1, d0, d1, alpha_func.bias, g)
         return x1 * share0.unsqueeze(1) + x2 * share1.unsqueeze(1)
 
     def forward(self, x: torch.Tensor, pos_edge_index: torch.Tensor, neg_edge_index: torch.Tensor) -> torch.Tensor:
         _cabi.require_gpu(x, pos_edge_index, neg_edge_index)
         graphs = self._graphs(pos_edge_index, neg_edge_index, x.size(0))
         if self.first_aggr:
-            h_b, h_u = self.lin_b(x), self.lin_u(x)
-            out_b = self._aggregate(graphs[0], h_b, h_b, self.alpha_b)
-            out_u = self._aggregate(graphs[1], h_u, h_u, self.alpha_u)
+            out_b = self._aggregate(graphs[0], self.lin_b, self.alpha_b, x)
+            out_u = self._aggregate(graphs[1], self.lin_u, self.alpha_u, x)
         else:
             h_b, h_u = x[..., :self.in_dim], x[..., self.in_dim:]
-            out_b = self._aggregate(graphs[0], self.lin_b(h_b), self.lin_b(h_u), self.alpha_b)
-            out_u = self._aggregate(graphs[0], self.lin_u(h_u), self.lin_u(h_b), self.alpha_u)
+            out_b = self._aggregate(graphs[0], self.lin_b, self.alpha_b, h_b, h_u)
+            out_u = self._aggregate(graphs[0], self.lin_u, self.alpha_u, h_u, h_b)
         return torch.cat([out_b, out_u], dim=-1)
 
     def __repr__(self) -> str:
