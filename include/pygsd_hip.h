@@ -140,6 +140,22 @@ int pygsd_gat_alpha_bwd_csr_f32(const int32_t* rowptr, const int32_t* col, const
                                 const float* out, int64_t ldo, int32_t n_rows, int32_t n_feat,
                                 float* ds_coo, float* alpha_coo, void* stream);
 
+/* Vectorised form of the above for n_feat % 4 == 0, n_feat <= 256, 16-byte aligned rows: float4 gathers,
+ * ds written in CSR (by-target) order and its per-row sum da_dst = gradient of a_dst produced in the same
+ * pass.  The by-source sums (gradient of a_src) and the backward aggregate then read ds / alpha through the
+ * by-source -> by-target slot map of the pattern (pygsd_segment_sum_f32 / pygsd_gather_f32). */
+int pygsd_gat_alpha_bwd_csr_v2_f32(const int32_t* rowptr, const int32_t* col, const float* a_src,
+                                   const float* a_dst, float negative_slope, const float* alpha,
+                                   const float* h, int64_t ldh, const float* g, int64_t ldg,
+                                   const float* out, int64_t ldo, int32_t n_rows, int32_t n_feat,
+                                   float* ds_csr, float* da_dst, void* stream);
+
+/* out[r] = sum over CSR row r of w[perm[slot]] (perm == NULL: w[slot]).  Unlike pygsd_csr_row_sum_f32 (one
+ * sequential sum per row, the reference's scatter order, used for degrees) this one splits a row over 16 lanes:
+ * fixed but different summation order, for gradient reductions. */
+int pygsd_segment_sum_f32(const int32_t* rowptr, const int32_t* perm, const float* w, int32_t n_rows,
+                          float* out, void* stream);
+
 /* Segment softmax over per-entry logits given in CSR order (one segment = one CSR row), max-shifted with
  * the + 1e-16 denominator of torch_geometric.utils.softmax: the attention of SNEAConv
  * (nn/signed/SNEAConv.py:135-146: alpha = softmax(tanh(alpha_func([x_j, x_i])), index)), whose logits mix

@@ -47,6 +47,10 @@ PROTOTYPES = {
                                           c_void_p]),
     "pygsd_segment_softmax_csr_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "pygsd_segment_softmax_bwd_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "pygsd_gat_alpha_bwd_csr_v2_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                                 c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
+                                                 c_void_p, c_void_p, c_void_p]),
+    "pygsd_segment_sum_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "pygsd_snea_alpha_csr_f32": (c_int32, [c_void_p] * 8 + [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_snea_alpha_bwd_csr_f32": (c_int32, [c_void_p] * 11 + [c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                                                 c_void_p]),

@@ -99,6 +99,100 @@ __global__ __launch_bounds__(256) void gat_alpha_bwd_kernel(const int32_t* __res
     }
 }
 
+// Vectorised variant (F % 4 == 0, 16-byte aligned rows, F <= 256): LPR = F/4 lanes hold one float4 each of a
+// feature row, so a wave-wide load fetches 64/LPR neighbour rows, UN of them in flight per lane before the
+// dot products (same gather shape as spmm_vec_kernel).  ds is written in CSR order (coalesced; the by-source
+// sums go through the pattern's by-source -> by-target slot map) and its row sum -- the gradient of a_dst --
+// is produced here.
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_alpha_bwd_vec_kernel(const int32_t* __restrict__ rowptr,
+                                                                const int32_t* __restrict__ col,
+                                                                const float* __restrict__ a_src,
+                                                                const float* __restrict__ a_dst, float slope,
+                                                                const float* __restrict__ alpha,
+                                                                const float* __restrict__ h, int64_t ldh,
+                                                                const float* __restrict__ g, int64_t ldg,
+                                                                const float* __restrict__ out, int64_t ldo,
+                                                                int32_t n_rows, int32_t n_feat,
+                                                                float* __restrict__ ds, float* __restrict__ da_dst)
+{
+    constexpr int NPW = 64 / LPR;
+    constexpr int UN = 4;
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + static_cast<int>(threadIdx.x >> 6));
+    if (row >= n_rows) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    const int sub = lane / LPR;
+    const int fl = (lane % LPR) * 4;
+    const bool fact = fl < n_feat;
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float rd = 0.f;
+    if (fact) {
+        g4 = *reinterpret_cast<const float4*>(g + static_cast<int64_t>(row) * ldg + fl);
+        const float4 o4 = *reinterpret_cast<const float4*>(out + static_cast<int64_t>(row) * ldo + fl);
+        rd = g4.x * o4.x + g4.y * o4.y + g4.z * o4.z + g4.w * o4.w;
+    }
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) rd += __shfl_xor(rd, off);          // <g_i, out_i> in every lane
+    const float ad = a_dst[row];
+    float acc = 0.f;
+    for (int base = beg; base < end; base += 64) {
+        const int cnt = (end - base) < 64 ? (end - base) : 64;
+        int c = 0;
+        float al = 0.f;
+        if (lane < cnt) {
+            c = col[base + lane];
+            al = alpha[base + lane];
+        }
+        for (int u = 0; u < cnt; u += NPW * UN) {
+            float4 hv[UN];
+            int cj[UN];
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                const int idx = u + k * NPW + sub;
+                cj[k] = __shfl(c, idx & 63);
+                hv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (fact && idx < cnt) hv[k] = *reinterpret_cast<const float4*>(h + static_cast<int64_t>(cj[k]) * ldh + fl);
+            }
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                const int idx = u + k * NPW + sub;
+                float dot = g4.x * hv[k].x + g4.y * hv[k].y + g4.z * hv[k].z + g4.w * hv[k].w;
+#pragma unroll
+                for (int off = 1; off < LPR; off <<= 1) dot += __shfl_xor(dot, off);
+                const float a = __shfl(al, idx & 63);
+                if (idx < cnt && (lane % LPR) == 0) {
+                    const float sc = a_src[cj[k]] + ad;
+                    const float d = a * (dot - rd) * (sc > 0.f ? 1.f : slope);
+                    ds[base + idx] = d;
+                    acc += d;
+                }
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) da_dst[row] = acc;
+}
+
+// out[r] = sum over CSR row r of w[perm[slot]] (perm == NULL: w[slot]); 16-lane teams, fixed (not sequential)
+// summation order -- for gradients, where pygsd_csr_row_sum_f32's reference scatter order is not required.
+__global__ __launch_bounds__(256) void segment_sum_kernel(const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ perm,
+                                                          const float* __restrict__ w, int32_t n_rows,
+                                                          float* __restrict__ out)
+{
+    const int t = threadIdx.x & 15;
+    const int64_t row = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 4;
+    float acc = 0.f;
+    if (row < n_rows) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        for (int e = beg + t; e < end; e += 16) acc += w[perm ? perm[e] : e];
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if (row < n_rows && t == 0) out[row] = acc;
+}
+
 // Generic segment softmax over per-entry logits already in CSR order (SNEAConv's tanh attention,
 // nn/signed/SNEAConv.py:135-146: alpha = softmax(tanh(lin([x_j, x_i])), index)): max-shifted, denominator
 // + 1e-16 like torch_geometric.utils.softmax.  One wavefront per segment, three coalesced passes.
@@ -268,6 +362,48 @@ extern "C" int pygsd_snea_alpha_bwd_csr_f32(const int32_t* rowptr, const int32_t
     hipLaunchKernelGGL(snea_alpha_bwd_kernel, dim3((static_cast<unsigned>(n_rows) + 3) / 4), dim3(256), 0, s, rowptr,
                        col, edge_type, s0, s1, d0, d1, bias, alpha, dshare0, dshare1, n_rows, dpre0, dpre1, dd0, dd1);
     return check_launch("snea_alpha_bwd_kernel");
+}
+
+extern "C" int pygsd_gat_alpha_bwd_csr_v2_f32(const int32_t* rowptr, const int32_t* col, const float* a_src,
+                                              const float* a_dst, float negative_slope, const float* alpha,
+                                              const float* h, int64_t ldh, const float* g, int64_t ldg,
+                                              const float* out, int64_t ldo, int32_t n_rows, int32_t n_feat,
+                                              float* ds_csr, float* da_dst, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_gat_alpha_bwd_csr_v2_f32: negative size");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(rowptr && a_src && a_dst && h && g && out && da_dst, "pygsd_gat_alpha_bwd_csr_v2_f32: null pointer");
+    PYGSD_REQUIRE(n_feat % 4 == 0 && n_feat <= 256 && ldh % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && aligned16(h) &&
+                      aligned16(g) && aligned16(out),
+                  "pygsd_gat_alpha_bwd_csr_v2_f32: needs n_feat %% 4 == 0, n_feat <= 256 and 16-byte aligned rows");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_SDDMM, s);
+    const dim3 grid((static_cast<unsigned>(n_rows) + 3) / 4), block(256);
+#define PYGSD_GAT_BWD(L)                                                                                             \
+    hipLaunchKernelGGL(gat_alpha_bwd_vec_kernel<L>, grid, block, 0, s, rowptr, col, a_src, a_dst, negative_slope, alpha, \
+                       h, ldh, g, ldg, out, ldo, n_rows, n_feat, ds_csr, da_dst)
+    const int quads = n_feat / 4;
+    if (quads <= 4) PYGSD_GAT_BWD(4);
+    else if (quads <= 8) PYGSD_GAT_BWD(8);
+    else if (quads <= 16) PYGSD_GAT_BWD(16);
+    else if (quads <= 32) PYGSD_GAT_BWD(32);
+    else PYGSD_GAT_BWD(64);
+#undef PYGSD_GAT_BWD
+    return check_launch("gat_alpha_bwd_vec_kernel");
+}
+
+extern "C" int pygsd_segment_sum_f32(const int32_t* rowptr, const int32_t* perm, const float* w, int32_t n_rows,
+                                     float* out, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0, "pygsd_segment_sum_f32: negative size");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(rowptr && out, "pygsd_segment_sum_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    const int64_t threads = static_cast<int64_t>(n_rows) * 16;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, s, rowptr,
+                       perm, w, n_rows, out);
+    return check_launch("segment_sum_kernel");
 }
 
 extern "C" int pygsd_segment_softmax_csr_f32(const int32_t* rowptr, const float* logits, int32_t n_rows, float* alpha,

@@ -15,7 +15,7 @@ import torch.nn as nn
 from ... import _cabi
 from ..._cabi import check, ptr, stream_ptr
 from ...dense import tall_linear
-from ...sparse import GLOBAL_PATTERNS, Pattern, _rows, _spmm_raw, gather_values
+from ...sparse import GLOBAL_PATTERNS, Pattern, _rows, _spmm_raw, gather_values, segment_sum_raw
 
 
 def _row_sum(csr, w_coo):
@@ -56,6 +56,20 @@ class _GatAggregate(torch.autograd.Function):
         hh, ldh = _rows(h)
         oo, ldo = _rows(out)
         ds = torch.empty(fwd.nnz, dtype=torch.float32, device=h.device)
+        f = h.size(1)
+        if fwd.nnz and f % 4 == 0 and f <= 256 and ldg % 4 == 0 and ldh % 4 == 0 and ldo % 4 == 0 and \
+                all(t.data_ptr() % 16 == 0 for t in (g, hh, oo)):
+            # vectorised path: ds in by-target slot order, d a_dst from the same pass
+            da_dst = torch.empty(fwd.n_rows, dtype=torch.float32, device=h.device)
+            with torch.cuda.device(h.device):
+                check(_cabi.lib().pygsd_gat_alpha_bwd_csr_v2_f32(ptr(fwd.rowptr), ptr(fwd.col), ptr(a_src), ptr(a_dst),
+                                                                 float(ctx.slope), ptr(alpha), ptr(hh), ldh, ptr(g),
+                                                                 ldg, ptr(oo), ldo, fwd.n_rows, f, ptr(ds),
+                                                                 ptr(da_dst), stream_ptr()),
+                      "pygsd_gat_alpha_bwd_csr_v2_f32")
+            m = pat.bwd_to_fwd
+            gh = _spmm_raw(bwd, gather_values(alpha, m), g, None, 1.0, 0.0, False)
+            return gh, segment_sum_raw(bwd.rowptr, m, ds, bwd.n_rows), da_dst, None, None
         a_coo = torch.empty_like(ds)
         if fwd.nnz:
             with torch.cuda.device(h.device):
@@ -117,7 +131,7 @@ class GATConv(nn.Module):
         wt = self.lin.weight.t()                                        # [in, heads * c]
         w3 = wt.reshape(wt.size(0), hds, c)
         y = tall_linear(x, torch.cat([wt, (w3 * self.att_src).sum(-1), (w3 * self.att_dst).sum(-1)], dim=1))
-        h = y[:, :hds * c].view(n, hds, c)
+        h = y[:, :hds * c].contiguous().view(n, hds, c)   # 16-byte aligned, densely packed rows for the gathers
         a_src, a_dst = y[:, hds * c:hds * c + hds], y[:, hds * c + hds:]
         if self.add_self_loops:
             edge_index = self._with_self_loops(edge_index, n)

@@ -20,7 +20,7 @@ import torch.nn as nn
 from ... import _cabi
 from ..._cabi import check, ptr, stream_ptr
 from ...dense import tall_linear
-from ...sparse import Pattern
+from ...sparse import Pattern, segment_sum_raw
 
 
 def _loop_free_plus_loops(edge_index: torch.Tensor) -> torch.Tensor:
@@ -37,20 +37,8 @@ class _Graph:
     def __init__(self, edge_index: torch.Tensor, edge_p: Optional[torch.Tensor], n: int):
         pat = Pattern(edge_index, n, n)
         self.fwd, self.bwd = pat.fwd, pat.bwd
-        nnz = self.fwd.nnz
         self.etype = None if edge_p is None else edge_p[self.fwd.perm.long()].to(torch.uint8).contiguous()
-        slot_of_edge = torch.empty(nnz, dtype=torch.int32, device=edge_index.device)
-        slot_of_edge[self.fwd.perm.long()] = torch.arange(nnz, dtype=torch.int32, device=edge_index.device)
-        self.bwd_to_fwd = slot_of_edge[self.bwd.perm.long()].contiguous()
-
-
-def _row_sum(rowptr, perm, w, n):
-    out = torch.zeros(n, dtype=torch.float32, device=w.device)
-    if w.numel():
-        with torch.cuda.device(w.device):
-            check(_cabi.lib().pygsd_csr_row_sum_f32(ptr(rowptr), ptr(perm), ptr(w), n, ptr(out), stream_ptr()),
-                  "pygsd_csr_row_sum_f32")
-    return out
+        self.bwd_to_fwd = pat.bwd_to_fwd
 
 
 class _SneaShares(torch.autograd.Function):
@@ -98,8 +86,8 @@ class _SneaShares(torch.autograd.Function):
                                                                ptr(g0), ptr(g1), n, ptr(dpre0), ptr(dpre1), ptr(dd0),
                                                                ptr(dd1), stream_ptr()),
                       "pygsd_snea_alpha_bwd_csr_f32")
-        ds0 = _row_sum(g.bwd.rowptr, g.bwd_to_fwd, dpre0, n)
-        ds1 = _row_sum(g.bwd.rowptr, g.bwd_to_fwd, dpre1, n) if typed else None
+        ds0 = segment_sum_raw(g.bwd.rowptr, g.bwd_to_fwd, dpre0, n)
+        ds1 = segment_sum_raw(g.bwd.rowptr, g.bwd_to_fwd, dpre1, n) if typed else None
         dbias = (dd0.sum() + dd1.sum() if typed else dd0.sum()).reshape(1)
         return ds0, ds1, dd0, dd1, dbias, None
 

@@ -100,6 +100,16 @@ def csr_from_coo(seg: Tensor, other: Tensor, n_seg: int, n_other: int) -> CSR:
     return CSR(n_seg, n_other, nnz, rowptr, col, perm)
 
 
+def segment_sum_raw(rowptr: Tensor, perm: Optional[Tensor], w: Tensor, n_rows: int) -> Tensor:
+    """out[r] = sum of w[perm[slot]] over CSR row r (pygsd_segment_sum_f32; perm None: w is in slot order)."""
+    out = torch.zeros(n_rows, dtype=torch.float32, device=w.device)
+    if w.numel() and n_rows:
+        with torch.cuda.device(w.device):
+            check(_cabi.lib().pygsd_segment_sum_f32(ptr(rowptr), ptr(perm), ptr(w), n_rows, ptr(out), stream_ptr()),
+                  "pygsd_segment_sum_f32")
+    return out
+
+
 def gather_values(src: Tensor, perm: Tensor) -> Tensor:
     """out[i] = src[perm[i]] on the device (fp32)."""
     _cabi.require_gpu(src, perm)
@@ -142,6 +152,17 @@ class Pattern:
         if self._bwd is None:
             self._bwd = csr_from_coo(self._gather, self._scatter, self.n_in, self.n_out)
         return self._bwd
+
+    @property
+    def bwd_to_fwd(self) -> Tensor:
+        """int32 [nnz]: for every slot of the by-source CSR, the slot of the same entry in the by-target CSR
+        (per-entry quantities produced in by-target order are read through it by the by-source reductions)."""
+        m = getattr(self, "_bwd_to_fwd", None)
+        if m is None:
+            slot_of_entry = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
+            slot_of_entry[self.fwd.perm.long()] = torch.arange(self.nnz, dtype=torch.int32, device=self.device)
+            m = self._bwd_to_fwd = slot_of_entry[self.bwd.perm.long()].contiguous()
+        return m
 
     @property
     def coo32(self) -> Tuple[Tensor, Tensor]:
