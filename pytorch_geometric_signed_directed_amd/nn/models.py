@@ -276,7 +276,7 @@ class DGCN_node_classification(nn.Module):
 
 
 def _cluster_head(z, w_prob, bias):
-    output = torch.mm(z, w_prob)
+    output = tall_linear(z, w_prob)
     if bias is not None:
         output = output + bias
     return F.normalize(z), F.log_softmax(output, dim=1), torch.argmax(output, dim=1), F.softmax(output, dim=1)
@@ -305,7 +305,7 @@ class DIGRAC_node_clustering(nn.Module):
         self._bias.data.fill_(0.0)
 
     def _mlp(self, x, w0, w1):
-        return torch.mm(self.dropout(self._relu(torch.mm(x, w0))), w1)
+        return tall_linear(self.dropout(self._relu(tall_linear(x, w0))), w1)
 
     def forward(self, edge_index, edge_weight, features):
         z = self._dimpa(self._mlp(features, self._w_s0, self._w_s1), self._mlp(features, self._w_t0, self._w_t1),
@@ -348,7 +348,7 @@ class SSSNET_node_clustering(nn.Module):
 
     def forward(self, edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, features
                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-        xs = [torch.mm(self._dropout(self._relu(torch.mm(features, getattr(self, f"_w_{s}0")))),
+        xs = [tall_linear(self._dropout(self._relu(tall_linear(features, getattr(self, f"_w_{s}0")))),
                        getattr(self, f"_w_{s}1")) for s in self._streams]
         z = self._simpa(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, *xs)
         return _cluster_head(z, self._W_prob, self._bias)
@@ -453,10 +453,10 @@ class SSSNET_link_prediction(SSSNET_node_clustering):
         self._reset_parameters()
 
     def forward(self, edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, features, query_edges):
-        xs = [torch.mm(self._dropout(self._relu(torch.mm(features, getattr(self, f"_w_{s}0")))),
+        xs = [tall_linear(self._dropout(self._relu(tall_linear(features, getattr(self, f"_w_{s}0")))),
                        getattr(self, f"_w_{s}1")) for s in self._streams]
         z = self._simpa(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, *xs)
-        output = torch.mm(_pair_rows(z, query_edges), self._W_prob)
+        output = tall_linear(_pair_rows(z, query_edges), self._W_prob)
         if self._bias is not None:
             output = output + self._bias
         return F.log_softmax(output, dim=1)
