@@ -126,6 +126,7 @@ class MagneticChebConv(MessagePassing):
         glorot(self.weight)
         zeros(self.bias)
         self._operator = None
+        self._op_memo = self._parts_memo = self._lam_memo = None
         self.cached_num_edges = None
         self.cached_q = None
 
@@ -144,8 +145,52 @@ class MagneticChebConv(MessagePassing):
     def _laplacian_kwargs(self):
         return dict(signed=self._signed, absolute_degree=getattr(self, "absolute_degree", True))
 
-    def _build_operator(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype):
+    @staticmethod
+    def _same(a, b):
+        """Memo keys hold tensors by identity + in-place version, everything else by value."""
+        if len(a) != len(b):
+            return False
+        for x, y in zip(a, b):
+            if isinstance(x, tuple) and isinstance(y, tuple) and len(x) == 2 and isinstance(x[0], torch.Tensor):
+                if x[0] is not y[0] or x[1] != y[1]:
+                    return False
+            elif x != y:
+                return False
+        return True
+
+    @staticmethod
+    def _tkey(t):
+        return None if t is None else (t, t._version)
+
+    def _operator_for(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype):
+        """`cached=False` (the reference default, MagNetConv.py:157-181) rebuilds the operator every forward.
+        The operator is a pure function of (edge_index, edge_weight, N, q, normalization, lambda_max), so the
+        last one is kept and reused while those inputs are THE SAME TENSORS, unmodified (identity + in-place
+        version counter) -- identical values, no re-sort.  A trainable q still recomputes the values every
+        call (they carry the gradient); only the sorted structure is reused (`_parts_memo`)."""
+        if isinstance(q, torch.Tensor) and q.requires_grad:
+            return self._build_operator(edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype)
+        lam = self._tkey(lambda_max) if isinstance(lambda_max, torch.Tensor) else lambda_max
+        key = (self._tkey(edge_index), self._tkey(edge_weight), num_nodes, float(q), normalization, lam, dtype)
+        memo = getattr(self, "_op_memo", None)
+        if memo is not None and self._same(memo[0], key):
+            return memo[1]
+        op = self._build_operator(edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype)
+        self._op_memo = (key, op)
+        return op
+
+    def _parts_for(self, edge_index, edge_weight, num_nodes, dtype):
+        key = (self._tkey(edge_index), self._tkey(edge_weight), num_nodes, dtype)
+        memo = getattr(self, "_parts_memo", None)
+        if memo is not None and self._same(memo[0], key):
+            return memo[1]
         parts = laplacian_parts(edge_index, edge_weight, num_nodes, dtype=dtype, **self._laplacian_kwargs())
+        if edge_weight is None or not edge_weight.requires_grad:
+            self._parts_memo = (key, parts)
+        return parts
+
+    def _build_operator(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype):
+        parts = self._parts_for(edge_index, edge_weight, num_nodes, dtype)
         if isinstance(q, torch.Tensor) and q.requires_grad:      # trainable q: generic differentiable route
             off_r, off_i, diag = laplacian_values(parts, q, normalization)
             return MagneticOperator(None, None, None, parts.index, off_r, off_i, diag, lambda_max, num_nodes)
@@ -207,13 +252,17 @@ class MagneticChebConv(MessagePassing):
                 if self.trainable_q:
                     raise RuntimeError(
                         'Cannot train q while not calculating maximum eigenvalue of Laplacian!')
-                lambda_max = self._lambda_max_eigsh(edge_index, edge_weight, None)
+                lkey = (self._tkey(edge_index), self._tkey(edge_weight), float(self.q))
+                lmemo = getattr(self, "_lam_memo", None)
+                if lmemo is not None and self._same(lmemo[0], lkey):
+                    lambda_max = lmemo[1]                        # same graph tensors: same eigenvalue
+                else:
+                    lambda_max = self._lambda_max_eigsh(edge_index, edge_weight, None)
+                    self._lam_memo = (lkey, lambda_max)
             if lambda_max is None:
-                lambda_max = torch.tensor(2.0, dtype=x_real.dtype, device=x_real.device)
-            if not isinstance(lambda_max, torch.Tensor):
-                lambda_max = torch.tensor(lambda_max, dtype=x_real.dtype, device=x_real.device)
-            self._operator = self._build_operator(edge_index, x_real.size(self.node_dim), edge_weight,
-                                                  self.q, self.normalization, lambda_max, x_real.dtype)
+                lambda_max = 2.0
+            self._operator = self._operator_for(edge_index, x_real.size(self.node_dim), edge_weight,
+                                                self.q, self.normalization, lambda_max, x_real.dtype)
 
         op = self._operator
         fixed = op.csr is not None            # operator values carry no gradient (q not trainable)

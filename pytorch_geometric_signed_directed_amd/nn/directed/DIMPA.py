@@ -28,6 +28,6 @@ class DIMPA(torch.nn.Module):
         for h in range(1, 1 + self._hop):
             cur_s = self.conv_layer(cur_s, edge_index, edge_weight)
             cur_t = self.conv_layer(cur_t, edge_index_t, edge_weight)
-            feat_s = feat_s + self._w_s[h] * cur_s
-            feat_t = feat_t + self._w_t[h] * cur_t
+            feat_s = torch.addcmul(feat_s, self._w_s[h], cur_s)          # feat + w[h] * cur in one pass
+            feat_t = torch.addcmul(feat_t, self._w_t[h], cur_t)
         return torch.cat([feat_s, feat_t], dim=1)

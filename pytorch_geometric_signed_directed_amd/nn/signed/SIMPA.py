@@ -39,23 +39,25 @@ class SIMPA(torch.nn.Module):
         """One (positive, negative) feature pair: feat_p = sum_h wp[h] Ap^h x_pos and the mixed
         paths Ap^m An Ap^h x_neg, in the reference's accumulation order (SIMPA.py:77-93)."""
         feat_p = wp[0] * x_pos
-        feat_n = torch.zeros_like(feat_p)
+        feat_n = None
         cur_p, aux_n = x_pos, x_neg
         j = 0
+        last = self._hop_p - 1
         for h in range(self._hop_p):
             if h > 0:
                 cur_p = self.conv_layer_p(cur_p, ei_p, w_p)
-                aux_n = self.conv_layer_p(aux_n, ei_p, w_p)
-                feat_p = feat_p + wp[h] * cur_p
-            if h != self._hop_p - 1:
+                if h != last:      # the reference also advances aux_n at the last hop, but never reads it again
+                    aux_n = self.conv_layer_p(aux_n, ei_p, w_p)
+                feat_p = torch.addcmul(feat_p, wp[h], cur_p)            # feat_p + wp[h] * cur_p, one pass
+            if h != last:
                 cur_n = self.conv_layer_n(aux_n, ei_n, w_n)
-                feat_n = feat_n + wn[j] * cur_n
+                feat_n = wn[j] * cur_n if feat_n is None else torch.addcmul(feat_n, wn[j], cur_n)
                 j += 1
                 for _ in range(self._hop_p - 2 - h):
                     cur_n = self.conv_layer_p(cur_n, ei_p, w_p)
-                    feat_n = feat_n + wn[j] * cur_n
+                    feat_n = torch.addcmul(feat_n, wn[j], cur_n)
                     j += 1
-        return feat_p, feat_n
+        return feat_p, (torch.zeros_like(feat_p) if feat_n is None else feat_n)
 
     def forward(self, edge_index_p: torch.LongTensor, edge_weight_p: torch.FloatTensor,
                 edge_index_n: torch.LongTensor, edge_weight_n: torch.FloatTensor,

@@ -514,3 +514,38 @@ def test_segment_softmax_and_sum_midsize():
     close(alpha, a64.detach().numpy())
     close(sums, s64.detach().numpy())
     assert float((logits.grad.cpu().double() - l64.grad).abs().max()) < 1e-6
+
+
+def test_uncached_layer_reuses_the_operator_only_for_unmodified_graph_tensors():
+    """cached=False (the reference default) rebuilds the operator per forward; here the last operator is kept
+    while edge_index / edge_weight are the same tensor objects at the same in-place version.  Any in-place
+    edit, a different tensor, or a different q / lambda_max must rebuild -- outputs always equal a fresh layer's."""
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    g = load_golden("magnet_k2_sym_w")
+    ei, w = g.t("edge_index", D), g.t("edge_weight", D)
+    xr, xi = g.t("x_real", D), g.t("x_imag", D)
+    torch.manual_seed(0)
+    layer = MagNetConv(xr.size(1), 4, 2, 0.1, False, cached=False).to(D)
+
+    def fresh(ei_, w_, lam=None):
+        ref = MagNetConv(xr.size(1), 4, 2, 0.1, False, cached=False).to(D)
+        ref.load_state_dict(layer.state_dict())
+        return ref(xr, xi, ei_.clone(), w_.clone(), lam)
+
+    o1 = layer(xr, xi, ei, w)
+    op1 = layer._operator
+    o2 = layer(xr, xi, ei, w)
+    assert layer._operator is op1 and torch.equal(o1[0], o2[0])            # memo hit
+    w.mul_(2.0)                                                            # in-place edit bumps the version
+    o3 = layer(xr, xi, ei, w)
+    assert layer._operator is not op1
+    want = fresh(ei, w)
+    close(o3[0], want[0].detach().cpu().numpy()); close(o3[1], want[1].detach().cpu().numpy())
+    op3 = layer._operator
+    layer(xr, xi, ei.clone(), w)                                           # another tensor object
+    assert layer._operator is not op3
+    op4 = layer._operator
+    o5 = layer(xr, xi, ei, w, 3.0)                                         # another lambda_max
+    assert layer._operator is not op4
+    want = fresh(ei, w, 3.0)
+    close(o5[0], want[0].detach().cpu().numpy()); close(o5[1], want[1].detach().cpu().numpy())

@@ -68,13 +68,17 @@ def magnetic(name, cls, n, e, h, K, signed, **kw):
     layer_u = cls(h, h, K, 0.25, False, cached=False, **kw).to(dev)
     layer_u.load_state_dict(layer.state_dict())
 
-    def step_u():
+    def step_u(rebuild=True):
         layer_u.zero_grad(set_to_none=True); xr.grad = xi.grad = None
+        if rebuild:          # as if a new graph tensor arrived: the layer's operator memo cannot hit
+            layer_u._op_memo = layer_u._parts_memo = None
         o = layer_u(xr, xi, ei, w)
         (o[0].sum() + o[1].sum()).backward()
     ms_u, prof_u = timed(step_u, iters=5, warm=2)
     out[name]["uncached_ms_per_step"] = ms_u
     out[name]["uncached_build_ms"] = prof_u["build"]["launches_per_step"] * prof_u["build"]["ms_per_launch"]
+    ms_m, _ = timed(lambda: step_u(False), iters=5, warm=2)
+    out[name]["uncached_same_tensors_ms_per_step"] = ms_m      # cached=False, unchanged graph tensors
     print(name, json.dumps(out[name]), flush=True)
     del layer, layer_u, xr, xi, ei
     torch.cuda.empty_cache()

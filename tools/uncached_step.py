@@ -11,10 +11,15 @@ xr = torch.randn(n, h, generator=g).to(dev).requires_grad_()
 xi = torch.randn(n, h, generator=g).to(dev).requires_grad_()
 torch.manual_seed(0)
 layer = MagNetConv(h, h, 1, 0.25, False, cached=False).to(dev)
-def step():
+def step(rebuild):
     layer.zero_grad(set_to_none=True); xr.grad = xi.grad = None
+    if rebuild:                       # a NEW graph tensor every step: the operator memo cannot hit
+        layer._op_memo = layer._parts_memo = None
     o = layer(xr, xi, ei); (o[0].sum() + o[1].sum()).backward()
-for _ in range(2): step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(5): step()
-torch.cuda.synchronize(); print("uncached ms/step", (time.perf_counter() - t0) / 5 * 1e3)
+for rebuild in (True, False):
+    for _ in range(2): step(rebuild)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): step(rebuild)
+    torch.cuda.synchronize()
+    print("cached=False,", "operator rebuilt every step" if rebuild else "same graph tensors (memo hit)",
+          "ms/step", (time.perf_counter() - t0) / 5 * 1e3)
