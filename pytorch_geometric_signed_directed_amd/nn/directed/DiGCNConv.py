@@ -6,7 +6,7 @@ from torch.nn import Parameter
 from ... import _cabi
 from ...message_passing import MessagePassing
 from ...dense import tall_linear
-from ...sparse import Pattern, spmm
+from ...sparse import GLOBAL_PATTERNS, Pattern, spmm
 from .._magnetic import glorot, zeros
 
 
@@ -56,7 +56,10 @@ class DiGCNConv(MessagePassing):
             # cached=True (the default) silently keeps the FIRST operator (DiGCNConv.py:75-85)
             self.cached_result = edge_index, edge_weight
             n = x.size(self.node_dim)
-            self._pattern = Pattern(edge_index, n, n, self.flow)
+            # cached=False re-groups the edges per call in the reference; the grouping of an unmodified
+            # edge_index tensor is looked up instead (identity + in-place version)
+            self._pattern = (Pattern(edge_index, n, n, self.flow) if self.cached
+                             else GLOBAL_PATTERNS.get(edge_index, n, n, self.flow))
 
         _, norm = self.cached_result
         return self.update(spmm(self._pattern, x, norm))
