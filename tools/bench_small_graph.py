@@ -42,15 +42,9 @@ for _ in range(50):
 torch.cuda.synchronize()
 eager_ms = (time.perf_counter() - t0) / 50 * 1e3
 
-graph = torch.cuda.CUDAGraph()
-s = torch.cuda.Stream()
-s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    for _ in range(3):
-        step()
-torch.cuda.current_stream().wait_stream(s)
-with torch.cuda.graph(graph):
-    static_loss = step()
+from pytorch_geometric_signed_directed_amd.hipgraph import capture_step  # noqa: E402
+replay = capture_step(step, warmup=3)
+graph, static_loss = replay.graph, replay.outputs
 torch.cuda.synchronize()
 ref = [p.detach().clone() for p in model.parameters()]
 graph.replay()
