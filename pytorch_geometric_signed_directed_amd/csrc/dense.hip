@@ -50,8 +50,10 @@ struct DenseFwdArgs {
 // of ONE node row: the epilogue is one float4 store per tile instead of four scalar stores.
 // FIN > 0 fixes f_in at compile time: the feature loop unrolls and all of a Chebyshev term's 16-byte
 // loads are in flight before its first MFMA.
-template <int NT, int FIN>
-__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs p)
+// WAVES = 8 when the W slice leaves room for only one block per CU (f_in = 128, K = 2: 104 KB): two
+// wavefronts per SIMD instead of one, so one's row loads overlap the other's MFMAs.
+template <int NT, int FIN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs p)
     constexpr int ws = nc + kPad;
     const int f_in = FIN > 0 ? FIN : p.f_in;
     const int wrows = p.k1 * f_in;
-    for (int idx = tid; idx < wrows * nc; idx += 256) {
+    for (int idx = tid; idx < wrows * nc; idx += WAVES * 64) {
         const int r = idx / nc, c = idx - r * nc;
         lds[r * ws + c] = p.w[static_cast<int64_t>(r) * p.f_out + n0 + c];
     }
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs p)
 
     const int lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int n_tiles = (p.n_rows + 15) >> 4;
-    for (int tile = static_cast<int>(blockIdx.x) * 4 + (tid >> 6); tile < n_tiles;
-         tile += static_cast<int>(gridDim.x) * 4) {
+    for (int tile = static_cast<int>(blockIdx.x) * WAVES + (tid >> 6); tile < n_tiles;
+         tile += static_cast<int>(gridDim.x) * WAVES) {
         const int r0 = tile << 4;
         const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;  // clamped: stores are masked
         f32x4 acc_r[NT], acc_i[NT];
@@ -397,8 +399,13 @@ int set_lds(Kern kern, size_t bytes)
 template <int NT, int FIN>
 int launch_fwd_fin(const DenseFwdArgs& a, unsigned gy, size_t lds_bytes, hipStream_t s)
 {
-    if (int rc = set_lds(dense_fwd_kernel<NT, FIN>, lds_bytes)) return rc;
-    hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN>), dim3(row_blocks(a.n_rows, 2048), gy), dim3(256), lds_bytes, s, a);
+    if (lds_bytes > 80 * 1024) {        // one block per CU: give it 8 wavefronts
+        if (int rc = set_lds(dense_fwd_kernel<NT, FIN, 8>, lds_bytes)) return rc;
+        hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN, 8>), dim3(row_blocks(a.n_rows, 1024), gy), dim3(512), lds_bytes, s, a);
+        return check_launch("dense_fwd_kernel");
+    }
+    if (int rc = set_lds(dense_fwd_kernel<NT, FIN, 4>, lds_bytes)) return rc;
+    hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN, 4>), dim3(row_blocks(a.n_rows, 2048), gy), dim3(256), lds_bytes, s, a);
     return check_launch("dense_fwd_kernel");
 }
 

@@ -274,7 +274,7 @@ def test_fullsize_linearity_and_adjoint():
 
 # ------------------------------------------------------------------ fused MFMA dense stage
 @pytest.mark.parametrize("f_in,f_out,k1", [(16, 16, 1), (32, 48, 2), (48, 32, 3), (64, 64, 2), (64, 64, 4),
-                                            (64, 128, 2), (128, 64, 2), (128, 128, 2), (16, 64, 2)])
+                                            (64, 128, 2), (128, 64, 2), (128, 128, 2), (128, 128, 3), (16, 64, 2)])
 @pytest.mark.parametrize("n", [1, 37, 1000])
 def test_dense_stage_matches_reference_formula(f_in, f_out, k1, n):
     """out_real = sum_k (A_k - B_k) W_k + b, out_imag = sum_k (A_k + B_k) W_k + b and its gradients,
