@@ -223,7 +223,7 @@ def main():
                        "nodes": n, "edges": e, "hidden": hidden, "operator_nnz": int(nnz),
                        "parallelism": "single GPU" if world == 1 else f"node-range shards x{world}, "
                                                                        "RCCL all-gather of features"},
-            "roofline": {"bound": "hbm", "kernel": "spmm_vec_kernel<16,dual> (pygsd_spmm2_csr_f32)",
+            "roofline": {"bound": "hbm", "kernel": "spmm_vec_kernel<16,true,true> = LPR 16, dual operator, deep pipelining (pygsd_spmm2_csr_f32)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": int(launches), "avg_launch_ms": avg_ms,
