@@ -10,8 +10,9 @@ resident in HBM before the timed region.  A "step" = layer forward + loss.backwa
 loss = out_real.sum() + out_imag.sum() and gradients w.r.t. x_real, x_imag, weight, bias.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the same graph is sharded by
-node range across the ranks (strong scaling; `parallel.ShardedMagNetConv`), features exchanged by
-all-gather over xGMI each propagate.
+node range across the ranks (strong scaling; `parallel.ShardedMagNetConv`).  Default work layout: a
+p_r x p_c process grid (row blocks of the operator x column slices of the features) with two
+all-to-alls per propagate over xGMI; `--layout rows` = the plain all-gather of whole feature blocks.
 
 Extra objects in the JSON line: `roofline` (dominant kernel = the fused dual-value SpMM, timed by
 HIP events around every launch inside the timed region, algorithmic bytes per SURVEY.md 8(d)) and
@@ -92,6 +93,9 @@ def main():
     ap.add_argument("--edges", type=int, default=20000000)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", choices=("auto", "rows", "grid"), default="auto",
+                    help="multi-GPU work layout (parallel.ShardedMagNetConv): rows = all-gather of whole feature "
+                         "blocks, grid = p_r x p_c process grid with column-slice all-to-alls (auto picks grid)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the node-sharded layer even with one rank (exercises the RCCL path on 1 GPU)")
     args = ap.parse_args()
@@ -148,7 +152,7 @@ def main():
     else:
         from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv
         layer = ShardedMagNetConv(hidden, hidden, K=1, q=0.25, num_nodes=n, edge_index=edge_index,
-                                  edge_weight=None, device=device)
+                                  edge_weight=None, device=device, layout=args.layout)
         xr_loc, xi_loc = layer.shard_rows(x_real).requires_grad_(), layer.shard_rows(x_imag).requires_grad_()
         del x_real, x_imag
 
@@ -190,12 +194,20 @@ def main():
     if rank == 0:
         nnz = op_nnz()                      # E_s + N (folded diagonal)
         e_s = nnz - n
-        per_launch_nnz, per_launch_rows = nnz, n
-        if world > 1:
+        per_launch_nnz, per_launch_rows, width = nnz, n, hidden
+        parallelism = "single GPU"
+        if sharded and getattr(layer, "layout", "rows") == "grid":
+            # rank (i, j) multiplies row block i (1 / p_r of the entries) by column slice j (hidden / p_c columns)
+            p_r, p_c = layer.plan.p_r, layer.plan.p_c
+            per_launch_nnz, per_launch_rows, e_s, width = nnz / p_r, n / p_r, e_s / p_r, hidden // p_c
+            parallelism = (f"node-range ownership x{world}, {p_r} x {p_c} process grid: column-slice all-to-all in, "
+                           f"row-group all-to-all out (RCCL)")
+        elif world > 1 or sharded:
             per_launch_nnz, per_launch_rows = nnz / world, n / world
             e_s = e_s / world
+            parallelism = f"node-range shards x{world}, RCCL all-gather of features"
         # one fused launch = the real SpMM (E_s + N entries) + the imaginary SpMM (E_s entries)
-        alg_bytes = spmm_bytes(per_launch_nnz, per_launch_rows, hidden) + spmm_bytes(e_s, per_launch_rows, hidden)
+        alg_bytes = spmm_bytes(per_launch_nnz, per_launch_rows, width) + spmm_bytes(e_s, per_launch_rows, width)
         avg_ms = kernel_ms / max(launches, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         traffic = None
@@ -221,8 +233,7 @@ def main():
             "config": {"workload": f"MagNetConv K=1 q=0.25 sym cached, DSBM(5 clusters, cyclic eta=0.1, "
                                    f"size_ratio 1.5, p={p:.3e}) {n} nodes / {e} edges, h={hidden}, fp32",
                        "nodes": n, "edges": e, "hidden": hidden, "operator_nnz": int(nnz),
-                       "parallelism": "single GPU" if world == 1 else f"node-range shards x{world}, "
-                                                                       "RCCL all-gather of features"},
+                       "parallelism": parallelism},
             "roofline": {"bound": "hbm", "kernel": "spmm_vec_kernel<16,true,true> = LPR 16, dual operator, deep pipelining (pygsd_spmm2_csr_f32)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

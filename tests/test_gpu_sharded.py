@@ -1,7 +1,7 @@
-"""GPU: ShardedMagNetConv (HIP compute, node-range shards) against the un-sharded MagNetConv and the
-oracle.  Two ranks share the one GPU of the test box, exchanging through gloo (RCCL refuses two ranks
-on one device; the 8-GPU RCCL run is the driver's) -- the compute path, packing, local CSRs, the
-Chebyshev adjoint over gathered blocks and the parameter all-reduce are the production code."""
+"""GPU: ShardedMagNetConv (HIP compute, node-range ownership; row layout and p_r x p_c grid layout) against
+the oracle.  2 .. 8 ranks share the one GPU of the test box, exchanging through gloo (RCCL refuses two ranks
+on one device; the 8-GPU RCCL run is the driver's) -- the compute path, packing / slicing, operator
+blocks, the Chebyshev adjoint over exchanged blocks and the parameter all-reduce are the production code."""
 import os
 import socket
 
@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, k, f, ret):
+def _worker(rank, world, port, n, k, f, layout, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -34,7 +34,8 @@ def _worker(rank, world, port, n, k, f, ret):
         xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
         gr, gi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
         torch.manual_seed(11)
-        layer = ShardedMagNetConv(f, f, k, 0.25, n, ei.to(dev), w.to(dev), device=dev)
+        layer = ShardedMagNetConv(f, f, k, 0.25, n, ei.to(dev), w.to(dev), device=dev, layout=layout)
+        assert layer.layout == layout
         with torch.no_grad():
             layer.bias.uniform_(-0.5, 0.5)
             dist.broadcast(layer.bias.data, 0)
@@ -62,11 +63,17 @@ def _worker(rank, world, port, n, k, f, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,k,f", [(2, 1000, 1, 64), (2, 1003, 2, 64), (3, 500, 3, 16), (2, 300, 2, 6)])
-def test_sharded_layer_matches_oracle(world, n, k, f):
+@pytest.mark.parametrize("world,n,k,f,layout", [
+    (2, 1000, 1, 64, "rows"), (2, 1003, 2, 64, "rows"), (3, 500, 3, 16, "rows"), (2, 300, 2, 6, "rows"),
+    (2, 1003, 1, 64, "grid"),          # 1 x 2
+    (4, 900, 2, 64, "grid"),           # 1 x 4, two Chebyshev orders (the z term lives in the grid layout)
+    (4, 701, 3, 32, "grid"),           # 1 x 4 at 8-float slices
+    (8, 1203, 2, 64, "grid"),          # 2 x 4: the 8-GPU configuration
+])
+def test_sharded_layer_matches_oracle(world, n, k, f, layout):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n, k, f, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, k, f, layout, ret), nprocs=world, join=True)
     assert len(ret) == world
     assert max(ret.values()) <= 1e-5, dict(ret)
 

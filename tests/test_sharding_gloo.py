@@ -97,3 +97,74 @@ def test_sharded_rows_equal_unsharded_oracle(world, n):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+# ------------------------------------------------------------------------------------------------
+# grid layout (GridPlan): column-slice exchange, (row block i) x (column slice j) product, exchange back
+# ------------------------------------------------------------------------------------------------
+def test_grid_plan_geometry():
+    from pytorch_geometric_signed_directed_amd.parallel import GridPlan
+    assert [GridPlan.choose_cols(w, 64) for w in (1, 2, 4, 8)] == [1, 2, 4, 4]
+    assert GridPlan.choose_cols(8, 12) == 1 and GridPlan.choose_cols(8, 24) == 2      # 16-byte aligned slices only
+    p = GridPlan(1000, 8, 5, 64)
+    assert (p.p_r, p.p_c, p.i, p.j, p.fc) == (2, 4, 1, 1, 16)
+    assert p.block_rows == 4 * p.n_pad and p.block_lo == 4 * p.n_pad and list(p.row_group()) == [4, 5, 6, 7]
+    assert p.group_splits() == [0, 0, 0, 0, 1, 1, 1, 1]
+    a = torch.arange(p.n_pad * 64, dtype=torch.float32).view(p.n_pad, 64)
+    b = -a
+    chunks = p.slice_chunks(a, b)
+    assert chunks.shape == (8, p.n_pad, 32)
+    for d in range(8):
+        j = d % 4
+        assert torch.equal(chunks[d][:, :16], a[:, 16 * j:16 * j + 16]) and torch.equal(chunks[d][:, 16:], b[:, 16 * j:16 * j + 16])
+    recv = torch.stack([chunks[j] for j in range(4)])          # what a row group hands back for these rows
+    ra, rb = p.merge_slices(recv)
+    assert torch.equal(ra, a) and torch.equal(rb, b)
+    with pytest.raises(ValueError):
+        GridPlan(10, 6, 0, 64, 4)
+
+
+def _grid_worker(rank, world, port, n, f, ret):
+    from pytorch_geometric_signed_directed_amd.parallel import GridPlan, collect_slices, return_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(321)
+        e = 10 * n
+        ei = torch.randint(0, n, (2, e), generator=g)
+        w = torch.rand(e, generator=g) + 0.5
+        xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+        plan = GridPlan(n, world, rank, f)
+        fc = plan.fc
+        op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0)
+        t_r = R.propagate(xr, op[0], op[2], n)                           # un-sharded oracle
+        t_i = R.propagate(xi, op[1], op[3], n)
+        full = collect_slices(plan, plan.shard_rows(xr), plan.shard_rows(xi))
+        cols = slice(plan.j * fc, (plan.j + 1) * fc)
+        ok = full.shape == (plan.n_total, 2 * fc)
+        ok = ok and torch.equal(full[:n, :fc], xr[:, cols]) and torch.equal(full[:n, fc:], xi[:, cols])
+        ok = ok and float(full[n:].abs().sum()) == 0.0
+        # product of operator row block i with column slice j, by the oracle
+        ys = []
+        for op_index, op_val, part in ((op[0], op[2], full[:, :fc]), (op[1], op[3], full[:, fc:])):
+            tgt = op_index[1]
+            keep = ((tgt >= plan.block_lo) & (tgt < plan.block_lo + plan.block_rows)).nonzero(as_tuple=True)[0]
+            sub = op_index[:, keep].clone()
+            sub[1] -= plan.block_lo
+            ys.append(R.propagate(part, sub, op_val[keep], plan.block_rows))
+        ra, rb = return_rows(plan, ys[0], ys[1])
+        ok = ok and ra.shape == (plan.n_pad, f)
+        ok = ok and torch.equal(ra[:plan.n_local], t_r[plan.lo:plan.hi]) and torch.equal(rb[:plan.n_local], t_i[plan.lo:plan.hi])
+        ok = ok and float(ra[plan.n_local:].abs().sum()) == 0.0
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,f", [(2, 40, 8), (4, 41, 16), (8, 50, 16), (3, 30, 8)])
+def test_grid_exchanges_reproduce_unsharded_oracle_rows(world, n, f):
+    """2 = 1x2, 4 = 1x4, 8 = 2x4 grids, and 3 ranks (no column split possible: 3x1)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_grid_worker, args=(world, _free_port(), n, f, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
