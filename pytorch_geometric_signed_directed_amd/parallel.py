@@ -110,9 +110,11 @@ class GridPlan(ShardPlan):
     @staticmethod
     def choose_cols(world_size: int, n_feat: int) -> int:
         """Largest p_c <= 4 dividing the world with 16-byte-aligned column slices (fc % 4 == 0): two packed
-        slices of >= 16 floats still fill the 128-byte line a gather costs anyway."""
+        slices of >= 16 floats still fill the 128-byte line a gather costs anyway.  Received volume relative to
+        one full feature pair: rows (1 - 1/P); grid (1 - 1/P) / p_c + (1 - 1/p_c) / P -- a 1 x 2 grid on two
+        ranks moves exactly what the row layout moves, so two ranks stay in the row layout."""
         for p_c in (4, 2):
-            if world_size % p_c == 0 and n_feat % (4 * p_c) == 0:
+            if world_size % p_c == 0 and world_size > p_c - 1 + (p_c == 2) and n_feat % (4 * p_c) == 0:
                 return p_c
         return 1
 

@@ -34,8 +34,9 @@ def _worker(rank, world, port, n, k, f, layout, ret):
         xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
         gr, gi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
         torch.manual_seed(11)
-        layer = ShardedMagNetConv(f, f, k, 0.25, n, ei.to(dev), w.to(dev), device=dev, layout=layout)
-        assert layer.layout == layout
+        layer = ShardedMagNetConv(f, f, k, 0.25, n, ei.to(dev), w.to(dev), device=dev, layout=layout,
+                                  grid_cols=2 if (layout == "grid" and world == 2) else None)   # force the 1 x 2 grid
+        assert layer.layout == layout and (layout == "rows" or layer.plan.p_c > 1)
         with torch.no_grad():
             layer.bias.uniform_(-0.5, 0.5)
             dist.broadcast(layer.bias.data, 0)

@@ -104,7 +104,7 @@ def test_sharded_rows_equal_unsharded_oracle(world, n):
 # ------------------------------------------------------------------------------------------------
 def test_grid_plan_geometry():
     from pytorch_geometric_signed_directed_amd.parallel import GridPlan
-    assert [GridPlan.choose_cols(w, 64) for w in (1, 2, 4, 8)] == [1, 2, 4, 4]
+    assert [GridPlan.choose_cols(w, 64) for w in (1, 2, 4, 6, 8)] == [1, 1, 4, 2, 4]
     assert GridPlan.choose_cols(8, 12) == 1 and GridPlan.choose_cols(8, 24) == 2      # 16-byte aligned slices only
     p = GridPlan(1000, 8, 5, 64)
     assert (p.p_r, p.p_c, p.i, p.j, p.fc) == (2, 4, 1, 1, 16)
@@ -134,7 +134,7 @@ def _grid_worker(rank, world, port, n, f, ret):
         ei = torch.randint(0, n, (2, e), generator=g)
         w = torch.rand(e, generator=g) + 0.5
         xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
-        plan = GridPlan(n, world, rank, f)
+        plan = GridPlan(n, world, rank, f, 2 if world == 2 else None)      # two ranks: force the 1 x 2 grid
         fc = plan.fc
         op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0)
         t_r = R.propagate(xr, op[0], op[2], n)                           # un-sharded oracle
