@@ -2,7 +2,6 @@
 path; the torch_sparse.SparseTensor path is out of scope: torch_sparse is not part of this stack)."""
 from typing import Optional
 
-import torch
 from torch import Tensor
 
 from ... import _cabi

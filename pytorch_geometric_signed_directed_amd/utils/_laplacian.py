@@ -11,7 +11,7 @@ One host round-trip is inherent: the number of distinct symmetrised entries size
 """
 import ctypes
 import math
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

@@ -24,7 +24,6 @@ def _worker(rank, world, port, n, k, f, layout, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import ref_layers as R
-        from pytorch_geometric_signed_directed_amd.nn import MagNetConv
         from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv, all_gather_rows
         dev = torch.device("cuda:0")
         g = torch.Generator().manual_seed(7)

@@ -2,7 +2,6 @@
 gathered set exceeds the 256 MB Infinity Cache?  Launches the C-ABI directly with strided views."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
-from pytorch_geometric_signed_directed_amd import _cabi
 from pytorch_geometric_signed_directed_amd.sparse import Pattern
 
 from tools.colblock_probe_lib import run, timeit, dev

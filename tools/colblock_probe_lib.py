@@ -3,7 +3,6 @@ gathered set exceeds the 256 MB Infinity Cache?  Launches the C-ABI directly wit
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from pytorch_geometric_signed_directed_amd import _cabi
-from pytorch_geometric_signed_directed_amd.sparse import Pattern
 
 dev = torch.device("cuda:0")
 lib, P = _cabi.lib(), _cabi.ptr

@@ -2,7 +2,6 @@
 (F=64, ~40M entries, uniform random columns), single and dual operator.  Feeds the nnz_hint threshold."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
-from pytorch_geometric_signed_directed_amd import _cabi
 from pytorch_geometric_signed_directed_amd.sparse import Pattern
 from tools.colblock_probe_lib import run, timeit
 
