@@ -447,7 +447,6 @@ def test_digcn_conv_bf16_layer():
 def test_spmm_variants_are_bitwise_identical():
     """The nnz hint only selects a tuning variant (deep gather pipelining vs high occupancy); every lane
     group accumulates its neighbours in the same order in both, so the outputs are bit-identical."""
-    import ctypes
     from pytorch_geometric_signed_directed_amd import _cabi
     from pytorch_geometric_signed_directed_amd.sparse import Pattern
     d = dev()
