@@ -502,6 +502,34 @@ def snea_cases():
          **{"sd." + k: npy(v) for k, v in model.state_dict().items()})
 
 
+def sdgnn_case():
+    """SDGNN: embeddings through two SDRLayers (4 GATConv aggregators each) and its three objectives (all
+    deterministic: no negative sampling), plus the motif-count matrix the triangle loss weights edges with."""
+    from torch_geometric_signed_directed.nn.signed.SDGNN import SDGNN
+    n = 40
+    g = torch.Generator().manual_seed(95)
+    pairs = torch.randint(0, n, (170, 2), generator=g)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    sign = torch.where(torch.rand(pairs.size(0), generator=g) < 0.6, 1, -1)
+    edge_index_s = torch.cat([pairs, sign[:, None]], dim=1)
+    edge_index_s = torch.cat([edge_index_s, edge_index_s[:6] * torch.tensor([1, 1, -1]), edge_index_s[6:12]])
+    init = torch.randn(n, 8, generator=g)
+    torch.manual_seed(96)
+    model = SDGNN(n, edge_index_s, in_dim=8, out_dim=8, layer_num=2, init_emb=init)
+    with torch.no_grad():
+        for prm in model.parameters():
+            if prm.dim() == 1 and prm.numel() > 1:
+                prm.add_(torch.rand(prm.shape, generator=g) - 0.5)
+    z = model()
+    pos, neg = model.pos_edge_index, model.neg_edge_index
+    tri = model.tri_weight.tocoo()
+    save("model_sdgnn", edge_index_s=npy(edge_index_s), init_emb=npy(init), z=npy(z),
+         loss_sign=npy(model.loss_sign(z, pos, neg)), loss_direction=npy(model.loss_direction(z, pos, neg)),
+         loss_tri=npy(model.loss_tri(z, pos, neg)), loss_total=npy(model.loss()),
+         tri_row=tri.row.astype(np.int64), tri_col=tri.col.astype(np.int64), tri_val=tri.data.astype(np.int64),
+         **{"sd." + k: npy(v) for k, v in model.state_dict().items()})
+
+
 def sgcn_model_and_sign_losses():
     """SGCN.forward (z) with given initial embeddings, and the signed objectives with the random negative
     draws of PyG replaced by fixed index sets (patched into the reference module), so the arithmetic is pinned."""
@@ -589,6 +617,7 @@ def main():
     models()
     sgcn_model_and_sign_losses()
     snea_cases()
+    sdgnn_case()
 
 
 if __name__ == "__main__":

@@ -532,3 +532,94 @@ class SNEA(SGCN):
 
     def forward(self) -> torch.Tensor:
         return torch.tanh(self.weight(super().forward()))
+
+
+class SDGNN(nn.Module):
+    """nn/signed/SDGNN.py:66-267: trainable node embeddings through `layer_num` SDRLayers (four GATConv
+    aggregators: positive out / in, negative out / in neighbourhoods), objective = sign + lamb_d * direction +
+    lamb_t * triangle loss.  The reference enumerates neighbour sets and triangle motifs with Python dict / set
+    loops; here the same sets are sparse 0/1 matrices and the 12 motif counts are sparse products (host side, once
+    at construction -- not part of the device path)."""
+
+    def __init__(self, node_num: int, edge_index_s, in_dim: int = 20, out_dim: int = 20, layer_num: int = 2,
+                 init_emb: Optional[torch.Tensor] = None, init_emb_grad: bool = True, lamb_d: float = 5.0,
+                 lamb_t: float = 1.0, **kwargs):
+        super().__init__(**kwargs)
+        from ..utils.signed import (Sign_Direction_Loss, Sign_Product_Entropy_Loss, Sign_Triangle_Loss,
+                                    create_spectral_features)
+        from .signed.GATConv import SDRLayer
+        self.node_num, self.in_dim, self.out_dim, self.layer_num = node_num, in_dim, out_dim, layer_num
+        self.device = edge_index_s.device
+        self.lamb_d, self.lamb_t = lamb_d, lamb_t
+        self.pos_edge_index = edge_index_s[edge_index_s[:, 2] > 0][:, :2].t().contiguous()
+        self.neg_edge_index = edge_index_s[edge_index_s[:, 2] < 0][:, :2].t().contiguous()
+        if init_emb is None:
+            init_emb = create_spectral_features(self.pos_edge_index, self.neg_edge_index, node_num, in_dim
+                                                ).to(self.device)
+        self.x = Parameter(init_emb, requires_grad=init_emb_grad)
+        self.edge_lists = self.build_edge_lists(edge_index_s)
+        self.layers = []
+        for i in range(layer_num):
+            layer = SDRLayer(in_dim if i == 0 else out_dim, out_dim, edge_lists=self.edge_lists)
+            self.add_module(f'SDRLayer_{i}', layer)
+            self.layers.append(layer)
+        self.loss_sign = Sign_Product_Entropy_Loss()
+        self.loss_direction = Sign_Direction_Loss(emb_dim=out_dim)
+        self.loss_tri = Sign_Triangle_Loss(emb_dim=out_dim, edge_weight=self.tri_weight)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for layer in self.layers:
+            layer.reset_parameters()
+
+    def build_edge_lists(self, edge_index_s):
+        """The reference's `build_adj_lists` + `map_adj_to_edges` (SDGNN.py:139-250): neighbour SETS (duplicate
+        listings collapse) as edge lists [2, E] (node, neighbour) for positive-out, positive-in, negative-out,
+        negative-in, and `self.tri_weight[i, j]` = number of balanced motifs closed by the signed edge i -> j.
+        With P / N the 0/1 matrices of positive / negative edges, the reference's 16 set-intersection counts are
+        the entries of the products X Y, X Y^T, X^T Y^T, X^T Y (X, Y in {P, N}); its masks select
+          positive edge: PP + PP^T + NN^T + N^T N^T + P^T P + N^T N
+          negative edge: PN + NP + NP^T + P^T N^T + N^T P^T + P^T N
+        and an edge listed with both signs keeps the negative count (the reference writes it last)."""
+        import numpy as np
+        import scipy.sparse as sp
+        e = edge_index_s.detach().cpu().numpy()
+        n = self.node_num
+
+        def binary(rows):
+            m = sp.coo_matrix((np.ones(len(rows), np.int64), (rows[:, 0], rows[:, 1])), shape=(n, n)).tocsr()
+            m.sum_duplicates()
+            m.data[:] = 1
+            return m
+
+        P, N = binary(e[e[:, 2] > 0]), binary(e[e[:, 2] < 0])
+        PT, NT = P.T.tocsr(), N.T.tocsr()
+        m_pos = P @ P + P @ PT + N @ NT + NT @ NT + PT @ P + NT @ N
+        m_neg = P @ N + N @ P + N @ PT + PT @ NT + NT @ PT + PT @ N
+        only_pos = P - P.multiply(N)                              # edges whose last-written weight is the positive one
+        self.tri_weight = (m_pos.multiply(only_pos) + m_neg.multiply(N)).tocsc()
+        lists = []
+        for m in (P, PT, N, NT):                                  # out-neighbours of P^T = in-neighbours of P
+            coo = m.tocoo()
+            lists.append(torch.from_numpy(np.stack([coo.row, coo.col]).astype(np.int64)).to(self.device))
+        return lists
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.pos_edge_index, self.neg_edge_index = fn(self.pos_edge_index), fn(self.neg_edge_index)
+        moved = [fn(e) for e in self.edge_lists]
+        self.edge_lists[:] = moved                                # the SDRLayers hold this same list object
+        self.device = self.x.device
+        return out
+
+    def forward(self) -> torch.Tensor:
+        x = self.x
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+    def loss(self) -> torch.Tensor:
+        z = self.forward()
+        return (self.loss_sign(z, self.pos_edge_index, self.neg_edge_index)
+                + self.lamb_d * self.loss_direction(z, self.pos_edge_index, self.neg_edge_index)
+                + self.lamb_t * self.loss_tri(z, self.pos_edge_index, self.neg_edge_index))

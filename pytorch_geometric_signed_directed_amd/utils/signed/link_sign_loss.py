@@ -149,3 +149,35 @@ class Sign_Direction_Loss(nn.Module):
         d = self.score_function1(z[neg_edge_index[0]]) - self.score_function2(z[neg_edge_index[1]])
         q = torch.where(d > 0.5, d, torch.full_like(d, 0.5))
         return pos_loss + (q - d).pow(2).sum()
+
+
+class Sign_Triangle_Loss(nn.Module):
+    """SDGNN's triangle loss (link_sign_loss.py:10-51): BCE of lin([z_i, z_j]) against the edge sign, every edge
+    weighted by the number of balanced triangles it closes.  `edge_weight` is the reference's scipy matrix
+    (any format); the per-edge weights are looked up ONCE per edge list and kept on the device (the reference
+    indexes the scipy matrix with Python lists on every call)."""
+
+    def __init__(self, emb_dim: int, edge_weight) -> None:
+        super().__init__()
+        self.lin = nn.Linear(emb_dim * 2, 1)
+        self.edge_weight = edge_weight
+        self._memo = []
+
+    def _weights(self, edge_index: Tensor, device) -> Tensor:
+        for src, ver, w in self._memo:
+            if src is edge_index and ver == edge_index._version:
+                return w
+        import numpy as np
+        ij = edge_index.detach().cpu().numpy()
+        w = np.asarray(self.edge_weight.tocsr()[ij[0], ij[1]]).reshape(-1, 1)
+        w = torch.from_numpy(w).to(device)
+        self._memo = (self._memo + [(edge_index, edge_index._version, w)])[-4:]
+        return w
+
+    def forward(self, z: Tensor, pos_edge_index: Tensor, neg_edge_index: Tensor) -> Tensor:
+        rs1 = self.lin(torch.cat([z[pos_edge_index[0]], z[pos_edge_index[1]]], dim=1))
+        rs2 = self.lin(torch.cat([z[neg_edge_index[0]], z[neg_edge_index[1]]], dim=1))
+        w1, w2 = self._weights(pos_edge_index, z.device), self._weights(neg_edge_index, z.device)
+        pos_loss = F.binary_cross_entropy_with_logits(rs1, torch.ones_like(rs1), weight=w1.to(rs1.dtype), reduction='sum')
+        neg_loss = F.binary_cross_entropy_with_logits(rs2, torch.zeros_like(rs2), weight=w2.to(rs2.dtype), reduction='sum')
+        return pos_loss + neg_loss

@@ -260,3 +260,26 @@ def test_snea_model():
     close(z, g["z"])
     m.loss().backward()
     assert m.x.grad is not None and torch.isfinite(m.x.grad).all()        # init_emb_grad defaults to True
+
+
+def test_sdgnn_model():
+    """SDGNN: z through two SDRLayers and the three deterministic objectives against the reference; the motif
+    weights (sparse-product restatement of the reference's set loops) must equal its matrix entry for entry."""
+    import scipy.sparse as sp
+    from pytorch_geometric_signed_directed_amd.nn import SDGNN
+    g = load_golden("model_sdgnn")
+    m = SDGNN(40, g.t("edge_index_s"), in_dim=8, out_dim=8, layer_num=2, init_emb=g.t("init_emb"))
+    want = sp.coo_matrix((g["tri_val"], (g["tri_row"], g["tri_col"])), shape=(40, 40)).tocsr()
+    assert abs(m.tri_weight.tocsr() - want).sum() == 0
+    m = load(m, g)
+    assert all(e.is_cuda for e in m.edge_lists) and m.layers[0].edge_lists is m.edge_lists
+    z = m()
+    close(z, g["z"])
+    pos, neg = m.pos_edge_index, m.neg_edge_index
+    close(m.loss_sign(z, pos, neg), g["loss_sign"])
+    close(m.loss_direction(z, pos, neg), g["loss_direction"])
+    close(m.loss_tri(z, pos, neg), g["loss_tri"])
+    loss = m.loss()
+    close(loss, g["loss_total"])
+    loss.backward()
+    assert torch.isfinite(m.x.grad).all() and m.x.grad.abs().sum() > 0
