@@ -530,6 +530,29 @@ def sdgnn_case():
          **{"sd." + k: npy(v) for k, v in model.state_dict().items()})
 
 
+def sigat_case():
+    """SiGAT: 38 GATConv aggregators over the motif neighbourhoods + MLP, link-sign product loss."""
+    from torch_geometric_signed_directed.nn.signed.SiGAT import SiGAT
+    n = 40
+    g = torch.Generator().manual_seed(97)
+    pairs = torch.randint(0, n, (420, 2), generator=g)           # dense enough that every motif list is non-empty
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    sign = torch.where(torch.rand(pairs.size(0), generator=g) < 0.55, 1, -1)
+    edge_index_s = torch.cat([pairs, sign[:, None]], dim=1)
+    init = torch.randn(n, 8, generator=g)
+    torch.manual_seed(98)
+    model = SiGAT(n, edge_index_s, in_dim=8, out_dim=8, init_emb=init)
+    assert all(e.dim() == 2 and e.size(1) > 0 for e in model.edge_lists)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if prm.dim() == 1 and prm.numel() > 1:
+                prm.add_(torch.rand(prm.shape, generator=g) - 0.5)
+    z = model()
+    save("model_sigat", edge_index_s=npy(edge_index_s), init_emb=npy(init), z=npy(z), loss=npy(model.loss()),
+         list_sizes=np.array([e.size(1) for e in model.edge_lists]),
+         **{"sd." + k: npy(v) for k, v in model.state_dict().items()})
+
+
 def sgcn_model_and_sign_losses():
     """SGCN.forward (z) with given initial embeddings, and the signed objectives with the random negative
     draws of PyG replaced by fixed index sets (patched into the reference module), so the arithmetic is pinned."""
@@ -618,6 +641,7 @@ def main():
     sgcn_model_and_sign_losses()
     snea_cases()
     sdgnn_case()
+    sigat_case()
 
 
 if __name__ == "__main__":

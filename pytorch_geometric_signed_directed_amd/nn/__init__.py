@@ -6,4 +6,4 @@ from .models import (DGCN_node_classification, DIGRAC_node_clustering, DiGCN_Inc
                      MagNet_node_classification, MSGNN_link_prediction, MSGNN_node_classification,
                      SSSNET_node_clustering)
 from .models import (DGCN_link_prediction, DiGCN_Inception_Block_link_prediction, DiGCN_link_prediction,  # noqa: F401
-                     SDGNN, SGCN, SNEA, SSSNET_link_prediction)
+                     SDGNN, SGCN, SiGAT, SNEA, SSSNET_link_prediction)

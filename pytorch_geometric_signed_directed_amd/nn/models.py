@@ -6,7 +6,7 @@ example scripts run unchanged; all message passing goes through the HIP layers.
 Reference files: nn/directed/MagNet_node_classification.py, MagNet_link_prediction.py,
 DiGCN_node_classification.py, DiGCN_Inception_Block.py, DiGCN_Inception_Block_node_classification.py,
 DIGRAC_node_clustering.py, nn/general/MSGNN.py, nn/signed/SSSNET_node_clustering.py, the *_link_prediction.py
-variants of DGCN / DiGCN / DiGCN_Inception_Block / SSSNET, nn/signed/SGCN.py.
+variants of DGCN / DiGCN / DiGCN_Inception_Block / SSSNET, nn/signed/SGCN.py, SNEA.py, SDGNN.py, SiGAT.py.
 """
 from typing import Optional, Tuple
 
@@ -534,6 +534,45 @@ class SNEA(SGCN):
         return torch.tanh(self.weight(super().forward()))
 
 
+def _signed_matrices(edge_index_s, n):
+    """0/1 scipy CSR matrices of the positive and of the negative edges of an [E, 3] (source, target, sign)
+    list; duplicate listings collapse (the reference keeps neighbour SETS)."""
+    import numpy as np
+    import scipy.sparse as sp
+    e = edge_index_s.detach().cpu().numpy()
+
+    def binary(rows):
+        m = sp.coo_matrix((np.ones(len(rows), np.int64), (rows[:, 0], rows[:, 1])), shape=(n, n)).tocsr()
+        m.sum_duplicates()
+        m.data[:] = 1
+        return m
+
+    return binary(e[e[:, 2] > 0]), binary(e[e[:, 2] < 0])
+
+
+def _motif_counts(P, N):
+    """The 16 common-neighbour counts of the reference's `get_features` / `get_tri_features` (SDGNN.py:147-196,
+    SiGAT.py:88-137) for ALL node pairs at once, in its order d1_1 .. d4_4:
+    d1 = out(u) & in(v): X Y;  d2 = out(u) & out(v): X Y^T;  d3 = in(u) & out(v): X^T Y^T;  d4 = in(u) & in(v): X^T Y,
+    each for (X, Y) = (P, P), (P, N), (N, P), (N, N)."""
+    PT, NT = P.T.tocsr(), N.T.tocsr()
+    pairs = ((P, N), (PT, NT))
+    out = []
+    for left, right in ((0, 0), (0, 1), (1, 1), (1, 0)):          # d1: X Y, d2: X Y^T, d3: X^T Y^T, d4: X^T Y
+        for x in range(2):
+            for y in range(2):
+                out.append((pairs[left][x] @ pairs[right][y]).tocsr())
+    return out
+
+
+def _edge_list(m, device):
+    """scipy matrix -> [2, E] (row node, column node) LongTensor (E may be 0)."""
+    import numpy as np
+    coo = m.tocoo()
+    keep = coo.data != 0
+    return torch.from_numpy(np.stack([coo.row[keep], coo.col[keep]]).astype(np.int64)).to(device)
+
+
 class SDGNN(nn.Module):
     """nn/signed/SDGNN.py:66-267: trainable node embeddings through `layer_num` SDRLayers (four GATConv
     aggregators: positive out / in, negative out / in neighbourhoods), objective = sign + lamb_d * direction +
@@ -581,28 +620,13 @@ class SDGNN(nn.Module):
           positive edge: PP + PP^T + NN^T + N^T N^T + P^T P + N^T N
           negative edge: PN + NP + NP^T + P^T N^T + N^T P^T + P^T N
         and an edge listed with both signs keeps the negative count (the reference writes it last)."""
-        import numpy as np
-        import scipy.sparse as sp
-        e = edge_index_s.detach().cpu().numpy()
-        n = self.node_num
-
-        def binary(rows):
-            m = sp.coo_matrix((np.ones(len(rows), np.int64), (rows[:, 0], rows[:, 1])), shape=(n, n)).tocsr()
-            m.sum_duplicates()
-            m.data[:] = 1
-            return m
-
-        P, N = binary(e[e[:, 2] > 0]), binary(e[e[:, 2] < 0])
-        PT, NT = P.T.tocsr(), N.T.tocsr()
-        m_pos = P @ P + P @ PT + N @ NT + NT @ NT + PT @ P + NT @ N
-        m_neg = P @ N + N @ P + N @ PT + PT @ NT + NT @ PT + PT @ N
+        P, N = _signed_matrices(edge_index_s, self.node_num)
+        d = _motif_counts(P, N)
+        m_pos = d[0] + d[4] + d[7] + d[11] + d[12] + d[15]        # mask [1,0,0,0, 1,0,0,1, 0,0,0,1, 1,0,0,1]
+        m_neg = d[1] + d[2] + d[6] + d[9] + d[10] + d[13]         # mask [0,1,1,0, 0,0,1,0, 0,1,1,0, 0,1,0,0]
         only_pos = P - P.multiply(N)                              # edges whose last-written weight is the positive one
         self.tri_weight = (m_pos.multiply(only_pos) + m_neg.multiply(N)).tocsc()
-        lists = []
-        for m in (P, PT, N, NT):                                  # out-neighbours of P^T = in-neighbours of P
-            coo = m.tocoo()
-            lists.append(torch.from_numpy(np.stack([coo.row, coo.col]).astype(np.int64)).to(self.device))
-        return lists
+        return [_edge_list(m, self.device) for m in (P, P.T, N, N.T)]   # out-neighbours of P^T = in-neighbours of P
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -623,3 +647,70 @@ class SDGNN(nn.Module):
         return (self.loss_sign(z, self.pos_edge_index, self.neg_edge_index)
                 + self.lamb_d * self.loss_direction(z, self.pos_edge_index, self.neg_edge_index)
                 + self.lamb_t * self.loss_tri(z, self.pos_edge_index, self.neg_edge_index))
+
+
+class SiGAT(nn.Module):
+    """nn/signed/SiGAT.py:13-203: one GATConv aggregator per motif neighbourhood -- positive / negative
+    (undirected, out, in) and, for the positive and for the negative out-edges, the 16 subsets closed by at
+    least one triangle of each type -- concatenated with the embedding, then Linear-Tanh-Linear; objective =
+    link-sign product loss.  The 38 neighbourhoods come from the same sparse products as SDGNN's weights."""
+
+    def __init__(self, node_num: int, edge_index_s, in_dim: int = 20, out_dim: int = 20,
+                 init_emb: Optional[torch.Tensor] = None, init_emb_grad: bool = True, **kwargs):
+        super().__init__(**kwargs)
+        from ..utils.signed import Link_Sign_Product_Loss, create_spectral_features
+        from .signed.GATConv import GATConv
+        self.in_dim, self.out_dim, self.node_num = in_dim, out_dim, node_num
+        self.device = edge_index_s.device
+        self.pos_edge_index = edge_index_s[edge_index_s[:, 2] > 0][:, :2].t().contiguous()
+        self.neg_edge_index = edge_index_s[edge_index_s[:, 2] < 0][:, :2].t().contiguous()
+        if init_emb is None:
+            init_emb = create_spectral_features(self.pos_edge_index, self.neg_edge_index, node_num, in_dim
+                                                ).to(self.device)
+        self.x = Parameter(init_emb, requires_grad=init_emb_grad)
+        self.edge_lists = self.build_edge_lists(edge_index_s)
+        self.aggs = []
+        for i in range(len(self.edge_lists)):
+            self.aggs.append(GATConv(in_channels=in_dim, out_channels=out_dim))
+            self.add_module('agg_{}'.format(i), self.aggs[-1])
+        self.mlp_layer = nn.Sequential(nn.Linear(out_dim * (len(self.edge_lists) + 1), out_dim), nn.Tanh(),
+                                       nn.Linear(out_dim, out_dim))
+        self.lsp_loss = Link_Sign_Product_Loss()
+        self.reset_parameters()
+
+    def build_edge_lists(self, edge_index_s):
+        P, N = _signed_matrices(edge_index_s, self.node_num)
+        d = _motif_counts(P, N)
+
+        def union(m):
+            u = (m + m.T).tocsr()
+            u.data[:] = 1
+            return u
+
+        mats = [union(P), P, P.T, union(N), N, N.T]
+        mats += [P.multiply(c > 0) for c in d] + [N.multiply(c > 0) for c in d]
+        return [_edge_list(m, self.device) for m in mats]
+
+    def reset_parameters(self):
+        for agg in self.aggs:
+            agg.reset_parameters()
+
+        def init_weights(m):
+            if isinstance(m, nn.Linear):
+                torch.nn.init.kaiming_normal_(m.weight)
+                m.bias.data.fill_(0.01)
+        self.mlp_layer.apply(init_weights)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.pos_edge_index, self.neg_edge_index = fn(self.pos_edge_index), fn(self.neg_edge_index)
+        self.edge_lists[:] = [fn(e) for e in self.edge_lists]
+        self.device = self.x.device
+        return out
+
+    def forward(self) -> torch.Tensor:
+        neigh = [agg(self.x, edges) for edges, agg in zip(self.edge_lists, self.aggs)]
+        return self.mlp_layer(torch.cat([self.x] + neigh, 1))
+
+    def loss(self) -> torch.Tensor:
+        return self.lsp_loss(self.forward(), self.pos_edge_index, self.neg_edge_index)

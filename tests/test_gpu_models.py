@@ -283,3 +283,18 @@ def test_sdgnn_model():
     close(loss, g["loss_total"])
     loss.backward()
     assert torch.isfinite(m.x.grad).all() and m.x.grad.abs().sum() > 0
+
+
+def test_sigat_model():
+    """SiGAT: 38 motif neighbourhoods (sizes must equal the reference's), 38 GATConv aggregates + MLP, product loss."""
+    from pytorch_geometric_signed_directed_amd.nn import SiGAT
+    g = load_golden("model_sigat")
+    m = SiGAT(40, g.t("edge_index_s"), in_dim=8, out_dim=8, init_emb=g.t("init_emb"))
+    assert [e.size(1) for e in m.edge_lists] == g["list_sizes"].tolist()
+    m = load(m, g)
+    z = m()
+    close(z, g["z"])
+    loss = m.loss()
+    close(loss, g["loss"])
+    loss.backward()
+    assert torch.isfinite(m.x.grad).all() and m.agg_37.lin.weight.grad.abs().sum() > 0
