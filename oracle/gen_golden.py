@@ -553,6 +553,37 @@ def sigat_case():
          **{"sd." + k: npy(v) for k, v in model.state_dict().items()})
 
 
+def digcl_case():
+    """DiGCL: 3-layer GCNConv encoder (prelu) on two weighted views, projection head, both contrastive losses."""
+    from torch_geometric_signed_directed.nn.directed.DiGCL import DiGCL
+    n = 40
+    ei, w = toy_graph(101)
+    ei2, w2 = toy_graph(102, e=120)
+    g = torch.Generator().manual_seed(103)
+    x1, x2 = torch.randn(n, 6, generator=g), torch.randn(n, 6, generator=g)
+    torch.manual_seed(104)
+    model = DiGCL(6, 'prelu', 8, 5, 0.4, 3)
+    with torch.no_grad():
+        for prm in model.parameters():
+            if prm.dim() == 1 and prm.numel() > 1:
+                prm.add_(torch.rand(prm.shape, generator=g) - 0.5)
+    model.eval()
+    z1 = model(x1, t(ei), t(w))
+    z2 = model(x2, t(ei2), t(w2))
+    z3 = model(x1, t(ei))                                   # unweighted view
+    # independent dense check of one GCNConv layer
+    conv = model.encoder.conv[0]
+    a = D._with_remaining_loops(ei, w, n, 1.0)
+    dis = D._inv_pow(a.sum(0), -0.5)
+    want = (dis[:, None] * a * dis[None, :]).T @ (x1.double().numpy() @ conv.lin.weight.detach().double().numpy().T) \
+        + conv.bias.detach().double().numpy()
+    close("gcnconv", conv(x1, t(ei), t(w)).detach(), want)
+    save("model_digcl", edge_index=ei, edge_weight=w, edge_index2=ei2, edge_weight2=w2, x1=npy(x1), x2=npy(x2),
+         z1=npy(z1), z2=npy(z2), z3=npy(z3), loss=npy(model.loss(z1, z2)), loss_sum=npy(model.loss(z1, z2, mean=False)),
+         loss_batched=npy(model.loss(z1, z2, batch_size=16)),
+         **{"sd." + k: npy(v) for k, v in model.state_dict().items()})
+
+
 def sgcn_model_and_sign_losses():
     """SGCN.forward (z) with given initial embeddings, and the signed objectives with the random negative
     draws of PyG replaced by fixed index sets (patched into the reference module), so the arithmetic is pinned."""
@@ -642,6 +673,7 @@ def main():
     snea_cases()
     sdgnn_case()
     sigat_case()
+    digcl_case()
 
 
 if __name__ == "__main__":

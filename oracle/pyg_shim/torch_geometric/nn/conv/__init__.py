@@ -112,7 +112,38 @@ class GATConv(MessagePassing):
         return out if self.bias is None else out + self.bias
 
 
-class GCNConv(torch.nn.Module):
-    def __init__(self, *a, **k):
-        super().__init__()
-        raise NotImplementedError("GCNConv: out of scope for the shim")
+class GCNConv(MessagePassing):
+    """torch_geometric.nn.GCNConv restated from its documentation (defaults: improved=False, cached=False,
+    add_self_loops=True, normalize=True, bias=True): x' = lin(x) (no bias, glorot), gcn_norm over the target
+    column, out_i = sum_j norm_ji x'_j, + bias (zeros)."""
+
+    def __init__(self, in_channels, out_channels, improved=False, cached=False, add_self_loops=True,
+                 normalize=True, bias=True, **kwargs):
+        kwargs.setdefault('aggr', 'add')
+        super().__init__(**kwargs)
+        from ..dense.linear import Linear
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.improved, self.cached, self.add_self_loops, self.normalize = improved, cached, add_self_loops, normalize
+        self.lin = Linear(in_channels, out_channels, bias=False, weight_initializer='glorot')
+        if bias:
+            self.bias = torch.nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        from ..inits import glorot, zeros
+        glorot(self.lin.weight)
+        zeros(self.bias)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        from .gcn_conv import gcn_norm
+        if self.normalize:
+            edge_index, edge_weight = gcn_norm(edge_index, edge_weight, x.size(self.node_dim), self.improved,
+                                               self.add_self_loops, self.flow, x.dtype)
+        x = self.lin(x)
+        out = self.propagate(edge_index, x=x, edge_weight=edge_weight)
+        return out if self.bias is None else out + self.bias
+
+    def message(self, x_j, edge_weight):
+        return x_j if edge_weight is None else edge_weight.view(-1, 1) * x_j

@@ -298,3 +298,19 @@ def test_sigat_model():
     close(loss, g["loss"])
     loss.backward()
     assert torch.isfinite(m.x.grad).all() and m.agg_37.lin.weight.grad.abs().sum() > 0
+
+
+def test_digcl_model():
+    """DiGCL: GCNConv encoder (weighted and unweighted views), projection head and both contrastive losses."""
+    from pytorch_geometric_signed_directed_amd.nn.directed import DiGCL
+    g = load_golden("model_digcl")
+    m = load(DiGCL(6, 'prelu', 8, 5, 0.4, 3), g)
+    z1 = m(g.t("x1", D), g.t("edge_index", D), g.t("edge_weight", D))
+    z2 = m(g.t("x2", D), g.t("edge_index2", D), g.t("edge_weight2", D))
+    close(z1, g["z1"]); close(z2, g["z2"])
+    close(m(g.t("x1", D), g.t("edge_index", D)), g["z3"])
+    close(m.loss(z1, z2), g["loss"])
+    close(m.loss(z1, z2, mean=False), g["loss_sum"])
+    close(m.loss(z1, z2, batch_size=16), g["loss_batched"])
+    m.loss(z1, z2).backward()
+    assert m.encoder.conv[0].lin.weight.grad.abs().sum() > 0
