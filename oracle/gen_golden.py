@@ -584,6 +584,21 @@ def digcl_case():
          **{"sd." + k: npy(v) for k, v in model.state_dict().items()})
 
 
+def digcn_adjs_case():
+    """DiGCN / DiGCL operator pre-processing (utils/directed/get_adjs_DiGCN.py) on a toy graph."""
+    import torch_geometric_signed_directed.utils.directed.get_adjs_DiGCN as A
+    n = 40
+    ei, w = toy_graph(111)
+    out = {}
+    for name, res in (("second", A.get_second_directed_adj(t(ei), n, torch.float32, t(w))),
+                      ("second_unw", A.get_second_directed_adj(t(ei), n, torch.float32, None)),
+                      ("appr", A.get_appr_directed_adj(0.1, t(ei), n, torch.float32, t(w))),
+                      ("appr_unw", A.get_appr_directed_adj(0.2, t(ei), n, torch.float32, None)),
+                      ("fast", A.cal_fast_appr(0.1, t(ei), n, torch.float32, t(w)))):
+        out[name + "_index"], out[name + "_value"] = npy(res[0]), npy(res[1])
+    save("digcn_adjs", edge_index=ei, edge_weight=w, **out)
+
+
 def sgcn_model_and_sign_losses():
     """SGCN.forward (z) with given initial embeddings, and the signed objectives with the random negative
     draws of PyG replaced by fixed index sets (patched into the reference module), so the arithmetic is pinned."""
@@ -674,6 +689,7 @@ def main():
     sdgnn_case()
     sigat_case()
     digcl_case()
+    digcn_adjs_case()
 
 
 if __name__ == "__main__":
