@@ -596,7 +596,7 @@ def digcn_adjs_case():
                       ("appr_unw", A.get_appr_directed_adj(0.2, t(ei), n, torch.float32, None)),
                       ("fast", A.cal_fast_appr(0.1, t(ei), n, torch.float32, t(w)))):
         out[name + "_index"], out[name + "_value"] = npy(res[0]), npy(res[1])
-    save("digcn_adjs", edge_index=ei, edge_weight=w, **out)
+    save("adjs_digcn", edge_index=ei, edge_weight=w, **out)
 
 
 def sgcn_model_and_sign_losses():

@@ -145,7 +145,7 @@ def test_digcn_operator_preprocessing_matches_reference():
     import torch
     from conftest import load_golden
     from pytorch_geometric_signed_directed_amd.utils.directed import get_adjs_DiGCN as A
-    g = load_golden("digcn_adjs")
+    g = load_golden("adjs_digcn")
     ei, w = g.t("edge_index"), g.t("edge_weight")
     cases = {"second": A.get_second_directed_adj(ei, 40, torch.float32, w),
              "second_unw": A.get_second_directed_adj(ei, 40, torch.float32, None),
