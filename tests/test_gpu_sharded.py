@@ -64,10 +64,9 @@ def _worker(rank, world, port, n, k, f, layout, ret):
 
 
 @pytest.mark.parametrize("world,n,k,f,layout", [
-    (2, 1000, 1, 64, "rows"), (2, 1003, 2, 64, "rows"), (3, 500, 3, 16, "rows"), (2, 300, 2, 6, "rows"),
+    (2, 1003, 2, 64, "rows"), (3, 500, 3, 16, "rows"), (2, 300, 2, 6, "rows"),
     (2, 1003, 1, 64, "grid"),          # 1 x 2
-    (4, 900, 2, 64, "grid"),           # 1 x 4, two Chebyshev orders (the z term lives in the grid layout)
-    (4, 701, 3, 32, "grid"),           # 1 x 4 at 8-float slices
+    (4, 901, 3, 32, "grid"),           # 1 x 4 at 8-float slices, three Chebyshev orders (z term in the grid layout)
     (8, 1203, 2, 64, "grid"),          # 2 x 4: the 8-GPU configuration
 ])
 def test_sharded_layer_matches_oracle(world, n, k, f, layout):
