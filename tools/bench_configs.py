@@ -114,7 +114,7 @@ def signed_c3(n=500000, entries=10000000, h=64):
         simpa(pos, wp, neg, wn, xp, xn).sum().backward()
     ms, prof = timed(step2)
     out["C3_simpa_hop2"] = {"nodes": n, "hidden": h, "ms_per_step": ms, "entries_per_s": ei.size(1) / ms * 1e3,
-                            "kernels": prof, "note": "7 SpMM fwd + 7 bwd (5 on A_p, 2 on A_n) per step"}
+                            "kernels": prof, "note": "6 SpMM fwd + 6 bwd (4 on A_p, 2 on A_n) per step; the reference's unused last-hop product is skipped"}
     print("C3_simpa_hop2", json.dumps(out["C3_simpa_hop2"]), flush=True)
     torch.cuda.empty_cache()
 
