@@ -49,7 +49,7 @@ def build_inputs(n, e, hidden, device, seed=0):
     return edge_index.to(device), x_real.to(device), x_imag.to(device), p
 
 
-def cpu_baseline(hidden, steps=2, n=100000, e=2000000):
+def cpu_baseline(hidden, steps=2, n=100000, e=2000000, threads=None):
     """Reference op sequence (index_select -> mul -> scatter_add_, 4 propagates per order incl. the
     reference's duplicates, autograd backward) on the host cores, cached operator."""
     from oracle import ref_layers as R
@@ -57,7 +57,7 @@ def cpu_baseline(hidden, steps=2, n=100000, e=2000000):
     # ATen's index_select / scatter_add_ stop scaling long before a 256-thread host is full (measured
     # on the GPU box, EPYC 9575F: 8 thr 3.8 s, 32 thr 3.2 s, 128 thr 4.7 s, 256 thr 28 s per step), so
     # the baseline runs on the best-performing thread count, and reports that count as `cores`.
-    cores = min(os.cpu_count() or 1, 32)
+    cores = threads or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     ei_np, _, _ = graphs.dsbm_for_edges(n, e, seed=0)
     ei = torch.from_numpy(ei_np)
