@@ -235,11 +235,9 @@ __global__ __launch_bounds__(256) void segment_softmax_bwd_kernel(const int32_t*
 // The layer's message is the TARGET row times alpha, so all the aggregate needs per row is the share of
 // alpha that went to each type:  share_t[i] = sum_{e in row i, p_e = t} alpha_e.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float snea_logit(int e, int row, const int32_t* col, const uint8_t* ptype,
-                                            const float* s0, const float* s1, const float* d0v, const float* d1v,
-                                            float d0, float d1, float bias, bool& neg)
+__device__ __forceinline__ float snea_logit(int e, const int32_t* col, const uint8_t* ptype, const float* s0,
+                                            const float* s1, float d0, float d1, float bias, bool& neg)
 {
-    (void)d0v; (void)d1v;
     neg = ptype && ptype[e] != 0;
     const int j = col[e];
     return tanhf((neg ? s1[j] + d1 : s0[j] + d0) + bias);
@@ -263,15 +261,15 @@ __global__ __launch_bounds__(256) void snea_alpha_kernel(const int32_t* __restri
     bool neg;
     float mx = -INFINITY;
     for (int e = beg + lane; e < end; e += 64)
-        mx = fmaxf(mx, snea_logit(e, row, col, ptype, s0, s1, d0, d1, di0, di1, bias, neg));
+        mx = fmaxf(mx, snea_logit(e, col, ptype, s0, s1, di0, di1, bias, neg));
     mx = wave_max(mx);
     float sum = 0.f;
     for (int e = beg + lane; e < end; e += 64)
-        sum += expf(snea_logit(e, row, col, ptype, s0, s1, d0, d1, di0, di1, bias, neg) - mx);
+        sum += expf(snea_logit(e, col, ptype, s0, s1, di0, di1, bias, neg) - mx);
     sum = wave_sum(sum) + 1e-16f;
     float a0 = 0.f, a1 = 0.f;
     for (int e = beg + lane; e < end; e += 64) {
-        const float a = expf(snea_logit(e, row, col, ptype, s0, s1, d0, d1, di0, di1, bias, neg) - mx) / sum;
+        const float a = expf(snea_logit(e, col, ptype, s0, s1, di0, di1, bias, neg) - mx) / sum;
         alpha[e] = a;
         if (neg) a1 += a; else a0 += a;
     }
@@ -311,7 +309,7 @@ __global__ __launch_bounds__(256) void snea_alpha_bwd_kernel(const int32_t* __re
     float r0 = 0.f, r1 = 0.f;
     for (int e = beg + lane; e < end; e += 64) {
         bool neg;
-        const float t = snea_logit(e, row, col, ptype, s0, s1, d0, d1, di0, di1, bias, neg);
+        const float t = snea_logit(e, col, ptype, s0, s1, di0, di1, bias, neg);
         const float dp = alpha[e] * ((neg ? g1 : g0) - dot) * (1.f - t * t);
         dpre0[e] = neg ? 0.f : dp;
         if (dpre1) dpre1[e] = neg ? dp : 0.f;
