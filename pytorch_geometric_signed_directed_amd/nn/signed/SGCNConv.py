@@ -53,8 +53,49 @@ class SGCNConv(MessagePassing):
         parts = [self._mean_in(feat, n, ei) for feat, ei in aggregated] + [own]
         return tall_linear(torch.cat(parts, dim=-1), w.t(), lin.bias)
 
+    def _fused(self, x: Tensor, pos_edge_index: Tensor, neg_edge_index: Tensor) -> Tensor:
+        """Both branches from ONE GEMM when the Linear does not widen (in_dim >= out_dim): every block of
+        lin_b / lin_u becomes a column block of one [F_x, 4 or 6 * out_dim] matrix (zero blocks where a block
+        reads the other half of x), the biases ride on the own-feature blocks, and each mean aggregation adds
+        its result onto the previous block through the SpMM's beta * Z epilogue -- no concatenation, no
+        element-wise adds, one weight-gradient GEMM."""
+        f, o, n = self.in_dim, self.out_dim, x.size(0)
+        wb, wu = self.lin_b.weight, self.lin_u.weight
+        zeros = wb.new_zeros(f, o)
+        if self.first_aggr:             # columns: own_b | agg_b(pos) | own_u | agg_u(neg)
+            w_big = torch.cat([wb[:, f:].t(), wb[:, :f].t(), wu[:, f:].t(), wu[:, :f].t()], dim=1)
+            own = (0, 2)
+        else:                           # x = [lo | hi]; columns: own_b | pos_b | neg_b | own_u | pos_u | neg_u
+            top = torch.cat([wb[:, 2 * f:].t(), wb[:, :f].t(), zeros, zeros, zeros, wu[:, f:2 * f].t()], dim=1)
+            bot = torch.cat([zeros, zeros, wb[:, f:2 * f].t(), wu[:, 2 * f:].t(), wu[:, :f].t(), zeros], dim=1)
+            w_big = torch.cat([top, bot], dim=0)
+            own = (0, 3)
+        bias = None
+        if self.lin_b.bias is not None:
+            z = self.lin_b.bias.new_zeros(o)
+            blocks = [z] * (w_big.size(1) // o)
+            blocks[own[0]], blocks[own[1]] = self.lin_b.bias, self.lin_u.bias
+            bias = torch.cat(blocks)
+        y = tall_linear(x, w_big, bias).split(o, dim=1)
+        pos = GLOBAL_PATTERNS.get(pos_edge_index, n, n, self.flow)
+        neg = GLOBAL_PATTERNS.get(neg_edge_index, n, n, self.flow)
+        if self.first_aggr:
+            out_b = spmm(pos, y[1], None, z=y[0], beta=1.0, reduce=self.aggr)
+            out_u = spmm(neg, y[3], None, z=y[2], beta=1.0, reduce=self.aggr)
+        else:
+            out_b = spmm(neg, y[2], None, z=spmm(pos, y[1], None, z=y[0], beta=1.0, reduce=self.aggr), beta=1.0,
+                         reduce=self.aggr)
+            out_u = spmm(neg, y[5], None, z=spmm(pos, y[4], None, z=y[3], beta=1.0, reduce=self.aggr), beta=1.0,
+                         reduce=self.aggr)
+        return torch.cat([out_b, out_u], dim=-1)
+
     def forward(self, x: Union[Tensor, Tuple[Tensor, Tensor]], pos_edge_index: Tensor,
                 neg_edge_index: Tensor) -> Tensor:
+        if (isinstance(x, Tensor) and x.dim() == 2 and self.in_dim >= self.out_dim
+                and isinstance(pos_edge_index, Tensor) and isinstance(neg_edge_index, Tensor)):
+            _cabi.require_gpu(x, pos_edge_index, neg_edge_index)
+            out = self._fused(x, pos_edge_index, neg_edge_index)
+            return F.normalize(out, p=2, dim=-1) if self.norm_emb else out
         if isinstance(x, Tensor):
             x = (x, x)
         if not isinstance(pos_edge_index, Tensor) or not isinstance(neg_edge_index, Tensor):

@@ -549,3 +549,35 @@ def test_uncached_layer_reuses_the_operator_only_for_unmodified_graph_tensors():
     assert layer._operator is not op4
     want = fresh(ei, w, 3.0)
     close(o5[0], want[0].detach().cpu().numpy()); close(o5[1], want[1].detach().cpu().numpy())
+
+
+@pytest.mark.parametrize("first,in_dim,out_dim,bias", [(True, 64, 32, True), (False, 32, 32, True), (True, 16, 48, True),
+                                                        (False, 8, 24, False), (True, 20, 12, False)])
+def test_sgcn_midsize_all_paths_vs_oracle(first, in_dim, out_dim, bias):
+    """SGCNConv at 3000 nodes: the single-GEMM fused path (in_dim >= out_dim, incl. the zero-block deep layer)
+    and the aggregate-first path (widening Linear), outputs and all gradients against the oracle."""
+    from pytorch_geometric_signed_directed_amd.nn import SGCNConv
+    g = torch.Generator().manual_seed(17)
+    n = 3000
+    pos = torch.randint(0, n, (2, 24000), generator=g)
+    neg = torch.randint(0, n - 50, (2, 9000), generator=g)          # the last 50 nodes have no negative in-edge
+    x = torch.randn(n, in_dim if first else 2 * in_dim, generator=g)
+    gout = torch.randn(n, 2 * out_dim, generator=g)
+    torch.manual_seed(3)
+    layer = SGCNConv(in_dim, out_dim, first, bias=bias)
+    if bias:
+        with torch.no_grad():
+            layer.lin_b.bias.uniform_(-0.5, 0.5); layer.lin_u.bias.uniform_(-0.5, 0.5)
+    prm = {k: v.detach().clone().requires_grad_() for k, v in layer.named_parameters()}
+    xo = x.clone().requires_grad_()
+    want = R.sgcn_conv(xo, pos, neg, (prm["lin_b.weight"], prm.get("lin_b.bias")), (prm["lin_u.weight"], prm.get("lin_u.bias")),
+                       first, in_dim)
+    (want * gout).sum().backward()
+    layer.to(D)
+    xd = x.to(D).requires_grad_()
+    out = layer(xd, pos.to(D), neg.to(D))
+    close(out, want.detach().numpy())
+    (out * gout.to(D)).sum().backward()
+    close(xd.grad, xo.grad.numpy())
+    for k, p in layer.named_parameters():
+        close(p.grad, prm[k].grad.numpy(), tol=3e-5)
