@@ -26,6 +26,13 @@ from .signed.SGCNConv import SGCNConv
 from .signed.SIMPA import SIMPA
 
 
+def _conv1x1(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
+    """The reference's `Conv(x.t().unsqueeze(0))[0].t()` with kernel_size 1 is x W^T + b over the node rows:
+    the same parameters as a row-major GEMM (split-K weight gradient) instead of a transposed copy of the
+    [N, C] activations and a length-N convolution."""
+    return tall_linear(x, conv.weight[:, :, 0].t(), conv.bias)
+
+
 class _MagneticStack(nn.Module):
     """Chebs (ModuleList of magnetic convs) [+ complex ReLU] shared by the MagNet / MSGNN heads."""
 
@@ -49,8 +56,7 @@ class _MagneticStack(nn.Module):
         x = torch.cat((real, imag), dim=-1)
         if self.dropout > 0:
             x = F.dropout(x, self.dropout, training=self.training)
-        logits = self.Conv(x.t().unsqueeze(0))
-        return x, F.log_softmax(logits, dim=1)[0].t()
+        return x, F.log_softmax(_conv1x1(self.Conv, x), dim=1)
 
     def _link_head(self, real, imag, query_edges):
         a, b = query_edges[:, 0], query_edges[:, 1]
@@ -271,8 +277,7 @@ class DGCN_node_classification(nn.Module):
         x = self._three(x, edge_index, edge_in, edge_out, in_w, out_w, self.bias2)
         if self.dropout > 0:
             x = F.dropout(x, self.dropout, training=self.training)
-        x = self.Conv(x.t().unsqueeze(0))
-        return F.log_softmax(x[0].t(), dim=1)
+        return F.log_softmax(_conv1x1(self.Conv, x), dim=1)
 
 
 def _cluster_head(z, w_prob, bias):
