@@ -18,24 +18,51 @@ import torch.nn.functional as F
 Tensor = torch.Tensor
 
 
+def _rows_of(x: Tensor, edge_index: Tensor, row: int, cached: bool = True) -> Tensor:
+    """x[edge_index[row]]; on the device its backward is a segment reduce over the edge list's CSR
+    (sparse.gather_rows) instead of torch's sort-per-call index backward."""
+    if x.is_cuda:
+        from ...sparse import gather_rows
+        return gather_rows(x, edge_index, row, cached)
+    return x[edge_index[row]]
+
+
+_KEY_MEMO = []    # (edge_index, version, n, sorted unique keys): the samplers are called every training step
+
+
 def _edge_keys(edge_index: Tensor, n: int) -> Tensor:
-    return torch.unique(edge_index[0] * n + edge_index[1])
+    """Sorted unique keys i * n + j of an edge list; kept for the last few edge_index tensors (identity + in-place
+    version), so a training loop sorts each graph once, not on every loss evaluation."""
+    for k, (src, ver, nn_, keys) in enumerate(_KEY_MEMO):
+        if src is edge_index and ver == edge_index._version and nn_ == n:
+            _KEY_MEMO.append(_KEY_MEMO.pop(k))
+            return keys
+    keys = torch.unique(edge_index[0] * n + edge_index[1])
+    _KEY_MEMO.append((edge_index, edge_index._version, n, keys))
+    if len(_KEY_MEMO) > 6:
+        _KEY_MEMO.pop(0)
+    return keys
 
 
-def _listed(keys_sorted: Tensor, query: Tensor) -> Tensor:
-    if keys_sorted.numel() == 0:
-        return torch.zeros_like(query, dtype=torch.bool)
-    pos = torch.searchsorted(keys_sorted, query).clamp_(max=keys_sorted.numel() - 1)
-    return keys_sorted[pos] == query
+def _listed(key_sets, query: Tensor) -> Tensor:
+    """query keys that occur in any of the sorted key arrays."""
+    hit = torch.zeros_like(query, dtype=torch.bool)
+    for keys in key_sets:
+        if keys.numel():
+            pos = torch.searchsorted(keys, query).clamp_(max=keys.numel() - 1)
+            hit |= keys[pos] == query
+    return hit
 
 
-def negative_sampling(edge_index: Tensor, num_nodes: int, num_neg_samples: Optional[int] = None,
+def negative_sampling(edge_index, num_nodes: int, num_neg_samples: Optional[int] = None,
                       generator: Optional[torch.Generator] = None) -> Tensor:
     """Uniform (i, j) pairs that are not listed edges; [2, <= num_neg_samples] (fewer only on near-complete
-    graphs, as in PyG)."""
-    want = edge_index.size(1) if num_neg_samples is None else int(num_neg_samples)
-    keys = _edge_keys(edge_index, num_nodes)
-    dev = edge_index.device
+    graphs, as in PyG).  `edge_index` may be one [2, E] tensor or a tuple of them (their union is excluded;
+    passing the parts instead of a fresh concatenation lets the sorted keys be reused across calls)."""
+    parts = (edge_index,) if isinstance(edge_index, Tensor) else tuple(edge_index)
+    want = sum(p.size(1) for p in parts) if num_neg_samples is None else int(num_neg_samples)
+    key_sets = [_edge_keys(p, num_nodes) for p in parts]
+    dev = parts[0].device
     total = num_nodes * num_nodes
     out = torch.empty(0, dtype=torch.long, device=dev)
     for _ in range(8):
@@ -43,7 +70,7 @@ def negative_sampling(edge_index: Tensor, num_nodes: int, num_neg_samples: Optio
         if need <= 0:
             break
         cand = torch.randint(0, total, (int(need * 1.2) + 8,), device=dev, generator=generator)
-        cand = cand[~_listed(keys, cand)]
+        cand = cand[~_listed(key_sets, cand)]
         out = torch.unique(torch.cat([out, cand]))          # PyG also returns distinct pairs
     out = out[torch.randperm(out.numel(), device=dev, generator=generator)][:want]
     return torch.stack([out // num_nodes, out % num_nodes])
@@ -54,14 +81,14 @@ def structured_negative_sampling(edge_index: Tensor, num_nodes: int, generator: 
     """(i, j, k): for every edge (i, j) a node k such that (i, k) is not a listed edge (self pairs allowed,
     PyG's default contains_neg_self_loops=True)."""
     i, j = edge_index[0], edge_index[1]
-    keys = _edge_keys(edge_index, num_nodes)
+    key_sets = [_edge_keys(edge_index, num_nodes)]
     k = torch.randint(0, num_nodes, (i.numel(),), device=i.device, generator=generator)
     for _ in range(32):
-        bad = _listed(keys, i * num_nodes + k)
-        nbad = int(bad.sum())
-        if nbad == 0:
+        bad = _listed(key_sets, i * num_nodes + k)
+        idx = bad.nonzero(as_tuple=True)[0]
+        if idx.numel() == 0:
             break
-        k[bad] = torch.randint(0, num_nodes, (nbad,), device=i.device, generator=generator)
+        k[idx] = torch.randint(0, num_nodes, (idx.numel(),), device=i.device, generator=generator)
     return i, j, k
 
 
@@ -76,16 +103,27 @@ class Link_Sign_Entropy_Loss(nn.Module):
     def reset_parameters(self):
         self.lin.reset_parameters()
 
-    def discriminate(self, z: Tensor, edge_index: Tensor) -> Tensor:
-        return torch.log_softmax(self.lin(torch.cat([z[edge_index[0]], z[edge_index[1]]], dim=1)), dim=1)
+    def _node_scores(self, z: Tensor):
+        """lin([z_i, z_j]) = z_i W_1^T + z_j W_2^T + b: the two halves of the Linear are applied per NODE (N rows)
+        and only the 3-wide results are gathered per edge -- the reference gathers both 64-wide rows per edge and
+        runs the Linear over E rows (same value, re-associated)."""
+        d = z.size(1)
+        w = self.lin.weight
+        return z @ w[:, :d].t(), z @ w[:, d:].t() + self.lin.bias
+
+    def discriminate(self, z: Tensor, edge_index: Tensor, scores=None, cached: bool = True) -> Tensor:
+        src, dst = self._node_scores(z) if scores is None else scores
+        return torch.log_softmax(_rows_of(src, edge_index, 0, cached) + _rows_of(dst, edge_index, 1, cached), dim=1)
 
     def forward(self, z: Tensor, pos_edge_index: Tensor, neg_edge_index: Tensor,
                 none_edge_index: Optional[Tensor] = None) -> Tensor:
         if none_edge_index is None:
-            none_edge_index = negative_sampling(torch.cat([pos_edge_index, neg_edge_index], dim=1), z.size(0))
+            none_edge_index = negative_sampling((pos_edge_index, neg_edge_index), z.size(0))
+        scores = self._node_scores(z)
         nll = 0
         for label, ei in enumerate((pos_edge_index, neg_edge_index, none_edge_index)):
-            nll = nll + F.nll_loss(self.discriminate(z, ei), ei.new_full((ei.size(1),), label))
+            # F.nll_loss against a constant label = minus the mean of that column
+            nll = nll - self.discriminate(z, ei, scores, cached=label < 2)[:, label].mean()
         return nll / 3.0
 
 
@@ -93,26 +131,28 @@ class Sign_Structure_Loss(nn.Module):
     """Triplet terms of SGCN: linked-positive pairs closer than sampled non-neighbours, linked-negative pairs
     farther."""
 
-    def pos_embedding_loss(self, z: Tensor, pos_edge_index: Tensor, k: Optional[Tensor] = None) -> Tensor:
-        i, j = pos_edge_index[0], pos_edge_index[1]
+    @staticmethod
+    def _triplet(z: Tensor, edge_index: Tensor, k: Optional[Tensor]):
         if k is None:
-            i, j, k = structured_negative_sampling(pos_edge_index, z.size(0))
-        out = (z[i] - z[j]).pow(2).sum(dim=1) - (z[i] - z[k]).pow(2).sum(dim=1)
-        return torch.clamp(out, min=0).mean()
+            _, _, k = structured_negative_sampling(edge_index, z.size(0))
+        zi, zj = _rows_of(z, edge_index, 0), _rows_of(z, edge_index, 1)
+        zk = _rows_of(z, torch.stack([edge_index[0], k]), 1, cached=False)      # fresh samples: one-off grouping
+        return (zi - zj).pow(2).sum(dim=1), (zi - zk).pow(2).sum(dim=1)
+
+    def pos_embedding_loss(self, z: Tensor, pos_edge_index: Tensor, k: Optional[Tensor] = None) -> Tensor:
+        d_edge, d_sample = self._triplet(z, pos_edge_index, k)
+        return torch.clamp(d_edge - d_sample, min=0).mean()
 
     def neg_embedding_loss(self, z: Tensor, neg_edge_index: Tensor, k: Optional[Tensor] = None) -> Tensor:
-        i, j = neg_edge_index[0], neg_edge_index[1]
-        if k is None:
-            i, j, k = structured_negative_sampling(neg_edge_index, z.size(0))
-        out = (z[i] - z[k]).pow(2).sum(dim=1) - (z[i] - z[j]).pow(2).sum(dim=1)
-        return torch.clamp(out, min=0).mean()
+        d_edge, d_sample = self._triplet(z, neg_edge_index, k)
+        return torch.clamp(d_sample - d_edge, min=0).mean()
 
     def forward(self, z: Tensor, pos_edge_index: Tensor, neg_edge_index: Tensor) -> Tensor:
         return self.pos_embedding_loss(z, pos_edge_index) + self.neg_embedding_loss(z, neg_edge_index)
 
 
 def _edge_dots(z: Tensor, edge_index: Tensor) -> Tensor:
-    return (z[edge_index[0]] * z[edge_index[1]]).sum(dim=1)
+    return (_rows_of(z, edge_index, 0) * _rows_of(z, edge_index, 1)).sum(dim=1)
 
 
 class Link_Sign_Product_Loss(nn.Module):
@@ -143,10 +183,11 @@ class Sign_Direction_Loss(nn.Module):
         self.score_function2 = nn.Sequential(nn.Linear(emb_dim, 1), nn.Sigmoid())
 
     def forward(self, z: Tensor, pos_edge_index: Tensor, neg_edge_index: Tensor) -> Tensor:
-        d = self.score_function1(z[pos_edge_index[0]]) - self.score_function2(z[pos_edge_index[1]])
+        s1, s2 = self.score_function1(z), self.score_function2(z)       # per node (N rows), then gathered per edge
+        d = _rows_of(s1, pos_edge_index, 0) - _rows_of(s2, pos_edge_index, 1)
         q = torch.where(d > -0.5, torch.full_like(d, -0.5), d)
         pos_loss = (q - d).pow(2).sum()
-        d = self.score_function1(z[neg_edge_index[0]]) - self.score_function2(z[neg_edge_index[1]])
+        d = _rows_of(s1, neg_edge_index, 0) - _rows_of(s2, neg_edge_index, 1)
         q = torch.where(d > 0.5, d, torch.full_like(d, 0.5))
         return pos_loss + (q - d).pow(2).sum()
 
@@ -175,8 +216,10 @@ class Sign_Triangle_Loss(nn.Module):
         return w
 
     def forward(self, z: Tensor, pos_edge_index: Tensor, neg_edge_index: Tensor) -> Tensor:
-        rs1 = self.lin(torch.cat([z[pos_edge_index[0]], z[pos_edge_index[1]]], dim=1))
-        rs2 = self.lin(torch.cat([z[neg_edge_index[0]], z[neg_edge_index[1]]], dim=1))
+        dim = z.size(1)                      # lin([z_i, z_j]) = z_i W_1^T + (z_j W_2^T + b), evaluated per node
+        head, tail = z @ self.lin.weight[:, :dim].t(), z @ self.lin.weight[:, dim:].t() + self.lin.bias
+        rs1 = _rows_of(head, pos_edge_index, 0) + _rows_of(tail, pos_edge_index, 1)
+        rs2 = _rows_of(head, neg_edge_index, 0) + _rows_of(tail, neg_edge_index, 1)
         w1, w2 = self._weights(pos_edge_index, z.device), self._weights(neg_edge_index, z.device)
         pos_loss = F.binary_cross_entropy_with_logits(rs1, torch.ones_like(rs1), weight=w1.to(rs1.dtype), reduction='sum')
         neg_loss = F.binary_cross_entropy_with_logits(rs2, torch.zeros_like(rs2), weight=w2.to(rs2.dtype), reduction='sum')

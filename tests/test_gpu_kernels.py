@@ -598,3 +598,27 @@ def test_wide_dual_spmm_column_blocks_match_single_pass(monkeypatch):
     dense.index_put_((rows, pat.fwd.col.cpu().long()), va.cpu().double(), accumulate=True)
     want = 2.0 * (dense @ xa.cpu().double()) - za.cpu().double()
     assert torch.allclose(blocked[0].cpu().double(), want, atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f", [1, 3, 64])
+def test_gather_rows_backward_is_the_segment_sum(f):
+    """sparse.gather_rows: forward = x[edge_index[row]]; backward (value-less SpMM over the [E, F] gradient through
+    the edge list's CSR) = torch's index backward, for both rows, cached and one-off patterns."""
+    from pytorch_geometric_signed_directed_amd.sparse import gather_rows
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(23)
+    n, e = 700, 9000
+    ei = torch.randint(0, n - 5, (2, e), generator=g).to(d)          # the last nodes are never indexed
+    x = torch.randn(n, f, generator=g).to(d)
+    w = torch.randn(e, f, generator=g).to(d)
+    for row in (0, 1):
+        for cached in (True, False):
+            a = x.clone().requires_grad_()
+            b = x.clone().requires_grad_()
+            out = gather_rows(a, ei, row, cached)
+            assert torch.equal(out, b[ei[row]])
+            (out * w).sum().backward()
+            (b[ei[row]] * w).sum().backward()
+            assert torch.allclose(a.grad, b.grad, atol=1e-4, rtol=1e-5)
+            assert float(a.grad[n - 5:].abs().sum()) == 0.0
