@@ -18,6 +18,17 @@ import torch.nn.functional as F
 Tensor = torch.Tensor
 
 
+def _project(z: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+    """z @ weight^T (+ bias) for a tall z [N, d] and a weight with only a few output rows: the library's GEMMs
+    for 1..6 output columns run at ~100 GB/s (1.2 ms at N = 5 * 10^5, d = 64), so the weight is zero-padded to
+    16 output columns and the result sliced."""
+    k = weight.size(0)
+    if z.is_cuda and k < 16:
+        weight = F.pad(weight, (0, 0, 0, 16 - k))
+    out = (z @ weight.t())[:, :k]
+    return out if bias is None else out + bias
+
+
 def _rows_of(x: Tensor, edge_index: Tensor, row: int, cached: bool = True) -> Tensor:
     """x[edge_index[row]]; on the device its backward is a segment reduce over the edge list's CSR
     (sparse.gather_rows) instead of torch's sort-per-call index backward."""
@@ -109,7 +120,7 @@ class Link_Sign_Entropy_Loss(nn.Module):
         runs the Linear over E rows (same value, re-associated)."""
         d = z.size(1)
         w = self.lin.weight
-        return z @ w[:, :d].t(), z @ w[:, d:].t() + self.lin.bias
+        return _project(z, w[:, :d]), _project(z, w[:, d:], self.lin.bias)
 
     def discriminate(self, z: Tensor, edge_index: Tensor, scores=None, cached: bool = True) -> Tensor:
         src, dst = self._node_scores(z) if scores is None else scores
@@ -217,7 +228,7 @@ class Sign_Triangle_Loss(nn.Module):
 
     def forward(self, z: Tensor, pos_edge_index: Tensor, neg_edge_index: Tensor) -> Tensor:
         dim = z.size(1)                      # lin([z_i, z_j]) = z_i W_1^T + (z_j W_2^T + b), evaluated per node
-        head, tail = z @ self.lin.weight[:, :dim].t(), z @ self.lin.weight[:, dim:].t() + self.lin.bias
+        head, tail = _project(z, self.lin.weight[:, :dim]), _project(z, self.lin.weight[:, dim:], self.lin.bias)
         rs1 = _rows_of(head, pos_edge_index, 0) + _rows_of(tail, pos_edge_index, 1)
         rs2 = _rows_of(head, neg_edge_index, 0) + _rows_of(tail, neg_edge_index, 1)
         w1, w2 = self._weights(pos_edge_index, z.device), self._weights(neg_edge_index, z.device)
