@@ -235,6 +235,13 @@ def _spmm_raw(csr: CSR, val: Optional[Tensor], x: Tensor, z: Optional[Tensor], a
     f = x.size(1)
     if z is not None and tuple(z.shape) != (csr.n_rows, f):
         raise ValueError(f"z has shape {tuple(z.shape)}, expected {(csr.n_rows, f)}")
+    if f % 4 and x.dtype == torch.float32 and csr.nnz > 0 and csr.n_rows > 0:
+        # widths like a 5-class output layer: zero-pad to 16-byte rows so the vector kernel runs (the scalar
+        # fallback walks a row's neighbours one by one: 2.9 ms against ~1.1 ms at 2M nodes / 52M entries / F = 5)
+        pad = (0, 4 - f % 4)
+        y = _spmm_raw(csr, val, torch.nn.functional.pad(x, pad), None if z is None else torch.nn.functional.pad(z, pad),
+                      alpha, beta, mean)
+        return y[:, :f]
     if csr.nnz == 0 or f == 0 or csr.n_rows == 0:  # edgeless operator: nothing to gather
         y = torch.zeros((csr.n_rows, f), dtype=x.dtype, device=x.device)
         return y if z is None else y.add_(z, alpha=beta)
@@ -269,6 +276,12 @@ def _spmm2_raw(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, z
     if xa.size(0) != csr.n_cols:
         raise ValueError(f"x has {xa.size(0)} rows, operator expects {csr.n_cols}")
     f = xa.size(1)
+    if f % 4 and csr.nnz > 0 and csr.n_rows > 0:          # see _spmm_raw: pad to 16-byte rows for the vector kernel
+        pad = (0, 4 - f % 4)
+        P = torch.nn.functional.pad
+        ya, yb = _spmm2_raw(csr, val_a, val_b, P(xa, pad), P(xb, pad), None if za is None else P(za, pad),
+                            None if zb is None else P(zb, pad), alpha, beta)
+        return ya[:, :f], yb[:, :f]
     if csr.nnz == 0 or f == 0 or csr.n_rows == 0:
         ya = torch.zeros((csr.n_rows, f), dtype=torch.float32, device=xa.device)
         yb = torch.zeros_like(ya)

@@ -622,3 +622,26 @@ def test_gather_rows_backward_is_the_segment_sum(f):
             (b[ei[row]] * w).sum().backward()
             assert torch.allclose(a.grad, b.grad, atol=1e-4, rtol=1e-5)
             assert float(a.grad[n - 5:].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+def test_scalar_fallback_kernel_through_the_raw_abi():
+    """The host pads odd widths to 16-byte rows, so spmm_scalar_kernel is only reached by raw C-ABI callers with
+    unpadded / unaligned operands: it must still agree with the vector path (summation-order rounding only)."""
+    from pytorch_geometric_signed_directed_amd import _cabi
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, _spmm_raw
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    n, nnz, f = 2000, 40000, 5
+    ei = torch.randint(0, n, (2, nnz), generator=g).to(d)
+    pat = Pattern(ei, n, n)
+    csr = pat.fwd
+    x = torch.randn(n, f, generator=g).to(d)
+    z = torch.randn(n, f, generator=g).to(d)
+    v = pat.values_for(torch.randn(nnz, generator=g).to(d), "fwd")
+    y = torch.empty(n, f, device=d)
+    lib, P = _cabi.lib(), _cabi.ptr
+    _cabi.check(lib.pygsd_spmm_csr_f32(P(csr.rowptr), P(csr.col), P(v), P(x), f, P(y), f, P(z), f, n, f, 2.0, -1.0, 0, nnz,
+                                       None, _cabi.stream_ptr()), "spmm scalar")
+    want = _spmm_raw(csr, v, x, z, 2.0, -1.0, False)          # padded -> vector kernel
+    assert want.shape == (n, f) and torch.allclose(y, want, atol=1e-4, rtol=1e-5)
