@@ -4,9 +4,9 @@
 The reference evaluates, for every ordered cluster pair, w_kl = P[:, k]^T A P[:, l] with one sparse
 mat-vec each (K^2 of them) plus K more for the volumes.  Here the whole flow matrix W = P^T (A P) is ONE
 HIP SpMM (A P, width K) and one [K, N] x [N, K] product; the volumes are (colsum(A) + rowsum(A)) . P.
-The pair-selection logic on the K x K scalars (normalisation, 'sort' / 'std' / 'naive' thresholding, the
-`.item()` branches) is restated unchanged -- including the reference's behaviour that only the 'sort'
-branch keeps the autograd graph (the other branches rebuild a FloatTensor from the values)."""
+The pair selection on the K (K - 1) / 2 scalars (normalisation, 'sort' / 'std' / 'naive' thresholding) is
+evaluated for all pairs at once on the device instead of pair by pair with host reads -- keeping the reference's
+behaviour that only the 'sort' branch carries the autograd graph (the others rebuild a FloatTensor from values)."""
 from typing import Optional, Union
 
 import numpy as np
@@ -55,39 +55,37 @@ class Prob_Imbalance_Loss(torch.nn.Module):
                                  'plain'], 'Please input the correct normalization method name!'
         assert threshold in ['sort', 'std', 'naive'], 'Please input the correct threshold method name!'
         device = A.device
-        epsilon = torch.FloatTensor([1e-8]).to(device)
+        eps = 1e-8
         pat, val, deg = self._operator(A)
-        flow = torch.matmul(P[:, :K].t(), spmm(pat, P[:, :K].contiguous(), val))   # flow[k, l] = P_k^T A P_l
-        vol = torch.matmul(deg, P[:, :K])
-        second_max_vol = torch.topk(vol, 2).values[1] + epsilon
-        result = torch.zeros(1).to(device)
-        imbalance = []
-        imbalance_std = []
-        for k in range(K - 1):
-            for l in range(k + 1, K):  # noqa: E741
-                w_kl, w_lk = flow[k, l], flow[l, k]
-                if (w_kl - w_lk).item() != 0:
-                    if normalization == 'vol_sum':
-                        curr = torch.abs(w_kl - w_lk) / (vol[k] + vol[l] + epsilon) * 2
-                    elif normalization == 'vol_min':
-                        curr = torch.abs(w_kl - w_lk) / (w_kl + w_lk) * torch.min(vol[k], vol[l]) / second_max_vol
-                    elif normalization == 'vol_max':
-                        curr = torch.abs(w_kl - w_lk) / (torch.max(vol[k], vol[l]) + epsilon)
-                    else:
-                        curr = torch.abs(w_kl - w_lk) / (w_kl + w_lk)
-                    if threshold != 'std' or np.power((w_kl - w_lk).item(), 2) - 9 * (w_kl + w_lk).item() > 0:
-                        imbalance.append(curr)
-                    else:
-                        imbalance_std.append(curr)
-        imbalance_values = [curr.item() for curr in imbalance]
-        if threshold == 'sort':
-            ind_sorted = np.argsort(-np.array(imbalance_values))
-            for ind in ind_sorted[:int(self.sel)]:
-                result += imbalance[ind]
-            return torch.ones(1, requires_grad=True).to(device) - result / self.sel
-        elif len(imbalance) > 0:
-            return torch.ones(1, requires_grad=True).to(device) - torch.mean(torch.FloatTensor(imbalance)).to(device)
-        elif threshold == 'std':
-            return torch.ones(1, requires_grad=True).to(device) - torch.mean(torch.FloatTensor(imbalance_std)).to(device)
+        prob = P[:, :K]
+        flow = torch.matmul(prob.t(), spmm(pat, prob.contiguous(), val))          # flow[k, l] = P_k^T A P_l
+        vol = torch.matmul(deg, prob)                                             # probabilistic cluster volumes
+        # all cluster pairs k < l at once (the reference loops over them with a host read per pair)
+        k_idx, l_idx = torch.triu_indices(K, K, offset=1, device=device)
+        forth, back = flow[k_idx, l_idx], flow[l_idx, k_idx]
+        gap, total = forth - back, forth + back
+        if normalization == 'vol_sum':
+            score = gap.abs() / (vol[k_idx] + vol[l_idx] + eps) * 2
+        elif normalization == 'vol_min':
+            score = gap.abs() / total * torch.minimum(vol[k_idx], vol[l_idx]) / (torch.topk(vol, 2).values[1] + eps)
+        elif normalization == 'vol_max':
+            score = gap.abs() / (torch.maximum(vol[k_idx], vol[l_idx]) + eps)
         else:
-            return torch.ones(1, requires_grad=True).to(device)
+            score = gap.abs() / total
+        live = gap != 0                                                           # pairs with any imbalance at all
+        one = torch.ones(1, requires_grad=True).to(device)
+        if threshold == 'sort':
+            # the `sel` largest scores, summed WITH their autograd graph (the only differentiable branch, as in
+            # the reference); fewer live pairs than `sel` just contribute fewer terms to the same divisor
+            picked = torch.argsort(score.detach().masked_fill(~live, float('-inf')), descending=True)[:int(self.sel)]
+            picked = picked[live[picked]]
+            return one - score[picked].sum().reshape(1) / self.sel
+        significant = live & (gap.pow(2) - 9 * total > 0) if threshold == 'std' else live
+        values = score.detach()                                                   # value only: the reference rebuilds a
+        if bool(significant.any()):                                               # FloatTensor from the numbers here
+            return one - values[significant].mean()
+        if threshold == 'std' and bool(live.any()):
+            return one - values[live].mean()
+        if threshold == 'std':
+            return one - torch.mean(torch.empty(0, device=device))                # reference: mean of an empty list -> nan
+        return one
