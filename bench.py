@@ -85,6 +85,12 @@ def cpu_baseline(hidden, steps=2, n=100000, e=2000000, threads=None):
 
 
 def main():
+    # Only the JSON line may reach stdout.  RCCL prints a version banner through C stdio on stdout (flushed at
+    # exit, i.e. AFTER the result line), so the real stdout is kept aside for the result and fd 1 is pointed at
+    # stderr for everything else (C libraries and stray prints alike).
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -244,7 +250,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hidden)
-        print(json.dumps(line), flush=True)
+        result_out.write(json.dumps(line) + "\n")
+        result_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
