@@ -24,6 +24,12 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """Achieved parity errors of this run -> gpurun_out/parity_errors_<pid>.json (tests/tolerance.py)."""
+    import tolerance
+    tolerance.dump()
+
+
 class Golden(dict):
     def t(self, key, device=None):
         v = self.get(key)

@@ -2,7 +2,7 @@
 (oracle/ref_layers.py) on the same seeded inputs.
 
 Bars: index / structure work (COO->CSR, sort, complex-ReLU masks) is BIT-EXACT; floating-point
-aggregation is held to 1e-5 * scale (north_star: "within 1e-5 fp32"); summation order differs from
+aggregation is held to |got - want| <= 1e-5 (1 + |want|) per element (tests/tolerance.py; north_star: "within 1e-5 fp32"); summation order differs from
 the reference only inside a row's lane groups.
 """
 import numpy as np
@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import ref_layers as R
+from tolerance import close
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -29,15 +30,6 @@ def rand_graph(n_in, n_out, nnz, seed, long_row=0, empty_tail=0):
     if long_row:
         dst[:long_row] = min(3, hi - 1)
     return torch.stack([src, dst])
-
-
-def close(got, want, tol=TOL):
-    got = got.detach().cpu().double()
-    want = want.detach().cpu().double()
-    assert got.shape == want.shape, (got.shape, want.shape)
-    scale = max(1.0, float(want.abs().max())) if want.numel() else 1.0
-    err = float((got - want).abs().max()) / scale if want.numel() else 0.0
-    assert err <= tol, f"max err {err:.3e} > {tol}"
 
 
 # ------------------------------------------------------------------ structure (bit-exact)

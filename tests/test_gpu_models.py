@@ -5,16 +5,10 @@ import pytest
 import torch
 
 from conftest import load_golden
+from tolerance import close
 
 pytestmark = pytest.mark.gpu
 D = "cuda:0"
-
-
-def close(got, want, tol=1e-5):
-    got = got.detach().cpu().double().numpy()
-    want = np.asarray(want, np.float64)
-    assert got.shape == want.shape
-    assert float(np.abs(got - want).max()) <= tol * max(1.0, float(np.abs(want).max()))
 
 
 def load(model, g):
