@@ -1,6 +1,8 @@
 """Synthetic benchmark inputs: vectorised samplers for the reference's stochastic block models
-(distributions of data/directed/DSBM.py:10-55 + utils/directed/meta_graph_generation.py:6-94 and
-data/signed/SSBM.py:9-140).  The reference generators go through networkx / Python loops and are
+(distributions of data/directed/DSBM.py:10-55 + utils/directed/meta_graph_generation.py:6-94,
+data/signed/SSBM.py:9-140 and data/general/SDSBM.py:10-67).  tests/test_graph_samplers.py holds their
+block-pair edge counts and sign fractions to the statistics of the reference generators themselves
+(tests/golden/sbm_stats.npz, recorded by oracle/gen_sbm_stats.py).  The reference generators go through networkx / Python loops and are
 quadratic in N (19 s at N = 20k), so they cannot produce the 1M-node benchmark
 graphs; these samplers draw from the same block-pair edge distributions in O(E).
 
@@ -119,3 +121,42 @@ def ssbm(n: int, k: int, p: float, eta: float, size_ratio: float = 2.0, seed: in
     sign = np.concatenate([sign, sign])
     order = rng.permutation(ei.shape[1])
     return ei[:, order], sign[order], labels
+
+
+def signed_cyclic_meta_graph(k: int = 5, eta: float = 0.1, fill_val: float = 0.5) -> np.ndarray:
+    """The signed meta-graph of the reference's MSGNN tests (test/general_test.py:28-31): the cyclic DSBM
+    meta-graph with F[i, j] negated where (i + j) is odd."""
+    f = cyclic_meta_graph(k, eta, fill_val)
+    i, j = np.indices(f.shape)
+    f[(i + j) % 2 == 1] *= -1.0
+    return f
+
+
+def sdsbm(n: int, k: int, p: float, meta: np.ndarray, size_ratio: float = 1.5, eta: float = 0.1, seed: int = 0
+          ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Signed directed SBM (data/general/SDSBM.py:10-67): a DSBM on |meta|; an edge between clusters (a, b) is
+    negative where meta[a, b] < 0; then exactly floor(E * eta) edges chosen uniformly have their sign flipped.
+    Returns (edge_index int64 [2, E], weight float32 [E] in {+1, -1}, labels int64 [N])."""
+    ei, labels = dsbm(n, k, p, np.abs(meta), size_ratio, seed)
+    sign = np.where(meta[labels[ei[0]], labels[ei[1]]] < 0, -1.0, 1.0).astype(np.float32)
+    rng = np.random.default_rng([seed, 1])
+    flip = rng.choice(sign.size, size=int(sign.size * eta), replace=False)
+    sign[flip] *= -1.0
+    return ei, sign, labels
+
+
+def sdsbm_for_edges(n: int, e_target: int, k: int = 5, eta: float = 0.1, size_ratio: float = 1.5, seed: int = 0):
+    """SDSBM on the signed cyclic meta-graph with p chosen so that E[#edges] = e_target (BASELINE config C4)."""
+    meta = signed_cyclic_meta_graph(k, eta, 0.5)
+    sizes = block_sizes(n, k, size_ratio).astype(np.float64)
+    pairs = np.outer(sizes, sizes)
+    pairs[np.diag_indices(k)] -= sizes
+    p = e_target / float((pairs * np.abs(meta)).sum())
+    ei, sign, labels = sdsbm(n, k, p, meta, size_ratio, eta, seed)
+    return ei, sign, labels, p
+
+
+def block_counts(edge_index: np.ndarray, labels: np.ndarray, k: int, weight=None) -> np.ndarray:
+    """[k, k] number of edges from cluster a to cluster b (with `weight`: the sum of the weights instead)."""
+    key = labels[edge_index[0]] * k + labels[edge_index[1]]
+    return np.bincount(key, weights=weight, minlength=k * k).reshape(k, k)

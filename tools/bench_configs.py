@@ -38,12 +38,13 @@ def spmm_bytes(nnz, n, f, s=4, val=True):
 
 
 def magnetic(name, cls, n, e, h, K, signed, **kw):
-    ei_np, _, _ = graphs.dsbm_for_edges(n, e, seed=1)
-    ei = torch.from_numpy(ei_np).to(dev)
     w = None
-    if signed:
-        g = torch.Generator().manual_seed(1)
-        w = (torch.randint(0, 2, (ei.size(1),), generator=g) * 2 - 1).float().to(dev)   # SDSBM-style signs
+    if signed:      # SDSBM (data/general/SDSBM.py:10-67) on the signed cyclic meta-graph, 10 % of the signs flipped
+        ei_np, sign_np, _, _ = graphs.sdsbm_for_edges(n, e, seed=1)
+        w = torch.from_numpy(sign_np).to(dev)
+    else:
+        ei_np, _, _ = graphs.dsbm_for_edges(n, e, seed=1)
+    ei = torch.from_numpy(ei_np).to(dev)
     g = torch.Generator().manual_seed(0)
     xr = torch.randn(n, h, generator=g).to(dev).requires_grad_()
     xi = torch.randn(n, h, generator=g).to(dev).requires_grad_()
