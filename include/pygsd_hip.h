@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 3
+#define PYGSD_ABI_VERSION 4
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -312,6 +312,22 @@ int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* const* b, i
                                  float* const* da, float* const* db, float* dw, float* dbias,
                                  int32_t n_rows, int32_t f_in, int32_t f_out,
                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Node-id validation.  minmax[0] = min(minmax[0], min ids), minmax[1] = max(minmax[1], max ids) (the caller
+ * initialises minmax to {INT64_MAX, INT64_MIN}; several lists may be folded into one pair).  The host raises
+ * IndexError when an id falls outside [0, num_nodes) -- where the reference's index_select / scatter_add_
+ * raise (nn/directed/MagNetConv.py:196-240 via MessagePassing.propagate) -- instead of letting the SpMM gather
+ * out of bounds.
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_id_range_i64(const int64_t* ids, int64_t n, int64_t* minmax, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streaming float4 copy dst[0..n) = src[0..n) (n a multiple of 4, 16-byte aligned pointers, non-temporal
+ * loads and stores).  Measurement only: bench.py times it on >= 1 GiB in the same run as the yardstick of
+ * ACHIEVABLE HBM bandwidth (`roofline.achievable_peak`).  No reference counterpart.
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_stream_copy_f32(const float* src, float* dst, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel-timing recorder (measurement only; used by bench.py for the roofline object).

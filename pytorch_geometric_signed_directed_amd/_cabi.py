@@ -92,11 +92,13 @@ PROTOTYPES = {
     "pygsd_magnetic_dense_bwd_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                c_int32, c_void_p, c_size_t, c_void_p]),
+    "pygsd_id_range_i64": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "pygsd_stream_copy_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "pygsd_prof_enable": (c_int32, [c_int32]),
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def lib_path():
@@ -153,6 +155,31 @@ def require_gpu(*tensors):
                 "pytorch_geometric_signed_directed_amd ops run on MI355X (HIP) only; got a "
                 f"{t.device} tensor. There is no CPU fallback (the CPU restatement lives in oracle/ "
                 "and is test infrastructure).")
+
+
+_I64_MAX, _I64_MIN = (1 << 63) - 1, -(1 << 63)
+
+
+def check_node_ids(*bounded_lists, what="edge_index"):
+    """check_node_ids((bound, ids), (bound, ids), ...): raise IndexError unless every id of every list lies in
+    [0, its bound) -- where the reference's index_select / scatter_add_ raise.  One small kernel per list and
+    ONE device->host read for all of them."""
+    lists = [(int(b), t) for b, t in bounded_lists if t is not None and t.numel()]
+    if not lists:
+        return
+    dev = lists[0][1].device
+    minmax = torch.tensor([[_I64_MAX, _I64_MIN]] * len(lists), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        for k, (_, t) in enumerate(lists):
+            if t.dtype != torch.int64:
+                raise TypeError(f"{what} must be int64 (torch.long), got {t.dtype}")
+            t = t.contiguous()
+            check(lib().pygsd_id_range_i64(ptr(t), t.numel(), c_void_p(minmax.data_ptr() + 16 * k), stream_ptr()),
+                  "pygsd_id_range_i64")
+    for (bound, _), (lo, hi) in zip(lists, minmax.tolist()):
+        if lo < 0 or hi >= bound:
+            raise IndexError(f"{what} holds node id {lo if lo < 0 else hi}, outside [0, {bound}); the HIP path "
+                             "gathers and scatters rows by these ids")
 
 
 # ---- kernel-timing recorder (bench.py) --------------------------------------------------------

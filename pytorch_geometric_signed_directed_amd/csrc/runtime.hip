@@ -69,6 +69,75 @@ ProfScope::~ProfScope()
 
 using namespace pygsd;
 
+namespace {
+constexpr int kBlock = 256;
+
+// Streaming copy, 16 bytes per lane, non-temporal both ways: the achievable-HBM yardstick bench.py prices
+// the gather kernels against (MI355X_MICROARCH.md: "6.29 TB/s measured (float4 copy)").
+typedef float vec4f __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kBlock) void stream_copy_kernel(const vec4f* __restrict__ src,
+                                                            vec4f* __restrict__ dst, int64_t n4)
+{
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n4; i += stride) {
+        const vec4f v = __builtin_nontemporal_load(src + i);
+        __builtin_nontemporal_store(v, dst + i);
+    }
+}
+
+// min / max of an id list: one 64-bit atomic pair per wavefront.
+__global__ __launch_bounds__(kBlock) void id_range_kernel(const int64_t* __restrict__ ids, int64_t n,
+                                                         long long* __restrict__ minmax)
+{
+    long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        const long long v = ids[i];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(minmax, lo);
+        atomicMax(minmax + 1, hi);
+    }
+}
+}  // namespace
+
+extern "C" int pygsd_stream_copy_f32(const float* src, float* dst, int64_t n, void* stream)
+{
+    PYGSD_REQUIRE(n >= 0 && n % 4 == 0, "pygsd_stream_copy_f32: n must be a non-negative multiple of 4");
+    if (n == 0) return 0;
+    PYGSD_REQUIRE(src && dst, "pygsd_stream_copy_f32: null pointer");
+    PYGSD_REQUIRE(aligned16(src) && aligned16(dst), "pygsd_stream_copy_f32: pointers must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    const int64_t n4 = n / 4;
+    const int64_t blocks = (n4 + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(static_cast<unsigned>(blocks < 256 * 32 ? blocks : 256 * 32)),
+                       dim3(kBlock), 0, s, reinterpret_cast<const vec4f*>(src), reinterpret_cast<vec4f*>(dst), n4);
+    return check_launch("stream_copy_kernel");
+}
+
+extern "C" int pygsd_id_range_i64(const int64_t* ids, int64_t n, int64_t* minmax, void* stream)
+{
+    PYGSD_REQUIRE(n >= 0, "pygsd_id_range_i64: negative size");
+    PYGSD_REQUIRE(minmax, "pygsd_id_range_i64: null output");
+    if (n == 0) return 0;
+    PYGSD_REQUIRE(ids, "pygsd_id_range_i64: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_BUILD, s);
+    const int64_t blocks = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(id_range_kernel, dim3(static_cast<unsigned>(blocks < 2048 ? blocks : 2048)), dim3(kBlock), 0, s,
+                       ids, n, reinterpret_cast<long long*>(minmax));
+    return check_launch("id_range_kernel");
+}
+
 extern "C" int pygsd_version(void) { return PYGSD_ABI_VERSION; }
 
 extern "C" const char* pygsd_last_error(void) { return last_error().c_str(); }

@@ -19,10 +19,12 @@ import torch
 from torch.nn import Parameter
 
 from .. import _cabi
+from ..memo import TensorMemo
 from ..message_passing import MessagePassing
 from ..dense import FixedSpmm2, MagneticConvFunction, dense_supported, tall_linear
 from ..sparse import Pattern, spmm2
-from ..utils._laplacian import assemble_operator_csr, laplacian_parts, laplacian_values
+from ..utils._laplacian import (assemble_operator_csr, differentiable_parts, laplacian_parts,
+                                laplacian_values)
 
 Tensor = torch.Tensor
 
@@ -103,8 +105,12 @@ class MagneticChebConv(MessagePassing):
     _fused_message = True
     _signed = False
 
-    def _init_common(self, in_channels, out_channels, K, q, trainable_q, normalization, cached, bias):
+    def _init_common(self, in_channels, out_channels, K, q, trainable_q, normalization, cached, bias,
+                     operator_memo=None):
         assert K > 0
+        # operator_memo=False: rebuild the operator on every uncached forward exactly like the reference, even for
+        # unmodified graph tensors (memo.py documents the contract; None follows PYGSD_NO_OPERATOR_MEMO)
+        self._memo_switch = operator_memo
         assert normalization in [None, 'sym'], 'Invalid normalization'
         self.in_channels = in_channels
         self.out_channels = out_channels
@@ -126,7 +132,8 @@ class MagneticChebConv(MessagePassing):
         glorot(self.weight)
         zeros(self.bias)
         self._operator = None
-        self._op_memo = self._parts_memo = self._lam_memo = None
+        sw = getattr(self, "_memo_switch", None)
+        self._op_memo, self._parts_memo, self._lam_memo = TensorMemo(1, sw), TensorMemo(1, sw), TensorMemo(1, sw)
         self.cached_num_edges = None
         self.cached_q = None
 
@@ -145,53 +152,41 @@ class MagneticChebConv(MessagePassing):
     def _laplacian_kwargs(self):
         return dict(signed=self._signed, absolute_degree=getattr(self, "absolute_degree", True))
 
-    @staticmethod
-    def _same(a, b):
-        """Memo keys hold tensors by identity + in-place version, everything else by value."""
-        if len(a) != len(b):
-            return False
-        for x, y in zip(a, b):
-            if isinstance(x, tuple) and isinstance(y, tuple) and len(x) == 2 and isinstance(x[0], torch.Tensor):
-                if x[0] is not y[0] or x[1] != y[1]:
-                    return False
-            elif x != y:
-                return False
-        return True
-
-    @staticmethod
-    def _tkey(t):
-        return None if t is None else (t, t._version)
-
     def _operator_for(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype):
         """`cached=False` (the reference default, MagNetConv.py:157-181) rebuilds the operator every forward.
         The operator is a pure function of (edge_index, edge_weight, N, q, normalization, lambda_max), so the
-        last one is kept and reused while those inputs are THE SAME TENSORS, unmodified (identity + in-place
-        version counter) -- identical values, no re-sort.  A trainable q still recomputes the values every
-        call (they carry the gradient); only the sorted structure is reused (`_parts_memo`)."""
-        if isinstance(q, torch.Tensor) and q.requires_grad:
+        last one is kept and reused while those inputs are THE SAME TENSORS, unmodified (memo.TensorMemo: weakly
+        held identity + in-place version + storage) -- identical values, no re-sort.  Writes that bypass the
+        version counter (`.data`) are not seen: disable with `operator_memo=False` / PYGSD_NO_OPERATOR_MEMO=1.
+        A trainable q or an edge_weight with gradient recomputes the values every call (they carry the
+        gradient); only the sorted structure is reused (`_parts_memo`)."""
+        if (isinstance(q, torch.Tensor) and q.requires_grad) or (edge_weight is not None and edge_weight.requires_grad):
             return self._build_operator(edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype)
-        lam = self._tkey(lambda_max) if isinstance(lambda_max, torch.Tensor) else lambda_max
-        key = (self._tkey(edge_index), self._tkey(edge_weight), num_nodes, float(q), normalization, lam, dtype)
-        memo = getattr(self, "_op_memo", None)
-        if memo is not None and self._same(memo[0], key):
-            return memo[1]
-        op = self._build_operator(edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype)
-        self._op_memo = (key, op)
+        lam_t = lambda_max if isinstance(lambda_max, torch.Tensor) else None
+        tensors = (edge_index, edge_weight, lam_t)
+        key = (num_nodes, float(q), normalization, None if lam_t is not None else float(lambda_max), dtype)
+        op = self._op_memo.get(tensors, key)
+        if op is None:
+            op = self._build_operator(edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype)
+            self._op_memo.put(tensors, key, op)
         return op
 
     def _parts_for(self, edge_index, edge_weight, num_nodes, dtype):
-        key = (self._tkey(edge_index), self._tkey(edge_weight), num_nodes, dtype)
-        memo = getattr(self, "_parts_memo", None)
-        if memo is not None and self._same(memo[0], key):
-            return memo[1]
-        parts = laplacian_parts(edge_index, edge_weight, num_nodes, dtype=dtype, **self._laplacian_kwargs())
-        if edge_weight is None or not edge_weight.requires_grad:
-            self._parts_memo = (key, parts)
+        key = (num_nodes, dtype)
+        parts = self._parts_memo.get((edge_index, edge_weight), key)
+        if parts is None:
+            parts = laplacian_parts(edge_index, edge_weight, num_nodes, dtype=dtype, **self._laplacian_kwargs())
+            self._parts_memo.put((edge_index, edge_weight), key, parts)
+        if edge_weight is not None and edge_weight.requires_grad:
+            # the reference's Laplacian is differentiable w.r.t. edge_weight: keep the HIP-sorted pattern, recompute
+            # its ingredients with autograd-tracked tensor ops (never memoised: they hold this call's graph)
+            return differentiable_parts(parts, edge_index, edge_weight, **self._laplacian_kwargs())
         return parts
 
     def _build_operator(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype):
         parts = self._parts_for(edge_index, edge_weight, num_nodes, dtype)
-        if isinstance(q, torch.Tensor) and q.requires_grad:      # trainable q: generic differentiable route
+        if (isinstance(q, torch.Tensor) and q.requires_grad) or parts.differentiable:
+            # trainable q / edge_weight with gradient: generic differentiable route (edge-value gradients by SDDMM)
             off_r, off_i, diag = laplacian_values(parts, q, normalization)
             return MagneticOperator(None, None, None, parts.index, off_r, off_i, diag, lambda_max, num_nodes)
         off_r, off_i, diag, mir_r, mir_i = laplacian_values(parts, q, normalization, mirror=True)
@@ -226,6 +221,9 @@ class MagneticChebConv(MessagePassing):
         _cabi.require_gpu(x_real, x_imag, edge_index, edge_weight)
         if x_real.dtype != torch.float32 or x_imag.dtype != torch.float32:
             raise TypeError(f"{type(self).__name__} computes in float32 on the HIP path; got {x_real.dtype}")
+        if x_real.dim() != 2 or x_imag.dim() != 2:
+            raise NotImplementedError(f"{type(self).__name__}: the HIP path takes 2-D [N, F] inputs, got "
+                                      f"{tuple(x_real.shape)} (batched [B, N, F] is not implemented)")
         if self.trainable_q:
             self.q = Parameter(torch.clamp(self.q, 0, 0.25))
 
@@ -252,13 +250,10 @@ class MagneticChebConv(MessagePassing):
                 if self.trainable_q:
                     raise RuntimeError(
                         'Cannot train q while not calculating maximum eigenvalue of Laplacian!')
-                lkey = (self._tkey(edge_index), self._tkey(edge_weight), float(self.q))
-                lmemo = getattr(self, "_lam_memo", None)
-                if lmemo is not None and self._same(lmemo[0], lkey):
-                    lambda_max = lmemo[1]                        # same graph tensors: same eigenvalue
-                else:
-                    lambda_max = self._lambda_max_eigsh(edge_index, edge_weight, None)
-                    self._lam_memo = (lkey, lambda_max)
+                lambda_max = self._lam_memo.get((edge_index, edge_weight), float(self.q))
+                if lambda_max is None:                           # same graph tensors: same eigenvalue
+                    lambda_max = self._lam_memo.put((edge_index, edge_weight), float(self.q),
+                                                    self._lambda_max_eigsh(edge_index, edge_weight, None))
             if lambda_max is None:
                 lambda_max = 2.0
             self._operator = self._operator_for(edge_index, x_real.size(self.node_dim), edge_weight,

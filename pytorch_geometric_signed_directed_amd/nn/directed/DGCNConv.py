@@ -5,6 +5,7 @@ from typing import Optional
 from torch import Tensor
 
 from ... import _cabi
+from ...memo import TensorMemo
 from ...message_passing import MessagePassing
 from ...sparse import Pattern, spmm
 from ...utils._norm import gcn_norm
@@ -16,6 +17,7 @@ class DGCNConv(MessagePassing):
 
     def __init__(self, improved: bool = False, cached: bool = False, add_self_loops: bool = True,
                  normalize: bool = True, **kwargs):
+        self._memo_switch = kwargs.pop('operator_memo', None)     # memo.py: False = re-normalise every call
         kwargs.setdefault('aggr', 'add')
         super().__init__(**kwargs)
         self.improved = improved
@@ -30,7 +32,7 @@ class DGCNConv(MessagePassing):
         self._cached_edge_index = None
         self._cached_adj_t = None
         self._cached_pattern = None
-        self._norm_memo = []
+        self._norm_memo = TensorMemo(6, getattr(self, '_memo_switch', None))
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> Tensor:
         if not isinstance(edge_index, Tensor):
@@ -66,21 +68,14 @@ class DGCNConv(MessagePassing):
 
     # cached=False (the default) re-normalises and re-sorts on every call in the reference (DGCNConv.py:71-81).
     # gcn_norm is a pure function of (edge_index, edge_weight, N): the results for the last few operators are
-    # kept while the inputs are the same tensor objects at the same in-place version (DGCN_node_classification
-    # runs three operators through one instance, twice per forward).
+    # kept while the inputs are the same tensor objects at the same in-place version (memo.TensorMemo, weakly held;
+    # `operator_memo=False` / PYGSD_NO_OPERATOR_MEMO=1 switch it off) -- DGCN_node_classification runs three
+    # operators through one instance, twice per forward.
     def _memo_lookup(self, edge_index, edge_weight, n):
-        key = (edge_index._version, None if edge_weight is None else edge_weight._version, n)
-        for k, m in enumerate(self._norm_memo):
-            if m[0] is edge_index and m[1] is edge_weight and m[2] == key:
-                self._norm_memo.append(self._norm_memo.pop(k))
-                return m[3], m[4]
-        return None
+        return self._norm_memo.get((edge_index, edge_weight), n)
 
     def _memo_store(self, edge_index, edge_weight, n, norm_weight, pattern):
-        key = (edge_index._version, None if edge_weight is None else edge_weight._version, n)
-        self._norm_memo.append((edge_index, edge_weight, key, norm_weight, pattern))
-        if len(self._norm_memo) > 6:
-            self._norm_memo.pop(0)
+        self._norm_memo.put((edge_index, edge_weight), n, (norm_weight, pattern))
 
     def message(self, x_j: Tensor, edge_weight: Optional[Tensor]) -> Tensor:
         return x_j if edge_weight is None else edge_weight.view(-1, 1) * x_j

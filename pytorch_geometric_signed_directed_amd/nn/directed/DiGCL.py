@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from ... import _cabi
 from ...dense import tall_linear
+from ...memo import TensorMemo
 from ...sparse import Pattern, spmm
 from ...utils._norm import gcn_norm
 
@@ -30,7 +31,7 @@ class GCNConv(nn.Module):
             self.bias = nn.Parameter(torch.empty(out_channels))
         else:
             self.register_parameter('bias', None)
-        self._memo = []
+        self._memo = TensorMemo(4)            # DiGCL alternates two augmented views through one encoder
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -38,23 +39,19 @@ class GCNConv(nn.Module):
         self.lin.weight.data.uniform_(-a, a)
         if self.bias is not None:
             self.bias.data.fill_(0)
-        self._memo = []
+        self._memo = TensorMemo(4)            # DiGCL alternates two augmented views through one encoder
 
     def _operator(self, edge_index, edge_weight, n, dtype):
-        key = (edge_index._version, None if edge_weight is None else edge_weight._version, n)
-        for k, m in enumerate(self._memo):
-            if m[0] is edge_index and m[1] is edge_weight and m[2] == key:
-                self._memo.append(self._memo.pop(k))
-                return m[3], m[4]
+        hit = self._memo.get((edge_index, edge_weight), n)
+        if hit is not None:
+            return hit
         if self.normalize:
             ei, ew = gcn_norm(edge_index, edge_weight, n, self.improved, self.add_self_loops, dtype)
         else:
             ei, ew = edge_index, edge_weight
         pat = Pattern(ei, n, n)
         if not (edge_weight is not None and edge_weight.requires_grad):
-            self._memo.append((edge_index, edge_weight, key, pat, ew))
-            if len(self._memo) > 4:           # DiGCL alternates two augmented views through one encoder
-                self._memo.pop(0)
+            self._memo.put((edge_index, edge_weight), n, (pat, ew))
         return pat, ew
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor] = None):

@@ -14,8 +14,9 @@ class MagNetConv(MagneticChebConv):
 
     def __init__(self, in_channels: int, out_channels: int, K: int, q: float, trainable_q: bool,
                  normalization: str = 'sym', cached: bool = False, bias: bool = True, **kwargs):
+        operator_memo = kwargs.pop('operator_memo', None)      # memo.py: False = always rebuild like the reference
         kwargs.setdefault('aggr', 'add')
         super().__init__(**kwargs)
         # the reference sets flow='target_to_source' AFTER super().__init__ (MagNetConv.py:51),
         # which is a no-op: the effective flow is source_to_target
-        self._init_common(in_channels, out_channels, K, q, trainable_q, normalization, cached, bias)
+        self._init_common(in_channels, out_channels, K, q, trainable_q, normalization, cached, bias, operator_memo)

@@ -12,7 +12,8 @@ class MSConv(MagneticChebConv):
     def __init__(self, in_channels: int, out_channels: int, K: int, q: float, trainable_q: bool,
                  normalization: str = 'sym', bias: bool = True, cached: bool = False,
                  absolute_degree: bool = True, **kwargs):
+        operator_memo = kwargs.pop('operator_memo', None)      # memo.py: False = always rebuild like the reference
         kwargs.setdefault('aggr', 'add')
         super().__init__(**kwargs)
         self.absolute_degree = absolute_degree
-        self._init_common(in_channels, out_channels, K, q, trainable_q, normalization, cached, bias)
+        self._init_common(in_channels, out_channels, K, q, trainable_q, normalization, cached, bias, operator_memo)

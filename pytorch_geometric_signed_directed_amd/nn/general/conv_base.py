@@ -5,26 +5,22 @@ from typing import Optional
 from torch import Tensor
 
 from ... import _cabi
+from ...memo import TensorMemo
 from ...message_passing import MessagePassing
 from ...sparse import GLOBAL_PATTERNS, spmm
 from ...utils._norm import conv_norm_rw  # noqa: F401  (re-exported like the reference module)
 
 
-_FLIP_MEMO = []   # (edge_index, version, flipped): SIMPA / DIMPA flip the same edge_index every forward
+_FLIP_MEMO = TensorMemo(4)   # edge_index -> flipped: SIMPA / DIMPA flip the same edge_index every forward
 
 
 def flipped_edge_index(edge_index: Tensor) -> Tensor:
     """edge_index[[1, 0]] (reference SIMPA.py:99-100, DIMPA.py:50), memoised on the tensor object and its
     in-place version so that the normalisation and CSR caches keyed on the flipped tensor keep hitting
-    across forwards instead of re-sorting the graph every step."""
-    for k, (src, ver, out) in enumerate(_FLIP_MEMO):
-        if src is edge_index and ver == edge_index._version:
-            _FLIP_MEMO.append(_FLIP_MEMO.pop(k))
-            return out
-    out = edge_index[[1, 0]]
-    _FLIP_MEMO.append((edge_index, edge_index._version, out))
-    if len(_FLIP_MEMO) > 4:
-        _FLIP_MEMO.pop(0)
+    across forwards instead of re-sorting the graph every step (memo.TensorMemo: the source is held weakly)."""
+    out = _FLIP_MEMO.get((edge_index,))
+    if out is None:
+        out = _FLIP_MEMO.put((edge_index,), None, edge_index[[1, 0]])
     return out
 
 
@@ -34,6 +30,7 @@ class Conv_Base(MessagePassing):
 
     def __init__(self, fill_value: float = 0.5, cached: bool = False, add_self_loops: bool = True,
                  normalize: bool = True, **kwargs):
+        self._memo_switch = kwargs.pop('operator_memo', None)     # memo.py: False = re-normalise every call
         kwargs.setdefault('aggr', 'add')
         kwargs.setdefault('flow', 'target_to_source')
         super().__init__(**kwargs)
@@ -48,23 +45,17 @@ class Conv_Base(MessagePassing):
     def reset_parameters(self):
         self._cached_edge_index = None
         self._cached_adj_t = None
-        self._norm_memo = []
+        self._norm_memo = TensorMemo(4, getattr(self, '_memo_switch', None))   # DIMPA / directed SIMPA alternate two operators
 
     def _normalised(self, edge_index, edge_weight, n, dtype):
         """The reference recomputes conv_norm_rw on EVERY call (`cached` is accepted but never stored,
         conv_base.py:103-108).  The result is a pure function of (edge_index, edge_weight, n), so it is
         memoised on the identity + in-place version of the input tensors: same values, no re-sort."""
-        key = (edge_index._version, None if edge_weight is None else edge_weight._version, n)
-        memo = self._norm_memo
-        for k, m in enumerate(memo):
-            if m[0] is edge_index and m[1] is edge_weight and m[2] == key:
-                memo.append(memo.pop(k))
-                return m[3], m[4]
-        ei, ew = conv_norm_rw(edge_index, self.fill_value, edge_weight, n, self.add_self_loops, dtype)
-        memo.append((edge_index, edge_weight, key, ei, ew))
-        if len(memo) > 4:  # DIMPA / directed SIMPA alternate two operators through one instance
-            memo.pop(0)
-        return ei, ew
+        hit = self._norm_memo.get((edge_index, edge_weight), n)
+        if hit is None:
+            hit = self._norm_memo.put((edge_index, edge_weight), n,
+                                      conv_norm_rw(edge_index, self.fill_value, edge_weight, n, self.add_self_loops, dtype))
+        return hit
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> Tensor:
         _cabi.require_gpu(x, edge_index, edge_weight)

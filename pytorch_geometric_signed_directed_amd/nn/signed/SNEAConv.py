@@ -20,6 +20,7 @@ import torch.nn as nn
 from ... import _cabi
 from ..._cabi import check, ptr, stream_ptr
 from ...dense import tall_linear
+from ...memo import TensorMemo
 from ...sparse import Pattern, segment_sum_raw
 
 
@@ -102,7 +103,7 @@ class SNEAConv(nn.Module):
         self.lin_u = nn.Linear(in_dim, out_dim, bias)
         self.alpha_u = nn.Linear(out_dim * 2, 1)
         self.alpha_b = nn.Linear(out_dim * 2, 1)
-        self._memo = None
+        self._memo = TensorMemo(1)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -112,10 +113,9 @@ class SNEAConv(nn.Module):
         nn.init.xavier_normal_(self.alpha_u.weight)
 
     def _graphs(self, pos, neg, n):
-        key = (pos._version, neg._version, n)
-        m = self._memo
-        if m is not None and m[0] is pos and m[1] is neg and m[2] == key:
-            return m[3]
+        hit = self._memo.get((pos, neg), n)
+        if hit is not None:
+            return hit
         if self.first_aggr:
             out = (_Graph(_loop_free_plus_loops(pos), None, n), _Graph(_loop_free_plus_loops(neg), None, n))
         else:
@@ -124,8 +124,7 @@ class SNEAConv(nn.Module):
             flags = torch.cat([torch.zeros(e1.size(1), dtype=torch.bool, device=pos.device),
                                torch.ones(e2.size(1), dtype=torch.bool, device=pos.device)])
             out = (_Graph(torch.cat([e1, e2], dim=1), flags, n),)
-        self._memo = (pos, neg, key, out)
-        return out
+        return self._memo.put((pos, neg), n, out)
 
     def _project(self, lin, alpha_func, x):
         """(lin(x), <lin(x), a_src>, <lin(x), a_dst>) from ONE GEMM: the two attention projections are two

@@ -24,6 +24,7 @@ import torch
 
 from . import _cabi
 from ._cabi import check, ptr, stream_ptr
+from .memo import TensorMemo
 
 _COLBLOCK_BYTES = 768 << 20  # dual-operator gathered set above which _spmm2_raw column-blocks
 
@@ -33,7 +34,9 @@ Tensor = torch.Tensor
 def _rows(t: Tensor) -> Tuple[Tensor, int]:
     """Return (tensor with unit inner stride, row stride in elements)."""
     if t.dim() != 2:
-        raise ValueError(f"expected a [N, F] feature matrix, got shape {tuple(t.shape)}")
+        raise NotImplementedError(f"the HIP path takes 2-D [N, F] feature matrices; got shape {tuple(t.shape)} "
+                                  "(batched [B, N, F] inputs, which the reference's node_dim=-2 propagate accepts, "
+                                  "are not implemented: loop over the batch or fold it into F)")
     if t.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError(f"the HIP path stores features as float32 or bfloat16 (fp32 accumulate); got {t.dtype}")
     if t.size(1) > 0 and (t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1))):
@@ -79,12 +82,16 @@ def _long_rows_arg(csr: CSR, n_feat: int, dual: bool):
     return ctypes.byref(desc), (desc, ws)
 
 
-def csr_from_coo(seg: Tensor, other: Tensor, n_seg: int, n_other: int) -> CSR:
-    """Group COO entries by `seg` (stable) on the device -> CSR.  seg/other: int64 [nnz]."""
+def csr_from_coo(seg: Tensor, other: Tensor, n_seg: int, n_other: int, validate: bool = True) -> CSR:
+    """Group COO entries by `seg` (stable) on the device -> CSR.  seg/other: int64 [nnz].
+    validate: ids outside [0, n_seg) / [0, n_other) raise IndexError (one device->host read per build) instead
+    of producing a CSR whose SpMM gathers out of bounds; pass False only for ids already checked."""
     _cabi.require_gpu(seg, other)
     if seg.dtype != torch.int64 or other.dtype != torch.int64:
         raise TypeError("edge_index must be int64 (torch.long)")
     seg, other = seg.contiguous(), other.contiguous()
+    if validate:
+        _cabi.check_node_ids((n_seg, seg), (n_other, other))
     nnz = seg.numel()
     dev = seg.device
     lib = _cabi.lib()
@@ -123,6 +130,22 @@ def gather_values(src: Tensor, perm: Tensor) -> Tensor:
     return out
 
 
+def coo_from_csr(rowptr: Tensor, col: Tensor, perm: Tensor, dtype=torch.int64) -> Tuple[Tensor, Tensor]:
+    """Invert `csr_from_coo`: the (other, seg) id lists in their ORIGINAL COO order from a CSR grouped by `seg`
+    (slot k holds COO entry perm[k]: other id col[k], seg id = the row whose [rowptr[r], rowptr[r+1]) holds k)."""
+    nnz = col.numel()
+    n_rows = rowptr.numel() - 1
+    counts = (rowptr[1:] - rowptr[:-1]).long()
+    row_of_slot = torch.repeat_interleave(torch.arange(n_rows, dtype=dtype, device=col.device), counts,
+                                          output_size=nnz)
+    other = torch.empty(nnz, dtype=dtype, device=col.device)
+    seg = torch.empty(nnz, dtype=dtype, device=col.device)
+    p = perm.long()
+    other[p] = col.to(dtype)
+    seg[p] = row_of_slot
+    return other, seg
+
+
 class Pattern:
     """Sparsity structure of out[scatter[e]] (+)= w[e] * x[gather[e]] for one COO edge_index.
 
@@ -139,9 +162,10 @@ class Pattern:
         g, s = (0, 1) if flow == "source_to_target" else (1, 0)
         self.n_in, self.n_out, self.nnz = int(n_in), int(n_out), int(edge_index.size(1))
         self.device = edge_index.device
-        self._gather = edge_index[g].contiguous()
-        self._scatter = edge_index[s].contiguous()
-        self.fwd = csr_from_coo(self._scatter, self._gather, self.n_out, self.n_in)
+        # The pattern does NOT keep the caller's edge_index (nor views of it) alive: everything later derived
+        # from the COO list -- the by-source CSR, the int32 COO operands of the SDDMM, per-entry degrees -- is
+        # rebuilt from the by-target CSR (`coo_from_csr`), so a cached Pattern never pins the user's tensor.
+        self.fwd = csr_from_coo(edge_index[s], edge_index[g], self.n_out, self.n_in)
         self._bwd: Optional[CSR] = None
         self._coo32: Optional[Tuple[Tensor, Tensor]] = None
         self._inv_deg: Optional[Tensor] = None
@@ -150,7 +174,8 @@ class Pattern:
     @property
     def bwd(self) -> CSR:
         if self._bwd is None:
-            self._bwd = csr_from_coo(self._gather, self._scatter, self.n_in, self.n_out)
+            gather, scatter = coo_from_csr(self.fwd.rowptr, self.fwd.col, self.fwd.perm, torch.int64)
+            self._bwd = csr_from_coo(gather, scatter, self.n_in, self.n_out, validate=False)
         return self._bwd
 
     @property
@@ -168,7 +193,7 @@ class Pattern:
     def coo32(self) -> Tuple[Tensor, Tensor]:
         """(gather, scatter) row ids as int32, COO order (SDDMM operands)."""
         if self._coo32 is None:
-            self._coo32 = (self._gather.to(torch.int32), self._scatter.to(torch.int32))
+            self._coo32 = coo_from_csr(self.fwd.rowptr, self.fwd.col, self.fwd.perm, torch.int32)
         return self._coo32
 
     def mean_values(self) -> Tensor:
@@ -176,7 +201,7 @@ class Pattern:
         if self._inv_deg is None:
             rp = self.fwd.rowptr
             deg = (rp[1:] - rp[:-1]).clamp(min=1).to(torch.float32)
-            self._inv_deg = (1.0 / deg)[self._scatter]
+            self._inv_deg = (1.0 / deg)[self.coo32[1].long()]
         return self._inv_deg
 
     def values_for(self, w: Optional[Tensor], which: str) -> Optional[Tensor]:
@@ -465,27 +490,27 @@ def gather_rows(x: Tensor, edge_index: Tensor, row: int, cached: bool = True) ->
 # pattern cache for raw-tensor callers (MessagePassing.propagate with a plain edge_index)
 # ------------------------------------------------------------------------------------------------
 class PatternCache:
-    """Small LRU keyed on the edge_index TENSOR OBJECT (held alive, so its address cannot be reused)
-    and its in-place version counter.  Pure function of the tensor's content: never changes results,
-    only avoids re-sorting when a caller passes the same edge_index again (e.g. SIMPA's 7 calls)."""
+    """LRU of the last few patterns, keyed on the edge_index TENSOR OBJECT (held weakly), its in-place version
+    and storage (memo.TensorMemo).  Pure function of the tensor's content: never changes results, only avoids
+    re-sorting when a caller passes the same edge_index again (e.g. SIMPA's 7 calls).  Neither the cache nor
+    the patterns in it keep the caller's tensor alive; an entry goes away with its edge_index.  See memo.py for
+    the invalidation contract and the opt-outs (PYGSD_NO_OPERATOR_MEMO=1, memo.set_enabled(False))."""
 
     def __init__(self, capacity: int = 8):
-        self.capacity = capacity
-        self._items = []  # (edge_index, version, n_in, n_out, flow, pattern)
+        self._memo = TensorMemo(capacity)
 
     def get(self, edge_index: Tensor, n_in: int, n_out: int, flow: str) -> Pattern:
-        for k, it in enumerate(self._items):
-            if it[0] is edge_index and it[1] == edge_index._version and it[2:5] == (n_in, n_out, flow):
-                self._items.append(self._items.pop(k))
-                return it[5]
-        pat = Pattern(edge_index, n_in, n_out, flow)
-        self._items.append((edge_index, edge_index._version, n_in, n_out, flow, pat))
-        if len(self._items) > self.capacity:
-            self._items.pop(0)
+        key = (int(n_in), int(n_out), flow)
+        pat = self._memo.get((edge_index,), key)
+        if pat is None:
+            pat = self._memo.put((edge_index,), key, Pattern(edge_index, n_in, n_out, flow))
         return pat
 
     def clear(self):
-        self._items.clear()
+        self._memo.clear()
+
+    def __len__(self):
+        return len(self._memo)
 
 
 GLOBAL_PATTERNS = PatternCache()

@@ -23,11 +23,12 @@ Tensor = torch.Tensor
 
 class LaplacianParts:
     """Symmetrised pattern + the ingredients of the operator values (all COO, sorted by (row, col))."""
-    __slots__ = ("index", "a_sym", "theta", "deg", "n", "off_ptr")
+    __slots__ = ("index", "a_sym", "theta", "deg", "n", "off_ptr", "differentiable")
 
-    def __init__(self, index, a_sym, theta, deg, n, off_ptr):
+    def __init__(self, index, a_sym, theta, deg, n, off_ptr, differentiable=False):
         self.index, self.a_sym, self.theta, self.deg, self.n = index, a_sym, theta, deg, n
         self.off_ptr = off_ptr          # int32 [n + 1]: first sorted entry of each row
+        self.differentiable = differentiable    # a_sym / theta / deg carry the autograd graph of edge_weight
 
 
 def laplacian_parts(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, signed: bool,
@@ -38,6 +39,9 @@ def laplacian_parts(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, s
     dev = edge_index.device
     row, col = edge_index[0].contiguous(), edge_index[1].contiguous()
     e = row.numel()
+    # the sort keys are row * n + col and the later stages index deg[] / off_ptr[] by these ids: an id outside
+    # [0, n) (wrong num_nodes, edge_index of a larger graph) must raise as the reference's scatter does
+    _cabi.check_node_ids((n, row), (n, col))
     w = None
     if edge_weight is not None:
         w = edge_weight.detach().reshape(-1).contiguous()
@@ -66,6 +70,36 @@ def laplacian_parts(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, s
     return LaplacianParts(index, a_sym, theta, deg, n, off_ptr)
 
 
+def differentiable_parts(parts: LaplacianParts, edge_index: Tensor, edge_weight: Tensor, signed: bool,
+                          absolute_degree: bool) -> LaplacianParts:
+    """The same sorted pattern as `parts` (built by the HIP pipeline from the detached weights) with a_sym,
+    theta_arg and the degree recomputed by differentiable tensor ops, for an `edge_weight` that requires grad:
+    the reference's get_magnetic_(signed_)Laplacian is differentiable w.r.t. edge_weight (coalesce / scatter_add
+    of [w, +-w(, |w|)], get_magnetic_Laplacian.py:52-66, get_magnetic_signed_Laplacian.py:52-73).  Every listed
+    non-loop edge u -> v adds w/2 to A_s at (u, v) and (v, u) and +w / -w to the phase argument there; the slot of
+    an entry in the sorted pattern is a binary search over its (row * n + col) keys."""
+    n, es = parts.n, parts.a_sym.numel()
+    row, col = parts.index[0], parts.index[1]
+    keys = row * n + col                                            # ascending (sorted by (row, col))
+    u, v = edge_index[0], edge_index[1]
+    keep = u != v
+    u, v = u[keep], v[keep]
+    w = edge_weight.reshape(-1)[keep].to(torch.float32)
+    s_uv = torch.searchsorted(keys, u * n + v)
+    s_vu = torch.searchsorted(keys, v * n + u)
+    zeros = torch.zeros(es, dtype=torch.float32, device=w.device)
+    a_sym = (zeros.index_add(0, s_uv, w).index_add(0, s_vu, w)) * 0.5
+    theta = zeros.index_add(0, s_uv, w).index_add(0, s_vu, -w)
+    if not signed:
+        per_entry = a_sym
+    elif absolute_degree:
+        per_entry = (zeros.index_add(0, s_uv, w.abs()).index_add(0, s_vu, w.abs())) * 0.5
+    else:
+        per_entry = a_sym.abs()
+    deg = torch.zeros(n, dtype=torch.float32, device=w.device).index_add(0, row, per_entry)
+    return LaplacianParts(parts.index, a_sym, theta, deg, n, parts.off_ptr, differentiable=True)
+
+
 def assemble_operator_csr(parts: LaplacianParts, off_real: Tensor, off_imag: Tensor, mir_real: Tensor,
                           mir_imag: Tensor, diag: Tensor, lambda_max: float, diag_shift: float = -1.0):
     """Compute layout of the scaled operator 2 L / lambda_max + diag_shift I on the symmetrised pattern:
@@ -91,13 +125,14 @@ def assemble_operator_csr(parts: LaplacianParts, off_real: Tensor, off_imag: Ten
 
 def laplacian_values(parts: LaplacianParts, q, normalization: Optional[str], mirror: bool = False):
     """(off_real, off_imag, diag) of L [+ (mir_real, mir_imag): the values of the mirrored entries].
-    A float q runs the HIP kernel; a tensor q that requires grad (trainable_q) is evaluated with
-    differentiable element-wise tensor ops on the same ingredients (no mirror values there)."""
+    A float q runs the HIP kernel; a tensor q that requires grad (trainable_q), or ingredients that carry the
+    gradient of edge_weight (`differentiable_parts`), are evaluated with differentiable element-wise tensor ops
+    (no mirror values there)."""
     sym = normalization is not None
     diag = torch.ones_like(parts.deg) if sym else parts.deg
-    if isinstance(q, torch.Tensor) and q.requires_grad:
+    if (isinstance(q, torch.Tensor) and q.requires_grad) or parts.differentiable:
         if mirror:
-            raise ValueError("mirror values are only produced for a fixed q")
+            raise ValueError("mirror values are only produced for a fixed q and weights without gradient")
         row, col = parts.index[0], parts.index[1]
         phase_arg = (2 * math.pi * q) * parts.theta
         if sym:

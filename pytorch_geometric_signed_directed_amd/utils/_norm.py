@@ -38,6 +38,7 @@ def add_remaining_self_loops(edge_index: Tensor, edge_attr: Optional[Tensor], fi
     dev = edge_index.device
     row, col = edge_index[0].contiguous(), edge_index[1].contiguous()
     e, n = row.numel(), int(num_nodes)
+    _cabi.check_node_ids((n, row), (n, col))     # the loop scan indexes last[] by these ids
     w = _f32(edge_attr)
     lib = _cabi.lib()
     with torch.cuda.device(dev):
@@ -85,7 +86,15 @@ def _loops_torch(edge_index, edge_attr, fill_value, num_nodes):
     loops = torch.arange(num_nodes, dtype=edge_index.dtype, device=edge_index.device).unsqueeze(0).repeat(2, 1)
     tail = edge_attr.new_full((num_nodes,), fill_value)
     on = ~off
-    tail = tail.index_put((edge_index[0][on],), edge_attr[on])
+    # a node with several listed loops keeps the LAST one (as the HIP route and the reference do): pick the
+    # largest COO position per node, then gather through it -- index_put on repeated indices is unordered
+    pos = on.nonzero(as_tuple=True)[0]
+    if pos.numel():
+        node = edge_index[0][pos]
+        last = torch.full((num_nodes,), -1, dtype=torch.long, device=edge_index.device)
+        last = last.scatter_reduce(0, node, pos, reduce="amax", include_self=True)
+        has = last >= 0
+        tail = torch.where(has, edge_attr[last.clamp(min=0)], tail)
     return torch.cat([edge_index[:, off], loops], dim=1), torch.cat([edge_attr[off], tail], dim=0)
 
 

@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...memo import TensorMemo
+
 Tensor = torch.Tensor
 
 
@@ -38,20 +40,16 @@ def _rows_of(x: Tensor, edge_index: Tensor, row: int, cached: bool = True) -> Te
     return x[edge_index[row]]
 
 
-_KEY_MEMO = []    # (edge_index, version, n, sorted unique keys): the samplers are called every training step
+_KEY_MEMO = TensorMemo(6)    # edge_index -> sorted unique keys: the samplers are called every training step
 
 
 def _edge_keys(edge_index: Tensor, n: int) -> Tensor:
-    """Sorted unique keys i * n + j of an edge list; kept for the last few edge_index tensors (identity + in-place
-    version), so a training loop sorts each graph once, not on every loss evaluation."""
-    for k, (src, ver, nn_, keys) in enumerate(_KEY_MEMO):
-        if src is edge_index and ver == edge_index._version and nn_ == n:
-            _KEY_MEMO.append(_KEY_MEMO.pop(k))
-            return keys
-    keys = torch.unique(edge_index[0] * n + edge_index[1])
-    _KEY_MEMO.append((edge_index, edge_index._version, n, keys))
-    if len(_KEY_MEMO) > 6:
-        _KEY_MEMO.pop(0)
+    """Sorted unique keys i * n + j of an edge list; kept for the last few edge_index tensors (memo.TensorMemo:
+    weakly held identity + in-place version), so a training loop sorts each graph once, not on every loss
+    evaluation."""
+    keys = _KEY_MEMO.get((edge_index,), n)
+    if keys is None:
+        keys = _KEY_MEMO.put((edge_index,), n, torch.unique(edge_index[0] * n + edge_index[1]))
     return keys
 
 

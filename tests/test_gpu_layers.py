@@ -126,6 +126,65 @@ def test_magnetic_trainable_q_gradient():
             g.t("x_real", D), g.t("x_imag", D), g.t("edge_index", D), g.t("edge_weight", D))
 
 
+@pytest.mark.parametrize("name,signed", [("magnet_k2_sym_w", False), ("msconv_k2_sym_noabs", True),
+                                         ("msconv_k1_sym_abs", True), ("magnet_k2_none_w", False)])
+def test_magnetic_edge_weight_gradient(name, signed):
+    """An edge_weight that requires grad gets its gradient, as through the reference's differentiable
+    get_magnetic_(signed_)Laplacian (coalesce / scatter_add; get_magnetic_Laplacian.py:52-80): HIP-sorted pattern,
+    autograd-tracked ingredients, edge-value gradients through the SDDMM kernel."""
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv, MSConv
+    g = load_golden(name)
+    norm = None if str(g["normalization"]) == "none" else "sym"
+    k, fin, fout = int(g["K"]), g["weight"].shape[1], g["weight"].shape[2]
+    lam = float(g["lambda_max"]) if "lambda_max" in g else (2.0 if norm == "sym" else 5.0)
+    if signed:
+        layer = MSConv(fin, fout, k, float(g["q"]), False, normalization=norm, absolute_degree=bool(g["absolute_degree"]))
+    else:
+        layer = MagNetConv(fin, fout, k, float(g["q"]), False, normalization=norm)
+    layer.load_state_dict({"weight": g.t("weight"), "bias": g.t("bias")})
+    layer.to(D)
+    w_dev = g.t("edge_weight", D).clone().requires_grad_()
+    xr = g.t("x_real", D).requires_grad_()
+    o_r, o_i = layer(xr, g.t("x_imag", D), g.t("edge_index", D), w_dev, lambda_max=lam)
+    ((o_r * g.t("grad_real", D)).sum() + (o_i * g.t("grad_imag", D)).sum()).backward()
+    w_cpu = g.t("edge_weight").clone().requires_grad_()
+    xc = g.t("x_real").requires_grad_()
+    op = R.magnet_operator(g.t("edge_index"), w_cpu, g["x_real"].shape[0], float(g["q"]), norm, lam,
+                           signed=signed, absolute_degree=bool(g["absolute_degree"]))
+    w_r, w_i = R.magnet_conv(xc, g.t("x_imag"), op, g.t("weight"), g.t("bias"))
+    ((w_r * g.t("grad_real")).sum() + (w_i * g.t("grad_imag")).sum()).backward()
+    close(o_r, w_r)
+    close(o_i, w_i)
+    close(xr.grad, xc.grad)
+    assert w_dev.grad is not None
+    close(w_dev.grad, w_cpu.grad, 2e-5, what="d edge_weight")
+
+
+def test_node_ids_outside_the_graph_raise_index_error():
+    """ids >= num_nodes / negative ids raise (as the reference's index_select / scatter_add_ do)
+    instead of reading or writing device memory out of bounds."""
+    from pytorch_geometric_signed_directed_amd.nn import DGCNConv, MagNetConv
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, csr_from_coo
+    n = 50
+    ei = torch.randint(0, n, (2, 300), generator=torch.Generator().manual_seed(0))
+    bad_hi, bad_lo = ei.clone(), ei.clone()
+    bad_hi[1, 17] = n
+    bad_lo[0, 5] = -1
+    x = torch.randn(n, 8).to(D)
+    for bad in (bad_hi, bad_lo):
+        with pytest.raises(IndexError, match="outside"):
+            MagNetConv(8, 8, 1, 0.25, False).to(D)(x, x, bad.to(D))
+        with pytest.raises(IndexError, match="outside"):
+            Pattern(bad.to(D), n, n)
+        with pytest.raises(IndexError, match="outside"):
+            csr_from_coo(bad[1].to(D), bad[0].to(D), n, n)
+        with pytest.raises(IndexError, match="outside"):
+            DGCNConv()(x, bad.to(D), None)
+    Pattern(ei.to(D), n, n)                       # the valid list still builds
+    with pytest.raises(NotImplementedError, match="2-D"):
+        MagNetConv(8, 8, 1, 0.25, False).to(D)(x.unsqueeze(0), x.unsqueeze(0), ei.to(D))
+
+
 @pytest.mark.parametrize("name", golden_names("digcn_"))
 def test_digcn(name):
     from pytorch_geometric_signed_directed_amd.nn import DiGCNConv
@@ -614,6 +673,56 @@ def test_uncached_layer_reuses_the_operator_only_for_unmodified_graph_tensors():
     assert layer._operator is not op4
     want = fresh(ei, w, 3.0)
     close(o5[0], want[0].detach().cpu().numpy()); close(o5[1], want[1].detach().cpu().numpy())
+
+
+def test_operator_memo_opt_out_and_weak_keys():
+    """memo.py's contract: a write that bypasses the version counter (`.data`) is NOT seen by the memo (documented
+    hazard) and IS seen with the memo switched off (ctor kwarg, process switch); the memo holds its key tensors
+    weakly, so dropping the graph drops the cached operator."""
+    import gc
+    import weakref
+    from pytorch_geometric_signed_directed_amd import memo
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    from pytorch_geometric_signed_directed_amd.sparse import GLOBAL_PATTERNS
+    g = load_golden("magnet_k2_sym_w")
+    ei, w = g.t("edge_index", D), g.t("edge_weight", D).clone()
+    xr, xi = g.t("x_real", D), g.t("x_imag", D)
+    torch.manual_seed(0)
+    on = MagNetConv(xr.size(1), 4, 2, 0.1, False, cached=False).to(D)
+    off = MagNetConv(xr.size(1), 4, 2, 0.1, False, cached=False, operator_memo=False).to(D)
+    off.load_state_dict(on.state_dict())
+    a1, b1 = on(xr, xi, ei, w), off(xr, xi, ei, w)
+    assert torch.equal(a1[0], b1[0])
+    version = w._version
+    w.data.mul_(3.0)                                   # bypasses the version counter
+    assert w._version == version
+    a2, b2 = on(xr, xi, ei, w), off(xr, xi, ei, w)
+    assert torch.equal(a2[0], a1[0])                   # the hazard: stale operator (memo hit)
+    fresh = MagNetConv(xr.size(1), 4, 2, 0.1, False).to(D)
+    fresh.load_state_dict(on.state_dict())
+    want = fresh(xr, xi, ei.clone(), w.clone())
+    close(b2[0], want[0]); close(b2[1], want[1])       # opt-out rebuilds, like the reference
+    assert not torch.equal(b2[0], b1[0])
+    memo.clear_all()                                   # ... and so does an explicit clear
+    a3 = on(xr, xi, ei, w)
+    close(a3[0], want[0])
+    try:
+        memo.set_enabled(False)                        # process-wide switch (PYGSD_NO_OPERATOR_MEMO=1)
+        op = on._operator
+        on(xr, xi, ei, w)
+        assert on._operator is not op
+    finally:
+        memo.set_enabled(True)
+    # weak keys: neither the layer memo nor the global pattern cache keeps a dropped edge_index alive
+    tmp = ei.clone()
+    ref = weakref.ref(tmp)
+    on(xr, xi, tmp, w)
+    GLOBAL_PATTERNS.get(tmp, 40, 40, "source_to_target")
+    assert len(on._op_memo) == 1 and len(GLOBAL_PATTERNS) >= 1
+    before = len(GLOBAL_PATTERNS)
+    del tmp
+    gc.collect()
+    assert ref() is None and len(on._op_memo) == 0 and len(GLOBAL_PATTERNS) == before - 1
 
 
 @pytest.mark.parametrize("first,in_dim,out_dim,bias", [(True, 64, 32, True), (False, 32, 32, True), (True, 16, 48, True),
