@@ -329,6 +329,11 @@ int pygsd_id_range_i64(const int64_t* ids, int64_t n, int64_t* minmax, void* str
  * ------------------------------------------------------------------------------------------- */
 int pygsd_stream_copy_f32(const float* src, float* dst, int64_t n, void* stream);
 
+/* Keeps `stream` busy for `microseconds` (one idle lane polling the constant-rate wall clock).  Measurement
+ * only: the single-GPU rehearsal of the sharded propagate (tools/emulate_sharded.py) uses it as the wire time
+ * of an xGMI exchange on its communication stream.  No reference counterpart. */
+int pygsd_spin_us(double microseconds, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Kernel-timing recorder (measurement only; used by bench.py for the roofline object).
  * When enabled, every kernel launch of this library is bracketed by a pair of hipEvents on the

@@ -86,6 +86,14 @@ __global__ __launch_bounds__(kBlock) void stream_copy_kernel(const vec4f* __rest
     }
 }
 
+// Occupies the stream for `ticks` of the 100 MHz constant-rate counter: stands in for the wire time of an xGMI
+// exchange when the sharded propagate is rehearsed on ONE GPU (tools/emulate_sharded.py).
+__global__ void spin_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // min / max of an id list: one 64-bit atomic pair per wavefront.
 __global__ __launch_bounds__(kBlock) void id_range_kernel(const int64_t* __restrict__ ids, int64_t n,
                                                          long long* __restrict__ minmax)
@@ -122,6 +130,19 @@ extern "C" int pygsd_stream_copy_f32(const float* src, float* dst, int64_t n, vo
     hipLaunchKernelGGL(stream_copy_kernel, dim3(static_cast<unsigned>(blocks < 256 * 32 ? blocks : 256 * 32)),
                        dim3(kBlock), 0, s, reinterpret_cast<const vec4f*>(src), reinterpret_cast<vec4f*>(dst), n4);
     return check_launch("stream_copy_kernel");
+}
+
+extern "C" int pygsd_spin_us(double microseconds, void* stream)
+{
+    PYGSD_REQUIRE(microseconds >= 0.0 && microseconds <= 5e6, "pygsd_spin_us: duration outside [0, 5 s]");
+    int rate_khz = 0;
+    int dev = 0;
+    PYGSD_HIP_TRY(hipGetDevice(&dev));
+    PYGSD_HIP_TRY(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev));
+    if (rate_khz <= 0) rate_khz = 100000;    // gfx9: 100 MHz constant counter
+    const long long ticks = static_cast<long long>(microseconds * 1e-3 * rate_khz);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), ticks);
+    return check_launch("spin_kernel");
 }
 
 extern "C" int pygsd_id_range_i64(const int64_t* ids, int64_t n, int64_t* minmax, void* stream)

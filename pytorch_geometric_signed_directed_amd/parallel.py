@@ -1,52 +1,126 @@
 """Node-range sharding of the path across the GPUs of one node.
 
-The reference has no multi-device story at all, so this is new design, MI355X-first:
-one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI); rank g owns the node
-range [g*n_pad, (g+1)*n_pad) of every feature matrix and, of each operator, the CSR rows it
-PRODUCES: the by-target rows of its nodes for the forward product and the by-source rows of its
-nodes for the backward product.  Output rows are independent, so the only data-path exchange is an
-all-gather of the [n_pad, 2F] packed (real | imag) feature block before each propagate -- forward:
-the layer input, backward: the gradient of the propagated term.  No reduce-scatter, no atomics;
-weight gradients are all-reduced (tiny).  Equal-size ranges (the last one zero-padded) keep the
-collective a plain `all_gather_into_tensor` that RCCL spreads over all seven xGMI links.
+The reference has no multi-device story at all (no torch.distributed anywhere in it), so this is new design,
+MI355X-first: one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI).
 
-On the benchmark's random SBM graphs the halo is ~every row (a rank's 5M local entries touch 99% of
-the 1M source rows), so gathering whole blocks loses nothing against a halo list.
+Ownership.  Rank g OWNS a contiguous node range [bounds[g], bounds[g+1]) of every feature matrix (layer inputs,
+outputs, the dense stage and its dW / db partials are row-local).  The ranges are chosen for equal WORK, not
+equal size (`balanced_bounds`: prefix sums of 1 + in-degree + out-degree), then padded to one common length
+n_pad so that every collective is an equal-split one; node v of range g lives at PADDED id g * n_pad + (v -
+bounds[g]) and the pad rows are isolated nodes whose features stay zero.
 
-Grid layout (`GridPlan`, the default of `ShardedMagNetConv` when the width allows it).  On a locality-free
-graph the row layout is exchange-bound: every propagate moves (P-1)/P of BOTH feature matrices into every GPU
-(448 MB at P = 8, ~1.1 ms on xGMI) while the local product shrinks to 0.4 ms.  Gathered feature rows cost
-whole 128-byte lines, so a GPU can take a quarter of the COLUMNS of the packed (real | imag) rows at no loss of
-gather efficiency (measured, tools/narrow_probe.py: 41 M entries at 16 + 16 packed floats: 0.81 ms = the cost
-of one line per entry).  The P ranks therefore form a p_r x p_c grid (p_c <= 4): rank (i, j) multiplies row
-block i of the operator (a contiguous slice of the shared CSR, no re-sort) with column slice j of the
-features.  Exchange per propagate: an all-to-all that hands every rank the column slice j of all rows (1/p_c of
-the all-gather volume), and a second one inside the row group that returns the product to node-range
-ownership.  Ownership of inputs, outputs and the dense stage stays node-range, as in the row layout.
+Work layouts for the propagate  Y = S X  (and dX = S^T dY, which for the Hermitian / symmetric operators of
+this package is the same pattern with mirrored values):
 
-`ShardPlan`, `GridPlan`, `all_gather_rows` and `exchange` are device- and backend-agnostic (exercised with gloo on CPU in
-tests/test_sharding_gloo.py); `ShardedMagNetConv` is the HIP compute path.
+  rows   rank g multiplies ITS OWN operator rows with the all-gathered packed features -- one all-gather in,
+         nothing back.  The right shape for 2 ranks and for one-operand bf16 operators (a 128-byte row is
+         already one cache line, column slices would only add lines).
+  grid   the P ranks form a p_r x p_c grid; rank (i, j) multiplies ROW BLOCK i -- the i-th 1/p_r of EVERY rank's
+         range, so the products go back over all P-1 links, not only to p_c-1 neighbours -- with COLUMN SLICE j of
+         the packed (real | imag) features.  One all-to-all in (1 / p_c of the all-gather volume) and one
+         all-to-all back.  A gathered feature row costs whole 128-byte lines, so 16 + 16 packed floats cost
+         what 64 + 64 cost per line: the grid divides the exchange by p_c at the row layout's compute per rank.
+
+Overlap (both layouts).  xGMI is point-to-point: a collective finishes when the slowest LINK has moved its
+block, all links in parallel, so blocks do not arrive one peer after the other and splitting by peer buys
+nothing.  The propagate is therefore pipelined along the node dimension instead:
+  * every rank's range is cut into C PHASES; the operator's columns are split the same way (`split_phases`),
+    phase c's exchange moves sub-range c of every rank, and the partial product over column block c runs while
+    phase c + 1 is on the wire (accumulated through the SpMM's own beta * Z epilogue, Z = Y, no atomics);
+  * in the grid the last phase's product runs in R ROW CHUNKS and chunk r travels back while chunk r + 1 is
+    multiplied.
+All exchanges are issued up front as asynchronous collectives (RCCL runs them in order on the process
+group's own stream); the compute stream only waits for the piece it is about to read.
+
+`ShardPlan`, `split_phases`, `take_rows`, the exchanges and `PropagateEngine` are device- and backend-agnostic
+(exercised with gloo on CPU in tests/test_sharding_gloo.py, the product kernels swapped for a torch
+restatement); the operator builders and the layers at the bottom are the HIP compute path.
+`EmulatedExchange` rehearses one rank of a P-rank job on a single GPU with the wire time of every exchange
+played by a timed kernel on a separate stream (tools/emulate_sharded.py): the pipeline, its events and the
+per-rank kernels are the production ones, only the bytes do not cross a link.
 """
-from typing import Optional, Tuple
+import math
+import os
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
+from .sparse import CSR
+
 Tensor = torch.Tensor
 
 
-class ShardPlan:
-    """Contiguous, equal-size node ranges: rank g owns global ids [g*n_pad, (g+1)*n_pad)."""
+# ------------------------------------------------------------------------------------------------
+# ownership
+# ------------------------------------------------------------------------------------------------
+def balanced_bounds(cost: Tensor, world_size: int) -> List[int]:
+    """Contiguous ranges of (nearly) equal total `cost` (one entry per node): bounds[g] = first node whose
+    prefix cost reaches g / P of the total.  SURVEY.md 8(e) "equal-nnz row ranges (not equal-N)"."""
+    n = int(cost.numel())
+    if n == 0:
+        return [0] * (world_size + 1)
+    prefix = torch.cumsum(cost.double().cpu(), 0)
+    total = float(prefix[-1])
+    targets = torch.tensor([total * g / world_size for g in range(1, world_size)], dtype=torch.float64)
+    cuts = torch.searchsorted(prefix, targets, right=False).tolist()
+    bounds = [0] + [min(int(c) + 1, n) for c in cuts] + [n]
+    for g in range(1, len(bounds)):                      # monotone even for degenerate costs
+        bounds[g] = max(bounds[g], bounds[g - 1])
+    return bounds
 
-    def __init__(self, num_nodes: int, world_size: int, rank: int):
+
+def degree_cost(edge_index: Tensor, num_nodes: int) -> Tensor:
+    """1 + in-degree + out-degree per node: the entries of a node's row of the symmetrised operator (reciprocal
+    pairs counted twice -- a balance heuristic, not a count) plus its diagonal."""
+    ones = torch.ones(edge_index.size(1), dtype=torch.float32, device=edge_index.device)
+    deg = torch.ones(num_nodes, dtype=torch.float32, device=edge_index.device)
+    deg.index_add_(0, edge_index[0], ones)
+    deg.index_add_(0, edge_index[1], ones)
+    return deg
+
+
+class ShardPlan:
+    """Contiguous node ranges (equal size by default, `bounds` for balanced ones) padded to n_pad rows each;
+    n_pad is a multiple of `align` (the engine needs equal phases / row chunks)."""
+
+    def __init__(self, num_nodes: int, world_size: int, rank: int, bounds: Optional[Sequence[int]] = None,
+                 align: int = 1):
         if not (0 <= rank < world_size):
             raise ValueError(f"rank {rank} outside world of {world_size}")
         self.num_nodes, self.world_size, self.rank = int(num_nodes), int(world_size), int(rank)
-        self.n_pad = (self.num_nodes + world_size - 1) // world_size
-        self.n_total = self.n_pad * world_size          # padded node count (extra nodes are isolated)
-        self.lo = rank * self.n_pad
-        self.hi = min(self.lo + self.n_pad, self.num_nodes)
-        self.n_local = max(self.hi - self.lo, 0)        # real rows owned by this rank
+        if bounds is None:
+            step = (self.num_nodes + world_size - 1) // world_size
+            bounds = [min(g * step, self.num_nodes) for g in range(world_size + 1)]
+        bounds = [int(b) for b in bounds]
+        if len(bounds) != world_size + 1 or bounds[0] != 0 or bounds[-1] != self.num_nodes or \
+                any(bounds[g] > bounds[g + 1] for g in range(world_size)):
+            raise ValueError(f"bounds {bounds} do not partition {self.num_nodes} nodes over {world_size} ranks")
+        self.bounds = bounds
+        self.sizes = [bounds[g + 1] - bounds[g] for g in range(world_size)]
+        align = max(int(align), 1)
+        self.n_pad = max((max(self.sizes) + align - 1) // align * align, align)
+        self.n_total = self.n_pad * world_size          # padded node count (pad nodes are isolated)
+        self.lo, self.hi = bounds[rank], bounds[rank + 1]
+        self.n_local = self.hi - self.lo                # real rows owned by this rank
+        self.pad_lo = rank * self.n_pad                 # first padded id of this rank
+        self._index_cache = {}
+
+    # ---- global <-> padded ids ---------------------------------------------------------------------
+    def to_padded(self, ids: Tensor) -> Tensor:
+        """Global node ids -> padded ids g * n_pad + (v - bounds[g])."""
+        inner = torch.tensor(self.bounds[1:-1], dtype=ids.dtype, device=ids.device)
+        g = torch.searchsorted(inner, ids, right=True) if inner.numel() else torch.zeros_like(ids)
+        starts = torch.tensor(self.bounds[:-1], dtype=ids.dtype, device=ids.device)
+        return g * self.n_pad + ids - starts[g]
+
+    def global_index(self, device) -> Tensor:
+        """int64 [num_nodes]: padded id of every global node (to read a gathered [n_total, ...] buffer back in
+        global order)."""
+        key = str(device)
+        if key not in self._index_cache:
+            self._index_cache[key] = self.to_padded(torch.arange(self.num_nodes, dtype=torch.long, device=device))
+        return self._index_cache[key]
 
     def shard_rows(self, x: Tensor) -> Tensor:
         """Rows of a global [num_nodes, F] matrix owned by this rank, zero-padded to n_pad rows."""
@@ -56,286 +130,463 @@ class ShardPlan:
         return out
 
     def unshard_rows(self, gathered: Tensor) -> Tensor:
-        """[n_total, ...] gathered buffer -> the [num_nodes, ...] global matrix."""
-        return gathered[:self.num_nodes]
-
-    def owned(self, ids: Tensor) -> Tensor:
-        return (ids >= self.lo) & (ids < self.lo + self.n_pad)
-
-    def local_entries(self, edge_index: Tensor, by: int) -> Tuple[Tensor, Tensor]:
-        """Entries whose row `by` (0 = source, 1 = target) is owned by this rank.
-        Returns (positions in the COO list, the sub-COO with the owned row re-based to local ids)."""
-        keep = self.owned(edge_index[by]).nonzero(as_tuple=True)[0]
-        sub = edge_index[:, keep].clone()
-        sub[by] -= self.lo
-        return keep, sub
+        """[n_total, ...] gathered buffer (rank-major) -> the [num_nodes, ...] global matrix."""
+        return gathered.index_select(0, self.global_index(gathered.device))
 
 
-def all_gather_rows(x_local: Tensor, group=None) -> Tensor:
-    """[n_pad, C] per rank -> [world * n_pad, C], rank-major (== global node order under ShardPlan).
-    One collective; on RCCL it runs on the calling stream's NCCL stream semantics of torch."""
-    world = dist.get_world_size(group)
-    x_local = x_local.contiguous()
-    out = x_local.new_empty((world * x_local.size(0),) + tuple(x_local.shape[1:]))
-    try:
-        dist.all_gather_into_tensor(out, x_local, group=group)
-    except (RuntimeError, NotImplementedError):  # backends without the fused form
-        parts = list(out.chunk(world, dim=0))
-        dist.all_gather(parts, x_local, group=group)
+# ------------------------------------------------------------------------------------------------
+# exchanges
+# ------------------------------------------------------------------------------------------------
+class _Done:
+    def wait(self):
+        return True
+
+
+class DistExchange:
+    """torch.distributed collectives.  RCCL ("nccl"): asynchronous, on the process group's own stream;
+    `handle.wait()` makes the CURRENT stream wait, so compute queued before the wait overlaps the transfer.
+    gloo (tests; several ranks sharing one GPU): device tensors are staged through the host, synchronously."""
+    emulated = False
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world_size, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self._staged = dist.get_backend(group) == "gloo"
+
+    def _gather_sync(self, out: Tensor, inp: Tensor):
+        try:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+        except (RuntimeError, NotImplementedError):        # a backend without the fused form
+            dist.all_gather(list(out.unbind(0)), inp, group=self.group)
+
+    def all_gather(self, out: Tensor, inp: Tensor):
+        """out [world, ...] <- inp [...] of every rank."""
+        if self._staged:
+            if inp.is_cuda:
+                host = torch.empty(out.shape, dtype=out.dtype)
+                self._gather_sync(host, inp.cpu().contiguous())
+                out.copy_(host)
+            else:
+                self._gather_sync(out, inp.contiguous())
+            return _Done()
+        return dist.all_gather_into_tensor(out, inp.contiguous(), group=self.group, async_op=True)
+
+    def all_to_all(self, out: Tensor, inp: Tensor):
+        """chunk d of inp [world, ...] goes to rank d; chunk s of out comes from rank s."""
+        if self._staged and inp.is_cuda:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(host, inp.cpu().contiguous(), group=self.group)
+            out.copy_(host)
+            return _Done()
+        return dist.all_to_all_single(out, inp.contiguous(), group=self.group, async_op=True)
+
+    def all_reduce(self, t: Tensor) -> Tensor:
+        if self.world_size > 1:
+            if self._staged and t.is_cuda:
+                host = t.cpu()
+                dist.all_reduce(host, group=self.group)
+                t.copy_(host)
+            else:
+                dist.all_reduce(t, group=self.group)
+        return t
+
+    def broadcast_list(self, values: list, src: int = 0) -> list:
+        box = [values]
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
+
+class _StreamEvent:
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+        return True
+
+
+class EmulatedExchange:
+    """Rank `rank` of a `world_size`-rank job rehearsed on ONE GPU: every exchange is played on a separate HIP
+    stream as (a device copy of the bytes this rank would receive) + (a timed kernel of the wire time of the
+    busiest link, bytes_per_link / link_gbps).  The received VALUES are this rank's own data repeated -- the
+    rehearsal measures the pipeline (streams, events, per-rank kernels at their real sizes), it does not
+    compute a correct product."""
+    emulated = True
+
+    def __init__(self, world_size: int, rank: int, link_gbps: float = 61.0, latency_us: float = 10.0):
+        from . import _cabi
+        self._cabi = _cabi
+        self.world_size, self.rank = int(world_size), int(rank)
+        self.link_gbps, self.latency_us = float(link_gbps), float(latency_us)
+        self.stream = torch.cuda.Stream()
+        self.group = None
+        self.wire_us = 0.0                               # accumulated emulated wire time (reset by the caller)
+
+    def _play(self, out: Tensor, src: Tensor, bytes_per_link: float):
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        us = self.latency_us + bytes_per_link / (self.link_gbps * 1e3) if self.world_size > 1 else 0.0
+        self.wire_us += us
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            out.copy_(src)
+            if us > 0:
+                self._cabi.check(self._cabi.lib().pygsd_spin_us(us, self._cabi.stream_ptr()), "pygsd_spin_us")
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        out.record_stream(self.stream)
+        src.record_stream(self.stream)
+        return _StreamEvent(done)
+
+    def all_gather(self, out: Tensor, inp: Tensor):
+        return self._play(out, inp.unsqueeze(0).expand_as(out), inp.numel() * inp.element_size())
+
+    def all_to_all(self, out: Tensor, inp: Tensor):
+        return self._play(out, inp, inp[0].numel() * inp.element_size())
+
+    def all_reduce(self, t: Tensor) -> Tensor:
+        return t
+
+    def broadcast_list(self, values: list, src: int = 0) -> list:
+        return values
+
+
+# ------------------------------------------------------------------------------------------------
+# CSR surgery (pure index arithmetic; torch ops on whatever device the CSR lives on)
+# ------------------------------------------------------------------------------------------------
+def _row_of_slot(rowptr: Tensor, nnz: int) -> Tensor:
+    counts = (rowptr[1:] - rowptr[:-1]).long()
+    return torch.repeat_interleave(torch.arange(counts.numel(), dtype=torch.long, device=rowptr.device), counts,
+                                   output_size=nnz)
+
+
+def take_rows(csr: CSR, values: Sequence[Tensor], row_ids: Tensor) -> Tuple[CSR, Tuple[Tensor, ...]]:
+    """The sub-operator made of rows `row_ids` (int64, any order, no repeats needed) in THAT order; columns
+    untouched.  A row's entries keep their order."""
+    row_ids = row_ids.long()
+    rp = csr.rowptr.long()
+    counts = rp[row_ids + 1] - rp[row_ids]
+    new_ptr = torch.zeros(row_ids.numel() + 1, dtype=torch.long, device=rp.device)
+    new_ptr[1:] = torch.cumsum(counts, 0)
+    nnz = int(new_ptr[-1]) if row_ids.numel() else 0
+    owner = torch.repeat_interleave(torch.arange(row_ids.numel(), dtype=torch.long, device=rp.device), counts,
+                                    output_size=nnz)
+    src = torch.arange(nnz, dtype=torch.long, device=rp.device) - new_ptr[owner] + rp[row_ids][owner]
+    out = CSR(int(row_ids.numel()), csr.n_cols, nnz, new_ptr.to(torch.int32), csr.col[src].contiguous(), None)
+    return out, tuple(v[src].contiguous() for v in values)
+
+
+def split_phases(csr: CSR, values: Sequence[Tensor], n_pad: int, phases: int, world_size: int
+                 ) -> List[Tuple[CSR, Tuple[Tensor, ...]]]:
+    """Column blocks of an operator whose columns are PADDED node ids: block c holds the entries whose column
+    falls in sub-range c (of `phases`) of ITS rank's range, with the column re-based into phase c's exchange
+    buffer [world, n_pad / phases, ...] viewed as rows: (col // n_pad) * n_sub + (col % n_pad) % n_sub.
+    A row's entries keep their order inside a block."""
+    if phases == 1:
+        return [(csr, tuple(values))]
+    if n_pad % phases:
+        raise ValueError(f"n_pad = {n_pad} is not a multiple of {phases} phases")
+    n_sub = n_pad // phases
+    col = csr.col.long()
+    local = col % n_pad
+    phase = local // n_sub
+    compact = (col // n_pad) * n_sub + local % n_sub
+    rp = csr.rowptr.long()
+    out = []
+    for c in range(phases):
+        hit = phase == c
+        upto = torch.zeros(csr.nnz + 1, dtype=torch.long, device=col.device)
+        upto[1:] = torch.cumsum(hit.long(), 0)
+        new_ptr = upto[rp]
+        nnz_c = int(upto[-1])
+        sub = CSR(csr.n_rows, world_size * n_sub, nnz_c, new_ptr.to(torch.int32),
+                  compact[hit].to(torch.int32).contiguous(), None)
+        out.append((sub, tuple(v[hit].contiguous() for v in values)))
     return out
 
 
-def pack_pair(a: Tensor, b: Tensor) -> Tensor:
-    """[n, F], [n, F] -> [n, 2F] (real | imag side by side: one gathered row feeds both operators)."""
-    return torch.cat([a, b], dim=1)
+class PhasedOperator:
+    """One orientation of the operator rows a rank multiplies: per phase a CSR (columns = rows of that phase's
+    exchange buffer) and its value arrays.  dual: two value arrays on ONE pattern, applied to feature groups
+    0 and 1 in one traversal (magnetic real / imaginary parts)."""
+
+    def __init__(self, blocks: List[Tuple[CSR, Tuple[Tensor, ...]]], dual: bool, mean: bool = False):
+        self.blocks, self.dual, self.mean = blocks, dual, mean
+        self.n_rows = blocks[0][0].n_rows
+        self.nnz = sum(b[0].nnz for b in blocks)
+        if mean and len(blocks) > 1:
+            raise ValueError("a mean-reduced operator cannot be split into column blocks")
 
 
-class GridPlan(ShardPlan):
-    """p_r x p_c process grid over the same node-range ownership as ShardPlan: rank r = i * p_c + j owns node
-    block r (n_pad rows); as a worker it multiplies ROW BLOCK i = node blocks [i * p_c, (i + 1) * p_c) of the
-    operator with COLUMN SLICE j = features [j * fc, (j + 1) * fc) of both packed operands."""
+# ------------------------------------------------------------------------------------------------
+# product kernels (HIP); the CPU tests pass torch restatements with the same signatures
+# ------------------------------------------------------------------------------------------------
+def _hip_dual(csr, va, vb, xa, xb, ya, yb, lo, hi, alpha, accumulate):
+    from .sparse import spmm2_rows_into
+    spmm2_rows_into(csr, va, vb, xa, xb, ya, yb, lo, hi, alpha, accumulate)
 
-    def __init__(self, num_nodes: int, world_size: int, rank: int, n_feat: int, p_c: Optional[int] = None):
-        super().__init__(num_nodes, world_size, rank)
-        self.p_c = self.choose_cols(world_size, n_feat) if p_c is None else int(p_c)
-        if world_size % self.p_c or n_feat % self.p_c:
-            raise ValueError(f"grid of {self.p_c} column slices does not divide world {world_size} / width {n_feat}")
-        self.p_r = world_size // self.p_c
-        self.i, self.j = rank // self.p_c, rank % self.p_c
-        self.fc = n_feat // self.p_c
-        self.n_feat = n_feat
-        self.block_rows = self.p_c * self.n_pad                     # rows of operator row block i
-        self.block_lo = self.i * self.block_rows
+
+def _hip_single(csr, val, x, y, lo, hi, alpha, accumulate, mean):
+    from .sparse import spmm_rows_into
+    spmm_rows_into(csr, val, x, y, lo, hi, alpha, accumulate, mean)
+
+
+class PropagateEngine:
+    """Executes  Y_g = alpha * S_g X_g  (g = feature group) for the operator rows of one rank: exchanges in,
+    pipelined partial products, exchange back (grid only).  See the module docstring for the schedule."""
+
+    def __init__(self, plan: ShardPlan, exchange, p_c: int = 1, phases: int = 1, return_chunks: int = 1,
+                 kernels: Optional[Tuple[Callable, Callable]] = None):
+        self.plan, self.ex = plan, exchange
+        world = plan.world_size
+        if world % p_c:
+            raise ValueError(f"{p_c} column slices do not divide {world} ranks")
+        self.p_c, self.p_r = int(p_c), world // int(p_c)
+        self.grid = self.p_c > 1
+        self.i, self.j = plan.rank // self.p_c, plan.rank % self.p_c
+        self.phases = int(phases)
+        self.return_chunks = int(return_chunks) if self.grid else 1
+        if plan.n_pad % self.phases or (self.grid and plan.n_pad % (self.p_r * self.return_chunks)):
+            raise ValueError(f"n_pad = {plan.n_pad} must be a multiple of the phases ({self.phases}) and of "
+                             f"p_r x return chunks ({self.p_r} x {self.return_chunks}); build the plan with "
+                             f"align = PropagateEngine.alignment(...)")
+        self.n_sub = plan.n_pad // self.phases
+        self.n_blk = plan.n_pad // self.p_r if self.grid else plan.n_pad
+        self.n_rsub = self.n_blk // self.return_chunks
+        self.block_rows = world * self.n_blk if self.grid else plan.n_pad
+        self.dual_kernel, self.single_kernel = kernels or (_hip_dual, _hip_single)
+        self.timing = None                                   # dict of event lists when profiling
 
     @staticmethod
-    def choose_cols(world_size: int, n_feat: int) -> int:
-        """Largest p_c <= 4 dividing the world with 16-byte-aligned column slices (fc % 4 == 0): two packed
-        slices of >= 16 floats still fill the 128-byte line a gather costs anyway.  Received volume relative to
-        one full feature pair: rows (1 - 1/P); grid (1 - 1/P) / p_c + (1 - 1/p_c) / P -- a 1 x 2 grid on two
-        ranks moves exactly what the row layout moves, so two ranks stay in the row layout."""
-        for p_c in (4, 2):
-            if world_size % p_c == 0 and world_size > p_c - 1 + (p_c == 2) and n_feat % (4 * p_c) == 0:
-                return p_c
-        return 1
+    def alignment(world_size: int, p_c: int, phases: int, return_chunks: int) -> int:
+        p_r = world_size // p_c
+        a = phases
+        b = p_r * return_chunks if p_c > 1 else 1
+        return a * b // math.gcd(a, b)
 
-    # -- pure index bookkeeping of the two exchanges (used by the device path and by the CPU tests) ----------
-    def slice_chunks(self, a: Tensor, b: Tensor) -> Tensor:
-        """Row-layout [n_pad, F] pair -> [P, n_pad, 2 fc]: chunk d = the packed column slice j(d) = d % p_c of
-        my rows (the same slice for every rank of one grid column)."""
-        n, fc = a.size(0), self.fc
-        packed = torch.stack([a.reshape(n, self.p_c, fc), b.reshape(n, self.p_c, fc)], dim=2)   # [n, p_c, 2, fc]
-        slices = packed.permute(1, 0, 2, 3).reshape(self.p_c, n, 2 * fc)
+    # ---- which operator rows this rank multiplies, in product order ---------------------------------
+    def block_row_ids(self, device) -> Tensor:
+        """Padded ids of the rows of this rank's products.  rows layout: the own range.  grid: row block i =
+        the i-th 1/p_r of every rank's range, ordered (return chunk r, owner g, row in chunk) so that return
+        chunk r is a contiguous row range of the product and an equal-split all-to-all."""
+        plan = self.plan
+        if not self.grid:
+            return torch.arange(plan.pad_lo, plan.pad_lo + plan.n_pad, dtype=torch.long, device=device)
+        r = torch.arange(self.return_chunks, dtype=torch.long, device=device).view(-1, 1, 1)
+        g = torch.arange(plan.world_size, dtype=torch.long, device=device).view(1, -1, 1)
+        t = torch.arange(self.n_rsub, dtype=torch.long, device=device).view(1, 1, -1)
+        return (g * plan.n_pad + self.i * self.n_blk + r * self.n_rsub + t).reshape(-1)
+
+    def phased(self, csr: CSR, values: Sequence[Tensor], dual: bool, mean: bool = False) -> PhasedOperator:
+        """Operator rows (already restricted / ordered by `block_row_ids`, padded column ids) -> PhasedOperator."""
+        return PhasedOperator(split_phases(csr, values, self.plan.n_pad, self.phases, self.plan.world_size), dual, mean)
+
+    # ---- packing ------------------------------------------------------------------------------------
+    def _pack(self, xs: Sequence[Tensor], c: int) -> Tensor:
+        """Sub-range c of the local rows of every feature group, packed for the exchange.
+        rows: [n_sub, G * F] (groups side by side).  grid: [world, n_sub, G * fw], chunk d = column slice d % p_c."""
+        rows = slice(c * self.n_sub, (c + 1) * self.n_sub)
+        if not self.grid:
+            return torch.cat([x[rows] for x in xs], dim=1)
+        fw = xs[0].size(1) // self.p_c
+        stacked = torch.stack([x[rows].reshape(self.n_sub, self.p_c, fw) for x in xs], dim=2)   # [n_sub, p_c, G, fw]
+        slices = stacked.permute(1, 0, 2, 3).reshape(self.p_c, self.n_sub, len(xs) * fw)
         return slices.repeat(self.p_r, 1, 1)
 
-    def group_splits(self):
-        """dim-0 split sizes of the exchange inside my row group (1 chunk per member, 0 for everyone else)."""
-        g = self.row_group()
-        return [1 if d in g else 0 for d in range(self.world_size)]
+    def _merge(self, recv: Tensor, groups: int) -> List[Tensor]:
+        """recv [R, world, n_rsub, G * fw] (chunk s of return exchange r = rows (block i', chunk r) of MY range x
+        column slice j' from rank s = i' * p_c + j') -> per group the [n_pad, F] rows in local order
+        i' * n_blk + r * n_rsub + t."""
+        fw = recv.size(-1) // groups
+        v = recv.view(self.return_chunks, self.p_r, self.p_c, self.n_rsub, groups, fw)
+        v = v.permute(4, 1, 0, 3, 2, 5).reshape(groups, self.plan.n_pad, self.p_c * fw)
+        return [v[g] for g in range(groups)]
 
-    def row_group(self):
-        return range(self.i * self.p_c, (self.i + 1) * self.p_c)
+    # ---- the propagate ------------------------------------------------------------------------------
+    def run(self, xs: Sequence[Tensor], op, alpha: float = 1.0) -> List[Tensor]:
+        """xs: G local [n_pad, F] feature groups.  op: a dual PhasedOperator (G = 2) or a list of G single ones.
+        Returns G local [n_pad, F] products."""
+        plan, world, groups = self.plan, self.plan.world_size, len(xs)
+        dual = isinstance(op, PhasedOperator)
+        if dual and (not op.dual or groups != 2):
+            raise ValueError("a dual operator takes exactly two feature groups")
+        f = xs[0].size(1)
+        if self.grid and f % self.p_c:
+            raise ValueError(f"width {f} does not split into {self.p_c} column slices")
+        fw = f // self.p_c
+        ev = self._events()
+        self._mark(ev, "start")
+        works, bufs = [], []
+        for c in range(self.phases):                         # every exchange is issued before any product
+            send = self._pack(xs, c)
+            buf = send.new_empty((world, self.n_sub, groups * fw))
+            works.append(self.ex.all_to_all(buf, send) if self.grid else self.ex.all_gather(buf, send))
+            bufs.append(buf)
+        self._mark(ev, "packed")
+        ys = [xs[0].new_empty((self.block_rows, fw)) for _ in range(groups)]
+        chunk_rows = world * self.n_rsub
+        returns, recv = [], None
+        if self.grid:
+            recv = xs[0].new_empty((self.return_chunks, world, self.n_rsub, groups * fw))
+        for c in range(self.phases):
+            works[c].wait()
+            self._mark(ev, "arrived")
+            buf = bufs[c].view(world * self.n_sub, groups * fw)
+            last = c == self.phases - 1
+            spans = [(r * chunk_rows, (r + 1) * chunk_rows) for r in range(self.return_chunks)] \
+                if (last and self.grid) else [(0, self.block_rows)]
+            for r, (lo, hi) in enumerate(spans):
+                if dual:
+                    csr, (va, vb) = op.blocks[c]
+                    self.dual_kernel(csr, va, vb, buf[:, :fw], buf[:, fw:], ys[0], ys[1], lo, hi, alpha, c > 0)
+                else:
+                    for g in range(groups):
+                        csr, (val,) = op[g].blocks[c]
+                        self.single_kernel(csr, val, buf[:, g * fw:(g + 1) * fw], ys[g], lo, hi, alpha, c > 0,
+                                           op[g].mean)
+                if last and self.grid:                       # chunk r goes home while chunk r + 1 is multiplied
+                    pack = torch.cat([y[lo:hi] for y in ys], dim=1).view(world, self.n_rsub, groups * fw)
+                    returns.append(self.ex.all_to_all(recv[r], pack))
+            self._mark(ev, "multiplied")
+        if not self.grid:
+            self._mark(ev, "end")
+            return ys
+        for w in returns:
+            w.wait()
+        self._mark(ev, "returned")
+        out = self._merge(recv, groups)
+        self._mark(ev, "end")
+        return out
 
-    def merge_slices(self, recv: Tensor):
-        """[p_c, n_pad, 2 fc] (source rank j' of my row group -> its column slice of MY rows) -> row-layout
-        pair [n_pad, F], [n_pad, F]."""
-        n, fc = recv.size(1), self.fc
-        r = recv.reshape(self.p_c, n, 2, fc).permute(2, 1, 0, 3).reshape(2, n, self.p_c * fc)
-        return r[0], r[1]
+    # ---- instrumentation (bench.py / tools/emulate_sharded.py) ------------------------------------
+    def profile(self, on: bool = True):
+        self.timing = [] if on else None
 
-
-def exchange(out: Tensor, inp: Tensor, out_splits=None, in_splits=None, group=None) -> Tensor:
-    """all_to_all_single along dim 0 (splits in dim-0 units, None = equal): chunk d of `inp` goes to rank d,
-    chunk s of `out` comes from rank s; a split of 0 = nothing to exchange with that peer.  RCCL runs it as
-    one grouped send/recv.  gloo has no device all-to-all, so device tensors are staged through the host there
-    (test configurations only)."""
-    if dist.get_backend(group) == "gloo" and inp.is_cuda:
-        host = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(host, inp.cpu(), out_splits, in_splits, group=group)
-        out.copy_(host)
-    else:
-        dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=group)
-    return out
-
-
-def collect_slices(plan: "GridPlan", a_loc: Tensor, b_loc: Tensor, group=None) -> Tensor:
-    """Row-layout pair [n_pad, F] x 2 -> packed column slice j of ALL rows, [n_total, 2 fc] = (real | imag)."""
-    full = a_loc.new_empty((plan.world_size, plan.n_pad, 2 * plan.fc))
-    exchange(full, plan.slice_chunks(a_loc, b_loc), group=group)
-    return full.view(plan.n_total, 2 * plan.fc)
-
-
-def return_rows(plan: "GridPlan", ya: Tensor, yb: Tensor, group=None) -> Tuple[Tensor, Tensor]:
-    """(row block i, column slice j) products [p_c * n_pad, fc] x 2 -> node-range ownership [n_pad, F] x 2: inside
-    the row group, rank (i, j) hands rank (i, j') the rows of node block i * p_c + j' and receives the other
-    column slices of its own rows."""
-    pack = torch.cat([ya, yb], dim=1).view(plan.p_c, plan.n_pad, 2 * plan.fc)
-    recv = pack.new_empty((plan.p_c, plan.n_pad, 2 * plan.fc))
-    splits = plan.group_splits()
-    exchange(recv, pack, splits, splits, group)
-    return plan.merge_slices(recv)
-
-
-class _ShardedSpmmFn(torch.autograd.Function):
-    """y_local = S[my target rows, :] x  with x gathered from all ranks; backward
-    dx_local = S^T[my source rows, :] dy with dy gathered.  fp32 or bf16 storage (bf16 halves the
-    exchanged bytes as well as the gathered ones)."""
+    def _events(self):
+        if self.timing is None:
+            return None
+        self.timing.append([])
+        return self.timing[-1]
 
     @staticmethod
-    def forward(ctx, x_local, op):
-        from .sparse import _spmm_raw
-        full = all_gather_rows(x_local, op.group)
-        ctx.op = op
-        return _spmm_raw(op.fwd_csr, op.fwd_val, full, None, 1.0, 0.0, op.mean)
+    def _mark(ev, name):
+        if ev is not None and torch.cuda.is_available():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev.append((name, e))
+
+    def timing_summary(self) -> Optional[dict]:
+        """Per-propagate averages over the profiled runs (milliseconds on the compute stream):
+        total, pack, wait_in (compute stream stalled on an inbound exchange), product, wait_out + merge."""
+        if not self.timing:
+            return None
+        torch.cuda.synchronize()
+        acc = {"total_ms": 0.0, "pack_ms": 0.0, "wait_in_ms": 0.0, "product_ms": 0.0, "wait_out_ms": 0.0, "merge_ms": 0.0}
+        runs = 0
+        for ev in self.timing:
+            if not ev or ev[-1][0] != "end":
+                continue
+            runs += 1
+            acc["total_ms"] += ev[0][1].elapsed_time(ev[-1][1])
+            for (na, ea), (nb, eb) in zip(ev[:-1], ev[1:]):
+                dt = ea.elapsed_time(eb)
+                key = {"packed": "pack_ms", "arrived": "wait_in_ms", "multiplied": "product_ms",
+                       "returned": "wait_out_ms", "end": "merge_ms"}[nb]
+                acc[key] += dt
+        if not runs:
+            return None
+        out = {k: v / runs for k, v in acc.items()}
+        out["propagates"] = runs
+        out["exposed_exchange_ms"] = out["wait_in_ms"] + out["wait_out_ms"]
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# layout choice
+# ------------------------------------------------------------------------------------------------
+def choose_cols(world_size: int, n_feat: int) -> int:
+    """Largest p_c <= 4 dividing the world with 16-byte-aligned column slices (fw % 4 == 0): two packed slices
+    of >= 16 floats still fill the 128-byte line a gather costs anyway.  Received volume relative to one full
+    feature pair: rows (1 - 1/P); grid (1 - 1/P) / p_c in + (1 - 1/P) / p_c back.  A 1 x 2 grid on two ranks
+    moves exactly what the all-gather moves, so two ranks stay in the row layout."""
+    for p_c in (4, 2):
+        if world_size % p_c == 0 and world_size > p_c - 1 + (p_c == 2) and n_feat % (4 * p_c) == 0:
+            return p_c
+    return 1
+
+
+def _env_int(name: str, default: int) -> int:
+    try:
+        return max(int(os.environ.get(name, default)), 1)
+    except ValueError:
+        return default
+
+
+def default_pipeline(world_size: int, grid: bool) -> Tuple[int, int]:
+    """(phases, return chunks): 2 x 2 when there is an exchange to hide (PYGSD_SHARD_PHASES /
+    PYGSD_SHARD_RETURN_CHUNKS override)."""
+    if world_size == 1:
+        return 1, 1
+    return _env_int("PYGSD_SHARD_PHASES", 2), (_env_int("PYGSD_SHARD_RETURN_CHUNKS", 2) if grid else 1)
+
+
+def make_plan(num_nodes: int, exchange, edge_index: Optional[Tensor], p_c: int, phases: int, return_chunks: int,
+              balance: bool = True) -> ShardPlan:
+    """Equal-work ranges from the edge list (identical on every rank: rank 0's bounds are broadcast)."""
+    world, rank = exchange.world_size, exchange.rank
+    bounds = None
+    if balance and edge_index is not None and world > 1:
+        bounds = balanced_bounds(degree_cost(edge_index, num_nodes), world)
+        bounds = exchange.broadcast_list(bounds, 0)
+    return ShardPlan(num_nodes, world, rank, bounds, PropagateEngine.alignment(world, p_c, phases, return_chunks))
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd wrappers
+# ------------------------------------------------------------------------------------------------
+class _ShardedProduct(torch.autograd.Function):
+    """ys = S xs on the forward operator, d xs = S^T d ys on the transposed one (local rows in, local rows
+    out; the exchanges live inside the engine)."""
+
+    @staticmethod
+    def forward(ctx, engine, op_fwd, op_bwd, *xs):
+        ctx.engine, ctx.op_bwd = engine, op_bwd
+        return tuple(engine.run([x.contiguous() for x in xs], op_fwd))
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_local):
-        from .sparse import _spmm_raw
-        op = ctx.op
-        full = all_gather_rows(g_local.contiguous(), op.group)
-        return _spmm_raw(op.bwd_csr, op.bwd_val, full, None, 1.0, 0.0, False), None
+    def backward(ctx, *gs):
+        out = ctx.engine.run([g.contiguous() for g in gs], ctx.op_bwd)
+        return (None, None, None) + tuple(out)
 
 
-class ShardedOperator:
-    """A COO operator out[scatter] += w * x[gather] sharded by node range: this rank keeps the by-target
-    rows of its nodes (forward) and the by-source rows of its nodes (backward), both with GLOBAL column ids
-    into the all-gathered feature matrix.  `apply(x_local)` is differentiable w.r.t. x_local."""
-
-    def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, group=None,
-                 flow: str = "source_to_target", reduce: str = "add"):
-        from .sparse import csr_from_coo, gather_values
-        self.group = group
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-        self.plan = plan = ShardPlan(num_nodes, world, rank)
-        g, s = (0, 1) if flow == "source_to_target" else (1, 0)
-        coo = torch.stack([edge_index[g], edge_index[s]])            # row 0 = gather (source), row 1 = scatter
-        self.mean = reduce == "mean"
-        keep_t, sub_t = plan.local_entries(coo, by=1)
-        self.fwd_csr = csr_from_coo(sub_t[1], sub_t[0], plan.n_pad, plan.n_total)
-        keep_s, sub_s = plan.local_entries(coo, by=0)
-        self.bwd_csr = csr_from_coo(sub_s[0], sub_s[1], plan.n_pad, plan.n_total)
-        w = edge_weight
-        if self.mean:                                                  # backward of mean: 1 / in-degree per entry
-            deg = torch.zeros(plan.n_total, dtype=torch.float32, device=coo.device).index_add_(
-                0, coo[1], torch.ones(coo.size(1), dtype=torch.float32, device=coo.device)).clamp(min=1)
-            inv = (1.0 / deg)[coo[1]]
-            wb = inv if w is None else w.float() * inv
-        else:
-            wb = w
-        self.fwd_val = None if w is None else gather_values(w[keep_t], self.fwd_csr.perm)
-        self.bwd_val = None if wb is None else gather_values(wb[keep_s], self.bwd_csr.perm)
-        self.local_nnz = int(keep_t.numel())
-
-    def apply(self, x_local: Tensor) -> Tensor:
-        return _ShardedSpmmFn.apply(x_local, self)
-
-
-class ShardedDiGCNConv(torch.nn.Module):
-    """DiGCNConv (out = S^T (x W) + b, reference nn/directed/DiGCNConv.py:54-94) over a node-range-sharded
-    graph; fp32 or bf16 (`.to(torch.bfloat16)`: BASELINE config "DiGCN_Inception_Block ... bf16, 8xMI355X").
-    Parameters are replicated; their gradients are all-reduced by hooks during backward."""
-
-    def __init__(self, in_channels: int, out_channels: int, num_nodes: int, edge_index: Tensor,
-                 edge_weight: Tensor, bias: bool = True, device=None, group=None):
-        super().__init__()
-        from .nn import DiGCNConv
-        proto = DiGCNConv(in_channels, out_channels, bias=bias)
-        self.weight, self.bias = proto.weight, proto.bias
-        self.in_channels, self.out_channels = in_channels, out_channels
-        device = device or edge_index.device
-        self.to(device)
-        if edge_weight is None:
-            raise RuntimeError('Normalized adj matrix cannot be None. Please obtain the adj matrix in preprocessing.')
-        self.op = ShardedOperator(edge_index.to(device), edge_weight.to(device), num_nodes, group)
-        self.plan, self.group = self.op.plan, group
-        for prm in self.parameters():
-            prm.register_hook(self._allreduce)
-
-    def _allreduce(self, grad):
-        grad = grad.contiguous()
-        dist.all_reduce(grad, group=self.group)
-        return grad
-
-    def shard_rows(self, x: Tensor) -> Tensor:
-        return self.plan.shard_rows(x)
-
-    def forward(self, x_local: Tensor) -> Tensor:
-        from .dense import tall_linear
-        out = self.op.apply(tall_linear(x_local, self.weight))
-        return out if self.bias is None else out + self.bias
+def _mask_pad_rows(plan: ShardPlan, *ts: Tensor):
+    """Upstream gradients of the pad rows are not part of the graph: zero them (out of place)."""
+    if plan.n_local == plan.n_pad:
+        return ts
+    out = []
+    for t in ts:
+        t = t.clone()
+        t[plan.n_local:] = 0
+        out.append(t)
+    return tuple(out)
 
 
 class _ShardedMagneticFn(torch.autograd.Function):
-    """Forward / backward of one node-sharded MagNetConv layer (local rows only)."""
-
-    @staticmethod
-    def forward(ctx, x_real, x_imag, weight, bias, layer):
-        from .dense import dense_fwd_raw
-        from .sparse import _spmm2_raw
-        k1, f = weight.size(0), x_real.size(1)
-        ta, tb = [x_real.contiguous()], [x_imag.contiguous()]
-        csr, vr, vi = layer._fwd_csr, layer._fwd_vals[0], layer._fwd_vals[1]
-        for k in range(1, k1):
-            full = all_gather_rows(pack_pair(ta[k - 1], tb[k - 1]), layer.group)
-            if k == 1:
-                ya, yb = _spmm2_raw(csr, vr, vi, full[:, :f], full[:, f:], None, None, 1.0, 0.0)
-            else:
-                ya, yb = _spmm2_raw(csr, vr, vi, full[:, :f], full[:, f:], ta[k - 2], tb[k - 2], 2.0, -1.0)
-            ta.append(ya)
-            tb.append(yb)
-        out_r, out_i = layer._dense_fwd(ta, tb, weight, bias)
-        ctx.layer, ctx.k1, ctx.has_bias = layer, k1, bias is not None
-        ctx.save_for_backward(weight, *ta, *tb)
-        return out_r, out_i
-
-    @staticmethod
-    @torch.autograd.function.once_differentiable
-    def backward(ctx, g_r, g_i):
-        from .sparse import _spmm2_raw
-        layer, k1 = ctx.layer, ctx.k1
-        saved = ctx.saved_tensors
-        weight = saved[0]
-        ta, tb = list(saved[1:1 + k1]), list(saved[1 + k1:1 + 2 * k1])
-        da, db, dw, dbias = layer._dense_bwd(ta, tb, weight, g_r, g_i)
-        f = da[0].size(1)
-        csr, vr, vi = layer._bwd_csr, layer._bwd_vals[0], layer._bwd_vals[1]
-        gx_r = gx_i = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            for k in range(k1 - 1, 1, -1):
-                full = all_gather_rows(pack_pair(da[k], db[k]), layer.group)
-                da[k - 1], db[k - 1] = _spmm2_raw(csr, vr, vi, full[:, :f], full[:, f:], da[k - 1], db[k - 1],
-                                                  2.0, 1.0)
-                da[k - 2].sub_(da[k])
-                db[k - 2].sub_(db[k])
-            if k1 > 1:
-                full = all_gather_rows(pack_pair(da[1], db[1]), layer.group)
-                gx_r, gx_i = _spmm2_raw(csr, vr, vi, full[:, :f], full[:, f:], da[0], db[0], 1.0, 1.0)
-            else:
-                gx_r, gx_i = da[0], db[0]
-        # parameter gradients: sum of the per-shard partials
-        dist.all_reduce(dw, group=layer.group)
-        if ctx.has_bias:
-            dist.all_reduce(dbias, group=layer.group)
-        return gx_r, gx_i, dw, (dbias if ctx.has_bias else None), None
-
-
-class _GridMagneticFn(torch.autograd.Function):
-    """One MagNetConv layer in the grid layout (GridPlan): per Chebyshev order one slice exchange, one dual
-    SpMM over (row block i) x (column slice j), one exchange back to node-range ownership."""
+    """Forward / backward of one node-sharded MagNetConv / MSConv layer (local rows only): the Chebyshev
+    recurrence over engine products, the fused MFMA dense stage on the local rows, dW / db all-reduced."""
 
     @staticmethod
     def forward(ctx, x_real, x_imag, weight, bias, layer):
         k1 = weight.size(0)
+        eng = layer.engine
         ta, tb = [x_real.contiguous()], [x_imag.contiguous()]
-        mine = []                                     # T_k restricted to (row block i, column slice j), packed
         for k in range(1, k1):
-            full = layer._collect_slices(ta[k - 1], tb[k - 1])
-            mine.append(layer._own_block(full))
-            z = mine[k - 2] if k >= 2 else None
-            ya, yb = layer._grid_product(full, z, 1.0 if k == 1 else 2.0, 0.0 if k == 1 else -1.0, False)
-            ra, rb = layer._return_rows(ya, yb)
-            ta.append(ra)
-            tb.append(rb)
+            ya, yb = eng.run([ta[k - 1], tb[k - 1]], layer.op_fwd, 1.0 if k == 1 else 2.0)
+            if k >= 2:                                      # T_k = 2 S T_{k-1} - T_{k-2} on the local rows
+                ya, yb = ya - ta[k - 2], yb - tb[k - 2]
+            ta.append(ya.contiguous())
+            tb.append(yb.contiguous())
         out_r, out_i = layer._dense_fwd(ta, tb, weight, bias)
         ctx.layer, ctx.k1, ctx.has_bias = layer, k1, bias is not None
         ctx.save_for_backward(weight, *ta, *tb)
@@ -348,120 +599,154 @@ class _GridMagneticFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         weight = saved[0]
         ta, tb = list(saved[1:1 + k1]), list(saved[1 + k1:1 + 2 * k1])
+        g_r, g_i = _mask_pad_rows(layer.plan, g_r.contiguous(), g_i.contiguous())
         da, db, dw, dbias = layer._dense_bwd(ta, tb, weight, g_r, g_i)
         gx_r = gx_i = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             # d T_{k-1} += 2 S^T d T_k ; d T_{k-2} -= d T_k   (k = K .. 2), then gX = d T_0 + S^T d T_1
+            eng = layer.engine
             for k in range(k1 - 1, 0, -1):
-                full = layer._collect_slices(da[k], db[k])
-                ya, yb = layer._grid_product(full, None, 2.0 if k >= 2 else 1.0, 0.0, True)
-                ra, rb = layer._return_rows(ya, yb)
+                ra, rb = eng.run([da[k], db[k]], layer.op_bwd, 2.0 if k >= 2 else 1.0)
                 da[k - 1] = da[k - 1] + ra
                 db[k - 1] = db[k - 1] + rb
                 if k >= 2:
                     da[k - 2] = da[k - 2] - da[k]
                     db[k - 2] = db[k - 2] - db[k]
             gx_r, gx_i = da[0], db[0]
-        dist.all_reduce(dw, group=layer.group)
+        layer.exchange.all_reduce(dw)                       # parameter gradients: sum of the per-shard partials
         if ctx.has_bias:
-            dist.all_reduce(dbias, group=layer.group)
+            layer.exchange.all_reduce(dbias)
         return gx_r, gx_i, dw, (dbias if ctx.has_bias else None), None
 
 
-class ShardedMagNetConv(torch.nn.Module):
-    """MagNetConv over a node-range-sharded graph: each rank owns the rows [lo, hi) of the features (inputs,
-    outputs, dense stage).  Parameters are replicated (same seed => same init on every rank); their gradients
-    come back all-reduced.  forward(x_real_local, x_imag_local) -> local output rows.
+# ------------------------------------------------------------------------------------------------
+# operator builders (HIP)
+# ------------------------------------------------------------------------------------------------
+def _incident(pid: Tensor, lo: int, hi: int, stride: int, width: int) -> Tensor:
+    """Edges with an endpoint among the padded ids {g * stride + [lo, hi) for every g} (width = hi - lo)."""
+    a, b = pid[0] % stride, pid[1] % stride
+    return ((a >= lo) & (a < hi)) | ((b >= lo) & (b < hi))
 
-    layout = "rows": every rank multiplies its own operator rows with the all-gathered features.
-    layout = "grid": p_r x p_c process grid (GridPlan, see the module docstring) -- 1 / p_c of the exchange
-                     volume at the same gather efficiency.
-    layout = "auto" (default): grid whenever the input width splits into 16-byte-aligned column slices.
-    """
+
+def build_magnetic_rows(proto, edge_index: Tensor, edge_weight: Optional[Tensor], plan: ShardPlan, engine, q: float,
+                        normalization: Optional[str], lambda_max: float, exchange, how: str = "distributed"):
+    """The rows of the scaled magnetic operator this rank multiplies (`engine.block_row_ids`, padded ids), both
+    orientations: -> (CSR, (vf_real, vf_imag), (vb_real, vb_imag), global nnz).
+
+    how = "distributed": no rank ever builds the whole operator.  (1) every rank runs the HIP pipeline
+    (symmetrise -> sort -> merge -> degree) on the edges incident to its OWNED nodes, which gives the exact
+    degree of those nodes; the degrees are all-gathered (N floats).  (2) it runs the pipeline on the edges
+    incident to the rows it MULTIPLIES (the same set in the row layout), overrides the degree with the global
+    one, evaluates the values and assembles the CSR; only the wanted rows are kept.  The rows are complete, in
+    the same (row, col) order and with the same summation order as the single-GPU build.
+    how = "global": build the whole operator, slice (single-process rehearsal; cross-check in the tests)."""
+    from .utils._laplacian import assemble_operator_csr, laplacian_parts, laplacian_values
+    dev = edge_index.device
+    pid = plan.to_padded(edge_index)
+    kw = proto._laplacian_kwargs()
+    rows = engine.block_row_ids(dev)
+    w = edge_weight
+    if how == "global" or exchange.world_size == 1:
+        parts = laplacian_parts(pid, w, plan.n_total, dtype=torch.float32, **kw)
+    else:
+        own = ((pid[0] >= plan.pad_lo) & (pid[0] < plan.pad_lo + plan.n_pad)) | \
+              ((pid[1] >= plan.pad_lo) & (pid[1] < plan.pad_lo + plan.n_pad))
+        mine = laplacian_parts(pid[:, own].contiguous(), None if w is None else w[own], plan.n_total,
+                               dtype=torch.float32, **kw)
+        deg = torch.empty((exchange.world_size, plan.n_pad), dtype=torch.float32, device=dev)
+        exchange.all_gather(deg, mine.deg[plan.pad_lo:plan.pad_lo + plan.n_pad].contiguous()).wait()
+        if engine.grid:
+            lo = engine.i * engine.n_blk
+            need = _incident(pid, lo, lo + engine.n_blk, plan.n_pad, engine.n_blk)
+            parts = laplacian_parts(pid[:, need].contiguous(), None if w is None else w[need], plan.n_total,
+                                    dtype=torch.float32, **kw)
+        else:
+            parts = mine
+        parts.deg = deg.view(-1)
+    off_r, off_i, diag, mir_r, mir_i = laplacian_values(parts, q, normalization, mirror=True)
+    csr, vf, vb = assemble_operator_csr(parts, off_r, off_i, mir_r, mir_i, diag, float(lambda_max), -1.0)
+    sub, vals = take_rows(csr, (vf[0], vf[1], vb[0], vb[1]), rows)
+    # entries of the whole operator: every row block counted once (by its column-slice-0 rank)
+    local = torch.tensor([float(sub.nnz) if engine.j == 0 else 0.0], dtype=torch.float64, device=dev)
+    global_nnz = int(exchange.all_reduce(local).item()) - (plan.n_total - plan.num_nodes)
+    return sub, (vals[0], vals[1]), (vals[2], vals[3]), global_nnz
+
+
+# ------------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------------
+class ShardedMagNetConv(torch.nn.Module):
+    """MagNetConv / MSConv (signed=True) over a node-range-sharded graph: each rank owns the rows
+    [plan.lo, plan.hi) of the features (inputs, outputs, dense stage).  Parameters are replicated (same seed =>
+    same init on every rank); their gradients come back all-reduced.
+    forward(x_real_local, x_imag_local) -> local output rows ([n_pad, F]; `shard_rows` / `plan.unshard_rows`).
+
+    layout = "rows" | "grid" | "auto" (grid whenever the width splits into 16-byte column slices and there are
+    more than two ranks); phases / return_chunks: the pipeline depth (module docstring; default 2 / 2);
+    balance: equal-work node ranges instead of equal-size ones; lambda_max: as the reference's forward argument
+    (default 2.0 for 'sym'; normalization=None computes it with eigsh on the whole edge list, like MagNetConv);
+    exchange: a DistExchange (default, over `group`) or an EmulatedExchange; build: "distributed" (default: no
+    rank assembles the whole operator) or "global" (build everything, keep the rows).
+    Reference: nn/directed/MagNetConv.py:122-249, nn/general/MSConv.py:121-230 (the layer); no reference
+    counterpart for the sharding."""
 
     def __init__(self, in_channels: int, out_channels: int, K: int, q: float, num_nodes: int,
-                 edge_index: Tensor, edge_weight: Optional[Tensor] = None, normalization: str = "sym",
+                 edge_index: Tensor, edge_weight: Optional[Tensor] = None, normalization: Optional[str] = "sym",
                  bias: bool = True, device=None, group=None, signed: bool = False,
-                 absolute_degree: bool = True, layout: str = "auto", grid_cols: Optional[int] = None):
+                 absolute_degree: bool = True, layout: str = "auto", grid_cols: Optional[int] = None,
+                 phases: Optional[int] = None, return_chunks: Optional[int] = None, balance: bool = True,
+                 lambda_max: Optional[float] = None, exchange=None, build: str = "distributed", kernels=None,
+                 operator_rows=None):
         super().__init__()
         from .nn import MagNetConv, MSConv
-        from .sparse import csr_from_coo, gather_values
-        self.group = group
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self.exchange = exchange if exchange is not None else DistExchange(group)
+        self.group = getattr(self.exchange, "group", group)
+        world = self.exchange.world_size
         if layout not in ("auto", "rows", "grid"):
             raise ValueError(f"unknown layout {layout!r}")
-        p_c = grid_cols if grid_cols is not None else GridPlan.choose_cols(world, in_channels)
+        p_c = grid_cols if grid_cols is not None else choose_cols(world, in_channels)
         if layout == "auto":
             layout = "grid" if (p_c > 1 and in_channels % (4 * p_c) == 0) else "rows"
+        if layout == "rows":
+            p_c = 1
+        elif p_c <= 1 or world % p_c or in_channels % p_c:
+            raise ValueError(f"grid of {p_c} column slices does not divide world {world} / width {in_channels}")
         self.layout = layout
-        self.plan = GridPlan(num_nodes, world, rank, in_channels, p_c) if layout == "grid" \
-            else ShardPlan(num_nodes, world, rank)
+        d_ph, d_rc = default_pipeline(world, layout == "grid")
+        phases = d_ph if phases is None else int(phases)
+        return_chunks = d_rc if return_chunks is None else int(return_chunks)
         device = device or edge_index.device
+        edge_index = edge_index.to(device)
+        edge_weight = None if edge_weight is None else edge_weight.to(device)
+        self.plan = make_plan(num_nodes, self.exchange, edge_index, p_c, phases, return_chunks, balance)
+        self.engine = PropagateEngine(self.plan, self.exchange, p_c, phases, return_chunks, kernels)
         proto = (MSConv(in_channels, out_channels, K, q, False, normalization, bias, True, absolute_degree)
                  if signed else MagNetConv(in_channels, out_channels, K, q, False, normalization, True, bias))
         self.weight = proto.weight
         self.bias = proto.bias
         self.in_channels, self.out_channels = in_channels, out_channels
         self.to(device)
-        # every rank builds the global operator (degrees are global), padded to n_total isolated-extended
-        # nodes, then keeps only the entries whose produced row it owns
-        lam = torch.tensor(2.0, dtype=torch.float32, device=device)
-        op = proto._build_operator(edge_index.to(device), self.plan.n_total,
-                                   None if edge_weight is None else edge_weight.to(device), q, normalization,
-                                   lam, torch.float32)
-        if layout == "grid":
-            self._init_grid(op, num_nodes)
-            return
-        coo, vr, vi = op.coo()                                            # row 0 = source, row 1 = target
-        self.global_nnz = int(coo.size(1)) - (self.plan.n_total - num_nodes)
-        n_tot, n_pad = self.plan.n_total, self.plan.n_pad
-        keep_t, sub_t = self.plan.local_entries(coo, by=1)   # forward: rows = my targets, cols = sources
-        self._fwd_csr = csr_from_coo(sub_t[1], sub_t[0], n_pad, n_tot)
-        keep_s, sub_s = self.plan.local_entries(coo, by=0)   # backward: rows = my sources, cols = targets
-        self._bwd_csr = csr_from_coo(sub_s[0], sub_s[1], n_pad, n_tot)
-        self._fwd_vals = (gather_values(vr[keep_t], self._fwd_csr.perm), gather_values(vi[keep_t], self._fwd_csr.perm))
-        self._bwd_vals = (gather_values(vr[keep_s], self._bwd_csr.perm), gather_values(vi[keep_s], self._bwd_csr.perm))
-        self.local_nnz = int(keep_t.numel())
-        del op
-
-    # ---- grid layout -------------------------------------------------------------------------------
-    def _init_grid(self, op, num_nodes):
-        """Row block i of the shared CSR (the operator's pattern is symmetric, so the same slice with the
-        mirrored values is row block i of the transposed operator): a contiguous range of rowptr / col /
-        values -- no re-sort."""
-        from .sparse import CSR
-        plan = self.plan
-        csr = op.csr
-        lo, hi = plan.block_lo, plan.block_lo + plan.block_rows
-        e0, e1 = int(csr.rowptr[lo]), int(csr.rowptr[hi])
-        rowptr = (csr.rowptr[lo:hi + 1] - e0).contiguous()
-        self._grid_csr = CSR(plan.block_rows, plan.n_total, e1 - e0, rowptr, csr.col[e0:e1].contiguous(), None)
-        self._grid_fwd_vals = tuple(v[e0:e1].contiguous() for v in op.values_fwd)
-        self._grid_bwd_vals = tuple(v[e0:e1].contiguous() for v in op.values_bwd)
-        self.global_nnz = int(csr.nnz) - (plan.n_total - num_nodes)
-        self.local_nnz = e1 - e0
-
-    def _collect_slices(self, a_loc: Tensor, b_loc: Tensor) -> Tensor:
-        return collect_slices(self.plan, a_loc, b_loc, self.group)
-
-    def _own_block(self, full: Tensor) -> Tensor:
-        plan = self.plan
-        return full[plan.block_lo:plan.block_lo + plan.block_rows]
-
-    def _grid_product(self, full: Tensor, z: Optional[Tensor], alpha: float, beta: float, transposed: bool):
-        from .sparse import _spmm2_raw
-        fc = self.plan.fc
-        vr, vi = self._grid_bwd_vals if transposed else self._grid_fwd_vals
-        za, zb = (None, None) if z is None else (z[:, :fc], z[:, fc:])
-        return _spmm2_raw(self._grid_csr, vr, vi, full[:, :fc], full[:, fc:], za, zb, alpha, beta)
-
-    def _return_rows(self, ya: Tensor, yb: Tensor):
-        return return_rows(self.plan, ya, yb, self.group)
+        if lambda_max is None:
+            if normalization == "sym":
+                lambda_max = 2.0
+            else:     # the reference computes it from the whole Laplacian (get_magnetic_Laplacian.py:88-92)
+                lambda_max = proto._lambda_max_eigsh(edge_index, edge_weight, num_nodes)
+        self.lambda_max = float(lambda_max)
+        if operator_rows is not None:       # rows prepared by the caller (the CPU tests: no HIP build there)
+            csr, vf, vb, self.global_nnz = operator_rows(self.plan, self.engine)
+        else:
+            if self.exchange.emulated:      # a rehearsal has no peers to gather degrees from
+                build = "global"
+            csr, vf, vb, self.global_nnz = build_magnetic_rows(proto, edge_index, edge_weight, self.plan, self.engine,
+                                                              q, normalization, self.lambda_max, self.exchange, build)
+        self.local_nnz = csr.nnz
+        self.op_fwd = self.engine.phased(csr, vf, dual=True)
+        self.op_bwd = self.engine.phased(csr, vb, dual=True)
 
     # dense stage: the fused MFMA kernels when the shape is tiled by them, library GEMMs otherwise
     def _dense_fwd(self, ta, tb, weight, bias):
         from .dense import dense_fwd_raw, dense_supported
-        if dense_supported(self.in_channels, self.out_channels, weight.size(0)):
+        if ta[0].is_cuda and dense_supported(self.in_channels, self.out_channels, weight.size(0)):
             return dense_fwd_raw(ta, tb, weight, bias)
         rr = sum(torch.matmul(ta[k], weight[k]) for k in range(weight.size(0)))
         ii = sum(torch.matmul(tb[k], weight[k]) for k in range(weight.size(0)))
@@ -470,7 +755,7 @@ class ShardedMagNetConv(torch.nn.Module):
 
     def _dense_bwd(self, ta, tb, weight, g_r, g_i):
         from .dense import dense_bwd_raw, dense_supported
-        if dense_supported(self.in_channels, self.out_channels, weight.size(0)):
+        if ta[0].is_cuda and dense_supported(self.in_channels, self.out_channels, weight.size(0)):
             return dense_bwd_raw(ta, tb, weight, g_r, g_i)
         p, m = g_r + g_i, g_i - g_r
         k1 = weight.size(0)
@@ -483,9 +768,156 @@ class ShardedMagNetConv(torch.nn.Module):
         return self.plan.shard_rows(x)
 
     def forward(self, x_real_local: Tensor, x_imag_local: Tensor):
-        fn = _GridMagneticFn if self.layout == "grid" else _ShardedMagneticFn
-        return fn.apply(x_real_local, x_imag_local, self.weight, self.bias, self)
+        return _ShardedMagneticFn.apply(x_real_local, x_imag_local, self.weight, self.bias, self)
 
-    def allreduce_grads(self):
-        """Kept for API symmetry: parameter gradients are already all-reduced inside backward."""
-        return None
+
+class ShardedOperator:
+    """A COO operator out[scatter] += w * x[gather] sharded by node range in the row layout: this rank keeps the
+    by-target rows of its nodes (forward) and the by-source rows of its nodes (backward), columns = padded ids
+    into the all-gathered features.  fp32 or bf16 features (bf16 halves the exchanged bytes as well as the
+    gathered ones; its partial products would round once per phase, so bf16 runs un-phased)."""
+
+    def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], plan: ShardPlan, engine: PropagateEngine,
+                 flow: str = "source_to_target", reduce: str = "add"):
+        from .sparse import csr_from_coo, gather_values
+        if engine.grid:
+            raise ValueError("ShardedOperator multiplies its own rows: row layout only")
+        self.plan, self.engine = plan, engine
+        g, s = (0, 1) if flow == "source_to_target" else (1, 0)
+        pid = plan.to_padded(edge_index)
+        gather, scatter = pid[g], pid[s]
+        mean = reduce == "mean"
+        if mean and engine.phases > 1:
+            raise ValueError("reduce='mean' needs an un-phased engine")
+        lo, hi = plan.pad_lo, plan.pad_lo + plan.n_pad
+        keep_t = ((scatter >= lo) & (scatter < hi)).nonzero(as_tuple=True)[0]
+        fwd = csr_from_coo(scatter[keep_t] - lo, gather[keep_t], plan.n_pad, plan.n_total)
+        keep_s = ((gather >= lo) & (gather < hi)).nonzero(as_tuple=True)[0]
+        bwd = csr_from_coo(gather[keep_s] - lo, scatter[keep_s], plan.n_pad, plan.n_total)
+        w = edge_weight
+        if mean:                                                       # backward of mean: 1 / in-degree per entry
+            ones = torch.ones(pid.size(1), dtype=torch.float32, device=pid.device)
+            deg = torch.zeros(plan.n_total, dtype=torch.float32, device=pid.device).index_add_(0, scatter, ones)
+            inv = (1.0 / deg.clamp(min=1))[scatter]
+            wb = inv if w is None else w.float() * inv
+        else:
+            wb = w
+        vf = None if w is None else gather_values(w[keep_t], fwd.perm)
+        vb = None if wb is None else gather_values(wb[keep_s], bwd.perm)
+        self.local_nnz = int(keep_t.numel())
+        self.op_fwd = PhasedOperator(split_phases(fwd, _vals(vf, fwd), plan.n_pad, engine.phases, plan.world_size),
+                                     False, mean)
+        self.op_bwd = PhasedOperator(split_phases(bwd, _vals(vb, bwd), plan.n_pad, engine.phases, plan.world_size),
+                                     False)
+
+
+def _vals(v: Optional[Tensor], csr: CSR) -> Tuple[Tensor]:
+    if v is None:
+        v = torch.ones(csr.nnz, dtype=torch.float32, device=csr.col.device)
+    return (v,)
+
+
+class ShardedDiGCNConv(torch.nn.Module):
+    """DiGCNConv (out = S^T (x W) + b, reference nn/directed/DiGCNConv.py:54-94) over a node-range-sharded
+    graph; fp32 or bf16 (`.to(torch.bfloat16)`: BASELINE config "DiGCN_Inception_Block ... bf16, 8xMI355X").
+    Parameters are replicated; their gradients are all-reduced by hooks during backward."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_nodes: int, edge_index: Tensor,
+                 edge_weight: Tensor, bias: bool = True, device=None, group=None, exchange=None,
+                 phases: int = 1, balance: bool = True, plan: Optional[ShardPlan] = None, kernels=None):
+        super().__init__()
+        from .nn import DiGCNConv
+        proto = DiGCNConv(in_channels, out_channels, bias=bias)
+        self.weight, self.bias = proto.weight, proto.bias
+        self.in_channels, self.out_channels = in_channels, out_channels
+        device = device or edge_index.device
+        self.to(device)
+        if edge_weight is None:
+            raise RuntimeError('Normalized adj matrix cannot be None. Please obtain the adj matrix in preprocessing.')
+        self.exchange = exchange if exchange is not None else DistExchange(group)
+        edge_index = edge_index.to(device)
+        self.plan = plan or make_plan(num_nodes, self.exchange, edge_index, 1, phases, 1, balance)
+        self.engine = PropagateEngine(self.plan, self.exchange, 1, phases, 1, kernels)
+        self.op = ShardedOperator(edge_index, edge_weight.to(device), self.plan, self.engine)
+        for prm in self.parameters():
+            prm.register_hook(self._allreduce)
+
+    def _allreduce(self, grad):
+        return self.exchange.all_reduce(grad.contiguous())
+
+    def shard_rows(self, x: Tensor) -> Tensor:
+        return self.plan.shard_rows(x)
+
+    def aggregate(self, xw_local: Tensor) -> Tensor:
+        (out,) = _ShardedProduct.apply(self.engine, [self.op.op_fwd], [self.op.op_bwd], xw_local)
+        return out
+
+    def forward(self, x_local: Tensor) -> Tensor:
+        from .dense import tall_linear
+        out = self.aggregate(tall_linear(x_local, self.weight))
+        out = out if self.bias is None else out + self.bias
+        return _zero_pad_rows(self.plan, out)
+
+
+def _zero_pad_rows(plan: ShardPlan, t: Tensor) -> Tensor:
+    if plan.n_local == plan.n_pad:
+        return t
+    mask = torch.zeros((plan.n_pad, 1), dtype=t.dtype, device=t.device)
+    mask[:plan.n_local] = 1
+    return t * mask
+
+
+class ShardedDiGCNInceptionBlock(torch.nn.Module):
+    """DiGCN_InceptionBlock (reference nn/directed/DiGCN_Inception_Block.py:9-47: x0 = Linear(x), x1 / x2 =
+    DiGCNConv on the first- / second-order proximity operators) over a node-range-sharded graph, fp32 or bf16.
+    The two convolutions share ONE exchange per propagate: the projections x W1 and x W2 are packed side by side
+    into one all-gather, and each operator reads its own column half of the gathered rows.
+    forward(x_local) -> (x0, x1, x2) local rows.  Same state_dict keys as the reference block
+    (ln.weight, ln.bias, conv1.weight, conv1.bias, conv2.weight, conv2.bias)."""
+
+    def __init__(self, in_dim: int, out_dim: int, num_nodes: int, edge_index: Tensor, edge_weight: Tensor,
+                 edge_index2: Tensor, edge_weight2: Tensor, device=None, group=None, exchange=None,
+                 phases: int = 1, balance: bool = True, kernels=None):
+        super().__init__()
+        from .nn import DiGCNConv
+        self.ln = torch.nn.Linear(in_dim, out_dim)
+        self.conv1, self.conv2 = DiGCNConv(in_dim, out_dim), DiGCNConv(in_dim, out_dim)
+        device = device or edge_index.device
+        self.to(device)
+        self.exchange = exchange if exchange is not None else DistExchange(group)
+        edge_index, edge_index2 = edge_index.to(device), edge_index2.to(device)
+        both = torch.cat([edge_index, edge_index2], dim=1)
+        self.plan = make_plan(num_nodes, self.exchange, both, 1, phases, 1, balance)
+        self.engine = PropagateEngine(self.plan, self.exchange, 1, phases, 1, kernels)
+        self.op1 = ShardedOperator(edge_index, edge_weight.to(device), self.plan, self.engine)
+        self.op2 = ShardedOperator(edge_index2, edge_weight2.to(device), self.plan, self.engine)
+        for prm in self.parameters():
+            prm.register_hook(self._allreduce)
+
+    def _allreduce(self, grad):
+        return self.exchange.all_reduce(grad.contiguous())
+
+    def shard_rows(self, x: Tensor) -> Tensor:
+        return self.plan.shard_rows(x)
+
+    def forward(self, x_local: Tensor):
+        from .dense import tall_linear
+        x0 = tall_linear(x_local, self.ln.weight.t(), self.ln.bias)
+        p1, p2 = tall_linear(x_local, self.conv1.weight), tall_linear(x_local, self.conv2.weight)
+        x1, x2 = _ShardedProduct.apply(self.engine, [self.op1.op_fwd, self.op2.op_fwd],
+                                       [self.op1.op_bwd, self.op2.op_bwd], p1, p2)
+        if self.conv1.bias is not None:
+            x1, x2 = x1 + self.conv1.bias, x2 + self.conv2.bias
+        return tuple(_zero_pad_rows(self.plan, t) for t in (x0, x1, x2))
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers kept for callers / tests
+# ------------------------------------------------------------------------------------------------
+def all_gather_rows(x_local: Tensor, group=None) -> Tensor:
+    """[n_pad, C] per rank -> [world * n_pad, C], rank-major (padded-id order under ShardPlan)."""
+    ex = DistExchange(group)
+    x_local = x_local.contiguous()
+    out = x_local.new_empty((ex.world_size,) + tuple(x_local.shape))
+    ex.all_gather(out, x_local).wait()
+    return out.view((ex.world_size * x_local.size(0),) + tuple(x_local.shape[1:]))

@@ -346,6 +346,79 @@ def _spmm2_raw(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, z
     return ya, yb
 
 
+def spmm2_rows_into(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, ya: Tensor, yb: Tensor,
+                    row_lo: int = 0, row_hi: Optional[int] = None, alpha: float = 1.0,
+                    accumulate: bool = False) -> None:
+    """Rows [row_lo, row_hi) of the dual product, written IN PLACE into preallocated outputs:
+        ya[r] = alpha * sum_e val_a[e] xa[col[e]] (+ ya[r] if accumulate), same for b.
+    The building block of the sharded, pipelined propagate (parallel.py): one launch per (column block of the
+    operator, row chunk), partial products accumulated through the kernel's own beta * Z epilogue with Z = Y
+    (each output row is read and written by the one wavefront that owns it).  fp32, F % 4 == 0."""
+    _cabi.require_gpu(xa, xb, ya, yb, val_a, val_b)
+    row_hi = csr.n_rows if row_hi is None else row_hi
+    n_rows, f = row_hi - row_lo, xa.size(1)
+    if n_rows <= 0 or f == 0:
+        return
+    if f % 4 or any(t.dtype != torch.float32 for t in (xa, xb, ya, yb)):
+        raise TypeError("spmm2_rows_into: float32 features with a width that is a multiple of 4")
+    xa, lda = _rows(xa)
+    xb, ldb = _rows(xb)
+    ldy = ya.stride(0)
+    if lda != ldb or yb.stride(0) != ldy or ya.stride(1) != 1 or yb.stride(1) != 1:
+        raise ValueError("spmm2_rows_into: operands of one product must share their row stride")
+    if csr.nnz == 0:
+        if not accumulate:
+            ya[row_lo:row_hi].zero_()
+            yb[row_lo:row_hi].zero_()
+        return
+    off_y = 4 * row_lo * ldy
+    pya, pyb = c_void_p(ya.data_ptr() + off_y), c_void_p(yb.data_ptr() + off_y)
+    with torch.cuda.device(xa.device):
+        check(_cabi.lib().pygsd_spmm2_csr_f32(c_void_p(csr.rowptr.data_ptr() + 4 * row_lo), ptr(csr.col), ptr(val_a),
+                                              ptr(val_b), ptr(xa), ptr(xb), lda, pya, pyb, ldy,
+                                              pya if accumulate else None, pyb if accumulate else None,
+                                              ldy if accumulate else 0, n_rows, f, float(alpha),
+                                              1.0 if accumulate else 0.0, csr.nnz, None, stream_ptr()),
+              "pygsd_spmm2_csr_f32")
+
+
+def spmm_rows_into(csr: CSR, val: Optional[Tensor], x: Tensor, y: Tensor, row_lo: int = 0,
+                   row_hi: Optional[int] = None, alpha: float = 1.0, accumulate: bool = False,
+                   mean: bool = False) -> None:
+    """Single-operator form of `spmm2_rows_into`; float32 (F % 4 == 0) or bfloat16 storage (F % 8 == 0, fp32
+    values and accumulation).  `mean` divides by the row's entry count and is only meaningful for an operator
+    that is NOT split into column blocks."""
+    _cabi.require_gpu(x, y, val)
+    row_hi = csr.n_rows if row_hi is None else row_hi
+    n_rows, f = row_hi - row_lo, x.size(1)
+    if n_rows <= 0 or f == 0:
+        return
+    bf16 = x.dtype == torch.bfloat16
+    if x.dtype != y.dtype or x.dtype not in (torch.float32, torch.bfloat16) or f % (8 if bf16 else 4):
+        raise TypeError("spmm_rows_into: float32 (F % 4 == 0) or bfloat16 (F % 8 == 0) features, same dtype in and out")
+    x, ldx = _rows(x)
+    ldy = y.stride(0)
+    if y.stride(1) != 1:
+        raise ValueError("spmm_rows_into: output rows must have unit inner stride")
+    if csr.nnz == 0:
+        if not accumulate:
+            y[row_lo:row_hi].zero_()
+        return
+    esz = 2 if bf16 else 4
+    py = c_void_p(y.data_ptr() + esz * row_lo * ldy)
+    rp = c_void_p(csr.rowptr.data_ptr() + 4 * row_lo)
+    z, ldz, beta = (py, ldy, 1.0) if accumulate else (None, 0, 0.0)
+    with torch.cuda.device(x.device):
+        if bf16:
+            check(_cabi.lib().pygsd_spmm_csr_bf16(rp, ptr(csr.col), ptr(val), ptr(x), ldx, py, ldy, z, ldz, n_rows, f,
+                                                  float(alpha), beta, 1 if mean else 0, stream_ptr()),
+                  "pygsd_spmm_csr_bf16")
+        else:
+            check(_cabi.lib().pygsd_spmm_csr_f32(rp, ptr(csr.col), ptr(val), ptr(x), ldx, py, ldy, z, ldz, n_rows, f,
+                                                 float(alpha), beta, 1 if mean else 0, csr.nnz, None, stream_ptr()),
+                  "pygsd_spmm_csr_f32")
+
+
 def _sddmm_raw(ia: Tensor, ib: Tensor, a: Tensor, b: Tensor) -> Tensor:
     """out[e] = <a[ia[e]], b[ib[e]]>."""
     _cabi.require_gpu(ia, ib, a, b)

@@ -1,8 +1,8 @@
-"""CPU, world_size 2 and 3, gloo: the node-range sharding plan and the all-gather exchange of
-pytorch_geometric_signed_directed_amd.parallel.  Each rank keeps only the operator rows it
-produces, gathers the packed (real | imag) feature blocks, evaluates its local rows with the ORACLE
-(the HIP kernels cannot run here) and must reproduce exactly the rows of the un-sharded oracle
-result -- forward and backward (dX = by-source rows x gathered upstream gradient)."""
+"""CPU, gloo, 2 .. 8 ranks: the node-range sharding of pytorch_geometric_signed_directed_amd.parallel end to end --
+equal-work ownership plan, padded ids, column phases, interleaved row blocks, row-chunked returns, packing,
+both exchanges, merges, the Chebyshev recurrence / its adjoint over exchanged blocks, parameter all-reduce -- with
+the two product kernels swapped for torch restatements (tests/sharding_cpu.py) and the operator rows taken
+from the oracle.  Every rank must reproduce its rows of the UN-SHARDED oracle layer, outputs and gradients."""
 import os
 import socket
 
@@ -12,15 +12,21 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import ref_layers as R
-from pytorch_geometric_signed_directed_amd.parallel import ShardPlan, all_gather_rows, pack_pair
+from pytorch_geometric_signed_directed_amd.parallel import (PropagateEngine, ShardPlan, balanced_bounds, choose_cols,
+                                                            degree_cost, split_phases, take_rows)
+from pytorch_geometric_signed_directed_amd.sparse import CSR
+import sharding_cpu as C
 
 
-def test_plan_partitions_every_node_once():
-    for n, w in [(10, 2), (11, 3), (7, 8), (1000, 8), (1, 2)]:
+# ------------------------------------------------------------------------------------------------
+# single-process: plan, CSR surgery, engine geometry
+# ------------------------------------------------------------------------------------------------
+def test_plan_partitions_every_node_once_and_pads():
+    for n, w, align in [(10, 2, 1), (11, 3, 4), (7, 8, 2), (1000, 8, 8), (1, 2, 1)]:
         seen = []
         for r in range(w):
-            p = ShardPlan(n, w, r)
-            assert p.n_total >= n and p.n_total - n < w
+            p = ShardPlan(n, w, r, align=align)
+            assert p.n_pad % align == 0 and p.n_total == w * p.n_pad and p.n_pad >= max(p.sizes)
             seen += list(range(p.lo, p.hi))
             x = torch.arange(n, dtype=torch.float32).unsqueeze(1)
             s = p.shard_rows(x)
@@ -29,142 +35,216 @@ def test_plan_partitions_every_node_once():
         assert seen == list(range(n))
 
 
-def test_local_entries_rebase():
-    ei = torch.tensor([[0, 5, 9, 3, 7], [9, 0, 4, 3, 8]])
-    p = ShardPlan(10, 2, 1)                      # owns [5, 10)
-    keep, sub = p.local_entries(ei, by=1)
-    assert keep.tolist() == [0, 4] and sub.tolist() == [[0, 7], [4, 3]]
-    keep, sub = p.local_entries(ei, by=0)
-    assert keep.tolist() == [1, 2, 4] and sub.tolist() == [[0, 4, 2], [0, 4, 8]]
+def test_padded_ids_round_trip_with_uneven_and_empty_ranges():
+    p = ShardPlan(10, 4, 2, bounds=[0, 5, 5, 6, 10], align=3)
+    assert p.sizes == [5, 0, 1, 4] and p.n_pad == 6 and (p.lo, p.hi, p.n_local, p.pad_lo) == (5, 6, 1, 12)
+    ids = torch.arange(10)
+    assert p.to_padded(ids).tolist() == [0, 1, 2, 3, 4, 12, 18, 19, 20, 21]
+    x = torch.randn(10, 3)
+    gathered = torch.cat([ShardPlan(10, 4, r, bounds=p.bounds, align=3).shard_rows(x) for r in range(4)])
+    assert torch.equal(p.unshard_rows(gathered), x)
+    with pytest.raises(ValueError):
+        ShardPlan(10, 2, 0, bounds=[0, 11, 10])
 
 
+def test_balanced_bounds_equalise_work_not_size():
+    """A graph whose first nodes carry almost all the edges (an un-permuted SBM with a dense block): equal-size
+    ranges put ~all the entries on rank 0, equal-work ranges spread them (SURVEY.md 8(e) "Load balance")."""
+    g = torch.Generator().manual_seed(0)
+    n, world = 4000, 4
+    heavy = torch.randint(0, 400, (2, 36000), generator=g)
+    light = torch.randint(0, n, (2, 4000), generator=g)
+    ei = torch.cat([heavy, light], dim=1)
+    cost = degree_cost(ei, n)
+    bounds = balanced_bounds(cost, world)
+    work = [float(cost[bounds[r]:bounds[r + 1]].sum()) for r in range(world)]
+    even = [float(cost[r * 1000:(r + 1) * 1000].sum()) for r in range(world)]
+    assert max(work) / (sum(work) / world) < 1.05 < 3.0 < max(even) / (sum(even) / world)
+    assert bounds[0] == 0 and bounds[-1] == n and sorted(bounds) == bounds
+    assert balanced_bounds(torch.ones(7), 7) == list(range(8))
+    assert balanced_bounds(torch.zeros(0), 3) == [0, 0, 0, 0]
+
+
+def _random_csr(n_rows, n_cols, nnz, seed):
+    g = torch.Generator().manual_seed(seed)
+    rows, cols = torch.randint(0, n_rows, (nnz,), generator=g), torch.randint(0, n_cols, (nnz,), generator=g)
+    csr = C.cpu_csr_from_coo(rows, cols, n_rows, n_cols)
+    return csr, torch.randn(nnz, generator=g)
+
+
+def _apply(csr, val, x):
+    y = torch.zeros(csr.n_rows, x.size(1))
+    C.cpu_single(csr, val, x, y, 0, csr.n_rows, 1.0, False, False)
+    return y
+
+
+def test_take_rows_and_split_phases_preserve_the_product():
+    world, n_pad, phases = 3, 8, 4
+    n = world * n_pad
+    csr, val = _random_csr(n, n, 300, 1)
+    x = torch.randn(n, 5, generator=torch.Generator().manual_seed(2))
+    want = _apply(csr, val, x)
+    rows = torch.tensor([5, 0, 23, 7, 7])
+    sub, (v,) = take_rows(csr, (val,), rows)
+    assert torch.equal(_apply(sub, v, x), want[rows])
+    blocks = split_phases(csr, (val,), n_pad, phases, world)
+    assert sum(b[0].nnz for b in blocks) == csr.nnz
+    n_sub = n_pad // phases
+    acc = torch.zeros_like(want)
+    for c, (blk, (vc,)) in enumerate(blocks):
+        # the exchange buffer of phase c: sub-range c of every rank, rank-major
+        buf = x.view(world, n_pad, 5)[:, c * n_sub:(c + 1) * n_sub].reshape(world * n_sub, 5)
+        assert blk.n_cols == world * n_sub
+        acc += _apply(blk, vc, buf)
+    assert torch.allclose(acc, want, atol=1e-5)
+
+
+@pytest.mark.parametrize("world,p_c,phases,chunks", [(8, 4, 2, 2), (4, 4, 1, 3), (8, 2, 3, 1), (4, 1, 2, 1), (6, 2, 2, 2)])
+def test_row_blocks_cover_every_padded_row_exactly_once(world, p_c, phases, chunks):
+    align = PropagateEngine.alignment(world, p_c, phases, chunks)
+    seen = torch.zeros(0, dtype=torch.long)
+    for rank in range(world):
+        plan = ShardPlan(1000, world, rank, align=align)
+        eng = PropagateEngine(plan, type("Ex", (), {"world_size": world, "rank": rank})(), p_c, phases, chunks, C.KERNELS)
+        ids = eng.block_row_ids("cpu")
+        assert ids.numel() == eng.block_rows and ids.unique().numel() == ids.numel()
+        if eng.j == 0:
+            seen = torch.cat([seen, ids])
+    assert torch.equal(seen.sort().values, torch.arange(plan.n_total))
+    assert [choose_cols(w, 64) for w in (1, 2, 4, 6, 8)] == [1, 1, 4, 2, 4]
+    assert choose_cols(8, 12) == 1 and choose_cols(8, 24) == 2              # 16-byte aligned slices only
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-process
+# ------------------------------------------------------------------------------------------------
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, ret):
+def _graph(n, seed, skew):
+    g = torch.Generator().manual_seed(seed)
+    e = 10 * n
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if skew:                                        # most edges among the first tenth of the nodes
+        ei[:, :e // 2] = torch.randint(0, max(n // 10, 2), (2, e // 2), generator=g)
+    w = torch.rand(e, generator=g) + 0.5
+    return g, ei, w
+
+
+def _magnetic_worker(rank, world, port, cfg, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.manual_seed(0)
-        g = torch.Generator().manual_seed(123)
-        e, f = 12 * n, 5
-        ei = torch.randint(0, n, (2, e), generator=g)
-        w = torch.rand(e, generator=g) + 0.5
+        from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv, all_gather_rows
+        n, f, k, layout, phases, chunks, signed, skew = cfg
+        g, ei, w = _graph(n, 123, skew)
+        if signed:
+            w = w * (torch.randint(0, 2, w.shape, generator=g) * 2 - 1)
         xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
         gr, gi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
-        plan = ShardPlan(n, world, rank)
-        # un-sharded oracle (reference op sequence) incl. gradients
-        op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0)
-        a, b = xr.clone().requires_grad_(), xi.clone().requires_grad_()
-        t_r = R.propagate(a, op[0], op[2], n)
-        t_i = R.propagate(b, op[1], op[3], n)
-        ((t_r * gr).sum() + (t_i * gi).sum()).backward()
-        # ---- sharded forward: gather packed blocks, evaluate owned target rows only
-        full = all_gather_rows(pack_pair(plan.shard_rows(xr), plan.shard_rows(xi)))
-        assert full.shape == (plan.n_total, 2 * f)
-        assert torch.equal(plan.unshard_rows(full), torch.cat([xr, xi], dim=1))
-        outs = []
-        for op_index, op_val, cols in ((op[0], op[2], slice(0, f)), (op[1], op[3], slice(f, 2 * f))):
-            keep, sub = plan.local_entries(op_index, by=1)
-            outs.append(R.propagate(full[:, cols], sub, op_val[keep], plan.n_pad))
-        ok = torch.equal(outs[0][:plan.n_local], t_r.detach()[plan.lo:plan.hi]) and \
-            torch.equal(outs[1][:plan.n_local], t_i.detach()[plan.lo:plan.hi])
-        ok = ok and float(outs[0][plan.n_local:].abs().sum()) == 0.0
-        # ---- sharded backward: gather the upstream gradient, evaluate owned SOURCE rows
-        gfull = all_gather_rows(pack_pair(plan.shard_rows(gr), plan.shard_rows(gi)))
-        grads = []
-        for op_index, op_val, cols in ((op[0], op[2], slice(0, f)), (op[1], op[3], slice(f, 2 * f))):
-            keep, sub = plan.local_entries(op_index, by=0)
-            # dX[src] += w * dT[tgt]: gather at row 1 (targets, global), scatter at row 0 (sources, local)
-            grads.append(R.propagate(gfull[:, cols], sub, op_val[keep], plan.n_pad, flow="target_to_source"))
-        ok = ok and torch.allclose(grads[0][:plan.n_local], a.grad[plan.lo:plan.hi], rtol=0, atol=1e-6)
-        ok = ok and torch.allclose(grads[1][:plan.n_local], b.grad[plan.lo:plan.hi], rtol=0, atol=1e-6)
-        # ---- parameter-gradient style all-reduce: per-shard partial sums add up to the global sum
-        part = outs[0][:plan.n_local].sum(0)
-        dist.all_reduce(part)
-        ok = ok and torch.allclose(part, t_r.detach().sum(0), rtol=1e-5, atol=1e-5)
-        ret[rank] = bool(ok)
+        torch.manual_seed(11)
+        layer = ShardedMagNetConv(f, f, k, 0.25, n, ei, w, signed=signed, layout=layout, phases=phases,
+                                  return_chunks=chunks, grid_cols=2 if (layout == "grid" and world == 2) else None,
+                                  kernels=C.KERNELS, operator_rows=C.oracle_operator_rows(ei, w, n, 0.25, signed=signed))
+        assert layer.layout == layout and layer.engine.phases == phases
+        plan = layer.plan
+        if skew:
+            assert plan.sizes != [plan.sizes[0]] * world            # balanced ranges are uneven here
+        with torch.no_grad():
+            layer.bias.uniform_(-0.5, 0.5)
+            dist.broadcast(layer.bias.data, 0)
+        a, b = layer.shard_rows(xr).requires_grad_(), layer.shard_rows(xi).requires_grad_()
+        o_r, o_i = layer(a, b)
+        # the loss deliberately touches the pad rows: their upstream gradient must not leak into dW / db
+        ((o_r * layer.shard_rows(gr)).sum() + (o_i * layer.shard_rows(gi)).sum() + 3.0 * o_r[plan.n_local:].sum()).backward()
+        got = [plan.unshard_rows(all_gather_rows(t.detach())) for t in (o_r, o_i, a.grad, b.grad)]
+        # un-sharded oracle (reference op sequence)
+        weight, bias = layer.weight.detach().clone(), layer.bias.detach().clone()
+        c, d = xr.clone().requires_grad_(), xi.clone().requires_grad_()
+        wt, bs = weight.clone().requires_grad_(), bias.clone().requires_grad_()
+        op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0, signed=signed)
+        w_r, w_i = R.magnet_conv(c, d, op, wt, bs, duplicate=False)
+        ((w_r * gr).sum() + (w_i * gi).sum()).backward()
+        worst = 0.0
+        for x, y in zip(got + [layer.weight.grad, layer.bias.grad], [w_r.detach(), w_i.detach(), c.grad, d.grad, wt.grad, bs.grad]):
+            worst = max(worst, float((x - y).abs().max()) / max(1.0, float(y.abs().max())))
+        ret[rank] = worst
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 40), (3, 41)])
-def test_sharded_rows_equal_unsharded_oracle(world, n):
+@pytest.mark.parametrize("world,cfg", [
+    # n, f, K, layout, phases, return chunks, signed, skewed graph
+    (2, (40, 8, 1, "rows", 1, 1, False, False)),
+    (2, (41, 8, 2, "rows", 2, 1, False, True)),
+    (3, (50, 4, 3, "rows", 3, 1, True, True)),
+    (2, (40, 8, 2, "grid", 2, 2, False, False)),        # 1 x 2
+    (4, (45, 16, 3, "grid", 2, 3, True, True)),         # 1 x 4, Chebyshev order 3 through the grid
+    (8, (70, 16, 2, "grid", 2, 2, False, True)),        # 2 x 4: the 8-GPU configuration, interleaved row blocks
+    (8, (64, 16, 1, "grid", 1, 1, True, False)),        # 2 x 4 un-pipelined
+    (6, (50, 8, 2, "grid", 2, 2, False, False)),        # 3 x 2
+])
+def test_sharded_magnetic_layer_equals_unsharded_oracle(world, cfg):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n, ret), nprocs=world, join=True)
-    assert dict(ret) == {r: True for r in range(world)}
+    mp.spawn(_magnetic_worker, args=(world, _free_port(), cfg, ret), nprocs=world, join=True)
+    assert len(ret) == world and max(ret.values()) <= 2e-6, dict(ret)
 
 
-# ------------------------------------------------------------------------------------------------
-# grid layout (GridPlan): column-slice exchange, (row block i) x (column slice j) product, exchange back
-# ------------------------------------------------------------------------------------------------
-def test_grid_plan_geometry():
-    from pytorch_geometric_signed_directed_amd.parallel import GridPlan
-    assert [GridPlan.choose_cols(w, 64) for w in (1, 2, 4, 6, 8)] == [1, 1, 4, 2, 4]
-    assert GridPlan.choose_cols(8, 12) == 1 and GridPlan.choose_cols(8, 24) == 2      # 16-byte aligned slices only
-    p = GridPlan(1000, 8, 5, 64)
-    assert (p.p_r, p.p_c, p.i, p.j, p.fc) == (2, 4, 1, 1, 16)
-    assert p.block_rows == 4 * p.n_pad and p.block_lo == 4 * p.n_pad and list(p.row_group()) == [4, 5, 6, 7]
-    assert p.group_splits() == [0, 0, 0, 0, 1, 1, 1, 1]
-    a = torch.arange(p.n_pad * 64, dtype=torch.float32).view(p.n_pad, 64)
-    b = -a
-    chunks = p.slice_chunks(a, b)
-    assert chunks.shape == (8, p.n_pad, 32)
-    for d in range(8):
-        j = d % 4
-        assert torch.equal(chunks[d][:, :16], a[:, 16 * j:16 * j + 16]) and torch.equal(chunks[d][:, 16:], b[:, 16 * j:16 * j + 16])
-    recv = torch.stack([chunks[j] for j in range(4)])          # what a row group hands back for these rows
-    ra, rb = p.merge_slices(recv)
-    assert torch.equal(ra, a) and torch.equal(rb, b)
-    with pytest.raises(ValueError):
-        GridPlan(10, 6, 0, 64, 4)
-
-
-def _grid_worker(rank, world, port, n, f, ret):
-    from pytorch_geometric_signed_directed_amd.parallel import GridPlan, collect_slices, return_rows
+def _digcn_worker(rank, world, port, n, f, phases, block, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = torch.Generator().manual_seed(321)
-        e = 10 * n
-        ei = torch.randint(0, n, (2, e), generator=g)
-        w = torch.rand(e, generator=g) + 0.5
-        xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
-        plan = GridPlan(n, world, rank, f, 2 if world == 2 else None)      # two ranks: force the 1 x 2 grid
-        fc = plan.fc
-        op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0)
-        t_r = R.propagate(xr, op[0], op[2], n)                           # un-sharded oracle
-        t_i = R.propagate(xi, op[1], op[3], n)
-        full = collect_slices(plan, plan.shard_rows(xr), plan.shard_rows(xi))
-        cols = slice(plan.j * fc, (plan.j + 1) * fc)
-        ok = full.shape == (plan.n_total, 2 * fc)
-        ok = ok and torch.equal(full[:n, :fc], xr[:, cols]) and torch.equal(full[:n, fc:], xi[:, cols])
-        ok = ok and float(full[n:].abs().sum()) == 0.0
-        # product of operator row block i with column slice j, by the oracle
-        ys = []
-        for op_index, op_val, part in ((op[0], op[2], full[:, :fc]), (op[1], op[3], full[:, fc:])):
-            tgt = op_index[1]
-            keep = ((tgt >= plan.block_lo) & (tgt < plan.block_lo + plan.block_rows)).nonzero(as_tuple=True)[0]
-            sub = op_index[:, keep].clone()
-            sub[1] -= plan.block_lo
-            ys.append(R.propagate(part, sub, op_val[keep], plan.block_rows))
-        ra, rb = return_rows(plan, ys[0], ys[1])
-        ok = ok and ra.shape == (plan.n_pad, f)
-        ok = ok and torch.equal(ra[:plan.n_local], t_r[plan.lo:plan.hi]) and torch.equal(rb[:plan.n_local], t_i[plan.lo:plan.hi])
-        ok = ok and float(ra[plan.n_local:].abs().sum()) == 0.0
-        ret[rank] = bool(ok)
+        from pytorch_geometric_signed_directed_amd.parallel import (ShardedDiGCNConv, ShardedDiGCNInceptionBlock,
+                                                                    all_gather_rows)
+        C.patch_device_builders()
+        g, ei, w = _graph(n, 5, True)
+        w = w / 8
+        _, ei2, w2 = _graph(n, 6, False)
+        w2 = w2 / 8
+        x, go = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+        torch.manual_seed(13)
+        if block:
+            layer = ShardedDiGCNInceptionBlock(f, f, n, ei, w, ei2, w2, phases=phases, kernels=C.KERNELS)
+        else:
+            layer = ShardedDiGCNConv(f, f, n, ei, w, phases=phases, kernels=C.KERNELS)
+        with torch.no_grad():
+            for prm in layer.parameters():
+                prm.uniform_(-0.5, 0.5)
+                dist.broadcast(prm.data, 0)
+        plan = layer.plan
+        a = layer.shard_rows(x).requires_grad_()
+        outs = layer(a)
+        outs = outs if block else (outs,)
+        loss = sum(((k + 1.0) * o * layer.shard_rows(go)).sum() for k, o in enumerate(outs))
+        loss.backward()
+        got = [plan.unshard_rows(all_gather_rows(t.detach())) for t in outs + (a.grad,)]
+        xo = x.clone().requires_grad_()
+        sd = {k: v.detach().clone().requires_grad_() for k, v in layer.named_parameters()}
+        if block:
+            want = (xo @ sd["ln.weight"].t() + sd["ln.bias"],
+                    R.digcn_conv(xo, ei, w, sd["conv1.weight"], sd["conv1.bias"]),
+                    R.digcn_conv(xo, ei2, w2, sd["conv2.weight"], sd["conv2.bias"]))
+        else:
+            want = (R.digcn_conv(xo, ei, w, sd["weight"], sd["bias"]),)
+        sum(((k + 1.0) * o * go).sum() for k, o in enumerate(want)).backward()
+        worst = 0.0
+        pairs = list(zip(got, [t.detach() for t in want] + [xo.grad]))
+        pairs += [(prm.grad, sd[k].grad) for k, prm in layer.named_parameters()]
+        for x1, y1 in pairs:
+            worst = max(worst, float((x1 - y1).abs().max()) / max(1.0, float(y1.abs().max())))
+        ret[rank] = worst
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,f", [(2, 40, 8), (4, 41, 16), (8, 50, 16), (3, 30, 8)])
-def test_grid_exchanges_reproduce_unsharded_oracle_rows(world, n, f):
-    """2 = 1x2, 4 = 1x4, 8 = 2x4 grids, and 3 ranks (no column split possible: 3x1)."""
+@pytest.mark.parametrize("world,n,f,phases,block", [(2, 50, 8, 1, False), (3, 61, 4, 2, False), (2, 50, 8, 1, True),
+                                                    (4, 90, 8, 2, True)])
+def test_sharded_digcn_and_inception_block_equal_unsharded_oracle(world, n, f, phases, block):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_grid_worker, args=(world, _free_port(), n, f, ret), nprocs=world, join=True)
-    assert dict(ret) == {r: True for r in range(world)}
+    mp.spawn(_digcn_worker, args=(world, _free_port(), n, f, phases, block, ret), nprocs=world, join=True)
+    assert len(ret) == world and max(ret.values()) <= 2e-6, dict(ret)
