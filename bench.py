@@ -1,7 +1,7 @@
 """bench.py -- edges/sec (fwd+bwd) of MagNetConv on a synthetic DSBM graph, one JSON line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--nodes 1000000] [--edges 20000000]
-                    [--hidden 64] [--no-cpu-baseline]
+                    [--hidden 64] [--no-cpu-baseline] [--layout auto|rows|grid] [--phases C] [--return-chunks R]
 
 Metric (BASELINE.json): input edges per second, forward + backward of ONE MagNetConv layer
 (K=1, q=0.25, sym normalisation, in = out = hidden, fp32), operator cached (steady state), on a DSBM
@@ -9,22 +9,33 @@ graph (5 clusters, cyclic meta-graph eta=0.1, size_ratio 1.5) of 1M nodes / 20M 
 resident in HBM before the timed region.  A "step" = layer forward + loss.backward() with
 loss = out_real.sum() + out_imag.sum() and gradients w.r.t. x_real, x_imag, weight, bias.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the same graph is sharded by
-node range across the ranks (strong scaling; `parallel.ShardedMagNetConv`).  Default work layout: a
-p_r x p_c process grid (row blocks of the operator x column slices of the features) with two
-all-to-alls per propagate over xGMI; `--layout rows` = the plain all-gather of whole feature blocks.
+Timing.  W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; `value` and
+`ms_per_step` come from that wall-clock interval (max over ranks).  Every timed step is also bracketed by HIP
+events on the compute stream: `ms_per_step_median` / `_min` / `_max` are their statistics.  The per-launch
+event recorder (pygsd_prof_*) is OFF in that pass; a second, untimed pass of K steps runs with it on and feeds
+the `roofline` object (average launch duration of the dominant kernel, measured live in this run).
 
-Extra objects in the JSON line: `roofline` (dominant kernel = the fused dual-value SpMM, timed by
-HIP events around every launch inside the timed region, algorithmic bytes per SURVEY.md 8(d)) and
-`cpu_baseline` (the oracle's reference op sequence timed on this box's host cores, rank 0, N=1).
+N > 1.  `python bench.py --gpus N` works as typed: without WORLD_SIZE in the environment it re-executes itself
+under `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); the driver's own torchrun
+launch is detected and used as is.  The same graph is sharded by node range over the ranks (strong scaling;
+parallel.ShardedMagNetConv: equal-work ranges, grid or row layout, exchanges overlapped with the partial
+products).  The `exchange` object reports, per step, the compute-stream time of the propagates split into
+product / exposed exchange wait / packing, and the duration of the exchanges run alone.
+
+Extra objects in the JSON line: `roofline` (dominant kernel = the fused dual-value SpMM; algorithmic bytes per
+SURVEY.md 8(d); `achievable_peak` = a streaming float4 copy of 2 x 1 GiB timed in this run) and `cpu_baseline`
+(the oracle's reference op sequence on this box's host cores, rank 0, N=1: operator cached and, as the reference
+defaults to, rebuilt every forward).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -49,15 +60,18 @@ def build_inputs(n, e, hidden, device, seed=0):
     return edge_index.to(device), x_real.to(device), x_imag.to(device), p
 
 
-def cpu_baseline(hidden, steps=2, n=100000, e=2000000, threads=None):
+def cpu_baseline(hidden, steps=5, n=100000, e=2000000, threads=None):
     """Reference op sequence (index_select -> mul -> scatter_add_, 4 propagates per order incl. the
-    reference's duplicates, autograd backward) on the host cores, cached operator."""
+    reference's duplicates, autograd backward) on the host cores: `cached=True` (steady state, comparable with the
+    GPU figure) and `cached=False` (the reference's default, MagNetConv.py:45,157-181: operator rebuilt by every
+    forward).  Median of `steps` timed steps each, after one warm-up."""
     from oracle import ref_layers as R
     from pytorch_geometric_signed_directed_amd import graphs
     # ATen's index_select / scatter_add_ stop scaling long before a 256-thread host is full (measured
     # on the GPU box, EPYC 9575F: 8 thr 3.8 s, 32 thr 3.2 s, 128 thr 4.7 s, 256 thr 28 s per step), so
     # the baseline runs on the best-performing thread count, and reports that count as `cores`.
-    cores = threads or min(os.cpu_count() or 1, 32)
+    available = os.cpu_count() or 1
+    cores = threads or min(available, 32)
     torch.set_num_threads(cores)
     ei_np, _, _ = graphs.dsbm_for_edges(n, e, seed=0)
     ei = torch.from_numpy(ei_np)
@@ -67,30 +81,75 @@ def cpu_baseline(hidden, steps=2, n=100000, e=2000000, threads=None):
     torch.manual_seed(0)
     w = torch.empty(2, hidden, hidden).uniform_(-1, 1).mul_((6.0 / (2 * hidden)) ** 0.5).requires_grad_()
     b = torch.zeros(hidden, requires_grad=True)
-    op = R.magnet_operator(ei, None, n, 0.25, "sym", 2.0)
+    cached_op = R.magnet_operator(ei, None, n, 0.25, "sym", 2.0)
 
-    def step():
+    def step(op=None):
+        op = op if op is not None else R.magnet_operator(ei, None, n, 0.25, "sym", 2.0)
         o_r, o_i = R.magnet_conv(xr, xi, op, w, b, duplicate=True)
         (o_r.sum() + o_i.sum()).backward()
 
-    step()  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": ei.size(1) / dt, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ref_layers.magnet_conv (reference op sequence, 4 propagates/order), DSBM "
-                      f"{n} nodes / {ei.size(1)} edges, h={hidden}, cached operator, {steps} fwd+bwd steps "
-                      f"({dt:.2f} s/step)"}
+    def timed(op, count):
+        step(op)  # warm-up
+        ts = []
+        for _ in range(count):
+            t0 = time.perf_counter()
+            step(op)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    t_cached = timed(cached_op, steps)
+    t_rebuilt = timed(None, max(steps - 2, 3))
+    med_c, med_u = statistics.median(t_cached), statistics.median(t_rebuilt)
+    edges = ei.size(1)
+    return {"value": edges / med_c, "unit": "edges/s", "cores": cores, "cores_available": available, "kind": "port",
+            "value_uncached": edges / med_u,
+            "seconds_per_step": {"cached_median": med_c, "cached_min": min(t_cached), "cached_max": max(t_cached),
+                                 "uncached_median": med_u, "uncached_min": min(t_rebuilt), "uncached_max": max(t_rebuilt)},
+            "scaled_from": "C2 size (DSBM 100k nodes / 2M edges = north-star / 10): the reference's per-propagate "
+                           "[nnz, F] message temporaries are 10.7 GB each at the north-star size; edges/s of this "
+                           "path is size-independent to first order (gather / scatter bound), so the figure is "
+                           "quoted as measured, not rescaled",
+            "sample": f"oracle/ref_layers.magnet_conv (reference op sequence, 4 propagates/order), DSBM {n} nodes / "
+                      f"{edges} edges, h={hidden}: `value` = operator cached, median of {len(t_cached)} fwd+bwd steps "
+                      f"({med_c:.2f} s/step); `value_uncached` = operator rebuilt every forward (reference default, "
+                      f"MagNetConv.py:45), median of {len(t_rebuilt)} ({med_u:.2f} s/step); {cores} of "
+                      f"{available} host threads (ATen scatter_add_ anti-scales beyond)"}
+
+
+def stream_copy_rate(device, gib=1.0, reps=7):
+    """GB/s (read + write) of the library's streaming float4 copy on `gib` GiB: the achievable-HBM yardstick."""
+    from pytorch_geometric_signed_directed_amd import _cabi
+    n = int(gib * (1 << 30)) // 4
+    src = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    lib = _cabi.lib()
+    times = []
+    for k in range(reps + 2):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _cabi.check(lib.pygsd_stream_copy_f32(_cabi.ptr(src), _cabi.ptr(dst), n, _cabi.stream_ptr()), "pygsd_stream_copy_f32")
+        b.record()
+        b.synchronize()
+        if k >= 2:
+            times.append(a.elapsed_time(b))
+    assert torch.equal(src[:1024], dst[:1024])
+    return 2.0 * n * 4 / (statistics.median(times) * 1e-3) / 1e9
+
+
+def self_launch(args_list, gpus):
+    """`python bench.py --gpus N` typed by hand: re-execute under torch.distributed.run, one rank per GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + args_list
+    return subprocess.call(cmd, env=env)
 
 
 def main():
-    # Only the JSON line may reach stdout.  RCCL prints a version banner through C stdio on stdout (flushed at
-    # exit, i.e. AFTER the result line), so the real stdout is kept aside for the result and fd 1 is pointed at
-    # stderr for everything else (C libraries and stray prints alike).
-    sys.stdout.flush()
-    result_out = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -101,18 +160,28 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layout", choices=("auto", "rows", "grid"), default="auto",
                     help="multi-GPU work layout (parallel.ShardedMagNetConv): rows = all-gather of whole feature "
-                         "blocks, grid = p_r x p_c process grid with column-slice all-to-alls (auto picks grid)")
+                         "blocks, grid = p_r x p_c process grid with column-slice all-to-alls (auto picks grid "
+                         "above two ranks)")
+    ap.add_argument("--phases", type=int, default=None, help="column phases of the pipelined propagate (default 2)")
+    ap.add_argument("--return-chunks", type=int, default=None, help="row chunks of the grid's return (default 2)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the node-sharded layer even with one rank (exercises the RCCL path on 1 GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+
+    # Only the JSON line may reach stdout.  RCCL prints a version banner through C stdio on stdout (flushed at
+    # exit, i.e. AFTER the result line), so the real stdout is kept aside for the result and fd 1 is pointed at
+    # stderr for everything else (C libraries and stray prints alike).
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run "
-                             "--nproc-per-node N (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
@@ -142,6 +211,7 @@ def main():
     edge_index, x_real, x_imag, p = build_inputs(n, args.edges, hidden, device)
     e = edge_index.size(1)
     torch.manual_seed(0)
+    layer_s = None
     if not sharded:
         layer = MagNetConv(hidden, hidden, K=1, q=0.25, trainable_q=False, cached=True).to(device)
         x_real.requires_grad_()
@@ -157,19 +227,21 @@ def main():
             return layer._operator.nnz
     else:
         from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv
-        layer = ShardedMagNetConv(hidden, hidden, K=1, q=0.25, num_nodes=n, edge_index=edge_index,
-                                  edge_weight=None, device=device, layout=args.layout)
-        xr_loc, xi_loc = layer.shard_rows(x_real).requires_grad_(), layer.shard_rows(x_imag).requires_grad_()
-        del x_real, x_imag
+        layer_s = ShardedMagNetConv(hidden, hidden, K=1, q=0.25, num_nodes=n, edge_index=edge_index,
+                                    edge_weight=None, device=device, layout=args.layout, phases=args.phases,
+                                    return_chunks=args.return_chunks)
+        xr_loc = layer_s.shard_rows(x_real).requires_grad_()
+        xi_loc = layer_s.shard_rows(x_imag).requires_grad_()
+        del x_real, x_imag, edge_index
 
         def step():
-            layer.zero_grad(set_to_none=True)
+            layer_s.zero_grad(set_to_none=True)
             xr_loc.grad = xi_loc.grad = None
-            o_r, o_i = layer(xr_loc, xi_loc)
+            o_r, o_i = layer_s(xr_loc, xi_loc)
             (o_r.sum() + o_i.sum()).backward()
 
         def op_nnz():
-            return layer.global_nnz
+            return layer_s.global_nnz
 
     def sync():
         torch.cuda.synchronize(device)
@@ -177,52 +249,119 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    def reduce_max(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=device)
+        if dist.get_backend() == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
+    # ---- pass 1: the headline.  K steps between barriers; per-step HIP events; no per-launch recorder.
     sync()
+    marks = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        step()
+        b.record()
+        marks.append((a, b))
+    sync()
+    dt = reduce_max(time.perf_counter() - t0)
+    per_step = [a.elapsed_time(b) for a, b in marks]
+    med = reduce_max(statistics.median(per_step))
+
+    # ---- pass 2 (untimed): per-launch recorder and propagate instrumentation on.
     _cabi.prof_reset()
     _cabi.prof_enable(True)
+    if layer_s is not None:
+        layer_s.engine.profile(True)
     sync()
-    t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
-    dt = time.perf_counter() - t0
     _cabi.prof_enable(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     launches, kernel_ms = _cabi.prof_collect("spmm2")
     other = {k: _cabi.prof_collect(k) for k in ("dense", "dense_bwd")}
     _cabi.prof_reset()
+    exchange = None
+    if layer_s is not None:
+        summary = layer_s.engine.timing_summary() or {}
+        layer_s.engine.profile(False)
+        # the exchanges alone (nothing to overlap with): one un-profiled propagate's worth of collectives
+        eng = layer_s.engine
+        alone = []
+        for _ in range(5):
+            sync()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            bufs, works = [], []
+            for c in range(eng.phases):
+                send = eng._pack([xr_loc.detach(), xi_loc.detach()], c)
+                buf = send.new_empty((world, eng.n_sub, send.size(-1)))
+                works.append(eng.ex.all_to_all(buf, send) if eng.grid else eng.ex.all_gather(buf, send))
+                bufs.append(buf)
+            for w_ in works:
+                w_.wait()
+            if eng.grid:
+                fw2 = 2 * (hidden // eng.p_c)
+                back = xr_loc.new_zeros((eng.return_chunks, world, eng.n_rsub, fw2))
+                recv = torch.empty_like(back)
+                for w_ in [eng.ex.all_to_all(recv[r], back[r]) for r in range(eng.return_chunks)]:
+                    w_.wait()
+            b.record()
+            b.synchronize()
+            alone.append(a.elapsed_time(b))
+        exchange = {"layout": layer_s.layout, "p_r": eng.p_r, "p_c": eng.p_c, "phases": eng.phases,
+                    "return_chunks": eng.return_chunks, "propagates_per_step": 2,
+                    "propagate_ms": summary.get("total_ms"), "product_ms": summary.get("product_ms"),
+                    "pack_ms": summary.get("pack_ms"), "merge_ms": summary.get("merge_ms"),
+                    "exposed_exchange_ms": summary.get("exposed_exchange_ms"),
+                    "exchange_alone_ms": reduce_max(statistics.median(alone)),
+                    "node_range_sizes": layer_s.plan.sizes, "n_pad": layer_s.plan.n_pad,
+                    "note": "per propagate, compute-stream time of rank 0: product = partial SpMM launches, exposed = "
+                            "the compute stream waiting for an inbound phase or the return; exchange_alone = the same "
+                            "collectives with nothing to overlap"}
 
     if rank == 0:
         nnz = op_nnz()                      # E_s + N (folded diagonal)
         e_s = nnz - n
-        per_launch_nnz, per_launch_rows, width = nnz, n, hidden
         parallelism = "single GPU"
-        if sharded and getattr(layer, "layout", "rows") == "grid":
-            # rank (i, j) multiplies row block i (1 / p_r of the entries) by column slice j (hidden / p_c columns)
-            p_r, p_c = layer.plan.p_r, layer.plan.p_c
-            per_launch_nnz, per_launch_rows, e_s, width = nnz / p_r, n / p_r, e_s / p_r, hidden // p_c
-            parallelism = (f"node-range ownership x{world}, {p_r} x {p_c} process grid: column-slice all-to-all in, "
-                           f"row-group all-to-all out (RCCL)")
-        elif world > 1 or sharded:
-            per_launch_nnz, per_launch_rows = nnz / world, n / world
-            e_s = e_s / world
-            parallelism = f"node-range shards x{world}, RCCL all-gather of features"
-        # one fused launch = the real SpMM (E_s + N entries) + the imaginary SpMM (E_s entries)
-        alg_bytes = spmm_bytes(per_launch_nnz, per_launch_rows, width) + spmm_bytes(e_s, per_launch_rows, width)
+        launches_per_product = 1
+        if layer_s is not None:
+            eng = layer_s.engine
+            launches_per_product = eng.phases - 1 + (eng.return_chunks if eng.grid else 1)
+            parallelism = (f"node-range ownership x{world} (equal-work ranges), {layer_s.layout} layout"
+                           + (f" {eng.p_r} x {eng.p_c} grid" if eng.grid else "")
+                           + f", {eng.phases} column phases" + (f" x {eng.return_chunks} return chunks" if eng.grid else "")
+                           + ", exchanges overlapped with the partial products (RCCL)")
+        if layer_s is None:
+            # one fused launch = the real SpMM (E_s + N entries) + the imaginary SpMM (E_s entries)
+            alg_total = (spmm_bytes(nnz, n, hidden) + spmm_bytes(e_s, n, hidden)) * launches
+        else:
+            # a rank's launches of one product together traverse its row block once: entries / p_r at width F / p_c
+            eng = layer_s.engine
+            rows, width = eng.block_rows, hidden // eng.p_c
+            loc = layer_s.local_nnz
+            per_product = spmm_bytes(loc, rows, width) + spmm_bytes(max(loc - rows, 0), rows, width)
+            alg_total = per_product * (launches / max(launches_per_product, 1))
         avg_ms = kernel_ms / max(launches, 1)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-        traffic = None
+        achieved = alg_total / (kernel_ms * 1e-3) / 1e9 if launches else 0.0
+        copy_rate = stream_copy_rate(device)
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and layer_s is None:
             with open(pmc) as fh:
                 rec = json.load(fh)
             if rec.get("nodes") == n and rec.get("hidden") == hidden and rec.get("n_gpus", 1) == world:
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/pmc_traffic.json -- REPLAYED from a separate rocprofv3 --pmc run of this "
+                                  "command (tools/capture_profiles.sh), not measured in this run: "
+                                  + str(rec.get("source", "")))
         line = {
             "metric": "edges/sec (fwd+bwd) MagNetConv, 1M nodes/20M edges, h=64; % HBM roofline",
             "value": e * args.steps / dt,
@@ -231,6 +370,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_median": med,
+            "ms_per_step_min": min(per_step),
+            "ms_per_step_max": max(per_step),
+            "value_at_median": e / (med * 1e-3),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -240,14 +383,26 @@ def main():
                                    f"size_ratio 1.5, p={p:.3e}) {n} nodes / {e} edges, h={hidden}, fp32",
                        "nodes": n, "edges": e, "hidden": hidden, "operator_nnz": int(nnz),
                        "parallelism": parallelism},
-            "roofline": {"bound": "hbm", "kernel": "spmm_vec_kernel<16,true,true> = LPR 16, dual operator, deep pipelining (pygsd_spmm2_csr_f32)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "spmm_vec_kernel<LPR, dual, deep> (pygsd_spmm2_csr_f32)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "achievable_peak": copy_rate,
+                         "frac_of_achievable": achieved / copy_rate if copy_rate else None,
+                         "limiter": "L2-miss (fabric) traffic served by Infinity Cache + HBM together: the gathered "
+                                    "feature set (2 x N x F x 4 B) is of the order of the 256 MiB Infinity Cache, so "
+                                    "`achieved` is a fabric-side rate and may exceed what DRAM alone delivers "
+                                    "(`achievable_peak` = streaming float4 copy of 2 x 1 GiB in this run); gfx950's "
+                                    "rocprofv3 exposes no MALL-hit / DRAM-side split (TCC_EA0_RDREQ_DRAM counts "
+                                    "requests routed to the memory side, cache hits included)",
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "launches": int(launches), "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_total / max(launches, 1)},
             "kernel_ms_per_step": {"spmm2": kernel_ms / args.steps,
                                    **{k: v[1] / args.steps for k, v in other.items()}},
         }
+        if exchange is not None:
+            line["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hidden)
         result_out.write(json.dumps(line) + "\n")

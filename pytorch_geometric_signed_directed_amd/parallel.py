@@ -153,6 +153,11 @@ class DistExchange:
         self.world_size, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self._staged = dist.get_backend(group) == "gloo"
 
+    @staticmethod
+    def _wire(t: Tensor) -> Tensor:
+        """gloo moves bytes: bf16 payloads travel as int16 (not every gloo build knows the type)."""
+        return t.view(torch.int16) if t.dtype == torch.bfloat16 else t
+
     def _gather_sync(self, out: Tensor, inp: Tensor):
         try:
             dist.all_gather_into_tensor(out, inp, group=self.group)
@@ -164,26 +169,29 @@ class DistExchange:
         if self._staged:
             if inp.is_cuda:
                 host = torch.empty(out.shape, dtype=out.dtype)
-                self._gather_sync(host, inp.cpu().contiguous())
+                self._gather_sync(self._wire(host), self._wire(inp.cpu().contiguous()))
                 out.copy_(host)
             else:
-                self._gather_sync(out, inp.contiguous())
+                self._gather_sync(self._wire(out), self._wire(inp.contiguous()))
             return _Done()
         return dist.all_gather_into_tensor(out, inp.contiguous(), group=self.group, async_op=True)
 
     def all_to_all(self, out: Tensor, inp: Tensor):
         """chunk d of inp [world, ...] goes to rank d; chunk s of out comes from rank s."""
-        if self._staged and inp.is_cuda:
-            host = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(host, inp.cpu().contiguous(), group=self.group)
-            out.copy_(host)
+        if self._staged:
+            if inp.is_cuda:
+                host = torch.empty(out.shape, dtype=out.dtype)
+                dist.all_to_all_single(self._wire(host), self._wire(inp.cpu().contiguous()), group=self.group)
+                out.copy_(host)
+            else:
+                dist.all_to_all_single(self._wire(out), self._wire(inp.contiguous()), group=self.group)
             return _Done()
         return dist.all_to_all_single(out, inp.contiguous(), group=self.group, async_op=True)
 
     def all_reduce(self, t: Tensor) -> Tensor:
         if self.world_size > 1:
-            if self._staged and t.is_cuda:
-                host = t.cpu()
+            if self._staged:
+                host = t.detach().float().cpu()            # sums in fp32 whatever the storage type
                 dist.all_reduce(host, group=self.group)
                 t.copy_(host)
             else:
@@ -411,6 +419,12 @@ class PropagateEngine:
         if dual and (not op.dual or groups != 2):
             raise ValueError("a dual operator takes exactly two feature groups")
         f = xs[0].size(1)
+        quantum = self.p_c * (8 if xs[0].dtype == torch.bfloat16 else 4)
+        if f % quantum and xs[0].is_cuda:
+            # the vector kernels address 16-byte row pieces: zero-pad odd widths (e.g. a 6-wide layer), slice after
+            pad = (0, quantum - f % quantum)
+            out = self.run([torch.nn.functional.pad(x, pad) for x in xs], op, alpha)
+            return [y[:, :f] for y in out]
         if self.grid and f % self.p_c:
             raise ValueError(f"width {f} does not split into {self.p_c} column slices")
         fw = f // self.p_c

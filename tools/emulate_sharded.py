@@ -1,0 +1,115 @@
+"""Rehearse ONE rank of a P-rank sharded MagNetConv step on a single MI355X (no multi-GPU box is available to
+this build; the driver's 8-GPU run is the real measurement).
+
+    python tools/emulate_sharded.py [--world 8] [--rank 0] [--link-gbps 61] [--nodes 1000000] [--edges 20000000]
+
+What is real: the plan (equal-work ranges), this rank's operator rows at their real size (1 / p_r of the
+north-star operator, split into column phases), every kernel it would launch (partial dual SpMMs at the sliced
+width, the fused dense stage on its n_pad rows, packing / merging), the stream / event pipeline of
+parallel.PropagateEngine.  What is played: each exchange is a device copy of the bytes this rank would receive
+plus a timed kernel of the wire time of the busiest link (bytes_per_link / link rate + a fixed latency) on a
+separate stream (parallel.EmulatedExchange).  Received values are stand-ins, so outputs are not checked here
+(tests/test_gpu_sharded.py does that over gloo).
+
+For each pipeline shape it reports the step time, the per-propagate split (product / exposed exchange / pack /
+merge), the emulated wire time and the overlap fraction = 1 - exposed / wire.  The projection for P GPUs is this
+rank's step time (ranks are symmetric on a balanced SBM): speed-up = single-GPU step / emulated step.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run_shape(args, edge_index, x_real, x_imag, layout, phases, chunks, link_gbps):
+    from pytorch_geometric_signed_directed_amd.parallel import EmulatedExchange, ShardedMagNetConv
+    dev = x_real.device
+    ex = EmulatedExchange(args.world, args.rank, link_gbps, args.latency_us)
+    torch.manual_seed(0)
+    layer = ShardedMagNetConv(args.hidden, args.hidden, 1, 0.25, args.nodes, edge_index, None, device=dev,
+                              layout=layout, phases=phases, return_chunks=chunks, exchange=ex)
+    xr = layer.shard_rows(x_real).requires_grad_()
+    xi = layer.shard_rows(x_imag).requires_grad_()
+
+    def step():
+        layer.zero_grad(set_to_none=True)
+        xr.grad = xi.grad = None
+        o_r, o_i = layer(xr, xi)
+        (o_r.sum() + o_i.sum()).backward()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(args.steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        step()
+        b.record()
+        b.synchronize()
+        times.append(a.elapsed_time(b))
+    layer.engine.profile(True)
+    ex.wire_us = 0.0
+    for _ in range(args.steps):
+        step()
+    summary = layer.engine.timing_summary()
+    wire_ms = ex.wire_us / 1e3 / (2 * args.steps)                  # per propagate
+    eng = layer.engine
+    rec = {"layout": layout, "p_r": eng.p_r, "p_c": eng.p_c, "phases": phases, "return_chunks": chunks,
+           "link_gbps": link_gbps, "step_ms_median": statistics.median(times), "step_ms_min": min(times),
+           "per_propagate": summary, "wire_ms_per_propagate": wire_ms,
+           "overlap_fraction": (1.0 - summary["exposed_exchange_ms"] / wire_ms) if wire_ms > 0 else None,
+           "local_operator_entries": layer.local_nnz, "rows_multiplied": eng.block_rows, "n_pad": layer.plan.n_pad}
+    del layer
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--link-gbps", type=float, nargs="+", default=[61.0],
+                    help="emulated rate of one xGMI link, one direction (76.8 GB/s peak x 0.8)")
+    ap.add_argument("--latency-us", type=float, default=10.0)
+    ap.add_argument("--nodes", type=int, default=1000000)
+    ap.add_argument("--edges", type=int, default=20000000)
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--single-gpu-ms", type=float, default=None, help="measured 1-GPU step (bench.py) for the ratio")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "emulated_sharded.json"))
+    args = ap.parse_args()
+    from pytorch_geometric_signed_directed_amd import graphs
+    dev = torch.device("cuda:0")
+    ei = torch.from_numpy(graphs.dsbm_for_edges(args.nodes, args.edges, seed=0)[0]).to(dev)
+    g = torch.Generator().manual_seed(0)
+    x_real = torch.randn(args.nodes, args.hidden, generator=g).to(dev)
+    x_imag = torch.randn(args.nodes, args.hidden, generator=g).to(dev)
+    shapes = [("grid", 1, 1), ("grid", 2, 2), ("grid", 2, 4), ("grid", 4, 4), ("rows", 1, 1), ("rows", 2, 1)]
+    if args.world <= 2:
+        shapes = [("rows", 1, 1), ("rows", 2, 1), ("rows", 4, 1)]
+    out = {"world": args.world, "rank": args.rank, "nodes": args.nodes, "edges": int(ei.size(1)), "hidden": args.hidden,
+           "latency_us": args.latency_us, "single_gpu_ms": args.single_gpu_ms, "runs": []}
+    for gbps in args.link_gbps:
+        for layout, phases, chunks in shapes:
+            try:
+                rec = run_shape(args, ei, x_real, x_imag, layout, phases, chunks, gbps)
+            except Exception as exc:  # noqa: BLE001  (a shape that does not divide: report and go on)
+                rec = {"layout": layout, "phases": phases, "return_chunks": chunks, "link_gbps": gbps, "error": repr(exc)}
+            if args.single_gpu_ms and "step_ms_median" in rec:
+                rec["projected_speedup"] = args.single_gpu_ms / rec["step_ms_median"]
+            out["runs"].append(rec)
+            print(json.dumps(rec), flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,6 @@
-"""Condense gpurun_out/prof_{stats,fetch,write,l2} (tools/capture_profiles.sh) into the tracked summaries:
-profiles/r1_bench_kernel_stats.csv, profiles/r1_pmc_summary.json, profiles/pmc_traffic.json (the `traffic`
-field of bench.py's roofline object) and profiles/r1_bench_line.json.
+"""Condense gpurun_out/prof_{stats,fetch,write,l2,dram} (tools/capture_profiles.sh) into the tracked summaries:
+profiles/<round>_bench_kernel_stats.csv, profiles/<round>_pmc_summary.json, profiles/pmc_traffic.json (the
+`traffic` field of bench.py's roofline object) and profiles/<round>_bench_line.json (round = $ROUND, default r2).
 HBM bytes per MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE tallies the 128-B
 requests of 16-B-per-lane reads as 64 B, so fetched bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE * 1024 as is."""
 import csv
@@ -14,6 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
+ROUND = os.environ.get("ROUND", "r2")
 
 
 def short(name):
@@ -39,12 +40,12 @@ def counters(directory):
 
 def main():
     merged = {}
-    for d in ("prof_fetch", "prof_write", "prof_l2"):
+    for d in ("prof_fetch", "prof_write", "prof_l2", "prof_dram"):
         for k, cs in counters(d).items():
             merged.setdefault(k, {}).update(cs)
     summary = {"command": "tools/capture_profiles.sh: rocprofv3 --pmc <C> --output-format csv -- python bench.py "
                           "--no-cpu-baseline --steps 3 --warmup 1 (one pass per counter group: FETCH_SIZE | WRITE_SIZE | "
-                          "TCC_HIT_sum TCC_MISS_sum)",
+                          "TCC_HIT_sum TCC_MISS_sum | TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum)",
                "correction": __doc__.split("HBM bytes per")[1].strip(), "kernels": {}}
     for k, cs in sorted(merged.items()):
         ent = {c: {"dispatches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for c, v in cs.items()}
@@ -53,20 +54,25 @@ def main():
         if "TCC_HIT_sum" in cs and "TCC_MISS_sum" in cs:
             h, m = ent["TCC_HIT_sum"]["mean"], ent["TCC_MISS_sum"]["mean"]
             ent["l2_hit_rate"] = h / (h + m) if h + m else None
+        if "TCC_EA0_RDREQ_sum" in cs and "TCC_EA0_RDREQ_DRAM_sum" in cs:
+            # requests the L2 sent to the memory side, and the subset routed to DRAM (the MC behind the Infinity
+            # Cache -- the counter sits BEFORE the cache, so it is a routing split, not a MALL hit / miss split)
+            a, d = ent["TCC_EA0_RDREQ_sum"]["mean"], ent["TCC_EA0_RDREQ_DRAM_sum"]["mean"]
+            ent["ea_read_requests_routed_to_dram_fraction"] = d / a if a else None
         summary["kernels"][k] = ent
-    json.dump(summary, open(os.path.join(PROF, "r1_pmc_summary.json"), "w"), indent=1)
+    json.dump(summary, open(os.path.join(PROF, ROUND + "_pmc_summary.json"), "w"), indent=1)
     dual = [k for k in summary["kernels"] if k.startswith("spmm_vec_kernel<16,true")]
     if dual and "hbm_bytes_per_launch_corrected" in summary["kernels"][dual[0]]:
         json.dump({"nodes": 1000000, "hidden": 64, "n_gpus": 1, "kernel": dual[0],
                    "hbm_bytes_per_launch": summary["kernels"][dual[0]]["hbm_bytes_per_launch_corrected"],
-                   "source": "profiles/r1_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes)"},
+                   "source": "profiles/" + ROUND + "_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes)"},
                   open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
     stats = glob.glob(os.path.join(OUT, "prof_stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
-        shutil.copy(stats[0], os.path.join(PROF, "r1_bench_kernel_stats.csv"))
+        shutil.copy(stats[0], os.path.join(PROF, ROUND + "_bench_kernel_stats.csv"))
     line = os.path.join(OUT, "bench_line.json")
     if os.path.exists(line) and os.path.getsize(line):
-        shutil.copy(line, os.path.join(PROF, "r1_bench_line.json"))
+        shutil.copy(line, os.path.join(PROF, ROUND + "_bench_line.json"))
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if not isinstance(vv, dict)} for k, v in summary["kernels"].items()},
                      indent=1))
 
