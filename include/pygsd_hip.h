@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 4
+#define PYGSD_ABI_VERSION 5
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -131,14 +131,25 @@ int pygsd_sddmm_coo_f32(const int32_t* ia, const int32_t* ib, int64_t nnz,
  *                                gradient w.r.t. the pre-activation score s_e = a_src[col] + a_dst[r];
  *                                written, together with alpha, in COO order through perm (so that
  *                                d a_src / d a_dst are row sums over the two CSR orientations).
+ * long_rows (may be NULL; every entry point of this section and the segment / SNEA ones below take it): hub
+ * rows.  These kernels give one wavefront (16 lanes for the segment sum) to a row, which serialises a launch on a
+ * row with 10^5..10^6 entries (power-law graphs: SDGNN / SiGAT motif lists, nn/signed/SDGNN.py:198-254; the
+ * reference's scatter has no such cliff).  The caller lists the rows with MORE than PYGSD_LONG_ROW entries; the
+ * row kernels skip them and a segment-parallel path handles them: per 4096-entry segment the softmax statistics
+ * (max, sum exp) resp. the backward's row dot, folded per row IN SEGMENT ORDER, then the per-entry outputs and
+ * per-segment partial row sums, again added in segment order -- no atomics, run-to-run deterministic; results
+ * of hub rows agree with the single-wavefront order to fp32 rounding, all other rows bitwise.  Workspace:
+ * pygsd_segment_long_rows_workspace() bytes in long_rows->workspace.
  * ------------------------------------------------------------------------------------------- */
+int pygsd_segment_long_rows_workspace(int32_t n_long, int32_t max_entries, int64_t* bytes);
 int pygsd_gat_alpha_csr_f32(const int32_t* rowptr, const int32_t* col, const float* a_src, const float* a_dst,
-                            int32_t n_rows, float negative_slope, float* alpha, void* stream);
+                            int32_t n_rows, float negative_slope, float* alpha,
+                            const pygsd_long_rows* long_rows, void* stream);
 int pygsd_gat_alpha_bwd_csr_f32(const int32_t* rowptr, const int32_t* col, const int32_t* perm,
                                 const float* a_src, const float* a_dst, float negative_slope,
                                 const float* alpha, const float* h, int64_t ldh, const float* g, int64_t ldg,
                                 const float* out, int64_t ldo, int32_t n_rows, int32_t n_feat,
-                                float* ds_coo, float* alpha_coo, void* stream);
+                                float* ds_coo, float* alpha_coo, const pygsd_long_rows* long_rows, void* stream);
 
 /* Vectorised form of the above for n_feat % 4 == 0, n_feat <= 256, 16-byte aligned rows: float4 gathers,
  * ds written in CSR (by-target) order and its per-row sum da_dst = gradient of a_dst produced in the same
@@ -148,13 +159,13 @@ int pygsd_gat_alpha_bwd_csr_v2_f32(const int32_t* rowptr, const int32_t* col, co
                                    const float* a_dst, float negative_slope, const float* alpha,
                                    const float* h, int64_t ldh, const float* g, int64_t ldg,
                                    const float* out, int64_t ldo, int32_t n_rows, int32_t n_feat,
-                                   float* ds_csr, float* da_dst, void* stream);
+                                   float* ds_csr, float* da_dst, const pygsd_long_rows* long_rows, void* stream);
 
 /* out[r] = sum over CSR row r of w[perm[slot]] (perm == NULL: w[slot]).  Unlike pygsd_csr_row_sum_f32 (one
  * sequential sum per row, the reference's scatter order, used for degrees) this one splits a row over 16 lanes:
  * fixed but different summation order, for gradient reductions. */
 int pygsd_segment_sum_f32(const int32_t* rowptr, const int32_t* perm, const float* w, int32_t n_rows,
-                          float* out, void* stream);
+                          float* out, const pygsd_long_rows* long_rows, void* stream);
 
 /* Segment softmax over per-entry logits given in CSR order (one segment = one CSR row), max-shifted with
  * the + 1e-16 denominator of torch_geometric.utils.softmax: the attention of SNEAConv
@@ -162,9 +173,9 @@ int pygsd_segment_sum_f32(const int32_t* rowptr, const int32_t* perm, const floa
  * two feature sets per edge type and are therefore formed by the caller.
  * Backward: dlogits = alpha * (dalpha - sum_segment alpha * dalpha). */
 int pygsd_segment_softmax_csr_f32(const int32_t* rowptr, const float* logits, int32_t n_rows, float* alpha,
-                                  void* stream);
+                                  const pygsd_long_rows* long_rows, void* stream);
 int pygsd_segment_softmax_bwd_csr_f32(const int32_t* rowptr, const float* alpha, const float* dalpha,
-                                      int32_t n_rows, float* dlogits, void* stream);
+                                      int32_t n_rows, float* dlogits, const pygsd_long_rows* long_rows, void* stream);
 
 /* SNEAConv's attention, fused (nn/signed/SNEAConv.py:70-146).  Slot e of target row i has source col[e] and
  * edge_type[e] in {0: positive edge or self loop, 1: negative edge} (edge_type == NULL: all 0, s1/d1/share1 and
@@ -177,12 +188,13 @@ int pygsd_segment_softmax_bwd_csr_f32(const int32_t* rowptr, const float* alpha,
 int pygsd_snea_alpha_csr_f32(const int32_t* rowptr, const int32_t* col, const uint8_t* edge_type,
                              const float* s0, const float* s1, const float* d0, const float* d1,
                              const float* bias, int32_t n_rows, float* alpha, float* share0, float* share1,
-                             void* stream);
+                             const pygsd_long_rows* long_rows, void* stream);
 int pygsd_snea_alpha_bwd_csr_f32(const int32_t* rowptr, const int32_t* col, const uint8_t* edge_type,
                                  const float* s0, const float* s1, const float* d0, const float* d1,
                                  const float* bias, const float* alpha, const float* dshare0,
                                  const float* dshare1, int32_t n_rows,
-                                 float* dpre0, float* dpre1, float* dd0, float* dd1, void* stream);
+                                 float* dpre0, float* dpre1, float* dd0, float* dd1,
+                                 const pygsd_long_rows* long_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * COO -> CSR (operator build).  Groups the nnz entries by seg[e] (stable: entries of one group

@@ -43,20 +43,24 @@ PROTOTYPES = {
                                       c_int32, c_float, c_float, c_int64, c_void_p, c_void_p]),
     "pygsd_sddmm_coo_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                       c_int32, c_void_p, c_void_p]),
+    # the attention / segment entry points take (..., long_rows descriptor or NULL, stream) last
+    "pygsd_segment_long_rows_workspace": (c_int32, [c_int32, c_int32, c_void_p]),
     "pygsd_gat_alpha_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p,
-                                          c_void_p]),
-    "pygsd_segment_softmax_csr_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
-    "pygsd_segment_softmax_bwd_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p]),
+    "pygsd_segment_softmax_csr_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "pygsd_segment_softmax_bwd_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                                    c_void_p]),
     "pygsd_gat_alpha_bwd_csr_v2_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                                  c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
-                                                 c_void_p, c_void_p, c_void_p]),
-    "pygsd_segment_sum_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
-    "pygsd_snea_alpha_csr_f32": (c_int32, [c_void_p] * 8 + [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pygsd_segment_sum_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "pygsd_snea_alpha_csr_f32": (c_int32, [c_void_p] * 8 + [c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                            c_void_p]),
     "pygsd_snea_alpha_bwd_csr_f32": (c_int32, [c_void_p] * 11 + [c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                                c_void_p]),
+                                                                c_void_p, c_void_p]),
     "pygsd_gat_alpha_bwd_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                               c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
-                                              c_int32, c_void_p, c_void_p, c_void_p]),
+                                              c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_csr_from_coo_workspace": (c_int32, [c_int64, c_int32, ctypes.POINTER(c_size_t)]),
     "pygsd_csr_from_coo": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
@@ -99,7 +103,7 @@ PROTOTYPES = {
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def lib_path():

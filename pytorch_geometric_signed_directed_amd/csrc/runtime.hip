@@ -2,6 +2,8 @@
 // pygsd_last_error, pygsd_prof_*).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace pygsd {
 
 std::string& last_error()
@@ -76,14 +78,25 @@ constexpr int kBlock = 256;
 // the gather kernels against (MI355X_MICROARCH.md: "6.29 TB/s measured (float4 copy)").
 typedef float vec4f __attribute__((ext_vector_type(4)));
 
+// MODE bit 0: non-temporal loads, bit 1: non-temporal stores.  UN float4 per lane in flight before the first store.
+template <int MODE, int UN>
 __global__ __launch_bounds__(kBlock) void stream_copy_kernel(const vec4f* __restrict__ src,
                                                             vec4f* __restrict__ dst, int64_t n4)
 {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n4; i += stride) {
-        const vec4f v = __builtin_nontemporal_load(src + i);
-        __builtin_nontemporal_store(v, dst + i);
+    int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    for (; i + (UN - 1) * stride < n4; i += UN * stride) {
+        vec4f v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            v[u] = (MODE & 1) ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (MODE & 2) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+            else dst[i + u * stride] = v[u];
+        }
     }
+    for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 // Occupies the stream for `ticks` of the 100 MHz constant-rate counter: stands in for the wire time of an xGMI
@@ -126,9 +139,22 @@ extern "C" int pygsd_stream_copy_f32(const float* src, float* dst, int64_t n, vo
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_ELEMENTWISE, s);
     const int64_t n4 = n / 4;
-    const int64_t blocks = (n4 + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(static_cast<unsigned>(blocks < 256 * 32 ? blocks : 256 * 32)),
-                       dim3(kBlock), 0, s, reinterpret_cast<const vec4f*>(src), reinterpret_cast<vec4f*>(dst), n4);
+    // PYGSD_COPY_MODE (tuning probe only): 0 plain, 1 nt loads, 2 nt stores, 3 both; PYGSD_COPY_BLOCKS_PER_CU: grid size
+    const char* m = getenv("PYGSD_COPY_MODE");
+    const char* b = getenv("PYGSD_COPY_BLOCKS_PER_CU");
+    const int mode = m ? atoi(m) : 0;
+    const int64_t per_cu = b ? atoi(b) : 8;
+    int64_t blocks = (n4 + kBlock - 1) / kBlock;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    const dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
+    const vec4f* sp = reinterpret_cast<const vec4f*>(src);
+    vec4f* dp = reinterpret_cast<vec4f*>(dst);
+    switch (mode & 3) {
+        case 0: hipLaunchKernelGGL((stream_copy_kernel<0, 4>), grid, block, 0, s, sp, dp, n4); break;
+        case 1: hipLaunchKernelGGL((stream_copy_kernel<1, 4>), grid, block, 0, s, sp, dp, n4); break;
+        case 2: hipLaunchKernelGGL((stream_copy_kernel<2, 4>), grid, block, 0, s, sp, dp, n4); break;
+        default: hipLaunchKernelGGL((stream_copy_kernel<3, 4>), grid, block, 0, s, sp, dp, n4); break;
+    }
     return check_launch("stream_copy_kernel");
 }
 

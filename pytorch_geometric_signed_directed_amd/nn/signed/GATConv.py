@@ -15,15 +15,14 @@ import torch.nn as nn
 from ... import _cabi
 from ..._cabi import check, ptr, stream_ptr
 from ...dense import tall_linear
-from ...sparse import GLOBAL_PATTERNS, Pattern, _rows, _spmm_raw, gather_values, segment_sum_raw
+from ...sparse import (GLOBAL_PATTERNS, Pattern, _rows, _spmm_raw, gather_values, segment_long_rows_arg,
+                       segment_sum_raw)
 
 
 def _row_sum(csr, w_coo):
-    out = torch.empty(csr.n_rows, dtype=torch.float32, device=w_coo.device)
-    with torch.cuda.device(w_coo.device):
-        check(_cabi.lib().pygsd_csr_row_sum_f32(ptr(csr.rowptr), ptr(csr.perm), ptr(w_coo), csr.n_rows, ptr(out),
-                                                stream_ptr()), "pygsd_csr_row_sum_f32")
-    return out
+    """Per-row sums of COO-ordered values (gradient reductions: no reference summation order to keep), hub rows
+    through the segment-parallel path."""
+    return segment_sum_raw(csr.rowptr, csr.perm, w_coo, csr.n_rows, csr)
 
 
 class _GatAggregate(torch.autograd.Function):
@@ -38,9 +37,11 @@ class _GatAggregate(torch.autograd.Function):
         alpha = torch.empty(csr.nnz, dtype=torch.float32, device=h.device)
         if csr.nnz:
             with torch.cuda.device(h.device):
+                hubs, keep = segment_long_rows_arg(csr)
                 check(_cabi.lib().pygsd_gat_alpha_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(a_src), ptr(a_dst),
-                                                          csr.n_rows, float(slope), ptr(alpha), stream_ptr()),
+                                                          csr.n_rows, float(slope), ptr(alpha), hubs, stream_ptr()),
                       "pygsd_gat_alpha_csr_f32")
+                del keep
         out = _spmm_raw(csr, alpha if csr.nnz else None, h, None, 1.0, 0.0, False)
         ctx.pat, ctx.slope = pat, slope
         ctx.save_for_backward(h, a_src, a_dst, alpha, out)
@@ -62,22 +63,26 @@ class _GatAggregate(torch.autograd.Function):
             # vectorised path: ds in by-target slot order, d a_dst from the same pass
             da_dst = torch.empty(fwd.n_rows, dtype=torch.float32, device=h.device)
             with torch.cuda.device(h.device):
+                hubs, keep = segment_long_rows_arg(fwd)
                 check(_cabi.lib().pygsd_gat_alpha_bwd_csr_v2_f32(ptr(fwd.rowptr), ptr(fwd.col), ptr(a_src), ptr(a_dst),
                                                                  float(ctx.slope), ptr(alpha), ptr(hh), ldh, ptr(g),
                                                                  ldg, ptr(oo), ldo, fwd.n_rows, f, ptr(ds),
-                                                                 ptr(da_dst), stream_ptr()),
+                                                                 ptr(da_dst), hubs, stream_ptr()),
                       "pygsd_gat_alpha_bwd_csr_v2_f32")
+                del keep
             m = pat.bwd_to_fwd
             gh = _spmm_raw(bwd, gather_values(alpha, m), g, None, 1.0, 0.0, False)
-            return gh, segment_sum_raw(bwd.rowptr, m, ds, bwd.n_rows), da_dst, None, None
+            return gh, segment_sum_raw(bwd.rowptr, m, ds, bwd.n_rows, bwd), da_dst, None, None
         a_coo = torch.empty_like(ds)
         if fwd.nnz:
             with torch.cuda.device(h.device):
+                hubs, keep = segment_long_rows_arg(fwd)
                 check(_cabi.lib().pygsd_gat_alpha_bwd_csr_f32(ptr(fwd.rowptr), ptr(fwd.col), ptr(fwd.perm), ptr(a_src),
                                                               ptr(a_dst), float(ctx.slope), ptr(alpha), ptr(hh), ldh,
                                                               ptr(g), ldg, ptr(oo), ldo, fwd.n_rows, h.size(1),
-                                                              ptr(ds), ptr(a_coo), stream_ptr()),
+                                                              ptr(ds), ptr(a_coo), hubs, stream_ptr()),
                       "pygsd_gat_alpha_bwd_csr_f32")
+                del keep
         gh = _spmm_raw(bwd, gather_values(a_coo, bwd.perm) if bwd.nnz else None, g, None, 1.0, 0.0, False)
         return gh, _row_sum(bwd, ds), _row_sum(fwd, ds), None, None
 

@@ -21,7 +21,7 @@ from ... import _cabi
 from ..._cabi import check, ptr, stream_ptr
 from ...dense import tall_linear
 from ...memo import TensorMemo
-from ...sparse import Pattern, segment_sum_raw
+from ...sparse import Pattern, segment_long_rows_arg, segment_sum_raw
 
 
 def _loop_free_plus_loops(edge_index: torch.Tensor) -> torch.Tensor:
@@ -56,10 +56,12 @@ class _SneaShares(torch.autograd.Function):
         share1 = torch.zeros(n, dtype=torch.float32, device=s0.device) if typed else None
         if g.fwd.nnz:
             with torch.cuda.device(s0.device):
+                hubs, keep = segment_long_rows_arg(g.fwd)
                 check(_cabi.lib().pygsd_snea_alpha_csr_f32(ptr(g.fwd.rowptr), ptr(g.fwd.col), ptr(g.etype), ptr(s0),
                                                            ptr(s1), ptr(d0), ptr(d1), ptr(bias), n, ptr(alpha),
-                                                           ptr(share0), ptr(share1), stream_ptr()),
+                                                           ptr(share0), ptr(share1), hubs, stream_ptr()),
                       "pygsd_snea_alpha_csr_f32")
+                del keep
         ctx.g, ctx.typed = g, typed
         ctx.save_for_backward(s0, s1, d0, d1, bias, alpha)
         if typed:
@@ -82,13 +84,15 @@ class _SneaShares(torch.autograd.Function):
         dd1 = torch.zeros(n, dtype=torch.float32, device=dev) if typed else None
         if nnz:
             with torch.cuda.device(dev):
+                hubs, keep = segment_long_rows_arg(g.fwd)
                 check(_cabi.lib().pygsd_snea_alpha_bwd_csr_f32(ptr(g.fwd.rowptr), ptr(g.fwd.col), ptr(g.etype), ptr(s0),
                                                                ptr(s1), ptr(d0), ptr(d1), ptr(bias), ptr(alpha),
                                                                ptr(g0), ptr(g1), n, ptr(dpre0), ptr(dpre1), ptr(dd0),
-                                                               ptr(dd1), stream_ptr()),
+                                                               ptr(dd1), hubs, stream_ptr()),
                       "pygsd_snea_alpha_bwd_csr_f32")
-        ds0 = segment_sum_raw(g.bwd.rowptr, g.bwd_to_fwd, dpre0, n)
-        ds1 = segment_sum_raw(g.bwd.rowptr, g.bwd_to_fwd, dpre1, n) if typed else None
+                del keep
+        ds0 = segment_sum_raw(g.bwd.rowptr, g.bwd_to_fwd, dpre0, n, g.bwd)
+        ds1 = segment_sum_raw(g.bwd.rowptr, g.bwd_to_fwd, dpre1, n, g.bwd) if typed else None
         dbias = (dd0.sum() + dd1.sum() if typed else dd0.sum()).reshape(1)
         return ds0, ds1, dd0, dd1, dbias, None
 

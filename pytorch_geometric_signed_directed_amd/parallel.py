@@ -155,12 +155,13 @@ class DistExchange:
 
     @staticmethod
     def _wire(t: Tensor) -> Tensor:
-        """gloo moves bytes: bf16 payloads travel as int16 (not every gloo build knows the type)."""
-        return t.view(torch.int16) if t.dtype == torch.bfloat16 else t
+        """gloo moves bytes: bf16 payloads travel as uint8 (gloo knows neither bf16 nor int16 everywhere)."""
+        return t.view(torch.uint8) if t.dtype == torch.bfloat16 else t
 
     def _gather_sync(self, out: Tensor, inp: Tensor):
+        flat = out.view((out.size(0) * out.size(1),) + tuple(out.shape[2:]))      # gloo wants the concatenated form
         try:
-            dist.all_gather_into_tensor(out, inp, group=self.group)
+            dist.all_gather_into_tensor(flat, inp, group=self.group)
         except (RuntimeError, NotImplementedError):        # a backend without the fused form
             dist.all_gather(list(out.unbind(0)), inp, group=self.group)
 

@@ -6,7 +6,7 @@ import torch
 
 from . import _cabi
 from ._cabi import check, ptr, stream_ptr
-from .sparse import CSR
+from .sparse import CSR, segment_long_rows_arg, segment_sum_raw
 
 Tensor = torch.Tensor
 
@@ -27,8 +27,10 @@ class _SegmentSoftmax(torch.autograd.Function):
         alpha = torch.empty_like(logits)
         if csr.nnz:
             with torch.cuda.device(logits.device):
+                hubs, keep = segment_long_rows_arg(csr)
                 check(_cabi.lib().pygsd_segment_softmax_csr_f32(ptr(csr.rowptr), ptr(logits), csr.n_rows, ptr(alpha),
-                                                                stream_ptr()), "pygsd_segment_softmax_csr_f32")
+                                                                hubs, stream_ptr()), "pygsd_segment_softmax_csr_f32")
+                del keep
         ctx.csr = csr
         ctx.save_for_backward(alpha)
         return alpha
@@ -42,9 +44,11 @@ class _SegmentSoftmax(torch.autograd.Function):
         out = torch.empty_like(alpha)
         if csr.nnz:
             with torch.cuda.device(alpha.device):
+                hubs, keep = segment_long_rows_arg(csr)
                 check(_cabi.lib().pygsd_segment_softmax_bwd_csr_f32(ptr(csr.rowptr), ptr(alpha), ptr(g), csr.n_rows,
-                                                                    ptr(out), stream_ptr()),
+                                                                    ptr(out), hubs, stream_ptr()),
                       "pygsd_segment_softmax_bwd_csr_f32")
+                del keep
         return out, None
 
 
@@ -55,6 +59,12 @@ class _SegmentSum(torch.autograd.Function):
         vals = vals.float().contiguous()
         if vals.numel() != csr.nnz:
             raise ValueError(f"segment_sum: {vals.numel()} values for {csr.nnz} CSR entries")
+        if csr.nnz and csr.n_rows and csr.hubs() is not None:
+            # hub rows: the sequential reference-order row sum below would take one thread through 10^5..10^6
+            # entries; the team / segment-parallel sum handles them (fixed, different summation order)
+            out = segment_sum_raw(csr.rowptr, None, vals, csr.n_rows, csr)
+            ctx.save_for_backward(rows)
+            return out
         out = torch.zeros(csr.n_rows, dtype=torch.float32, device=vals.device)
         if csr.nnz and csr.n_rows:
             with torch.cuda.device(vals.device):

@@ -82,6 +82,20 @@ def _long_rows_arg(csr: CSR, n_feat: int, dual: bool):
     return ctypes.byref(desc), (desc, ws)
 
 
+def segment_long_rows_arg(csr: "CSR"):
+    """(pointer-or-None, keepalive) for the long_rows argument of the attention / segment entry points."""
+    hubs = csr.hubs()
+    if hubs is None:
+        return None, None
+    rows, top = hubs
+    need = ctypes.c_int64(0)
+    check(_cabi.lib().pygsd_segment_long_rows_workspace(rows.numel(), top, ctypes.byref(need)),
+          "pygsd_segment_long_rows_workspace")
+    ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=rows.device)
+    desc = _cabi.LongRows(ptr(rows), rows.numel(), top, ptr(ws), need.value)
+    return ctypes.byref(desc), (desc, ws)
+
+
 def csr_from_coo(seg: Tensor, other: Tensor, n_seg: int, n_other: int, validate: bool = True) -> CSR:
     """Group COO entries by `seg` (stable) on the device -> CSR.  seg/other: int64 [nnz].
     validate: ids outside [0, n_seg) / [0, n_other) raise IndexError (one device->host read per build) instead
@@ -107,13 +121,17 @@ def csr_from_coo(seg: Tensor, other: Tensor, n_seg: int, n_other: int, validate:
     return CSR(n_seg, n_other, nnz, rowptr, col, perm)
 
 
-def segment_sum_raw(rowptr: Tensor, perm: Optional[Tensor], w: Tensor, n_rows: int) -> Tensor:
-    """out[r] = sum of w[perm[slot]] over CSR row r (pygsd_segment_sum_f32; perm None: w is in slot order)."""
+def segment_sum_raw(rowptr: Tensor, perm: Optional[Tensor], w: Tensor, n_rows: int, csr: Optional["CSR"] = None) -> Tensor:
+    """out[r] = sum of w[perm[slot]] over CSR row r (pygsd_segment_sum_f32; perm None: w is in slot order).
+    csr: the CSR `rowptr` belongs to -- its (cached) hub-row list routes rows with > PYGSD_LONG_ROW entries to the
+    segment-parallel path."""
     out = torch.zeros(n_rows, dtype=torch.float32, device=w.device)
     if w.numel() and n_rows:
         with torch.cuda.device(w.device):
-            check(_cabi.lib().pygsd_segment_sum_f32(ptr(rowptr), ptr(perm), ptr(w), n_rows, ptr(out), stream_ptr()),
+            hubs, keep = segment_long_rows_arg(csr) if csr is not None else (None, None)
+            check(_cabi.lib().pygsd_segment_sum_f32(ptr(rowptr), ptr(perm), ptr(w), n_rows, ptr(out), hubs, stream_ptr()),
                   "pygsd_segment_sum_f32")
+            del keep
     return out
 
 
@@ -346,6 +364,11 @@ def _spmm2_raw(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, z
     return ya, yb
 
 
+def _hint(csr: CSR, n_rows: int) -> int:
+    """nnz_hint of a row-range launch: the kernels pick their pipelining variant from entries per LAUNCHED row."""
+    return max(int(csr.nnz * (n_rows / max(csr.n_rows, 1))), 1)
+
+
 def spmm2_rows_into(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, ya: Tensor, yb: Tensor,
                     row_lo: int = 0, row_hi: Optional[int] = None, alpha: float = 1.0,
                     accumulate: bool = False) -> None:
@@ -378,7 +401,7 @@ def spmm2_rows_into(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tens
                                               ptr(val_b), ptr(xa), ptr(xb), lda, pya, pyb, ldy,
                                               pya if accumulate else None, pyb if accumulate else None,
                                               ldy if accumulate else 0, n_rows, f, float(alpha),
-                                              1.0 if accumulate else 0.0, csr.nnz, None, stream_ptr()),
+                                              1.0 if accumulate else 0.0, _hint(csr, n_rows), None, stream_ptr()),
               "pygsd_spmm2_csr_f32")
 
 
@@ -415,7 +438,8 @@ def spmm_rows_into(csr: CSR, val: Optional[Tensor], x: Tensor, y: Tensor, row_lo
                   "pygsd_spmm_csr_bf16")
         else:
             check(_cabi.lib().pygsd_spmm_csr_f32(rp, ptr(csr.col), ptr(val), ptr(x), ldx, py, ldy, z, ldz, n_rows, f,
-                                                 float(alpha), beta, 1 if mean else 0, csr.nnz, None, stream_ptr()),
+                                                 float(alpha), beta, 1 if mean else 0, _hint(csr, n_rows), None,
+                                                 stream_ptr()),
                   "pygsd_spmm_csr_f32")
 
 

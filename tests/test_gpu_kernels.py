@@ -296,8 +296,8 @@ def test_dense_stage_matches_reference_formula(f_in, f_out, k1, n):
     for k in range(k1):
         close(da[k], ad[k].grad)
         close(db[k], bd[k].grad)
-    close(dw, wd.grad, 2e-5)
-    close(dbias, bbd.grad, 2e-5)
+    close(dw, wd.grad, 2e-5, norm=True)          # reductions over the n rows (tests/tolerance.py)
+    close(dbias, bbd.grad, 2e-5, norm=True)
     # no-bias forward
     o_r, o_i = dense_fwd_raw([t.to(d) for t in a], [t.to(d) for t in b], w.to(d), None)
     close(o_r, want_r - bbd)

@@ -35,176 +35,178 @@ def _errs(pairs):
     return mixed, rel
 
 
-def _worker(rank, world, port, cfg, ret):
+def _magnetic_case(rank, world, cfg):
+    from oracle import ref_layers as R
+    from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv, all_gather_rows
+    n, k, f, layout, phases, chunks, signed, absdeg, build = cfg
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    e = 15 * n
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[:, :e // 3] = torch.randint(0, max(n // 8, 2), (2, e // 3), generator=g)      # skew: uneven balanced ranges
+    w = torch.rand(e, generator=g) + 0.5
+    if signed:
+        w = w * (torch.randint(0, 2, (e,), generator=g) * 2 - 1)
+    xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    gr, gi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    torch.manual_seed(11)
+    layer = ShardedMagNetConv(f, f, k, 0.25, n, ei.to(dev), w.to(dev), device=dev, layout=layout, signed=signed,
+                              absolute_degree=absdeg, phases=phases, return_chunks=chunks, build=build,
+                              grid_cols=2 if (layout == "grid" and world == 2) else None)   # force the 1 x 2 grid
+    assert layer.layout == layout and (layout == "rows" or layer.engine.p_c > 1)
+    with torch.no_grad():
+        layer.bias.uniform_(-0.5, 0.5)
+        dist.broadcast(layer.bias.data, 0)
+    a = layer.shard_rows(xr.to(dev)).requires_grad_()
+    b = layer.shard_rows(xi.to(dev)).requires_grad_()
+    o_r, o_i = layer(a, b)
+    ((o_r * layer.shard_rows(gr.to(dev))).sum() + (o_i * layer.shard_rows(gi.to(dev))).sum()).backward()
+    plan = layer.plan
+    got = [plan.unshard_rows(all_gather_rows(t.detach().contiguous())).cpu() for t in (o_r, o_i, a.grad, b.grad)]
+    # un-sharded oracle (reference op sequence, CPU)
+    weight, bias = layer.weight.detach().cpu(), layer.bias.detach().cpu()
+    c, d = xr.clone().requires_grad_(), xi.clone().requires_grad_()
+    wt, bs = weight.clone().requires_grad_(), bias.clone().requires_grad_()
+    op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0, signed=signed, absolute_degree=absdeg)
+    w_r, w_i = R.magnet_conv(c, d, op, wt, bs, duplicate=False)
+    ((w_r * gr).sum() + (w_i * gi).sum()).backward()
+    rows = _errs(zip(got, [w_r.detach(), w_i.detach(), c.grad, d.grad]))[0]          # absolute bar
+    prm = _errs([(layer.weight.grad.cpu(), wt.grad), (layer.bias.grad.cpu(), bs.grad)])[1]   # row reductions
+    return rows, prm, layer.global_nnz, int(op[0].size(1)) - n
+
+
+# n, K, f, layout, phases, return chunks, signed, absolute_degree, build -- grouped by world size: one process
+# group per world runs all of its configurations (spawning ranks costs more than the layers do)
+MAGNETIC = {
+    2: [(1003, 2, 64, "rows", 2, 1, False, True, "distributed"),
+        (300, 2, 6, "rows", 2, 1, False, True, "global"),               # width the vector kernel must pad
+        (1003, 1, 64, "grid", 2, 2, False, True, "distributed"),        # 1 x 2
+        # BASELINE C4: MSGNN's signed magnetic Laplacian (general/MSConv.py:121-230), h = 128, K = 2, node-partitioned
+        (900, 2, 128, "rows", 2, 1, True, True, "distributed")],
+    3: [(500, 3, 16, "rows", 1, 1, False, True, "distributed")],
+    4: [(901, 3, 32, "grid", 2, 2, False, True, "distributed"),         # 1 x 4 at 8-float slices, three orders
+        (900, 2, 128, "rows", 2, 1, True, False, "distributed"),        # C4
+        (900, 2, 128, "grid", 2, 2, True, True, "distributed")],        # C4
+    8: [(1203, 2, 64, "grid", 2, 2, False, True, "distributed"),        # 2 x 4: the 8-GPU configuration
+        (1203, 1, 64, "grid", 1, 1, False, True, "global"),             # 2 x 4 un-pipelined, global build
+        (1100, 2, 128, "rows", 2, 1, True, True, "distributed"),        # C4
+        (1100, 2, 128, "grid", 2, 2, True, False, "distributed")],      # C4
+}
+# n, f, dtype, inception block?, phases
+DIGCN = {
+    2: [(1001, 64, "float32", False, 2), (1000, 64, "bfloat16", False, 1),
+        # BASELINE C5: DiGCN_InceptionBlock (DiGCN_Inception_Block.py:31-47), sharded, fp32 and bf16
+        (1000, 64, "float32", True, 2)],
+    3: [(600, 16, "float32", False, 1)],
+    4: [(1200, 64, "float32", True, 1), (1200, 64, "bfloat16", True, 1)],
+    8: [(1600, 64, "bfloat16", True, 1)],
+}
+
+
+def _suite(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from oracle import ref_layers as R
-        from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv, all_gather_rows
-        n, k, f, layout, phases, chunks, signed, absdeg, build = cfg
-        dev = torch.device("cuda:0")
-        g = torch.Generator().manual_seed(7)
-        e = 15 * n
-        ei = torch.randint(0, n, (2, e), generator=g)
-        ei[:, :e // 3] = torch.randint(0, max(n // 8, 2), (2, e // 3), generator=g)      # skew: uneven balanced ranges
-        w = torch.rand(e, generator=g) + 0.5
-        if signed:
-            w = w * (torch.randint(0, 2, (e,), generator=g) * 2 - 1)
-        xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
-        gr, gi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
-        torch.manual_seed(11)
-        layer = ShardedMagNetConv(f, f, k, 0.25, n, ei.to(dev), w.to(dev), device=dev, layout=layout, signed=signed,
-                                  absolute_degree=absdeg, phases=phases, return_chunks=chunks, build=build,
-                                  grid_cols=2 if (layout == "grid" and world == 2) else None)   # force the 1 x 2 grid
-        assert layer.layout == layout and (layout == "rows" or layer.engine.p_c > 1)
-        with torch.no_grad():
-            layer.bias.uniform_(-0.5, 0.5)
-            dist.broadcast(layer.bias.data, 0)
-        a = layer.shard_rows(xr.to(dev)).requires_grad_()
-        b = layer.shard_rows(xi.to(dev)).requires_grad_()
-        o_r, o_i = layer(a, b)
-        ((o_r * layer.shard_rows(gr.to(dev))).sum() + (o_i * layer.shard_rows(gi.to(dev))).sum()).backward()
-        plan = layer.plan
-        got = [plan.unshard_rows(all_gather_rows(t.detach().contiguous())).cpu() for t in (o_r, o_i, a.grad, b.grad)]
-        # un-sharded oracle (reference op sequence, CPU)
-        weight, bias = layer.weight.detach().cpu(), layer.bias.detach().cpu()
-        c, d = xr.clone().requires_grad_(), xi.clone().requires_grad_()
-        wt, bs = weight.clone().requires_grad_(), bias.clone().requires_grad_()
-        op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0, signed=signed, absolute_degree=absdeg)
-        w_r, w_i = R.magnet_conv(c, d, op, wt, bs, duplicate=False)
-        ((w_r * gr).sum() + (w_i * gi).sum()).backward()
-        rows = _errs(zip(got, [w_r.detach(), w_i.detach(), c.grad, d.grad]))[0]          # absolute bar
-        prm = _errs([(layer.weight.grad.cpu(), wt.grad), (layer.bias.grad.cpu(), bs.grad)])[1]   # row reductions
-        ret[rank] = (rows, prm, layer.global_nnz, int(op[0].size(1)) - n)
+        out = {}
+        for cfg in MAGNETIC[world]:
+            out["magnetic " + str(cfg)] = _magnetic_case(rank, world, cfg)
+        for cfg in DIGCN[world]:
+            out["digcn " + str(cfg)] = _digcn_case(rank, world, *cfg)
+        if world == 4:
+            out["build"] = _build_case()
+        ret[rank] = out
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cfg", [
-    # n, K, f, layout, phases, return chunks, signed, absolute_degree, build
-    (2, (1003, 2, 64, "rows", 2, 1, False, True, "distributed")),
-    (3, (500, 3, 16, "rows", 1, 1, False, True, "distributed")),
-    (2, (300, 2, 6, "rows", 2, 1, False, True, "global")),              # width the vector kernel must pad
-    (2, (1003, 1, 64, "grid", 2, 2, False, True, "distributed")),       # 1 x 2
-    (4, (901, 3, 32, "grid", 2, 2, False, True, "distributed")),        # 1 x 4 at 8-float slices, three orders
-    (8, (1203, 2, 64, "grid", 2, 2, False, True, "distributed")),       # 2 x 4: the 8-GPU configuration
-    (8, (1203, 1, 64, "grid", 1, 1, False, True, "global")),            # 2 x 4 un-pipelined, global build
-    # BASELINE C4: MSGNN's signed magnetic Laplacian (general/MSConv.py:121-230), h = 128, K = 2, node-partitioned
-    (2, (900, 2, 128, "rows", 2, 1, True, True, "distributed")),
-    (4, (900, 2, 128, "rows", 2, 1, True, False, "distributed")),
-    (4, (900, 2, 128, "grid", 2, 2, True, True, "distributed")),
-    (8, (1100, 2, 128, "rows", 2, 1, True, True, "distributed")),
-    (8, (1100, 2, 128, "grid", 2, 2, True, False, "distributed")),
-])
-def test_sharded_layer_matches_oracle(world, cfg):
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_sharded_layers_match_oracle(world):
+    """Every configuration of MAGNETIC[world] / DIGCN[world] (incl. BASELINE C4 and C5 in sharded form) on `world`
+    ranks; world 4 also checks the distributed operator build against the rows of the global build."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), cfg, ret), nprocs=world, join=True)
+    mp.spawn(_suite, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert len(ret) == world
-    assert max(v[0] for v in ret.values()) <= 1e-5, dict(ret)      # outputs / dX: |d| <= 1e-5 (1 + |want|)
-    assert max(v[1] for v in ret.values()) <= 1e-5, dict(ret)      # dW / db: max-norm (row reductions)
-    # the layer's count of operator entries = the oracle's (both diagonal sets folded into one entry per node)
-    assert all(v[2] == v[3] for v in ret.values()), dict(ret)
+    for rank, out in ret.items():
+        for name, v in out.items():
+            if name.startswith("magnetic"):
+                assert v[0] <= 1e-5, (rank, name, v)      # outputs / dX: |d| <= 1e-5 (1 + |want|)
+                assert v[1] <= 1e-5, (rank, name, v)      # dW / db: max-norm (row reductions)
+                # the layer's count of operator entries = the oracle's (both diagonal sets folded into one per node)
+                assert v[2] == v[3], (rank, name, v)
+            elif name.startswith("digcn"):
+                assert v <= 1.0, (rank, name, v)
+            else:
+                assert v is True, (rank, name)
 
 
-def _digcn_worker(rank, world, port, n, f, dtype_name, block, phases, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from oracle import ref_layers as R
-        from pytorch_geometric_signed_directed_amd.parallel import (ShardedDiGCNConv, ShardedDiGCNInceptionBlock,
-                                                                    all_gather_rows)
-        dev = torch.device("cuda:0")
-        dtype = getattr(torch, dtype_name)
-        g = torch.Generator().manual_seed(5)
-        e = 12 * n
-        ei, ei2 = torch.randint(0, n, (2, e), generator=g), torch.randint(0, n, (2, e), generator=g)
-        w, w2 = torch.rand(e, generator=g) / 8, torch.rand(e, generator=g) / 8
-        x = torch.randn(n, f, generator=g)
-        go = torch.randn(n, f, generator=g)
-        torch.manual_seed(13)
-        if block:
-            layer = ShardedDiGCNInceptionBlock(f, f, n, ei.to(dev), w.to(dev), ei2.to(dev), w2.to(dev), device=dev,
-                                               phases=phases)
-        else:
-            layer = ShardedDiGCNConv(f, f, n, ei.to(dev), w.to(dev), device=dev, phases=phases)
-        with torch.no_grad():
-            for prm in layer.parameters():
-                prm.uniform_(-0.5, 0.5)
-                dist.broadcast(prm.data, 0)
-        sd = {k: v.detach().cpu().clone() for k, v in layer.named_parameters()}
-        layer.to(dtype)
-        a = layer.shard_rows(x.to(dev)).to(dtype).requires_grad_()
-        outs = layer(a)
-        outs = outs if block else (outs,)
-        sum(((k + 1.0) * o.float() * layer.shard_rows(go.to(dev))).sum() for k, o in enumerate(outs)).backward()
-        got = [layer.plan.unshard_rows(all_gather_rows(t.detach().float().contiguous())).cpu() for t in outs + (a.grad,)]
-        # oracle: fp32 arithmetic on inputs and parameters rounded to the storage dtype
-        rnd = (lambda t: t.to(dtype).float())
-        xo = rnd(x).requires_grad_()
-        p = {k: rnd(v).requires_grad_() for k, v in sd.items()}
-        if block:
-            want = (xo @ p["ln.weight"].t() + p["ln.bias"], R.digcn_conv(xo, ei, w, p["conv1.weight"], p["conv1.bias"]),
-                    R.digcn_conv(xo, ei2, w2, p["conv2.weight"], p["conv2.bias"]))
-        else:
-            want = (R.digcn_conv(xo, ei, w, p["weight"], p["bias"]),)
-        sum(((k + 1.0) * o * go).sum() for k, o in enumerate(want)).backward()
-        pairs = list(zip(got, [t.detach() for t in want] + [xo.grad]))
-        pairs += [(prm.grad.float().cpu(), p[k].grad) for k, prm in layer.named_parameters()]
-        # fp32: the 1e-5 bar.  bf16: every stored value (projection, product, gradient) is rounded to 8 bits of
-        # mantissa: relative 2^-8 of the quantity's scale per rounding, two roundings on the way to an output
-        # (x W, then S^T (x W)) and three to a gradient -- bound 3 * 2^-8 of the max norm, against 3e-2 last round
-        tol = 1e-5 if dtype is torch.float32 else 3 * 2.0 ** -8
-        ret[rank] = _errs(pairs)[1] / tol
-    finally:
-        dist.destroy_process_group()
+def _digcn_case(rank, world, n, f, dtype_name, block, phases):
+    from oracle import ref_layers as R
+    from pytorch_geometric_signed_directed_amd.parallel import (ShardedDiGCNConv, ShardedDiGCNInceptionBlock,
+                                                                all_gather_rows)
+    dev = torch.device("cuda:0")
+    dtype = getattr(torch, dtype_name)
+    g = torch.Generator().manual_seed(5)
+    e = 12 * n
+    ei, ei2 = torch.randint(0, n, (2, e), generator=g), torch.randint(0, n, (2, e), generator=g)
+    w, w2 = torch.rand(e, generator=g) / 8, torch.rand(e, generator=g) / 8
+    x = torch.randn(n, f, generator=g)
+    go = torch.randn(n, f, generator=g)
+    torch.manual_seed(13)
+    if block:
+        layer = ShardedDiGCNInceptionBlock(f, f, n, ei.to(dev), w.to(dev), ei2.to(dev), w2.to(dev), device=dev,
+                                           phases=phases)
+    else:
+        layer = ShardedDiGCNConv(f, f, n, ei.to(dev), w.to(dev), device=dev, phases=phases)
+    with torch.no_grad():
+        for prm in layer.parameters():
+            prm.uniform_(-0.5, 0.5)
+            dist.broadcast(prm.data, 0)
+    sd = {k: v.detach().cpu().clone() for k, v in layer.named_parameters()}
+    layer.to(dtype)
+    a = layer.shard_rows(x.to(dev)).to(dtype).requires_grad_()
+    outs = layer(a)
+    outs = outs if block else (outs,)
+    sum(((k + 1.0) * o.float() * layer.shard_rows(go.to(dev))).sum() for k, o in enumerate(outs)).backward()
+    got = [layer.plan.unshard_rows(all_gather_rows(t.detach().float().contiguous())).cpu() for t in outs + (a.grad,)]
+    # oracle: fp32 arithmetic on inputs and parameters rounded to the storage dtype
+    rnd = (lambda t: t.to(dtype).float())
+    xo = rnd(x).requires_grad_()
+    p = {k: rnd(v).requires_grad_() for k, v in sd.items()}
+    if block:
+        want = (xo @ p["ln.weight"].t() + p["ln.bias"], R.digcn_conv(xo, ei, w, p["conv1.weight"], p["conv1.bias"]),
+                R.digcn_conv(xo, ei2, w2, p["conv2.weight"], p["conv2.bias"]))
+    else:
+        want = (R.digcn_conv(xo, ei, w, p["weight"], p["bias"]),)
+    sum(((k + 1.0) * o * go).sum() for k, o in enumerate(want)).backward()
+    pairs = list(zip(got, [t.detach() for t in want] + [xo.grad]))
+    pairs += [(prm.grad.float().cpu(), p[k].grad) for k, prm in layer.named_parameters()]
+    # fp32: the 1e-5 bar.  bf16: every stored value (projection, product, gradient) is rounded to 8 bits of
+    # mantissa: relative 2^-8 of the quantity's scale per rounding, two roundings on the way to an output
+    # (x W, then S^T (x W)) and three to a gradient -- bound 3 * 2^-8 of the max norm, against 3e-2 last round
+    tol = 1e-5 if dtype is torch.float32 else 3 * 2.0 ** -8
+    return _errs(pairs)[1] / tol
 
 
-@pytest.mark.parametrize("world,n,f,dtype_name,block,phases", [
-    (2, 1001, 64, "float32", False, 2), (3, 600, 16, "float32", False, 1), (2, 1000, 64, "bfloat16", False, 1),
-    # BASELINE C5: DiGCN_InceptionBlock (DiGCN_Inception_Block.py:31-47), sharded, fp32 and bf16
-    (2, 1000, 64, "float32", True, 2), (4, 1200, 64, "float32", True, 1), (4, 1200, 64, "bfloat16", True, 1),
-    (8, 1600, 64, "bfloat16", True, 1),
-])
-def test_sharded_digcn_and_inception_block_match_oracle(world, n, f, dtype_name, block, phases):
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_digcn_worker, args=(world, _free_port(), n, f, dtype_name, block, phases, ret), nprocs=world, join=True)
-    assert len(ret) == world
-    assert max(ret.values()) <= 1.0, dict(ret)
-
-
-def test_distributed_build_equals_rows_of_the_global_build():
-    """Four ranks on one GPU: the rows a rank assembles from the edges incident to them (degrees all-gathered) are
-    the rows of the operator built whole -- same order, same values -- in both layouts."""
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_build_worker, args=(4, _free_port(), ret), nprocs=4, join=True)
-    assert len(ret) == 4 and all(ret.values()), dict(ret)
-
-
-def _build_worker(rank, world, port, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv
-        dev = torch.device("cuda:0")
-        g = torch.Generator().manual_seed(3)
-        n = 2000
-        ei = torch.randint(0, n, (2, 30000), generator=g).to(dev)
-        w = (torch.rand(30000, generator=g) + 0.5).to(dev)
-        ok = True
-        for layout, signed in (("rows", False), ("grid", True)):
-            kw = dict(device=dev, layout=layout, signed=signed, phases=2, return_chunks=2)
-            a = ShardedMagNetConv(32, 32, 1, 0.25, n, ei, w, build="distributed", **kw)
-            b = ShardedMagNetConv(32, 32, 1, 0.25, n, ei, w, build="global", **kw)
-            for (ca, va), (cb, vb) in zip(a.op_fwd.blocks + a.op_bwd.blocks, b.op_fwd.blocks + b.op_bwd.blocks):
-                ok = ok and torch.equal(ca.rowptr, cb.rowptr) and torch.equal(ca.col, cb.col)
-                ok = ok and all(torch.allclose(x, y, rtol=0, atol=1e-7) for x, y in zip(va, vb))
-            ok = ok and a.global_nnz == b.global_nnz
-        ret[rank] = bool(ok)
-    finally:
-        dist.destroy_process_group()
+def _build_case():
+    """The rows a rank assembles from the edges incident to them (degrees all-gathered) are the rows of the
+    operator built whole -- same order, same values -- in both layouts."""
+    from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    n = 2000
+    ei = torch.randint(0, n, (2, 30000), generator=g).to(dev)
+    w = (torch.rand(30000, generator=g) + 0.5).to(dev)
+    ok = True
+    for layout, signed in (("rows", False), ("grid", True)):
+        kw = dict(device=dev, layout=layout, signed=signed, phases=2, return_chunks=2)
+        a = ShardedMagNetConv(32, 32, 1, 0.25, n, ei, w, build="distributed", **kw)
+        b = ShardedMagNetConv(32, 32, 1, 0.25, n, ei, w, build="global", **kw)
+        for (ca, va), (cb, vb) in zip(a.op_fwd.blocks + a.op_bwd.blocks, b.op_fwd.blocks + b.op_bwd.blocks):
+            ok = ok and torch.equal(ca.rowptr, cb.rowptr) and torch.equal(ca.col, cb.col)
+            ok = ok and all(torch.allclose(x, y, rtol=0, atol=1e-7) for x, y in zip(va, vb))
+        ok = ok and a.global_nnz == b.global_nnz
+    return bool(ok)
 
 
 @pytest.mark.parametrize("gpus", [2, 4, 8])

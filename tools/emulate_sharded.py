@@ -91,7 +91,7 @@ def main():
     g = torch.Generator().manual_seed(0)
     x_real = torch.randn(args.nodes, args.hidden, generator=g).to(dev)
     x_imag = torch.randn(args.nodes, args.hidden, generator=g).to(dev)
-    shapes = [("grid", 1, 1), ("grid", 2, 2), ("grid", 2, 4), ("grid", 4, 4), ("rows", 1, 1), ("rows", 2, 1)]
+    shapes = [("grid", 1, 1), ("grid", 1, 2), ("grid", 1, 4), ("grid", 2, 2), ("grid", 2, 4), ("rows", 1, 1), ("rows", 2, 1)]
     if args.world <= 2:
         shapes = [("rows", 1, 1), ("rows", 2, 1), ("rows", 4, 1)]
     out = {"world": args.world, "rank": args.rank, "nodes": args.nodes, "edges": int(ei.size(1)), "hidden": args.hidden,
