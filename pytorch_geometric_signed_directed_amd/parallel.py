@@ -397,10 +397,12 @@ class PropagateEngine:
         rows = slice(c * self.n_sub, (c + 1) * self.n_sub)
         if not self.grid:
             return torch.cat([x[rows] for x in xs], dim=1)
-        fw = xs[0].size(1) // self.p_c
-        stacked = torch.stack([x[rows].reshape(self.n_sub, self.p_c, fw) for x in xs], dim=2)   # [n_sub, p_c, G, fw]
-        slices = stacked.permute(1, 0, 2, 3).reshape(self.p_c, self.n_sub, len(xs) * fw)
-        return slices.repeat(self.p_r, 1, 1)
+        fw, groups = xs[0].size(1) // self.p_c, len(xs)
+        out = xs[0].new_empty((self.plan.world_size, self.n_sub, groups * fw))
+        dst = out.view(self.p_r, self.p_c, self.n_sub, groups, fw)
+        for g, x in enumerate(xs):          # one strided copy per group writes all p_r replicas of the p_c slices
+            dst[:, :, :, g, :] = x[rows].view(self.n_sub, self.p_c, fw).permute(1, 0, 2)
+        return out
 
     def _merge(self, recv: Tensor, groups: int) -> List[Tensor]:
         """recv [R, world, n_rsub, G * fw] (chunk s of return exchange r = rows (block i', chunk r) of MY range x
@@ -575,18 +577,6 @@ class _ShardedProduct(torch.autograd.Function):
         return (None, None, None) + tuple(out)
 
 
-def _mask_pad_rows(plan: ShardPlan, *ts: Tensor):
-    """Upstream gradients of the pad rows are not part of the graph: zero them (out of place)."""
-    if plan.n_local == plan.n_pad:
-        return ts
-    out = []
-    for t in ts:
-        t = t.clone()
-        t[plan.n_local:] = 0
-        out.append(t)
-    return tuple(out)
-
-
 class _ShardedMagneticFn(torch.autograd.Function):
     """Forward / backward of one node-sharded MagNetConv / MSConv layer (local rows only): the Chebyshev
     recurrence over engine products, the fused MFMA dense stage on the local rows, dW / db all-reduced."""
@@ -614,8 +604,14 @@ class _ShardedMagneticFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         weight = saved[0]
         ta, tb = list(saved[1:1 + k1]), list(saved[1 + k1:1 + 2 * k1])
-        g_r, g_i = _mask_pad_rows(layer.plan, g_r.contiguous(), g_i.contiguous())
+        g_r, g_i = g_r.contiguous(), g_i.contiguous()
         da, db, dw, dbias = layer._dense_bwd(ta, tb, weight, g_r, g_i)
+        n_local = layer.plan.n_local
+        if n_local < layer.plan.n_pad:
+            # upstream gradient on the PAD rows is not part of the graph.  Their Chebyshev terms are zero (isolated
+            # nodes, zero features), so dW is unaffected and nothing leaks into real rows through S^T; only db
+            # = sum_rows (g_r + g_i) has to lose the pad rows' share
+            dbias = dbias - (g_r[n_local:] + g_i[n_local:]).sum(0)
         gx_r = gx_i = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             # d T_{k-1} += 2 S^T d T_k ; d T_{k-2} -= d T_k   (k = K .. 2), then gX = d T_0 + S^T d T_1
