@@ -60,7 +60,7 @@ def build_inputs(n, e, hidden, device, seed=0):
     return edge_index.to(device), x_real.to(device), x_imag.to(device), p
 
 
-def cpu_baseline(hidden, steps=5, n=100000, e=2000000, threads=None):
+def cpu_baseline(hidden, steps=4, n=100000, e=2000000, threads=None):
     """Reference op sequence (index_select -> mul -> scatter_add_, 4 propagates per order incl. the
     reference's duplicates, autograd backward) on the host cores: `cached=True` (steady state, comparable with the
     GPU figure) and `cached=False` (the reference's default, MagNetConv.py:45,157-181: operator rebuilt by every
@@ -88,21 +88,24 @@ def cpu_baseline(hidden, steps=5, n=100000, e=2000000, threads=None):
         o_r, o_i = R.magnet_conv(xr, xi, op, w, b, duplicate=True)
         (o_r.sum() + o_i.sum()).backward()
 
-    def timed(op, count):
-        step(op)  # warm-up
-        ts = []
-        for _ in range(count):
-            t0 = time.perf_counter()
-            step(op)
-            ts.append(time.perf_counter() - t0)
-        return ts
+    def once(op):
+        t0 = time.perf_counter()
+        step(op)
+        return time.perf_counter() - t0
 
-    t_cached = timed(cached_op, steps)
-    t_rebuilt = timed(None, max(steps - 2, 3))
+    once(cached_op)  # warm-up
+    once(None)
+    t_cached, t_rebuilt = [], []
+    for _ in range(steps):          # interleaved, so that slow drifts of the host hit both legs alike
+        t_cached.append(once(cached_op))
+        t_rebuilt.append(once(None))
+    t0 = time.perf_counter()
+    R.magnet_operator(ei, None, n, 0.25, "sym", 2.0)
+    build_s = time.perf_counter() - t0
     med_c, med_u = statistics.median(t_cached), statistics.median(t_rebuilt)
     edges = ei.size(1)
     return {"value": edges / med_c, "unit": "edges/s", "cores": cores, "cores_available": available, "kind": "port",
-            "value_uncached": edges / med_u,
+            "value_uncached": edges / med_u, "operator_build_seconds": build_s,
             "seconds_per_step": {"cached_median": med_c, "cached_min": min(t_cached), "cached_max": max(t_cached),
                                  "uncached_median": med_u, "uncached_min": min(t_rebuilt), "uncached_max": max(t_rebuilt)},
             "scaled_from": "C2 size (DSBM 100k nodes / 2M edges = north-star / 10): the reference's per-propagate "

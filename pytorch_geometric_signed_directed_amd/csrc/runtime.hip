@@ -139,11 +139,14 @@ extern "C" int pygsd_stream_copy_f32(const float* src, float* dst, int64_t n, vo
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_ELEMENTWISE, s);
     const int64_t n4 = n / 4;
-    // PYGSD_COPY_MODE (tuning probe only): 0 plain, 1 nt loads, 2 nt stores, 3 both; PYGSD_COPY_BLOCKS_PER_CU: grid size
+    // Defaults = the fastest shape of tools/copy_probe.py on MI355X (profiles/r2_copy_probe.json): plain loads and
+    // stores, ONE float4 per lane over an uncapped grid (the unrolled main loop never runs then) -- 6.16 TB/s (persistent grids of 4..64 blocks per
+    // CU and non-temporal variants: 4.2..5.4 TB/s; torch's copy_: 4.55 TB/s).  PYGSD_COPY_MODE (0 plain, 1 nt loads,
+    // 2 nt stores, 3 both) and PYGSD_COPY_BLOCKS_PER_CU exist for that probe only.
     const char* m = getenv("PYGSD_COPY_MODE");
     const char* b = getenv("PYGSD_COPY_BLOCKS_PER_CU");
     const int mode = m ? atoi(m) : 0;
-    const int64_t per_cu = b ? atoi(b) : 8;
+    const int64_t per_cu = b ? atoi(b) : (int64_t(1) << 20);
     int64_t blocks = (n4 + kBlock - 1) / kBlock;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     const dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);

@@ -243,9 +243,7 @@ class EmulatedExchange:
                 self._cabi.check(self._cabi.lib().pygsd_spin_us(us, self._cabi.stream_ptr()), "pygsd_spin_us")
             done = torch.cuda.Event()
             done.record(self.stream)
-        out.record_stream(self.stream)
-        src.record_stream(self.stream)
-        return _StreamEvent(done)
+        return _StreamEvent(done)        # buffers are the engine's persistent ones: nothing to keep alive
 
     def all_gather(self, out: Tensor, inp: Tensor):
         return self._play(out, inp.unsqueeze(0).expand_as(out), inp.numel() * inp.element_size())
@@ -365,6 +363,18 @@ class PropagateEngine:
         self.block_rows = world * self.n_blk if self.grid else plan.n_pad
         self.dual_kernel, self.single_kernel = kernels or (_hip_dual, _hip_single)
         self.timing = None                                   # dict of event lists when profiling
+        self._scratch = {}
+
+    def _buf(self, name: str, shape, like: Tensor) -> Tensor:
+        """Exchange / staging buffers live as long as the engine: a propagate never allocates for them (a
+        buffer handed to a collective on another stream would otherwise pin its allocator block until that
+        stream's event retires, and the next propagate would fall through to hipMalloc).  Reuse is safe: the
+        compute stream has waited for every exchange of the previous propagate before it packs the next one."""
+        key = (name, tuple(shape), like.dtype, like.device)
+        t = self._scratch.get(key)
+        if t is None:
+            t = self._scratch[key] = torch.empty(tuple(shape), dtype=like.dtype, device=like.device)
+        return t
 
     @staticmethod
     def alignment(world_size: int, p_c: int, phases: int, return_chunks: int) -> int:
@@ -396,9 +406,13 @@ class PropagateEngine:
         rows: [n_sub, G * F] (groups side by side).  grid: [world, n_sub, G * fw], chunk d = column slice d % p_c."""
         rows = slice(c * self.n_sub, (c + 1) * self.n_sub)
         if not self.grid:
-            return torch.cat([x[rows] for x in xs], dim=1)
+            f = xs[0].size(1)
+            out = self._buf(f"send{c}", (self.n_sub, len(xs) * f), xs[0])
+            for g, x in enumerate(xs):
+                out[:, g * f:(g + 1) * f] = x[rows]
+            return out
         fw, groups = xs[0].size(1) // self.p_c, len(xs)
-        out = xs[0].new_empty((self.plan.world_size, self.n_sub, groups * fw))
+        out = self._buf(f"send{c}", (self.plan.world_size, self.n_sub, groups * fw), xs[0])
         dst = out.view(self.p_r, self.p_c, self.n_sub, groups, fw)
         for g, x in enumerate(xs):          # one strided copy per group writes all p_r replicas of the p_c slices
             dst[:, :, :, g, :] = x[rows].view(self.n_sub, self.p_c, fw).permute(1, 0, 2)
@@ -436,15 +450,17 @@ class PropagateEngine:
         works, bufs = [], []
         for c in range(self.phases):                         # every exchange is issued before any product
             send = self._pack(xs, c)
-            buf = send.new_empty((world, self.n_sub, groups * fw))
+            buf = self._buf(f"recv{c}", (world, self.n_sub, groups * fw), send)
             works.append(self.ex.all_to_all(buf, send) if self.grid else self.ex.all_gather(buf, send))
             bufs.append(buf)
         self._mark(ev, "packed")
-        ys = [xs[0].new_empty((self.block_rows, fw)) for _ in range(groups)]
+        # the row layout hands its products to the caller (fresh tensors); the grid's are staging for the return
+        ys = [self._buf(f"y{g}", (self.block_rows, fw), xs[0]) if self.grid else xs[0].new_empty((self.block_rows, fw))
+              for g in range(groups)]
         chunk_rows = world * self.n_rsub
         returns, recv = [], None
         if self.grid:
-            recv = xs[0].new_empty((self.return_chunks, world, self.n_rsub, groups * fw))
+            recv = self._buf("back", (self.return_chunks, world, self.n_rsub, groups * fw), xs[0])
         for c in range(self.phases):
             works[c].wait()
             self._mark(ev, "arrived")
@@ -462,7 +478,10 @@ class PropagateEngine:
                         self.single_kernel(csr, val, buf[:, g * fw:(g + 1) * fw], ys[g], lo, hi, alpha, c > 0,
                                            op[g].mean)
                 if last and self.grid:                       # chunk r goes home while chunk r + 1 is multiplied
-                    pack = torch.cat([y[lo:hi] for y in ys], dim=1).view(world, self.n_rsub, groups * fw)
+                    pack = self._buf(f"home{r}", (world, self.n_rsub, groups * fw), xs[0])
+                    flat = pack.view(world * self.n_rsub, groups * fw)
+                    for g, y in enumerate(ys):
+                        flat[:, g * fw:(g + 1) * fw] = y[lo:hi]
                     returns.append(self.ex.all_to_all(recv[r], pack))
             self._mark(ev, "multiplied")
         if not self.grid:

@@ -105,6 +105,7 @@ DIGCN = {
 
 def _suite(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))   # the oracle runs in every rank: no oversubscription
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         out = {}

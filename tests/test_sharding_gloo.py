@@ -136,6 +136,7 @@ def _graph(n, seed, skew):
 
 def _magnetic_worker(rank, world, port, cfg, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))   # the oracle runs in every rank: no oversubscription
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv, all_gather_rows
@@ -196,6 +197,7 @@ def test_sharded_magnetic_layer_equals_unsharded_oracle(world, cfg):
 
 def _digcn_worker(rank, world, port, n, f, phases, block, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))   # the oracle runs in every rank: no oversubscription
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pytorch_geometric_signed_directed_amd.parallel import (ShardedDiGCNConv, ShardedDiGCNInceptionBlock,

@@ -10,8 +10,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import importlib  # noqa: E402
+
 import pytorch_geometric_signed_directed_amd.sparse as S  # noqa: E402
-from pytorch_geometric_signed_directed_amd.nn.signed import GATConv as G  # noqa: E402
+
+G = importlib.import_module("pytorch_geometric_signed_directed_amd.nn.signed.GATConv")   # the module, not the class
 
 
 def run(hub, use_hubs):
