@@ -626,29 +626,41 @@ __global__ __launch_bounds__(kHubThreads) void hub_gat_bwd_kernel(GatBwdHubArgs 
     rd = block_sum4(rd, sm);                              // <g_i, out_i>
     const float ad = a.a_dst[row];
     const int t = threadIdx.x & 15, team = threadIdx.x >> 4;
+    constexpr int kTeams = kHubThreads / 16, UN = 4;      // 4 entries per team in flight: the gathers are latency-bound
     float acc = 0.f;
-    for (int e0 = lo; e0 < hi; e0 += kHubThreads / 16) {
-        const int e = e0 + team;
-        float dot = 0.f;
-        int cj = 0;
-        if (e < hi) {
-            cj = a.col[e];
-            const float* hj = a.h + static_cast<int64_t>(cj) * a.ldh;
-            for (int f = t; f < a.n_feat; f += 16) dot = fmaf(gi[f], hj[f], dot);
+    for (int e0 = lo; e0 < hi; e0 += kTeams * UN) {
+        float dot[UN];
+        int cj[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int e = e0 + u * kTeams + team;
+            dot[u] = 0.f;
+            cj[u] = e < hi ? a.col[e] : 0;
         }
 #pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) dot += __shfl_xor(dot, off);
-        if (e < hi && t == 0) {
-            const float al = a.alpha[e];
-            const float sc = a.a_src[cj] + ad;
-            const float d = al * (dot - rd) * (sc > 0.f ? 1.f : a.slope);
-            if (a.csr_out) {
-                a.ds[e] = d;
-                acc += d;
-            } else {
-                const int p = a.perm[e];
-                a.ds[p] = d;
-                a.alpha_coo[p] = al;
+        for (int u = 0; u < UN; ++u) {
+            if (e0 + u * kTeams + team < hi) {
+                const float* hj = a.h + static_cast<int64_t>(cj[u]) * a.ldh;
+                for (int f = t; f < a.n_feat; f += 16) dot[u] = fmaf(gi[f], hj[f], dot[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) dot[u] += __shfl_xor(dot[u], off);
+            const int e = e0 + u * kTeams + team;
+            if (e < hi && t == 0) {
+                const float al = a.alpha[e];
+                const float sc = a.a_src[cj[u]] + ad;
+                const float d = al * (dot[u] - rd) * (sc > 0.f ? 1.f : a.slope);
+                if (a.csr_out) {
+                    a.ds[e] = d;
+                    acc += d;
+                } else {
+                    const int p = a.perm[e];
+                    a.ds[p] = d;
+                    a.alpha_coo[p] = al;
+                }
             }
         }
     }

@@ -227,7 +227,8 @@ class EmulatedExchange:
         self._cabi = _cabi
         self.world_size, self.rank = int(world_size), int(rank)
         self.link_gbps, self.latency_us = float(link_gbps), float(latency_us)
-        self.stream = torch.cuda.Stream()
+        # its own priority class, hence its own hardware queue: the timed kernel must not sit in front of compute work
+        self.stream = torch.cuda.Stream(priority=-1)
         self.group = None
         self.wire_us = 0.0                               # accumulated emulated wire time (reset by the caller)
 
