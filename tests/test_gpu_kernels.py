@@ -637,3 +637,27 @@ def test_scalar_fallback_kernel_through_the_raw_abi():
                                        None, _cabi.stream_ptr()), "spmm scalar")
     want = _spmm_raw(csr, v, x, z, 2.0, -1.0, False)          # padded -> vector kernel
     assert want.shape == (n, f) and torch.allclose(y, want, atol=1e-4, rtol=1e-5)
+
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,offset", [(1, 0), (2, 0), (1001, 0), (1000, 1), (70001, 1), (5000000, 0)])
+def test_id_range_kernel_exact(n, offset):
+    """pygsd_id_range_i64 (node-id validation): min / max of an int64 list, 16-byte vector loads with an odd tail,
+    unaligned lists (edge_index[1] of an odd-length edge list), several lists folded into one pair."""
+    from pytorch_geometric_signed_directed_amd import _cabi
+    g = torch.Generator().manual_seed(n + offset)
+    base = torch.randint(-5, 1 << 40, (n + offset,), generator=g)
+    base[(n + offset) // 2] = -7 if n > 1 else base[-1]
+    ids = base.to(dev())[offset:]
+    assert ids.data_ptr() % 16 == (8 * offset) % 16
+    minmax = torch.tensor([(1 << 63) - 1, -(1 << 63)], dtype=torch.int64, device=dev())
+    _cabi.check(_cabi.lib().pygsd_id_range_i64(_cabi.ptr(ids), n, _cabi.ptr(minmax), _cabi.stream_ptr()), "id_range")
+    want = base[offset:]
+    assert minmax.tolist() == [int(want.min()), int(want.max())]
+    more = torch.tensor([1 << 50, -99], dtype=torch.int64, device=dev())
+    _cabi.check(_cabi.lib().pygsd_id_range_i64(_cabi.ptr(more), 2, _cabi.ptr(minmax), _cabi.stream_ptr()), "id_range")
+    assert minmax.tolist() == [min(int(want.min()), -99), max(int(want.max()), 1 << 50)]
+    with pytest.raises(IndexError, match="outside"):
+        _cabi.check_node_ids((10, torch.tensor([0, 9, 10], device=dev())))
+    _cabi.check_node_ids((10, torch.tensor([0, 9], device=dev())), (3, None), (5, torch.empty(0, dtype=torch.long, device=dev())))

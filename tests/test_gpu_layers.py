@@ -527,6 +527,102 @@ def test_northstar_sampled_rows_vs_float64():
         close(got.detach()[idx], ref, what=what + " (1024 rows) vs float64")
 
 
+def test_c4_form_signed_k2_h128_vs_float64():
+    """BASELINE config C4 in its stated form on one GPU at a quarter of its size: MSGNN's MSConv (signed magnetic
+    Laplacian, general/MSConv.py:121-230), K = 2, h = 128, on an SDSBM graph (data/general/SDSBM.py) of 250k nodes /
+    5M signed edges -- column-blocked dual SpMM, Chebyshev recurrence in the epilogue, 128-wide MFMA dense stage --
+    against the float64 sparse evaluation: outputs, input gradients, parameter gradients."""
+    from oracle import sparse_f64 as S64
+    from pytorch_geometric_signed_directed_amd import graphs
+    from pytorch_geometric_signed_directed_amd.nn import MSConv
+    n, e, h, k = 250000, 5000000, 128, 2
+    ei_np, sign_np, _, _ = graphs.sdsbm_for_edges(n, e, seed=4)
+    g = torch.Generator().manual_seed(4)
+    xr, xi = torch.randn(n, h, generator=g), torch.randn(n, h, generator=g)
+    gr, gi = torch.randn(n, h, generator=g), torch.randn(n, h, generator=g)
+    torch.manual_seed(4)
+    layer = MSConv(h, h, k, 0.25, False, cached=True)
+    with torch.no_grad():
+        layer.bias.uniform_(-0.5, 0.5)
+    s64 = S64.magnetic_operator(ei_np, sign_np, n, 0.25, signed=True, absolute_degree=True)
+    want = S64.magnet_conv(xr.numpy(), xi.numpy(), s64, layer.weight.detach().numpy(), layer.bias.detach().numpy(),
+                           gr.numpy(), gi.numpy())
+    layer.to(D)
+    c, d = xr.to(D).requires_grad_(), xi.to(D).requires_grad_()
+    o_r, o_i = layer(c, d, torch.from_numpy(ei_np).to(D), torch.from_numpy(sign_np).to(D))
+    ((o_r * gr.to(D)).sum() + (o_i * gi.to(D)).sum()).backward()
+    close(o_r, want[0], what="out_real")
+    close(o_i, want[1], what="out_imag")
+    close(c.grad, want[2], what="dx_real")
+    close(d.grad, want[3], what="dx_imag")
+    close(layer.weight.grad, want[4], norm=True, what="dW")
+    close(layer.bias.grad, want[5], norm=True, what="db")
+
+
+def test_c3_full_size_sgcn_vs_reference_sequence():
+    """BASELINE config C3 at its stated size: SGCNConv (first aggregation, 64 -> 32) on an SSBM graph of 500k nodes /
+    10M signed entries (data/signed/SSBM.py), forward and backward, against the oracle's reference op sequence."""
+    from pytorch_geometric_signed_directed_amd import graphs
+    from pytorch_geometric_signed_directed_amd.nn import SGCNConv
+    n, entries, h = 500000, 10000000, 64
+    p = (entries / 2) / (n * (n - 1) / 2)
+    ei_np, sign, _ = graphs.ssbm(n, 5, p, 0.1, 2.0, seed=2)
+    ei = torch.from_numpy(ei_np)
+    pos, neg = ei[:, torch.from_numpy(sign > 0)].contiguous(), ei[:, torch.from_numpy(sign < 0)].contiguous()
+    g = torch.Generator().manual_seed(5)
+    x, go = torch.randn(n, h, generator=g), torch.randn(n, h // 2 * 2, generator=g)
+    torch.manual_seed(5)
+    conv = SGCNConv(h, h // 2, first_aggr=True)
+    sd = {k_: v.detach().clone() for k_, v in conv.state_dict().items()}
+    a = x.clone().requires_grad_()
+    want = R.sgcn_conv(a, pos, neg, (sd["lin_b.weight"], sd["lin_b.bias"]), (sd["lin_u.weight"], sd["lin_u.bias"]), True, h)
+    (want * go).sum().backward()
+    conv.to(D)
+    b = x.to(D).requires_grad_()
+    got = conv(b, pos.to(D), neg.to(D))
+    (got * go.to(D)).sum().backward()
+    close(got, want.detach(), what="SGCNConv out")
+    close(b.grad, a.grad, what="dx")
+
+
+def test_c5_form_bf16_inception_block_quarter_size():
+    """BASELINE config C5 in its stated form on one GPU at a quarter of its size: DiGCN_InceptionBlock
+    (DiGCN_Inception_Block.py:31-47) in bf16 storage on 500k nodes / 13M entries per operator, against the oracle in
+    fp32 on bf16-rounded inputs and parameters (bound: 3 roundings of 2^-8 relative to the max norm)."""
+    from pytorch_geometric_signed_directed_amd import graphs
+    from pytorch_geometric_signed_directed_amd.nn import DiGCN_InceptionBlock
+    n, e, h = 500000, 6250000, 64
+    ei_np = graphs.dsbm_for_edges(n, e, seed=3)[0]
+    src, dst = torch.from_numpy(ei_np)
+    loops = torch.arange(n)
+    g = torch.Generator().manual_seed(6)
+    ops = []
+    for k in range(2):                       # two symmetric, positively weighted, sym-normalised operators with loops
+        d2 = dst if k == 0 else dst[torch.randperm(dst.numel(), generator=g)]
+        wv = torch.rand(src.numel(), generator=g)
+        ei = torch.stack([torch.cat([src, d2, loops]), torch.cat([d2, src, loops])])
+        w = torch.cat([wv, wv, torch.ones(n)])
+        deg = torch.zeros(n).index_add_(0, ei[0], w)
+        ops.append((ei, deg[ei[0]].rsqrt() * w * deg[ei[1]].rsqrt()))
+    x, go = torch.randn(n, h, generator=g), torch.randn(n, h, generator=g)
+    torch.manual_seed(6)
+    ib = DiGCN_InceptionBlock(h, h)
+    rnd = (lambda t: t.to(torch.bfloat16).float())
+    sd = {k_: rnd(v.detach()) for k_, v in ib.state_dict().items()}
+    xo = rnd(x).requires_grad_()
+    want = (xo @ sd["ln.weight"].t() + sd["ln.bias"], R.digcn_conv(xo, ops[0][0], ops[0][1], sd["conv1.weight"], sd["conv1.bias"]),
+            R.digcn_conv(xo, ops[1][0], ops[1][1], sd["conv2.weight"], sd["conv2.bias"]))
+    sum((o * go).sum() for o in want).backward()
+    ib.to(D).to(torch.bfloat16)
+    xd = x.to(D).to(torch.bfloat16).requires_grad_()
+    got = ib(xd, ops[0][0].to(D), ops[0][1].to(D), ops[1][0].to(D), ops[1][1].to(D))
+    sum((o.float() * go.to(D)).sum() for o in got).backward()
+    tol = 3 * 2.0 ** -8
+    for k, (o, w_) in enumerate(zip(got, want)):
+        close(o.float(), w_.detach(), tol, norm=True, what=f"x{k} (bf16)")
+    close(xd.grad.float(), xo.grad, tol, norm=True, what="dx (bf16)")
+
+
 def test_sssnet_cut_objectives_match_reference():
     """the per-cluster sparse mat-vecs of SSSNET's losses as one HIP SpMM."""
     import scipy.sparse as sp

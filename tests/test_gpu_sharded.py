@@ -229,3 +229,49 @@ def test_bench_self_launches_its_ranks(gpus):
     assert rec["config"]["nodes"] == 20000 and "exchange" in rec and rec["exchange"]["propagates_per_step"] == 2
     for key in ("product_ms", "exposed_exchange_ms", "exchange_alone_ms"):
         assert key in rec["exchange"], rec["exchange"]
+
+
+
+def test_rccl_path_with_one_rank():
+    """The RCCL ("nccl") code path of the exchanges -- asynchronous stacked all_gather_into_tensor, equal-split
+    all_to_all_single, all_reduce, object broadcast -- and of bench.py's sharded mode, with the one rank a 1-GPU box
+    allows (RCCL refuses two ranks per device).  Runs in subprocesses: a process group per process."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PYGSD_DIST_BACKEND", None)
+    env.pop("PYGSD_BENCH_SHARE_GPU", None)
+    code = """
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from pytorch_geometric_signed_directed_amd.parallel import DistExchange, all_gather_rows
+ex = DistExchange()
+assert not ex._staged and ex.world_size == 1
+x = torch.arange(24, dtype=torch.float32, device="cuda").view(4, 6)
+out = torch.empty(1, 4, 6, device="cuda")
+ex.all_gather(out, x).wait()
+assert torch.equal(out[0], x)
+inp = x.view(1, 4, 6).clone()
+back = torch.empty(3, 1, 4, 6, device="cuda")
+works = [ex.all_to_all(back[r], inp * (r + 1)) for r in range(3)]
+for w in works:
+    w.wait()
+assert all(torch.equal(back[r, 0], x * (r + 1)) for r in range(3))
+t = torch.ones(5, dtype=torch.float64, device="cuda")
+assert float(ex.all_reduce(t).sum()) == 5.0
+assert ex.broadcast_list([0, 3, 7]) == [0, 3, 7]
+assert torch.equal(all_gather_rows(x), x)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+"""
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "2",
+                          "--warmup", "1", "--nodes", "20000", "--edges", "300000", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert rec["n_gpus"] == 1 and rec["exchange"]["layout"] == "rows" and rec["value"] > 0
