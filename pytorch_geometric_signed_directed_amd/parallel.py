@@ -216,17 +216,19 @@ class _StreamEvent:
 
 class EmulatedExchange:
     """Rank `rank` of a `world_size`-rank job rehearsed on ONE GPU: every exchange is played on a separate HIP
-    stream as (a device copy of the bytes this rank would receive) + (the wire time of the busiest link,
-    bytes_per_link / link_gbps + latency).  The wire time is spent by the copy engine, not by a kernel: a
-    device->pinned-host DMA of (wire time x the measured DMA rate) bytes occupies neither CUs nor a compute queue, so
-    it cannot sit in front of compute work the way a timed kernel in a shared hardware queue does (delay="spin"
-    keeps that older variant).  The received VALUES are this rank's own data repeated -- the rehearsal measures the
-    pipeline (streams, events, per-rank kernels at their real sizes), it does not compute a correct product."""
+    stream as (a device copy of the bytes this rank would receive) + (a timed kernel of the wire time of the
+    busiest link, bytes_per_link / link_gbps + latency: one idle lane polling the wall clock).  The received
+    VALUES are this rank's own data repeated -- the rehearsal measures the pipeline (streams, events, per-rank
+    kernels at their real sizes), it does not compute a correct product.  Two variants were tried and dropped
+    because they disturbed what they were meant to measure (profiles/r2_emulated_sharded_w8.json keeps the
+    default's numbers, reproduced in a later run): a high-priority side stream (compute kernels ran 2x slower in
+    about a third of the shapes) and spending the wire time on the copy engine (device -> pinned host transfers
+    serialised against the compute stream).  Known artefact of the default: when the runtime maps the side stream
+    to the hardware queue of the compute stream, the timed kernel sits in front of compute work and the wire time
+    shows up as packing time (seen in the row layout with two phases); those rows are left in the files."""
     emulated = True
-    _DMA_BYTES = 64 << 20
 
-    def __init__(self, world_size: int, rank: int, link_gbps: float = 61.0, latency_us: float = 10.0,
-                 delay: str = "dma"):
+    def __init__(self, world_size: int, rank: int, link_gbps: float = 61.0, latency_us: float = 10.0):
         from . import _cabi
         self._cabi = _cabi
         self.world_size, self.rank = int(world_size), int(rank)
@@ -234,32 +236,6 @@ class EmulatedExchange:
         self.stream = torch.cuda.Stream()
         self.group = None
         self.wire_us = 0.0                               # accumulated emulated wire time (reset by the caller)
-        self.delay = delay
-        self.dma_gbps = None
-        if delay == "dma":
-            self._dev = torch.empty(self._DMA_BYTES, dtype=torch.uint8, device="cuda")
-            self._host = torch.empty(self._DMA_BYTES, dtype=torch.uint8).pin_memory()
-            with torch.cuda.stream(self.stream):
-                times = []
-                for _ in range(4):
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record(self.stream)
-                    self._host.copy_(self._dev, non_blocking=True)
-                    b.record(self.stream)
-                    b.synchronize()
-                    times.append(a.elapsed_time(b))
-            self.dma_gbps = self._DMA_BYTES / (min(times[1:]) * 1e-3) / 1e9
-
-    def _wait_on_wire(self, us: float):
-        """Keep self.stream busy for `us` microseconds (called with that stream current)."""
-        if self.delay == "dma":
-            left = int(us * 1e-6 * self.dma_gbps * 1e9)
-            while left > 0:
-                n = min(left, self._DMA_BYTES)
-                self._host[:n].copy_(self._dev[:n], non_blocking=True)
-                left -= n
-        else:
-            self._cabi.check(self._cabi.lib().pygsd_spin_us(us, self._cabi.stream_ptr()), "pygsd_spin_us")
 
     def _play(self, out: Tensor, src: Tensor, bytes_per_link: float):
         ready = torch.cuda.Event()
@@ -270,7 +246,7 @@ class EmulatedExchange:
             self.stream.wait_event(ready)
             out.copy_(src)
             if us > 0:
-                self._wait_on_wire(us)
+                self._cabi.check(self._cabi.lib().pygsd_spin_us(us, self._cabi.stream_ptr()), "pygsd_spin_us")
             done = torch.cuda.Event()
             done.record(self.stream)
         return _StreamEvent(done)        # buffers are the engine's persistent ones: nothing to keep alive

@@ -7,8 +7,8 @@ What is real: the plan (equal-work ranges), this rank's operator rows at their r
 north-star operator, split into column phases), every kernel it would launch (partial dual SpMMs at the sliced
 width, the fused dense stage on its n_pad rows, packing / merging), the stream / event pipeline of
 parallel.PropagateEngine.  What is played: each exchange is a device copy of the bytes this rank would receive
-plus the wire time of the busiest link (bytes_per_link / link rate + a fixed latency), spent by a copy-engine
-transfer to pinned host memory on a separate stream (parallel.EmulatedExchange; --delay spin = a timed kernel).  Received values are stand-ins, so outputs are not checked here
+plus a timed kernel of the wire time of the busiest link (bytes_per_link / link rate + a fixed latency) on a
+separate stream (parallel.EmulatedExchange).  Received values are stand-ins, so outputs are not checked here
 (tests/test_gpu_sharded.py does that over gloo).
 
 For each pipeline shape it reports the step time, the per-propagate split (product / exposed exchange / pack /
@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 def run_shape(args, edge_index, x_real, x_imag, layout, phases, chunks, link_gbps):
     from pytorch_geometric_signed_directed_amd.parallel import EmulatedExchange, ShardedMagNetConv
     dev = x_real.device
-    ex = EmulatedExchange(args.world, args.rank, link_gbps, args.latency_us, args.delay)
+    ex = EmulatedExchange(args.world, args.rank, link_gbps, args.latency_us)
     torch.manual_seed(0)
     layer = ShardedMagNetConv(args.hidden, args.hidden, 1, 0.25, args.nodes, edge_index, None, device=dev,
                               layout=layout, phases=phases, return_chunks=chunks, exchange=ex)
@@ -62,7 +62,7 @@ def run_shape(args, edge_index, x_real, x_imag, layout, phases, chunks, link_gbp
     wire_ms = ex.wire_us / 1e3 / (2 * args.steps)                  # per propagate
     eng = layer.engine
     rec = {"layout": layout, "p_r": eng.p_r, "p_c": eng.p_c, "phases": phases, "return_chunks": chunks,
-           "link_gbps": link_gbps, "delay": args.delay, "dma_gbps": ex.dma_gbps, "step_ms_median": statistics.median(times), "step_ms_min": min(times),
+           "link_gbps": link_gbps, "step_ms_median": statistics.median(times), "step_ms_min": min(times),
            "per_propagate": summary, "wire_ms_per_propagate": wire_ms,
            "overlap_fraction": (1.0 - summary["exposed_exchange_ms"] / wire_ms) if wire_ms > 0 else None,
            "local_operator_entries": layer.local_nnz, "rows_multiplied": eng.block_rows, "n_pad": layer.plan.n_pad}
@@ -82,9 +82,6 @@ def main():
     ap.add_argument("--edges", type=int, default=20000000)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--delay", choices=("dma", "spin"), default="dma",
-                    help="how the wire time is spent on the communication stream: a copy-engine transfer to pinned host "
-                         "memory (default; uses no CU and no compute queue) or a timed kernel")
     ap.add_argument("--single-gpu-ms", type=float, default=None, help="measured 1-GPU step (bench.py) for the ratio")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "emulated_sharded.json"))
     args = ap.parse_args()
