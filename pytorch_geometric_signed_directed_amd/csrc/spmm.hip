@@ -16,6 +16,8 @@
 //   Epilogue: butterfly over the NPW lane groups, fused alpha / mean / beta*Z, one float4 store.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace pygsd {
 namespace {
 
@@ -289,6 +291,74 @@ __global__ __launch_bounds__(256) void spmm_long_finish_kernel(SpmmArgs p, const
     if (DUAL) st4(p.yb + yo, finish(b, p.alpha, p.beta, false, deg, p.zb ? p.zb + zo : nullptr));
 }
 
+// ------------------------------------------------------------------------------------------
+// Low-degree rows at narrow widths.  One wavefront per row wastes the machine when a row has fewer entries than
+// one wave-wide load fetches (NPW = 64 / LPR neighbours: 16 at F = 16, 8 at F = 32, 4 at F = 64): the signed SBM
+// parts (5-15 entries per row, SGCNConv / SIMPA) and the column blocks of the sharded grid product (10-20 entries
+// per row and phase at 16 + 16 packed floats).  Here every LPR-lane group owns its OWN row -- NPW rows per
+// wavefront -- and walks that row's entries in CSR order with UN gathers in flight; no cross-lane hand-off, no
+// butterfly: a group's accumulator IS the row's result, summed in the row's CSR (= the reference's scatter) order.
+// The loop runs to the longest row of the wavefront; lanes of finished rows idle.  The host picks this variant
+// from entries per row (launch_spmm).
+// ------------------------------------------------------------------------------------------
+template <int LPR, bool DUAL>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_packed_kernel(SpmmArgs p)
+{
+    constexpr int NPW = 64 / LPR;
+    constexpr int UN = 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int fl = (lane % LPR) * 4;
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t row = wave * NPW + sub;
+    const bool fact = fl < p.n_feat;
+    int beg = 0, end = 0;
+    bool mine = row < p.n_rows;
+    if (mine) {
+        beg = p.rowptr[row];
+        end = p.rowptr[row + 1];
+        if (p.skip_longer_than > 0 && end - beg > p.skip_longer_than) {   // hub row: spmm_long_kernel
+            mine = false;
+            end = beg;
+        }
+    }
+    const int deg = end - beg;
+    float4 acc_a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xa = p.xa + fl;
+    const float* xb = DUAL ? p.xb + fl : nullptr;
+    for (int e = beg; e < end; e += UN) {
+        int cj[UN];
+        float wa[UN], wb[UN];
+        float4 ga[UN], gb[UN];
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            const bool ok = e + k < end;
+            cj[k] = ok ? __builtin_nontemporal_load(p.col + e + k) : 0;
+            wa[k] = ok ? (p.va ? __builtin_nontemporal_load(p.va + e + k) : 1.f) : 0.f;
+            wb[k] = (DUAL && ok) ? __builtin_nontemporal_load(p.vb + e + k) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            const bool ok = fact && e + k < end;
+            const int64_t off = static_cast<int64_t>(cj[k]) * p.ldx;
+            ga[k] = ok ? ld4(xa + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (DUAL) gb[k] = ok ? ld4(xb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            fma4(acc_a, wa[k], ga[k]);
+            if (DUAL) fma4(acc_b, wb[k], gb[k]);
+        }
+    }
+    if (mine && fact) {
+        const int64_t yo = row * p.ldy + fl;
+        const int64_t zo = row * p.ldz + fl;
+        st4(p.ya + yo, finish(acc_a, p.alpha, p.beta, p.mean != 0, deg, p.za ? p.za + zo : nullptr));
+        if (DUAL) st4(p.yb + yo, finish(acc_b, p.alpha, p.beta, false, deg, p.zb ? p.zb + zo : nullptr));
+    }
+}
+
 // Generic fallback (any F, any alignment): lane <-> feature, neighbours walked sequentially with
 // wave-uniform (scalar) col/val loads, 256-byte coalesced row reads.
 template <bool DUAL>
@@ -356,6 +426,19 @@ int64_t long_workspace_bytes(int32_t n_long, int32_t max_entries, int32_t n_feat
     return static_cast<int64_t>(n_long) * n_seg * n_feat * static_cast<int64_t>(sizeof(float)) * (dual ? 2 : 1);
 }
 
+// Entries per row below which the rows-per-wavefront variant is used.  Measured (tools/packed_probe.py ->
+// profiles/r2_packed_probe.json; 20 M entries, Poisson row lengths, 1 M source rows; speed-up of the packed variant):
+//   single, F = 16 / 32: x2.8 / x2.0 at 4 entries per row, x1.7 / x1.6 at 6, x1.3 at 8, x0.85 at 12
+//   single, F = 64     : x1.24 at 4, x1.05 at 6, x0.92 at 8
+//   dual,   F = 16 / 32: x1.9 / x1.6 at 4, x1.2 / x1.07 at 6, x0.88 at 8;   dual, F = 64: x1.05 at 4, x0.90 at 6
+// (beyond the crossover one wavefront per row wins by up to 2.5x: it keeps 4-16 gathers in flight per lane where a
+// lane group walking its own row has 4).
+inline int64_t packed_threshold(int lpr, bool dual)
+{
+    if (dual) return lpr <= 8 ? 7 : lpr == 16 ? 5 : 0;
+    return lpr <= 8 ? 10 : lpr == 16 ? 7 : 4;
+}
+
 template <bool DUAL>
 int launch_spmm(SpmmArgs a, int64_t nnz_hint, const pygsd_long_rows* hubs, hipStream_t stream)
 {
@@ -386,7 +469,24 @@ int launch_spmm(SpmmArgs a, int64_t nnz_hint, const pygsd_long_rows* hubs, hipSt
     // measured crossover (tools/deep_light_probe.py, F=64, 40M entries): the deep variant wins by 1-4 % from
     // 28 entries per row (dual) / 48 (single) and loses up to 1.8x below; unknown -> light
     const bool deep = nnz_hint >= static_cast<int64_t>(DUAL ? 28 : 48) * a.n_rows;
-    if (quads <= 4) {
+    // rows-per-wavefront variant for low-degree rows at widths <= 128 (PYGSD_SPMM_PACKED = 0 / 1 forces it off / on:
+    // tools/packed_probe.py); unknown degree (nnz_hint == 0) keeps one wavefront per row
+    const int lpr = quads <= 4 ? 4 : quads <= 8 ? 8 : quads <= 16 ? 16 : quads <= 32 ? 32 : 64;
+    bool packed = false;
+    if (lpr <= 32) {
+        const char* force = getenv("PYGSD_SPMM_PACKED");
+        if (force) packed = force[0] == '1';
+        else packed = nnz_hint > 0 && nnz_hint < packed_threshold(lpr, DUAL) * static_cast<int64_t>(a.n_rows);
+    }
+    if (packed) {
+        const int npw = 64 / lpr;
+        const int64_t waves = (static_cast<int64_t>(a.n_rows) + npw - 1) / npw;
+        const dim3 pg(static_cast<unsigned>((waves + kWavesPerBlock - 1) / kWavesPerBlock));
+        if (lpr == 4) hipLaunchKernelGGL((spmm_packed_kernel<4, DUAL>), pg, block, 0, stream, a);
+        else if (lpr == 8) hipLaunchKernelGGL((spmm_packed_kernel<8, DUAL>), pg, block, 0, stream, a);
+        else if (lpr == 16) hipLaunchKernelGGL((spmm_packed_kernel<16, DUAL>), pg, block, 0, stream, a);
+        else hipLaunchKernelGGL((spmm_packed_kernel<32, DUAL>), pg, block, 0, stream, a);
+    } else if (quads <= 4) {
         launch_vec<4, DUAL>(a, deep, dim3(gx), block, stream);
     } else if (quads <= 8) {
         launch_vec<8, DUAL>(a, deep, dim3(gx), block, stream);

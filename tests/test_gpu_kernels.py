@@ -661,3 +661,46 @@ def test_id_range_kernel_exact(n, offset):
     with pytest.raises(IndexError, match="outside"):
         _cabi.check_node_ids((10, torch.tensor([0, 9, 10], device=dev())))
     _cabi.check_node_ids((10, torch.tensor([0, 9], device=dev())), (3, None), (5, torch.empty(0, dtype=torch.long, device=dev())))
+
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f,deg", [(16, 3), (32, 5), (64, 4), (128, 2), (32, 20)])
+def test_rows_per_wavefront_variant(f, deg):
+    """spmm_packed_kernel (low-degree rows: every LPR-lane group owns its own row) against the float64 product, and
+    against the one-wavefront-per-row kernel on the same inputs (both forced through PYGSD_SPMM_PACKED); single and
+    dual operator, alpha / beta / Z epilogue, mean, empty rows, a row count that is not a multiple of the rows per
+    wavefront.  Auto-selection (no env) must pick by entries per row and agree as well."""
+    import os
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, _spmm2_raw, _spmm_raw
+    d = dev()
+    n_in, n_out = 3000, 2501
+    ei = rand_graph(n_in, n_out, deg * n_out, 100 + f + deg, empty_tail=7)
+    g = torch.Generator().manual_seed(f * deg)
+    wa, wb = torch.randn(ei.size(1), generator=g), torch.randn(ei.size(1), generator=g)
+    xa, xb = torch.randn(n_in, f, generator=g), torch.randn(n_in, f, generator=g)
+    za, zb = torch.randn(n_out, f, generator=g), torch.randn(n_out, f, generator=g)
+    pat = Pattern(ei.to(d), n_in, n_out)
+    va, vb = pat.values_for(wa.to(d), "fwd"), pat.values_for(wb.to(d), "fwd")
+    A = torch.zeros(n_out, n_in, dtype=torch.float64).index_put_((ei[1], ei[0]), wa.double(), accumulate=True)
+    B = torch.zeros(n_out, n_in, dtype=torch.float64).index_put_((ei[1], ei[0]), wb.double(), accumulate=True)
+    ones = torch.zeros(n_out, n_in, dtype=torch.float64).index_put_((ei[1], ei[0]), torch.ones(ei.size(1), dtype=torch.float64),
+                                                                   accumulate=True)
+    cnt = ones.sum(1).clamp_min(1.0)
+    want = {"add": 2.0 * (A @ xa.double()) - za.double(), "mean": (ones @ xa.double()) / cnt[:, None],
+            "dual_a": 0.5 * (A @ xa.double()) + za.double(), "dual_b": 0.5 * (B @ xb.double()) + zb.double()}
+    results = {}
+    try:
+        for mode in ("0", "1", None):
+            if mode is None:
+                os.environ.pop("PYGSD_SPMM_PACKED", None)
+            else:
+                os.environ["PYGSD_SPMM_PACKED"] = mode
+            ya, yb = _spmm2_raw(pat.fwd, va, vb, xa.to(d), xb.to(d), za.to(d), zb.to(d), 0.5, 1.0)
+            results[mode] = {"add": _spmm_raw(pat.fwd, va, xa.to(d), za.to(d), 2.0, -1.0, False),
+                             "mean": _spmm_raw(pat.fwd, None, xa.to(d), None, 1.0, 0.0, True), "dual_a": ya, "dual_b": yb}
+    finally:
+        os.environ.pop("PYGSD_SPMM_PACKED", None)
+    for mode, res in results.items():
+        for k, got in res.items():
+            close(got, want[k], what=f"{k} (PYGSD_SPMM_PACKED={mode})")
