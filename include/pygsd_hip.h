@@ -57,8 +57,10 @@ const char* pygsd_last_error(void);
  * Deterministic: no atomics; the summation order inside a row is fixed by the CSR order.
  * nnz_hint: total number of CSR entries if the caller knows it (0 = unknown).  Tuning only: rows with
  * >= 48 entries on average (>= 28 in the dual-operator kernel) run a variant with deeper gather
- * pipelining, sparser ones (and unknown) a low-register variant with twice the wavefront occupancy;
- * results are identical.
+ * pipelining, sparser ones (and unknown) a low-register variant with twice the wavefront occupancy --
+ * bit-identical results; rows with fewer than ~4-10 entries on average at widths <= 128 (signed SBM parts)
+ * run a rows-per-wavefront variant in which every lane group owns its own row and sums it sequentially in
+ * CSR order (the reference's scatter order): equal to the other variants to fp32 rounding, deterministic.
  * long_rows (may be NULL): hub rows.  One wavefront owns one output row, so a row with 10^5..10^6 entries
  * (power-law graphs; the reference's scatter has no such cliff) would serialise the launch.  The caller
  * lists the rows with MORE than PYGSD_LONG_ROW entries; the row-per-wavefront kernel skips them and a
