@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 5
+#define PYGSD_ABI_VERSION 6
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -342,6 +342,17 @@ int pygsd_id_range_i64(const int64_t* ids, int64_t n, int64_t* minmax, void* str
  * ACHIEVABLE HBM bandwidth (`roofline.achievable_peak`).  No reference counterpart.
  * ------------------------------------------------------------------------------------------- */
 int pygsd_stream_copy_f32(const float* src, float* dst, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Send-buffer packing of the sharded propagate (no reference counterpart: the reference is single-device).
+ * xs[g] (g < groups <= 4): local feature group g, [n_rows, row_bytes] with row stride ld_bytes.  out, viewed as
+ * [phases][p_r][p_c][n_rows / phases][groups][row_bytes / p_c] bytes: for every column phase c the equal-split
+ * all-to-all input whose chunk d = i * p_c + j carries column slice j of rows [c, c + 1) * n_rows / phases, the
+ * groups side by side (p_r = p_c = 1: the all-gather input of the row layout).  Byte-wise, 16-byte units: fp32
+ * and bf16 alike; row_bytes / p_c and ld_bytes must be multiples of 16.
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_pack_slices(const void* const* xs, int32_t groups, int32_t n_rows, int32_t row_bytes, int64_t ld_bytes,
+                      int32_t p_r, int32_t p_c, int32_t phases, void* out, void* stream);
 
 /* Keeps `stream` busy for `microseconds` (one idle lane polling the constant-rate wall clock).  Measurement
  * only: the single-GPU rehearsal of the sharded propagate (tools/emulate_sharded.py) uses it as the wire time

@@ -99,6 +99,41 @@ __global__ __launch_bounds__(kBlock) void stream_copy_kernel(const vec4f* __rest
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// Packing for the sharded exchanges (parallel.PropagateEngine): G feature groups [n_rows, row_bytes] ->
+// out[phase c][replica i][slice j][row t][group g][slice bytes], i.e. for every column phase the all-to-all send buffer
+// whose chunk d = i * p_c + j holds column slice j of sub-range c of the local rows, groups side by side.  One thread
+// per 16-byte unit of the INPUT: read once, written p_r times (the replicas an equal-split all-to-all needs).
+struct PackArgs {
+    const uint4* x[4];
+    uint4* out;
+    int64_t ld_units;        // input row stride, 16-byte units
+    int32_t groups, n_rows, row_units, p_r, p_c, phases;
+};
+
+__global__ __launch_bounds__(kBlock) void pack_slices_kernel(PackArgs a)
+{
+    const int64_t per_group = static_cast<int64_t>(a.n_rows) * a.row_units;
+    const int64_t total = per_group * a.groups;
+    const int n_sub = a.n_rows / a.phases;
+    const int sl = a.row_units / a.p_c;                    // units per column slice
+    const int64_t chunk = static_cast<int64_t>(n_sub) * a.groups * sl;          // one (phase, replica, slice) chunk
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < total;
+         idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int g = static_cast<int>(idx / per_group);
+        const int64_t rem = idx - g * per_group;
+        const int row = static_cast<int>(rem / a.row_units);
+        const int u = static_cast<int>(rem - static_cast<int64_t>(row) * a.row_units);
+        const uint4 v = a.x[g][static_cast<int64_t>(row) * a.ld_units + u];
+        const int c = row / n_sub, t = row - c * n_sub;
+        const int j = u / sl, k = u - j * sl;
+        const int64_t inner = (static_cast<int64_t>(t) * a.groups + g) * sl + k;
+        for (int i = 0; i < a.p_r; ++i) {
+            const int64_t d = static_cast<int64_t>(c) * a.p_r * a.p_c + static_cast<int64_t>(i) * a.p_c + j;
+            a.out[d * chunk + inner] = v;
+        }
+    }
+}
+
 // Occupies the stream for `ticks` of the 100 MHz constant-rate counter: stands in for the wire time of an xGMI
 // exchange when the sharded propagate is rehearsed on ONE GPU (tools/emulate_sharded.py).
 __global__ void spin_kernel(long long ticks)
@@ -195,6 +230,33 @@ extern "C" int pygsd_stream_copy_f32(const float* src, float* dst, int64_t n, vo
         default: hipLaunchKernelGGL((stream_copy_kernel<3, 4>), grid, block, 0, s, sp, dp, n4); break;
     }
     return check_launch("stream_copy_kernel");
+}
+
+extern "C" int pygsd_pack_slices(const void* const* xs, int32_t groups, int32_t n_rows, int32_t row_bytes,
+                                 int64_t ld_bytes, int32_t p_r, int32_t p_c, int32_t phases, void* out, void* stream)
+{
+    PYGSD_REQUIRE(groups >= 1 && groups <= 4 && n_rows >= 0 && row_bytes >= 0 && p_r >= 1 && p_c >= 1 && phases >= 1,
+                  "pygsd_pack_slices: bad sizes (groups 1..4)");
+    if (n_rows == 0 || row_bytes == 0) return 0;
+    PYGSD_REQUIRE(xs && out && aligned16(out), "pygsd_pack_slices: null or unaligned output");
+    PYGSD_REQUIRE(n_rows % phases == 0, "pygsd_pack_slices: %d rows do not split into %d phases", n_rows, phases);
+    PYGSD_REQUIRE(row_bytes % (16 * p_c) == 0 && ld_bytes % 16 == 0 && ld_bytes >= row_bytes,
+                  "pygsd_pack_slices: column slices must be multiples of 16 bytes (row %d B, %d slices)", row_bytes, p_c);
+    PackArgs a{};
+    for (int g = 0; g < groups; ++g) {
+        PYGSD_REQUIRE(xs[g] && aligned16(xs[g]), "pygsd_pack_slices: group %d null or not 16-byte aligned", g);
+        a.x[g] = static_cast<const uint4*>(xs[g]);
+    }
+    a.out = static_cast<uint4*>(out);
+    a.ld_units = ld_bytes / 16;
+    a.groups = groups; a.n_rows = n_rows; a.row_units = row_bytes / 16; a.p_r = p_r; a.p_c = p_c; a.phases = phases;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    const int64_t total = static_cast<int64_t>(n_rows) * a.row_units * groups;
+    const int64_t blocks = (total + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(pack_slices_kernel, dim3(static_cast<unsigned>(blocks < (1 << 20) ? blocks : (1 << 20))), dim3(kBlock),
+                       0, s, a);
+    return check_launch("pack_slices_kernel");
 }
 
 extern "C" int pygsd_spin_us(double microseconds, void* stream)

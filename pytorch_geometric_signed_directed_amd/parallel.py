@@ -424,6 +424,27 @@ class PropagateEngine:
             dst[:, :, :, g, :] = x[rows].view(self.n_sub, self.p_c, fw).permute(1, 0, 2)
         return out
 
+    def _pack_phase(self, xs: Sequence[Tensor], c: int) -> Tensor:
+        """The send buffer of phase c.  On the GPU: one launch of pygsd_pack_slices per phase (every 16-byte unit of
+        the inputs read once, written p_r times; per phase, so that phase 0 is on the wire while phase 1 is packed);
+        elsewhere the tensor-op restatement `_pack`."""
+        if not xs[0].is_cuda:
+            return self._pack(xs, c)
+        from . import _cabi
+        ld = xs[0].stride(0)
+        if any(x.stride(1) != 1 or x.stride(0) != ld for x in xs):
+            raise ValueError("feature groups of one propagate must be row-major with one common row stride")
+        f, groups, esz = xs[0].size(1), len(xs), xs[0].element_size()
+        p_r, p_c = (self.p_r, self.p_c) if self.grid else (1, 1)
+        lead = (self.plan.world_size,) if self.grid else ()
+        out = self._buf(f"send{c}", lead + (self.n_sub, groups * (f // p_c)), xs[0])
+        first = c * self.n_sub * ld * esz
+        ptrs = (_cabi.c_void_p * groups)(*[x.data_ptr() + first for x in xs])
+        with torch.cuda.device(xs[0].device):
+            _cabi.check(_cabi.lib().pygsd_pack_slices(ptrs, groups, self.n_sub, f * esz, ld * esz, p_r, p_c, 1,
+                                                      _cabi.ptr(out), _cabi.stream_ptr()), "pygsd_pack_slices")
+        return out
+
     def _merge(self, recv: Tensor, groups: int) -> List[Tensor]:
         """recv [R, world, n_rsub, G * fw] (chunk s of return exchange r = rows (block i', chunk r) of MY range x
         column slice j' from rank s = i' * p_c + j') -> per group the [n_pad, F] rows in local order
@@ -454,19 +475,28 @@ class PropagateEngine:
         ev = self._events()
         self._mark(ev, "start")
         works, bufs = [], []
+        if xs[0].is_cuda:
+            ld = xs[0].stride(0)
+            if any(x.stride(1) != 1 or x.stride(0) != ld for x in xs):
+                xs = [x.contiguous() for x in xs]
         for c in range(self.phases):                         # every exchange is issued before any product
-            send = self._pack(xs, c)
+            send = self._pack_phase(xs, c)
             buf = self._buf(f"recv{c}", (world, self.n_sub, groups * fw), send)
             works.append(self.ex.all_to_all(buf, send) if self.grid else self.ex.all_gather(buf, send))
             bufs.append(buf)
         self._mark(ev, "packed")
-        # the row layout hands its products to the caller (fresh tensors); the grid's are staging for the return
-        ys = [self._buf(f"y{g}", (self.block_rows, fw), xs[0]) if self.grid else xs[0].new_empty((self.block_rows, fw))
-              for g in range(groups)]
+        # the row layout hands its products to the caller (fresh tensors).  The grid's products are written by the
+        # SpMM STRAIGHT INTO the return exchange's send buffer: group g = columns [g fw, (g + 1) fw) of rows that are
+        # already ordered (return chunk, owner, row) -- chunk r of `home` is the all-to-all input as it stands
         chunk_rows = world * self.n_rsub
-        returns, recv = [], None
+        returns, recv, home = [], None, None
         if self.grid:
+            home = self._buf("home", (self.return_chunks, world, self.n_rsub, groups * fw), xs[0])
+            flat = home.view(self.block_rows, groups * fw)
+            ys = [flat[:, g * fw:(g + 1) * fw] for g in range(groups)]
             recv = self._buf("back", (self.return_chunks, world, self.n_rsub, groups * fw), xs[0])
+        else:
+            ys = [xs[0].new_empty((self.block_rows, fw)) for _ in range(groups)]
         for c in range(self.phases):
             works[c].wait()
             self._mark(ev, "arrived")
@@ -484,11 +514,7 @@ class PropagateEngine:
                         self.single_kernel(csr, val, buf[:, g * fw:(g + 1) * fw], ys[g], lo, hi, alpha, c > 0,
                                            op[g].mean)
                 if last and self.grid:                       # chunk r goes home while chunk r + 1 is multiplied
-                    pack = self._buf(f"home{r}", (world, self.n_rsub, groups * fw), xs[0])
-                    flat = pack.view(world * self.n_rsub, groups * fw)
-                    for g, y in enumerate(ys):
-                        flat[:, g * fw:(g + 1) * fw] = y[lo:hi]
-                    returns.append(self.ex.all_to_all(recv[r], pack))
+                    returns.append(self.ex.all_to_all(recv[r], home[r]))
             self._mark(ev, "multiplied")
         if not self.grid:
             self._mark(ev, "end")

@@ -708,3 +708,24 @@ def test_rows_per_wavefront_variant(f, deg):
     for mode, res in results.items():
         for k, got in res.items():
             close(got, want[k], what=f"{k} (PYGSD_SPMM_PACKED={mode})")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,p_c,phases,f,dtype", [(8, 4, 2, 64, torch.float32), (4, 4, 1, 32, torch.float32),
+                                                      (6, 2, 3, 16, torch.float32), (4, 1, 2, 24, torch.float32),
+                                                      (8, 1, 1, 64, torch.bfloat16), (8, 2, 2, 32, torch.bfloat16)])
+def test_pack_slices_kernel_equals_the_tensor_op_packing(world, p_c, phases, f, dtype):
+    """pygsd_pack_slices (one launch for all phases, replicas and groups of a sharded propagate's send buffers)
+    against PropagateEngine._pack, the tensor-op restatement the CPU tests run -- bit-exact (pure data movement)."""
+    from pytorch_geometric_signed_directed_amd.parallel import PropagateEngine, ShardPlan
+    chunks = 2 if p_c > 1 else 1
+    plan = ShardPlan(1000, world, 1, align=PropagateEngine.alignment(world, p_c, phases, chunks))
+    eng = PropagateEngine(plan, type("Ex", (), {"world_size": world, "rank": 1})(), p_c, phases, chunks)
+    g = torch.Generator().manual_seed(world * f)
+    wide = torch.randn(plan.n_pad, 2 * f + 8, generator=g).to(dev()).to(dtype)
+    for xs in ([torch.randn(plan.n_pad, f, generator=g).to(dev()).to(dtype) for _ in range(2)],
+               [wide[:, 8:8 + f], wide[:, 8 + f:8 + 2 * f]]):                      # contiguous groups; strided column views
+        for c in range(phases):
+            want = eng._pack(xs, c).clone()
+            got = eng._pack_phase(xs, c)
+            assert got.shape == want.shape and torch.equal(got, want)

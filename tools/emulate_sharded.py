@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--edges", type=int, default=20000000)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--shapes", nargs="+", default=None, metavar="LAYOUT:C:R",
+                    help="pipeline shapes to run, e.g. grid:2:2 rows:1:1 (default: the built-in sweep)")
     ap.add_argument("--single-gpu-ms", type=float, default=None, help="measured 1-GPU step (bench.py) for the ratio")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "emulated_sharded.json"))
     args = ap.parse_args()
@@ -94,6 +96,8 @@ def main():
     shapes = [("grid", 1, 1), ("grid", 1, 2), ("grid", 1, 4), ("grid", 2, 2), ("grid", 2, 4), ("rows", 1, 1), ("rows", 2, 1)]
     if args.world <= 2:
         shapes = [("rows", 1, 1), ("rows", 2, 1), ("rows", 4, 1)]
+    if args.shapes:
+        shapes = [(t.split(":")[0], int(t.split(":")[1]), int(t.split(":")[2])) for t in args.shapes]
     out = {"world": args.world, "rank": args.rank, "nodes": args.nodes, "edges": int(ei.size(1)), "hidden": args.hidden,
            "latency_us": args.latency_us, "single_gpu_ms": args.single_gpu_ms, "runs": []}
     for gbps in args.link_gbps:
