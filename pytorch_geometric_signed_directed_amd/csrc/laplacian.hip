@@ -109,15 +109,56 @@ __global__ void row_starts(const int64_t* __restrict__ out_row, int64_t es, int3
     }
 }
 
+// Rows longer than this are NOT summed by one thread (the sequential sums below reproduce the reference's summation
+// order, which costs 0.1 us per entry of a single row: a 10^6-entry hub row made gcn_norm 129 ms instead of 0.7): the
+// sequential kernels skip them and long_row_sums adds them block-cooperatively -- per-thread strided partials, then a
+// fixed tree: deterministic, equal to the sequential sum to fp32 rounding.  Same threshold as PYGSD_LONG_ROW.
+constexpr int32_t kLongRow = PYGSD_LONG_ROW;
+
 // deg[r] = sum over the (row-sorted) entries of row r, sequential in sorted order
 __global__ void row_degree(const int32_t* __restrict__ off_ptr, const float* __restrict__ src, int32_t n,
                            int32_t use_abs, float* __restrict__ deg)
 {
     GRID_STRIDE(r, n)
     {
+        if (off_ptr[r + 1] - off_ptr[r] > kLongRow) continue;        // long_row_sums
         float d = 0.f;
         for (int32_t j = off_ptr[r]; j < off_ptr[r + 1]; ++j) d = d + (use_abs ? fabsf(src[j]) : src[j]);
         deg[r] = d;
+    }
+}
+
+// Every block scans its slice of the row pointer for long rows and sums each one it finds with all its threads.
+__global__ __launch_bounds__(256) void long_row_sums(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
+                                                     const float* __restrict__ w, int32_t n, int32_t use_abs,
+                                                     float* __restrict__ out)
+{
+    __shared__ float sm[4];
+    const int32_t per = (n + static_cast<int32_t>(gridDim.x) - 1) / static_cast<int32_t>(gridDim.x);
+    const int32_t r0 = static_cast<int32_t>(blockIdx.x) * per;
+    const int32_t r1 = r0 + per < n ? r0 + per : n;
+    for (int32_t r = r0; r < r1; ++r) {
+        const int32_t beg = rowptr[r], end = rowptr[r + 1];           // block-uniform
+        if (end - beg <= kLongRow) continue;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int32_t j = beg + static_cast<int32_t>(threadIdx.x);
+        for (; j + 3 * 256 < end; j += 4 * 256) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = w[perm ? perm[j + u * 256] : j + u * 256];
+                acc[u] += use_abs ? fabsf(v) : v;
+            }
+        }
+        for (; j < end; j += 256) {
+            const float v = w[perm ? perm[j] : j];
+            acc[0] += use_abs ? fabsf(v) : v;
+        }
+        float d = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) out[r] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        __syncthreads();
     }
 }
 
@@ -257,6 +298,7 @@ __global__ void csr_row_sum(const int32_t* __restrict__ rowptr, const int32_t* _
 {
     GRID_STRIDE(r, n)
     {
+        if (rowptr[r + 1] - rowptr[r] > kLongRow) continue;          // long_row_sums
         float d = 0.f;
         for (int32_t j = rowptr[r]; j < rowptr[r + 1]; ++j) d = d + w[perm ? perm[j] : j];
         deg[r] = d;
@@ -431,6 +473,8 @@ extern "C" int pygsd_maglap_merge(const float* w, int64_t n_edges, int32_t n, in
     const float* src = a_abs ? a_abs : a_sym;
     const int use_abs = (is_signed && !absolute_degree) ? 1 : 0;
     hipLaunchKernelGGL(row_degree, dim3(grid_for(n)), dim3(kBlock), 0, s, off_ptr, src, n, use_abs, deg);
+    hipLaunchKernelGGL(long_row_sums, dim3(n < 2048 ? 1 : 2048), dim3(256), 0, s, off_ptr, static_cast<const int32_t*>(nullptr),
+                       src, n, use_abs, deg);
     return check_launch("row_degree");
 }
 
@@ -559,6 +603,7 @@ extern "C" int pygsd_csr_row_sum_f32(const int32_t* rowptr, const int32_t* perm,
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_BUILD, s);
     hipLaunchKernelGGL(csr_row_sum, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, rowptr, perm, w, n_rows, out);
+    hipLaunchKernelGGL(long_row_sums, dim3(n_rows < 2048 ? 1 : 2048), dim3(256), 0, s, rowptr, perm, w, n_rows, 0, out);
     return check_launch("csr_row_sum");
 }
 

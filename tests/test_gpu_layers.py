@@ -843,6 +843,37 @@ def test_hub_rows_segment_softmax_and_snea_vs_float64():
         close(dev[k].grad, ref[k].grad, 2e-5, norm=True, what=name)
 
 
+def test_hub_rows_in_the_operator_builds():
+    """Degree sums of the operator builds are sequential per row (the reference's summation order); rows with more
+    than PYGSD_LONG_ROW entries are summed block-cooperatively instead (a 10^6-entry row made gcn_norm 129 ms).  gcn_norm
+    with a 60 000-entry target row and the magnetic Laplacian with a node of 5 500 distinct neighbours, against the
+    oracle (operator values; the sums differ from the sequential order by fp32 rounding only)."""
+    from pytorch_geometric_signed_directed_amd.utils._norm import conv_norm_rw, gcn_norm
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    n = 6000
+    g = torch.Generator().manual_seed(17)
+    ei = torch.randint(0, n, (2, 40000), generator=g)
+    hub_in = torch.stack([torch.randint(0, n, (60000,), generator=g), torch.full((60000,), 11)])       # duplicates stay
+    star = torch.stack([torch.full((5500,), 23), torch.randperm(n, generator=g)[:5500]])               # distinct neighbours
+    ei = torch.cat([ei, hub_in, star], dim=1)
+    ei = ei[:, torch.randperm(ei.size(1), generator=g)]
+    w = torch.rand(ei.size(1), generator=g) + 0.5
+    got_i, got_w = gcn_norm(ei.to(D), w.to(D), n)
+    want_i, want_w = R.gcn_norm(ei, w, n)
+    assert torch.equal(got_i.cpu(), want_i)
+    close(got_w, want_w, what="gcn_norm with a hub row")
+    got_i, got_w = conv_norm_rw(ei.to(D), 0.5, w.to(D), n)
+    want_i, want_w = R.conv_norm_rw(ei, w, n, 0.5)
+    assert torch.equal(got_i.cpu(), want_i)
+    close(got_w, want_w, what="conv_norm_rw with a hub row")
+    layer = MagNetConv(4, 4, 1, 0.25, False).to(D)
+    got = layer.__norm__(ei.to(D), n, w.to(D), 0.25, "sym", 2.0)
+    want = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0)
+    assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1])
+    close(got[2], want[2], 2e-6, what="magnetic operator, real part")
+    close(got[3], want[3], 2e-6, what="magnetic operator, imaginary part")
+
+
 def test_uncached_layer_reuses_the_operator_only_for_unmodified_graph_tensors():
     """cached=False (the reference default) rebuilds the operator per forward; here the last operator is kept
     while edge_index / edge_weight are the same tensor objects at the same in-place version.  Any in-place

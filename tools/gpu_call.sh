@@ -1,5 +1,2 @@
-mkdir -p gpurun_out
-rm -f gpurun_out/parity_errors_*.json
-( timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_gpu_r2h.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_r2h.log )
-tail -3 gpurun_out/pytest_gpu_r2h.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python -m pytest tests/test_gpu_layers.py tests/test_gpu_kernels.py -m gpu -q -p no:cacheprovider 2>&1 | tail -4
+timeout 300 python tools/hub_build_probe.py 2>&1 | tail -3
