@@ -199,6 +199,14 @@ class DistExchange:
                 dist.all_reduce(t, group=self.group)
         return t
 
+    def all_reduce_async(self, t: Tensor):
+        """Sum `t` over the ranks without holding up the compute stream: returns a handle whose wait() makes the
+        current stream wait for the result (RCCL: the reduction runs on the process group's stream meanwhile)."""
+        if self.world_size == 1 or self._staged:
+            self.all_reduce(t)
+            return _Done()
+        return dist.all_reduce(t, group=self.group, async_op=True)
+
     def broadcast_list(self, values: list, src: int = 0) -> list:
         box = [values]
         dist.broadcast_object_list(box, src=src, group=self.group)
@@ -259,6 +267,9 @@ class EmulatedExchange:
 
     def all_reduce(self, t: Tensor) -> Tensor:
         return t
+
+    def all_reduce_async(self, t: Tensor):
+        return _Done()
 
     def broadcast_list(self, values: list, src: int = 0) -> list:
         return values
@@ -663,6 +674,12 @@ class _ShardedMagneticFn(torch.autograd.Function):
             # nodes, zero features), so dW is unaffected and nothing leaks into real rows through S^T; only db
             # = sum_rows (g_r + g_i) has to lose the pad rows' share
             dbias = dbias - (g_r[n_local:] + g_i[n_local:]).sum(0)
+        # parameter gradients = sum of the per-shard partials: reduced on the communication stream WHILE the backward
+        # propagates below run (they do not depend on it); waited for at the end
+        pending = [layer.exchange.all_reduce_async(dw)]
+        if ctx.has_bias:
+            dbias = dbias.contiguous()
+            pending.append(layer.exchange.all_reduce_async(dbias))
         gx_r = gx_i = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             # d T_{k-1} += 2 S^T d T_k ; d T_{k-2} -= d T_k   (k = K .. 2), then gX = d T_0 + S^T d T_1
@@ -675,9 +692,8 @@ class _ShardedMagneticFn(torch.autograd.Function):
                     da[k - 2] = da[k - 2] - da[k]
                     db[k - 2] = db[k - 2] - db[k]
             gx_r, gx_i = da[0], db[0]
-        layer.exchange.all_reduce(dw)                       # parameter gradients: sum of the per-shard partials
-        if ctx.has_bias:
-            layer.exchange.all_reduce(dbias)
+        for h in pending:
+            h.wait()
         return gx_r, gx_i, dw, (dbias if ctx.has_bias else None), None
 
 
