@@ -110,6 +110,7 @@ class ShardPlan:
     def to_padded(self, ids: Tensor) -> Tensor:
         """Global node ids -> padded ids g * n_pad + (v - bounds[g])."""
         inner = torch.tensor(self.bounds[1:-1], dtype=ids.dtype, device=ids.device)
+        ids = ids.contiguous()
         g = torch.searchsorted(inner, ids, right=True) if inner.numel() else torch.zeros_like(ids)
         starts = torch.tensor(self.bounds[:-1], dtype=ids.dtype, device=ids.device)
         return g * self.n_pad + ids - starts[g]

@@ -32,8 +32,8 @@ def run_shape(args, edge_index, x_real, x_imag, layout, phases, chunks, link_gbp
     dev = x_real.device
     ex = EmulatedExchange(args.world, args.rank, link_gbps, args.latency_us)
     torch.manual_seed(0)
-    layer = ShardedMagNetConv(args.hidden, args.hidden, 1, 0.25, args.nodes, edge_index, None, device=dev,
-                              layout=layout, phases=phases, return_chunks=chunks, exchange=ex)
+    layer = ShardedMagNetConv(args.hidden, args.hidden, args.K, 0.25, args.nodes, edge_index, args.edge_weight, device=dev,
+                              layout=layout, phases=phases, return_chunks=chunks, exchange=ex, signed=args.signed)
     xr = layer.shard_rows(x_real).requires_grad_()
     xi = layer.shard_rows(x_imag).requires_grad_()
 
@@ -59,7 +59,7 @@ def run_shape(args, edge_index, x_real, x_imag, layout, phases, chunks, link_gbp
     for _ in range(args.steps):
         step()
     summary = layer.engine.timing_summary()
-    wire_ms = ex.wire_us / 1e3 / (2 * args.steps)                  # per propagate
+    wire_ms = ex.wire_us / 1e3 / (2 * args.K * args.steps)         # per propagate
     eng = layer.engine
     rec = {"layout": layout, "p_r": eng.p_r, "p_c": eng.p_c, "phases": phases, "return_chunks": chunks,
            "link_gbps": link_gbps, "step_ms_median": statistics.median(times), "step_ms_min": min(times),
@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--edges", type=int, default=20000000)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--K", type=int, default=1, help="Chebyshev order (2 K propagates per step)")
+    ap.add_argument("--signed", action="store_true", help="MSConv on an SDSBM graph (BASELINE config C4 with --hidden 128 --K 2)")
     ap.add_argument("--shapes", nargs="+", default=None, metavar="LAYOUT:C:R",
                     help="pipeline shapes to run, e.g. grid:2:2 rows:1:1 (default: the built-in sweep)")
     ap.add_argument("--single-gpu-ms", type=float, default=None, help="measured 1-GPU step (bench.py) for the ratio")
@@ -89,7 +91,12 @@ def main():
     args = ap.parse_args()
     from pytorch_geometric_signed_directed_amd import graphs
     dev = torch.device("cuda:0")
-    ei = torch.from_numpy(graphs.dsbm_for_edges(args.nodes, args.edges, seed=0)[0]).to(dev)
+    args.edge_weight = None
+    if args.signed:
+        ei_np, sign_np, _, _ = graphs.sdsbm_for_edges(args.nodes, args.edges, seed=1)
+        ei, args.edge_weight = torch.from_numpy(ei_np).to(dev), torch.from_numpy(sign_np).to(dev)
+    else:
+        ei = torch.from_numpy(graphs.dsbm_for_edges(args.nodes, args.edges, seed=0)[0]).to(dev)
     g = torch.Generator().manual_seed(0)
     x_real = torch.randn(args.nodes, args.hidden, generator=g).to(dev)
     x_imag = torch.randn(args.nodes, args.hidden, generator=g).to(dev)
@@ -99,7 +106,7 @@ def main():
     if args.shapes:
         shapes = [(t.split(":")[0], int(t.split(":")[1]), int(t.split(":")[2])) for t in args.shapes]
     out = {"world": args.world, "rank": args.rank, "nodes": args.nodes, "edges": int(ei.size(1)), "hidden": args.hidden,
-           "latency_us": args.latency_us, "single_gpu_ms": args.single_gpu_ms, "runs": []}
+           "K": args.K, "signed": args.signed, "latency_us": args.latency_us, "single_gpu_ms": args.single_gpu_ms, "runs": []}
     for gbps in args.link_gbps:
         for layout, phases, chunks in shapes:
             try:
