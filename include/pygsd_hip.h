@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 6
+#define PYGSD_ABI_VERSION 7
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -101,6 +101,12 @@ int pygsd_spmm_csr_bf16(const int32_t* rowptr, const int32_t* col, const float* 
                         int32_t n_rows, int32_t n_feat,
                         float alpha, float beta, int32_t mean,
                         void* stream);
+/* Same gather (bf16 X, fp32 values), but Y and Z are FLOAT arrays (ldy / ldz in floats): the partial products of a
+ * column-phased product (parallel.PropagateEngine) accumulate in fp32 through beta * Z with Z = Y, and the caller
+ * rounds the finished rows to bf16 once instead of once per phase.  No reference counterpart. */
+int pygsd_spmm_csr_bf16_acc_f32(const int32_t* rowptr, const int32_t* col, const float* val, const void* X,
+                                int64_t ldx, float* Y, int64_t ldy, const float* Z, int64_t ldz,
+                                int32_t n_rows, int32_t n_feat, float alpha, float beta, void* stream);
 
 /* Two operators sharing ONE sparsity pattern, two inputs, two outputs, one traversal:
  *   Ya = alpha * sum val_a[e] * Xa[col[e]] + beta * Za ;  Yb likewise with val_b / Xb / Zb.

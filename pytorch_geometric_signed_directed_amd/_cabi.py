@@ -38,6 +38,8 @@ PROTOTYPES = {
     "pygsd_spmm_csr_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                       c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_int32,
                                       c_void_p]),
+    "pygsd_spmm_csr_bf16_acc_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                              c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_void_p]),
     "pygsd_spmm2_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                       c_int32, c_float, c_float, c_int64, c_void_p, c_void_p]),
@@ -105,7 +107,7 @@ PROTOTYPES = {
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def lib_path():

@@ -526,6 +526,7 @@ struct SpmmBf16Args {
     int32_t n_rows, n_feat;
     float alpha, beta;
     int32_t mean;
+    int32_t acc_f32;   // != 0: y / z are float arrays (ldy / ldz in floats): fp32 accumulation across launches
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
@@ -596,6 +597,26 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_bf16_kernel(Spmm
     if (sub == 0 && fact) {
         const int deg = end - beg;
         const float d = p.mean ? static_cast<float>(deg > 1 ? deg : 1) : 1.f;
+        if (p.acc_f32) {
+            // partial products of a phased (sharded) product: kept in fp32 so that the bf16 rounding happens ONCE,
+            // when the caller stores the finished row, not once per phase
+            const float* zf = reinterpret_cast<const float*>(p.z);
+            float* yf = reinterpret_cast<float*>(p.y) + static_cast<int64_t>(row) * p.ldy + fl;
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (p.mean ? acc[j] / d : acc[j]) * p.alpha;
+            if (zf) {
+                const float4 z0 = *reinterpret_cast<const float4*>(zf + static_cast<int64_t>(row) * p.ldz + fl);
+                const float4 z1 = *reinterpret_cast<const float4*>(zf + static_cast<int64_t>(row) * p.ldz + fl + 4);
+                r[0] = fmaf(p.beta, z0.x, r[0]); r[1] = fmaf(p.beta, z0.y, r[1]);
+                r[2] = fmaf(p.beta, z0.z, r[2]); r[3] = fmaf(p.beta, z0.w, r[3]);
+                r[4] = fmaf(p.beta, z1.x, r[4]); r[5] = fmaf(p.beta, z1.y, r[5]);
+                r[6] = fmaf(p.beta, z1.z, r[6]); r[7] = fmaf(p.beta, z1.w, r[7]);
+            }
+            *reinterpret_cast<float4*>(yf) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4*>(yf + 4) = make_float4(r[4], r[5], r[6], r[7]);
+            return;
+        }
         float zz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (p.z) unpack8(*reinterpret_cast<const uint4*>(p.z + static_cast<int64_t>(row) * p.ldz + fl), zz);
         uint32_t o[8];
@@ -702,7 +723,25 @@ extern "C" int pygsd_spmm_csr_bf16(const int32_t* rowptr, const int32_t* col, co
     PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat),
                   "pygsd_spmm_csr_bf16: row stride smaller than n_feat");
     SpmmBf16Args a{rowptr, col, val, static_cast<const uint16_t*>(X), static_cast<uint16_t*>(Y),
-                   static_cast<const uint16_t*>(Z), ldx, ldy, ldz, n_rows, n_feat, alpha, beta, mean};
+                   static_cast<const uint16_t*>(Z), ldx, ldy, ldz, n_rows, n_feat, alpha, beta, mean, 0};
+    return launch_spmm_bf16(a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pygsd_spmm_csr_bf16_acc_f32(const int32_t* rowptr, const int32_t* col, const float* val, const void* X,
+                                           int64_t ldx, float* Y, int64_t ldy, const float* Z, int64_t ldz,
+                                           int32_t n_rows, int32_t n_feat, float alpha, float beta, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_spmm_csr_bf16_acc_f32: negative size");
+    if (n_rows == 0 || n_feat == 0) return 0;
+    PYGSD_REQUIRE(rowptr && col && X && Y, "pygsd_spmm_csr_bf16_acc_f32: null pointer");
+    PYGSD_REQUIRE(n_feat % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && (!Z || ldz % 4 == 0),
+                  "pygsd_spmm_csr_bf16_acc_f32: n_feat / ldx multiples of 8, fp32 row strides multiples of 4");
+    PYGSD_REQUIRE(aligned16(X) && aligned16(Y) && (!Z || aligned16(Z)),
+                  "pygsd_spmm_csr_bf16_acc_f32: pointers must be 16-byte aligned");
+    PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat),
+                  "pygsd_spmm_csr_bf16_acc_f32: row stride smaller than n_feat");
+    SpmmBf16Args a{rowptr, col, val, static_cast<const uint16_t*>(X), reinterpret_cast<uint16_t*>(Y),
+                   reinterpret_cast<const uint16_t*>(Z), ldx, ldy, ldz, n_rows, n_feat, alpha, beta, 0, 1};
     return launch_spmm_bf16(a, static_cast<hipStream_t>(stream));
 }
 

@@ -508,7 +508,10 @@ class PropagateEngine:
             ys = [flat[:, g * fw:(g + 1) * fw] for g in range(groups)]
             recv = self._buf("back", (self.return_chunks, world, self.n_rsub, groups * fw), xs[0])
         else:
-            ys = [xs[0].new_empty((self.block_rows, fw)) for _ in range(groups)]
+            # bf16 storage with more than one phase: the partial products accumulate in fp32 and are rounded ONCE
+            widen = xs[0].dtype == torch.bfloat16 and self.phases > 1
+            ys = [xs[0].new_empty((self.block_rows, fw), dtype=torch.float32 if widen else xs[0].dtype)
+                  for _ in range(groups)]
         for c in range(self.phases):
             works[c].wait()
             self._mark(ev, "arrived")
@@ -529,6 +532,8 @@ class PropagateEngine:
                     returns.append(self.ex.all_to_all(recv[r], home[r]))
             self._mark(ev, "multiplied")
         if not self.grid:
+            if ys[0].dtype != xs[0].dtype:
+                ys = [y.to(xs[0].dtype) for y in ys]
             self._mark(ev, "end")
             return ys
         for w in returns:
@@ -854,7 +859,7 @@ class ShardedOperator:
     """A COO operator out[scatter] += w * x[gather] sharded by node range in the row layout: this rank keeps the
     by-target rows of its nodes (forward) and the by-source rows of its nodes (backward), columns = padded ids
     into the all-gathered features.  fp32 or bf16 features (bf16 halves the exchanged bytes as well as the
-    gathered ones; its partial products would round once per phase, so bf16 runs un-phased)."""
+    gathered ones; with more than one phase its partial products accumulate in fp32 and are rounded once)."""
 
     def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], plan: ShardPlan, engine: PropagateEngine,
                  flow: str = "source_to_target", reduce: str = "add"):
@@ -903,7 +908,7 @@ class ShardedDiGCNConv(torch.nn.Module):
 
     def __init__(self, in_channels: int, out_channels: int, num_nodes: int, edge_index: Tensor,
                  edge_weight: Tensor, bias: bool = True, device=None, group=None, exchange=None,
-                 phases: int = 1, balance: bool = True, plan: Optional[ShardPlan] = None, kernels=None):
+                 phases: Optional[int] = None, balance: bool = True, plan: Optional[ShardPlan] = None, kernels=None):
         super().__init__()
         from .nn import DiGCNConv
         proto = DiGCNConv(in_channels, out_channels, bias=bias)
@@ -915,6 +920,7 @@ class ShardedDiGCNConv(torch.nn.Module):
             raise RuntimeError('Normalized adj matrix cannot be None. Please obtain the adj matrix in preprocessing.')
         self.exchange = exchange if exchange is not None else DistExchange(group)
         edge_index = edge_index.to(device)
+        phases = 1 if phases is None else int(phases)       # measured: a second phase does not pay for one-operand rows
         self.plan = plan or make_plan(num_nodes, self.exchange, edge_index, 1, phases, 1, balance)
         self.engine = PropagateEngine(self.plan, self.exchange, 1, phases, 1, kernels)
         self.op = ShardedOperator(edge_index, edge_weight.to(device), self.plan, self.engine)
@@ -956,7 +962,7 @@ class ShardedDiGCNInceptionBlock(torch.nn.Module):
 
     def __init__(self, in_dim: int, out_dim: int, num_nodes: int, edge_index: Tensor, edge_weight: Tensor,
                  edge_index2: Tensor, edge_weight2: Tensor, device=None, group=None, exchange=None,
-                 phases: int = 1, balance: bool = True, kernels=None):
+                 phases: Optional[int] = None, balance: bool = True, kernels=None):
         super().__init__()
         from .nn import DiGCNConv
         self.ln = torch.nn.Linear(in_dim, out_dim)
@@ -966,6 +972,7 @@ class ShardedDiGCNInceptionBlock(torch.nn.Module):
         self.exchange = exchange if exchange is not None else DistExchange(group)
         edge_index, edge_index2 = edge_index.to(device), edge_index2.to(device)
         both = torch.cat([edge_index, edge_index2], dim=1)
+        phases = 1 if phases is None else int(phases)       # see ShardedDiGCNConv
         self.plan = make_plan(num_nodes, self.exchange, both, 1, phases, 1, balance)
         self.engine = PropagateEngine(self.plan, self.exchange, 1, phases, 1, kernels)
         self.op1 = ShardedOperator(edge_index, edge_weight.to(device), self.plan, self.engine)

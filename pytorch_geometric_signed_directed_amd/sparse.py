@@ -417,8 +417,12 @@ def spmm_rows_into(csr: CSR, val: Optional[Tensor], x: Tensor, y: Tensor, row_lo
     if n_rows <= 0 or f == 0:
         return
     bf16 = x.dtype == torch.bfloat16
-    if x.dtype != y.dtype or x.dtype not in (torch.float32, torch.bfloat16) or f % (8 if bf16 else 4):
-        raise TypeError("spmm_rows_into: float32 (F % 4 == 0) or bfloat16 (F % 8 == 0) features, same dtype in and out")
+    mixed = bf16 and y.dtype == torch.float32          # bf16 gather, fp32 partial products (phased products)
+    if (x.dtype != y.dtype and not mixed) or x.dtype not in (torch.float32, torch.bfloat16) or f % (8 if bf16 else 4):
+        raise TypeError("spmm_rows_into: float32 (F % 4 == 0) or bfloat16 (F % 8 == 0) features; the output has the "
+                        "input's dtype, or float32 for bfloat16 inputs")
+    if mixed and mean:
+        raise ValueError("spmm_rows_into: fp32-accumulated bf16 products do not take mean")
     x, ldx = _rows(x)
     ldy = y.stride(0)
     if y.stride(1) != 1:
@@ -427,12 +431,15 @@ def spmm_rows_into(csr: CSR, val: Optional[Tensor], x: Tensor, y: Tensor, row_lo
         if not accumulate:
             y[row_lo:row_hi].zero_()
         return
-    esz = 2 if bf16 else 4
+    esz = 2 if (bf16 and not mixed) else 4
     py = c_void_p(y.data_ptr() + esz * row_lo * ldy)
     rp = c_void_p(csr.rowptr.data_ptr() + 4 * row_lo)
     z, ldz, beta = (py, ldy, 1.0) if accumulate else (None, 0, 0.0)
     with torch.cuda.device(x.device):
-        if bf16:
+        if mixed:
+            check(_cabi.lib().pygsd_spmm_csr_bf16_acc_f32(rp, ptr(csr.col), ptr(val), ptr(x), ldx, py, ldy, z, ldz, n_rows, f,
+                                                          float(alpha), beta, stream_ptr()), "pygsd_spmm_csr_bf16_acc_f32")
+        elif bf16:
             check(_cabi.lib().pygsd_spmm_csr_bf16(rp, ptr(csr.col), ptr(val), ptr(x), ldx, py, ldy, z, ldz, n_rows, f,
                                                   float(alpha), beta, 1 if mean else 0, stream_ptr()),
                   "pygsd_spmm_csr_bf16")

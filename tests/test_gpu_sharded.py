@@ -94,12 +94,12 @@ MAGNETIC = {
 }
 # n, f, dtype, inception block?, phases
 DIGCN = {
-    2: [(1001, 64, "float32", False, 2), (1000, 64, "bfloat16", False, 1),
+    2: [(1001, 64, "float32", False, 2), (1000, 64, "bfloat16", False, 1), (1000, 64, "bfloat16", False, 2),
         # BASELINE C5: DiGCN_InceptionBlock (DiGCN_Inception_Block.py:31-47), sharded, fp32 and bf16
         (1000, 64, "float32", True, 2)],
     3: [(600, 16, "float32", False, 1)],
-    4: [(1200, 64, "float32", True, 1), (1200, 64, "bfloat16", True, 1)],
-    8: [(1600, 64, "bfloat16", True, 1)],
+    4: [(1200, 64, "float32", True, 1), (1200, 64, "bfloat16", True, 2)],     # bf16, phased: fp32 partial products
+    8: [(1600, 64, "bfloat16", True, 1), (1600, 64, "bfloat16", True, 2)],
 }
 
 
