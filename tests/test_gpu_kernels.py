@@ -729,3 +729,30 @@ def test_pack_slices_kernel_equals_the_tensor_op_packing(world, p_c, phases, f, 
             want = eng._pack(xs, c).clone()
             got = eng._pack_phase(xs, c)
             assert got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_bf16_gather_with_fp32_partial_products():
+    """pygsd_spmm_csr_bf16_acc_f32 through sparse.spmm_rows_into: bf16 features, float output accumulated over two
+    column halves of the operator (Z = Y) and over row ranges, against the float64 product of the ROUNDED inputs --
+    fp32-accurate (1e-5), i.e. no bf16 rounding of the partial sums."""
+    from pytorch_geometric_signed_directed_amd.parallel import split_phases
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm_rows_into
+    d = dev()
+    n, f, world, n_pad = 1024, 64, 4, 256
+    ei = rand_graph(n, n, 30000, 5)
+    g = torch.Generator().manual_seed(9)
+    w = torch.rand(ei.size(1), generator=g)
+    x = torch.randn(n, f, generator=g).to(torch.bfloat16)
+    pat = Pattern(ei.to(d), n, n)
+    val = pat.values_for(w.to(d), "fwd")
+    A = torch.zeros(n, n, dtype=torch.float64).index_put_((ei[1], ei[0]), w.double(), accumulate=True)
+    want = 0.5 * (A @ x.double())
+    blocks = split_phases(pat.fwd, (val,), n_pad, 2, world)
+    y = torch.empty(n, f, dtype=torch.float32, device=d)
+    xd = x.to(d)
+    for c, (csr, (v,)) in enumerate(blocks):
+        buf = xd.view(world, n_pad, f)[:, c * 128:(c + 1) * 128].reshape(world * 128, f).contiguous()
+        for lo, hi in ((0, 500), (500, n)):
+            spmm_rows_into(csr, v, buf, y, lo, hi, 0.5, c > 0)
+    close(y, want, what="fp32 partial products of a bf16 gather")
