@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 7
+#define PYGSD_ABI_VERSION 8
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -270,6 +270,35 @@ int pygsd_maglap_assemble_csr(const int64_t* out_row, const int64_t* out_col, co
 int pygsd_maglap_values(const int64_t* out_row, const int64_t* out_col, const float* a_sym,
                         const float* theta, const float* deg, int64_t num_unique, float q, int32_t sym,
                         float* off_real, float* off_imag, float* mir_real, float* mir_imag, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused build of the scaled (signed) magnetic operator (csrc/magop.hip) -- the same result as
+ * pygsd_maglap_sort -> _merge -> _values -> _assemble_csr in two stages around ONE host read, for the
+ * case the layers run on every uncached forward (MagNetConv.py:157-181 / MSConv.py:150-180: fixed q,
+ * no gradient w.r.t. edge_weight).  Edge list in, compute layout out; no int64 COO intermediates.
+ *   pygsd_magop_stage1: range-check the node ids, emit both orientations as u64 keys, radix-sort on the
+ *                       ROW bits only (stable), order / coalesce every row inside one wavefront (rows of
+ *                       65..4096 symmetrised entries: one block, LDS), sum duplicates in sorted order and
+ *                       the row degree sequentially in column order.  Writes rowptr int32[n+1] (final CSR
+ *                       row pointer incl. the diagonal entry of every row), deg float[n] and the DEVICE
+ *                       int64 d_info[4] = { E_s, #rows with more than 4096 symmetrised entries (if > 0 the
+ *                       result is incomplete: use the pygsd_maglap_* pipeline), 1 if a node id was outside
+ *                       [0, n), one such id }.  w == NULL means all ones.  sym != 0 also prepares deg^-1/2.
+ *   pygsd_magop_stage2: S = 2 L / lambda_max + diag_shift I into col int32[E_s+n] and the four value arrays
+ *                       float[E_s+n] (each 16-byte aligned): vb_* = S[row, col], vf_* = S[col, row] (see
+ *                       pygsd_maglap_assemble_csr), columns ascending.  E_s need not be known to the host to
+ *                       launch it: arrays of the upper bound 2 n_edges + n serve (rowptr[n] = E_s + n), so the
+ *                       read of d_info can overlap this stage.
+ * Both stages take the same, untouched workspace of pygsd_magop_workspace(n_edges, n, w != NULL) bytes.
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_magop_workspace(int64_t n_edges, int32_t n, int32_t weighted, size_t* bytes);
+int pygsd_magop_stage1(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
+                       int32_t is_signed, int32_t absolute_degree, int32_t sym, void* workspace,
+                       size_t workspace_bytes, int32_t* rowptr, float* deg, int64_t* d_info, void* stream);
+int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, int32_t sym, float lambda_max,
+                       float diag_shift, void* workspace, size_t workspace_bytes, const int32_t* rowptr,
+                       const float* deg, int32_t* col, float* vb_real, float* vb_imag, float* vf_real,
+                       float* vf_imag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * add_remaining_self_loops + degree normalisation: torch_geometric's gcn_norm as called at

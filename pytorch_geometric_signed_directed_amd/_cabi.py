@@ -79,6 +79,11 @@ PROTOTYPES = {
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_maglap_values": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                       c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pygsd_magop_workspace": (c_int32, [c_int64, c_int32, c_int32, ctypes.POINTER(c_size_t)]),
+    "pygsd_magop_stage1": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                     c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pygsd_magop_stage2": (c_int32, [c_int64, c_int32, c_int32, c_float, c_int32, c_float, c_float, c_void_p, c_size_t,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_self_loops_workspace": (c_int32, [c_int64, ctypes.POINTER(c_size_t)]),
     "pygsd_self_loops_scan": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_size_t, c_void_p,
                                         c_void_p, c_void_p]),
@@ -107,7 +112,7 @@ PROTOTYPES = {
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def lib_path():

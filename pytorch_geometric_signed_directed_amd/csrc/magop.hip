@@ -1,0 +1,798 @@
+// Fused build of the scaled (signed) magnetic operator -- SURVEY.md 8(a) rows a3 / a4, the work the reference redoes on
+// EVERY forward unless cached=True (MagNetConv.py:157-181 -> __norm__ :78-120 -> get_magnetic_Laplacian.py:47-85,
+// MSConv.py:78-119 -> get_magnetic_signed_Laplacian.py:47-90): edge list in, compute layout out (ONE int32 CSR over the
+// symmetrised pattern incl. the diagonal + the four value arrays of include/pygsd_hip.h's pygsd_maglap_assemble_csr).
+//
+// The generic pipeline of laplacian.hip sorts 2E (64-bit key, 32-bit id) pairs over all ~41 key bits (6 radix passes of
+// 12 B per entry) and then makes five single-purpose passes through int64 COO intermediates.  Here:
+//   1. edge_keys      one read of the int64 edge list: node-id range check folded in, both orientations emitted as
+//                     u64 keys  row << 32 | col << 1 | dir  (self loops / bad ids -> row = n, a bucket nobody reads);
+//                     weights (if any) ride along as the 32-bit payload, so nothing is gathered through a permutation later
+//   2. rocPRIM radix sort on the ROW bits only (2 passes of 10 bits at 10^6 nodes, 8 B per entry without weights); stable, so a
+//      row's entries stay in list order
+//   3. key_row_starts row boundaries of the bucketed stream
+//   4. row_merge_*    one wavefront per row: the row's (col, dir, position) keys are sorted in registers (bitonic over
+//                     the lanes, DPP), duplicate runs are summed in sorted order (coalesce's order), the row's degree is
+//                     added sequentially in column order (scatter_add_'s order on the reference's CPU path); every
+//                     position of the stream gets ONE 16-byte record {col, A_s, Theta_arg, row} (or a "nothing here"
+//                     mark behind a row's distinct entries).  Rows of 65..4096 entries take a block-wide LDS sort;
+//                     longer rows are counted and the host falls back to laplacian.hip
+//   5. scan of (distinct entries + 1) -> final row pointer; ONE host read of {E_s, #rows left to the fallback, bad id}
+//   6. values_entries one thread per record (one 16-byte load): phase / normalisation / 2 x / lambda_max for both
+//                     orientations, the diagonal placed by its neighbour entry; a block's outputs are one contiguous
+//                     slot range of the final CSR, staged in LDS and written with aligned 16-byte stores
+// Narrow accesses were the limiter of the first version (4-byte loads / stores over nine streams ran at 2.4 TB/s whatever
+// the arithmetic or the gathers): every large stream here moves 8 or 16 bytes per lane.
+// HBM-bound integer / byte work; no atomics on the data path (one counter append per row longer than a wavefront).
+// Bit-compatible with the generic pipeline: same formulas in the same order (tests/test_gpu_kernels.py holds the two to
+// equality).
+#include <climits>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.hpp"
+
+namespace pygsd {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kBlockRowMax = 4096;     // rows up to this many symmetrised entries are sorted by one block in LDS
+
+inline unsigned grid_for(int64_t n)
+{
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 256 * 32) g = 256 * 32;
+    return static_cast<unsigned>(g < 1 ? 1 : g);
+}
+
+inline int bits_for(uint64_t v)
+{
+    int b = 1;
+    while (b < 64 && (v >> b) != 0) ++b;
+    return b;
+}
+
+#define GRID_STRIDE(i, n)                                                                  \
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < (n); \
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+
+// info[0] = E_s (written by finish_info), info[1] = rows too long for this pipeline, info[2] = 1 if an id was outside
+// [0, n), info[3] = one such id
+__global__ void edge_keys(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                          const float* __restrict__ w, int64_t e, int32_t n, uint64_t* __restrict__ keys,
+                          float* __restrict__ wout, int64_t* __restrict__ info)
+{
+    const uint64_t nn = static_cast<uint64_t>(n), drop = nn << 32;
+    GRID_STRIDE(k, e)
+    {
+        const int64_t r = row[k], c = col[k];
+        const bool bad_r = static_cast<uint64_t>(r) >= nn, bad_c = static_cast<uint64_t>(c) >= nn;
+        uint64_t kf = drop, kr = drop;
+        if (bad_r || bad_c) {
+            info[2] = 1;                                   // racing writers all store valid witnesses
+            info[3] = bad_r ? r : c;
+        } else if (r != c) {
+            kf = (static_cast<uint64_t>(r) << 32) | (static_cast<uint64_t>(c) << 1);
+            kr = (static_cast<uint64_t>(c) << 32) | (static_cast<uint64_t>(r) << 1) | 1u;
+        }
+        keys[k] = kf;
+        keys[e + k] = kr;
+        if (wout) {
+            const float we = w[k];
+            wout[k] = we;
+            wout[e + k] = we;
+        }
+    }
+}
+
+// rs[r] = first entry of the row-bucketed stream whose row is >= r, r = 0 .. n + 1 (row n = dropped entries)
+__global__ void key_row_starts(const uint64_t* __restrict__ keys, int64_t m, int32_t n, int32_t* __restrict__ rs)
+{
+    GRID_STRIDE(i, m + 1)
+    {
+        const int64_t prev = i == 0 ? -1 : static_cast<int64_t>(keys[i - 1] >> 32);
+        const int64_t cur = i == m ? static_cast<int64_t>(n) + 1 : static_cast<int64_t>(keys[i] >> 32);
+        for (int64_t r = prev + 1; r <= cur; ++r) rs[r] = static_cast<int32_t>(i);
+    }
+}
+
+// ---- in-register sort of one value per lane (64 lanes), ascending -------------------------------------------------
+// Bitonic network in its "flip" form: merge stage k first pairs lane i with i ^ (k - 1) (mirror inside the k-block),
+// then with i ^ j for j = k/4 .. 1; the lower lane of a pair always keeps the minimum, so there are no direction
+// flags.  18 of the 21 exchanges stay inside a 16-lane row and are DPP moves (no LDS crossbar round trip, no address
+// VGPR, no s_waitcnt): quad_perm for ^1 ^2 ^3, row_half_mirror / row_mirror for ^7 ^15, row_ror:8 for ^8, a
+// bank-masked row_shl:4 / row_shr:4 pair for ^4.  The three cross-row exchanges (^16, ^31, ^63) use ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ uint32_t dpp_xor4(uint32_t v)
+{
+    // lanes with bit 2 clear (banks 0, 2 of a row) read lane i + 4 (row_shl:4), the others lane i - 4 (row_shr:4)
+    int o = __builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x104, 0xF, 0x5, false);
+    o = __builtin_amdgcn_update_dpp(o, static_cast<int>(v), 0x114, 0xF, 0xA, false);
+    return static_cast<uint32_t>(o);
+}
+
+enum Exchange { X1, X2, X3, X4, X7, X8, X15, X16, X31, X63 };
+
+template <Exchange E>
+__device__ __forceinline__ uint32_t exchange32(uint32_t v, int lane)
+{
+    if constexpr (E == X1) return dpp_mov<0xB1>(v);             // quad_perm:[1,0,3,2]
+    else if constexpr (E == X2) return dpp_mov<0x4E>(v);        // quad_perm:[2,3,0,1]
+    else if constexpr (E == X3) return dpp_mov<0x1B>(v);        // quad_perm:[3,2,1,0]
+    else if constexpr (E == X4) return dpp_xor4(v);
+    else if constexpr (E == X7) return dpp_mov<0x141>(v);       // row_half_mirror
+    else if constexpr (E == X8) return dpp_mov<0x128>(v);       // row_ror:8
+    else if constexpr (E == X15) return dpp_mov<0x140>(v);      // row_mirror
+    else if constexpr (E == X16) return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, static_cast<int>(v)));
+    else if constexpr (E == X31) return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 31) << 2, static_cast<int>(v)));
+    else return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 63) << 2, static_cast<int>(v)));
+}
+
+template <Exchange E>
+__device__ __forceinline__ uint32_t exchange(uint32_t v, int lane) { return exchange32<E>(v, lane); }
+
+template <Exchange E>
+__device__ __forceinline__ uint64_t exchange(uint64_t v, int lane)
+{
+    const uint32_t lo = exchange32<E>(static_cast<uint32_t>(v), lane);
+    const uint32_t hi = exchange32<E>(static_cast<uint32_t>(v >> 32), lane);
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+// `lower`: this lane is the lower one of its pair
+template <Exchange E, typename KT>
+__device__ __forceinline__ KT compare_exchange(KT v, int lane, bool lower)
+{
+    const KT o = exchange<E>(v, lane);
+    const KT mn = v < o ? v : o, mx = v < o ? o : v;
+    return lower ? mn : mx;
+}
+
+template <typename KT>
+__device__ __forceinline__ KT wave_bitonic(KT v, int lane)
+{
+    const bool b0 = (lane & 1) == 0, b1 = (lane & 2) == 0, b2 = (lane & 4) == 0, b3 = (lane & 8) == 0,
+               b4 = (lane & 16) == 0, b5 = (lane & 32) == 0;
+    v = compare_exchange<X1>(v, lane, b0);                        // k = 2
+    v = compare_exchange<X3>(v, lane, b1);                        // k = 4
+    v = compare_exchange<X1>(v, lane, b0);
+    v = compare_exchange<X7>(v, lane, b2);                        // k = 8
+    v = compare_exchange<X2>(v, lane, b1);
+    v = compare_exchange<X1>(v, lane, b0);
+    v = compare_exchange<X15>(v, lane, b3);                       // k = 16
+    v = compare_exchange<X4>(v, lane, b2);
+    v = compare_exchange<X2>(v, lane, b1);
+    v = compare_exchange<X1>(v, lane, b0);
+    v = compare_exchange<X31>(v, lane, b4);                       // k = 32
+    v = compare_exchange<X8>(v, lane, b3);
+    v = compare_exchange<X4>(v, lane, b2);
+    v = compare_exchange<X2>(v, lane, b1);
+    v = compare_exchange<X1>(v, lane, b0);
+    v = compare_exchange<X63>(v, lane, b5);                       // k = 64
+    v = compare_exchange<X16>(v, lane, b4);
+    v = compare_exchange<X8>(v, lane, b3);
+    v = compare_exchange<X4>(v, lane, b2);
+    v = compare_exchange<X2>(v, lane, b1);
+    v = compare_exchange<X1>(v, lane, b0);
+    return v;
+}
+
+__device__ __forceinline__ float degree_source(float s, float a, int deg_mode)
+{
+    return deg_mode == 2 ? a / 2.f : (deg_mode == 1 ? fabsf(s / 2.f) : s / 2.f);
+}
+
+// One record per position of the row-bucketed stream (16 bytes, written and read as one dwordx4):
+//   x = col | (1 << 31 if the row's diagonal goes right AFTER this entry)
+//   y = A_s (fp32 bits), z = Theta_arg (fp32 bits)
+//   w = row | (1 << 31 if the row's diagonal goes right BEFORE this entry), or kNoEntry behind a row's distinct entries
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kNoEntry = 0xFFFFFFFFu;
+constexpr uint32_t kFlag = 0x80000000u;
+
+// A wavefront orders one row of <= 64 symmetrised entries in registers.  deg_mode: 0 = row sums of A_s, 1 = of |A_s|
+// (signed, absolute_degree off), 2 = of the |w| sums / 2 (signed, absolute_degree on).  `c2` / `w0` are the row's
+// keys (col << 1 | dir) and weights as loaded by lane = list position (prefetched by the caller for several rows).
+template <typename KT>
+__device__ __forceinline__ void merge_one_row(int32_t r, int32_t beg, int32_t cnt, uint32_t c2, float w0, bool weighted,
+                                              int lane, int32_t deg_mode, int32_t* __restrict__ ucnt,
+                                              float* __restrict__ deg, uint4* __restrict__ ent)
+{
+    const bool have = lane < cnt;
+    KT lk = have ? static_cast<KT>((static_cast<KT>(c2) << 6) | static_cast<KT>(lane)) : static_cast<KT>(~static_cast<KT>(0));
+    lk = wave_bitonic<KT>(lk, lane);
+    // invalid keys sorted last: lanes < cnt hold the row in (col, dir, list position) order
+    const int src = static_cast<int>(lk & 63);
+    const uint32_t c2s = static_cast<uint32_t>(lk >> 6);
+    const uint32_t colv = c2s >> 1;
+    const bool rev = (c2s & 1u) != 0;
+    const uint32_t prev = __shfl_up(colv, 1);
+    const bool head = have && (lane == 0 || prev != colv);
+    const uint64_t H = __ballot(head);
+    const uint64_t above = lane == 63 ? 0ull : ((H >> (lane + 1)) << (lane + 1));
+    const int end = above ? (__ffsll(static_cast<long long>(above)) - 1) : cnt;
+    const int len = end - lane;                                   // run length, meaningful on head lanes
+    const int u = __popcll(H);
+    const uint64_t below = (1ull << lane) - 1ull;
+    const int rank = __popcll(H & below);
+    const int heads_upto = __popcll(H & (below | (1ull << lane)));
+    float s = 0.f, t = 0.f, a = 0.f, d = 0.f;
+    if (weighted) {
+        const float wv = __shfl(w0, src);                         // weight of the entry this lane holds after the sort
+        for (int j = 0;; ++j) {                                   // runs are summed in sorted order, like coalesce
+            const bool act = head && j < len;
+            if (!__ballot(act)) break;
+            const float wj = __shfl(wv, lane + j);
+            const int rj = __shfl(static_cast<int>(rev), lane + j);
+            if (act) {
+                s = s + wj;
+                t = t + (rj ? -wj : wj);
+                a = a + fabsf(wj);
+            }
+        }
+        // degree: SEQUENTIAL sum over the distinct entries in column order (scatter_add_'s order on the reference's
+        // CPU path).  Compact the per-entry sources into lanes 0 .. u-1 (heads go to their rank, the other lanes
+        // fill the rest: a permutation), then lane-serial adds.
+        const int dest = head ? rank : u + (lane - heads_upto);
+        const float dense = __int_as_float(
+            __builtin_amdgcn_ds_permute(dest << 2, __float_as_int(degree_source(s, a, deg_mode))));
+        for (int k = 0; k < u; ++k) d = d + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dense), k));
+    } else {
+        // all ones: run sums are small integers and the degree is a sum of at most 64 multiples of 1/2 -- every
+        // order of summation gives the same fp32 value, so the row degree is a butterfly instead of 40 serial adds
+        const uint64_t D = __ballot(have && rev);
+        const uint64_t run = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << lane;
+        const int n1 = __popcll(D & run);
+        s = static_cast<float>(len);
+        t = static_cast<float>(len - 2 * n1);
+        a = s;
+        d = head ? degree_source(s, a, deg_mode) : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off);
+    }
+    const int left = __popcll(__ballot(head && static_cast<int32_t>(colv) < r));   // distinct entries left of the diagonal
+    if (have) {                                                   // one 16-byte store per lane: a permutation of the row
+        uint4 rec;
+        int pos;
+        if (head) {
+            rec.x = colv | ((left >= 1 && rank == left - 1) ? kFlag : 0u);
+            rec.y = __float_as_uint(s / 2.f);
+            rec.z = __float_as_uint(t);
+            rec.w = static_cast<uint32_t>(r) | ((left == 0 && rank == 0) ? kFlag : 0u);
+            pos = beg + rank;
+        } else {
+            rec = make_uint4(0u, 0u, 0u, kNoEntry);
+            pos = beg + u + (lane - heads_upto);
+        }
+        ent[pos] = rec;
+    }
+    if (lane == 0) {
+        ucnt[r] = u;
+        deg[r] = d;                                               // (deg^-1/2: row_tables, one THREAD per row)
+    }
+}
+
+// kRowsPerWave consecutive rows per wavefront: their row bounds and keys are loaded up front (independent loads in
+// flight -- one row per wavefront was latency-bound: ~3 dependent HBM round trips per 40-entry row).
+constexpr int kRowsPerWave = 4;
+
+template <typename KT>
+__global__ __launch_bounds__(256) void row_merge_wave(
+    const uint64_t* __restrict__ keys, const float* __restrict__ wsorted, const int32_t* __restrict__ rs, int32_t n,
+    int64_t m, int32_t deg_mode, int32_t* __restrict__ ucnt, float* __restrict__ deg, uint4* __restrict__ ent,
+    int32_t* __restrict__ long_rows, int32_t* __restrict__ n_long)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * kRowsPerWave;
+    if (r0 >= n) return;
+    const int rows = n - r0 < kRowsPerWave ? static_cast<int>(n - r0) : kRowsPerWave;
+    const int32_t bound = rs[r0 + (lane <= rows ? lane : rows)];   // lanes 0 .. rows hold the row bounds
+    int32_t beg[kRowsPerWave], cnt[kRowsPerWave];
+    uint32_t c2[kRowsPerWave];
+    float w0[kRowsPerWave];
+#pragma unroll
+    for (int j = 0; j < kRowsPerWave; ++j) {
+        beg[j] = __builtin_amdgcn_readlane(bound, j < rows ? j : rows);
+        cnt[j] = __builtin_amdgcn_readlane(bound, j + 1 < rows ? j + 1 : rows) - beg[j];
+    }
+    // unconditional loads from clamped addresses (a load under a lane mask gets its s_waitcnt inside the branch and the
+    // four rows' loads would serialise); lanes past a row's end read the next rows' keys and are masked afterwards
+#pragma unroll
+    for (int j = 0; j < kRowsPerWave; ++j) {
+        int64_t pos = static_cast<int64_t>(beg[j]) + lane;
+        pos = pos < m ? pos : m - 1;
+        c2[j] = static_cast<uint32_t>(__builtin_nontemporal_load(keys + pos));      // col << 1 | dir
+        w0[j] = wsorted ? wsorted[pos] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < kRowsPerWave; ++j) {
+        if (j >= rows) break;
+        const int32_t r = static_cast<int32_t>(r0) + j;
+        if (cnt[j] > 64) {
+            if (lane == 0) long_rows[atomicAdd(n_long, 1)] = r;
+            continue;
+        }
+        merge_one_row<KT>(r, beg[j], cnt[j], c2[j], w0[j], wsorted != nullptr, lane, deg_mode, ucnt, deg, ent);
+    }
+}
+
+// Rows of 65 .. kBlockRowMax entries: one block per listed row, bitonic sort of (col, dir, position) keys in LDS.
+__global__ __launch_bounds__(256) void row_merge_block(
+    const uint64_t* __restrict__ keys, const float* __restrict__ wsorted, const int32_t* __restrict__ rs,
+    int32_t deg_mode, int32_t* __restrict__ ucnt, float* __restrict__ deg, uint4* __restrict__ ent,
+    const int32_t* __restrict__ long_rows, const int32_t* __restrict__ n_long, int64_t* __restrict__ info)
+{
+    __shared__ uint64_t sk[kBlockRowMax];
+    __shared__ float sw[kBlockRowMax];
+    __shared__ float sd[kBlockRowMax];
+    __shared__ int32_t soff[kBlock + 1];
+    __shared__ int32_t sleft;
+    const int tid = threadIdx.x;
+    const int nl = *n_long;
+    for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+        const int32_t r = long_rows[li];
+        const int32_t beg = rs[r], cnt = rs[r + 1] - beg;
+        if (cnt > kBlockRowMax) {                                  // left to the generic pipeline (host falls back)
+            if (tid == 0) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
+                ucnt[r] = 0;
+                deg[r] = 0.f;
+            }
+            for (int i = tid; i < cnt; i += kBlock) ent[beg + i] = make_uint4(0u, 0u, 0u, kNoEntry);
+            continue;
+        }
+        int n2 = kBlock;
+        while (n2 < cnt) n2 <<= 1;
+        for (int i = tid; i < n2; i += kBlock) {
+            sk[i] = i < cnt ? ((static_cast<uint64_t>(static_cast<uint32_t>(keys[beg + i])) << 12) | static_cast<uint64_t>(i))
+                            : ~0ull;
+            if (wsorted && i < cnt) sw[i] = wsorted[beg + i];
+        }
+        if (tid == 0) sleft = 0;
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (n2 >> 1); t += kBlock) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int l = i | j;
+                    const bool up = (i & k) == 0;
+                    const uint64_t x = sk[i], y = sk[l];
+                    if ((x > y) == up) {
+                        sk[i] = y;
+                        sk[l] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // sk[p] >> 13 = col, bit 12 = dir, low 12 bits = list position inside the row
+        const int ch = n2 / kBlock, p0 = tid * ch;
+        int heads = 0, left = 0;
+        for (int p = p0; p < p0 + ch; ++p)
+            if (p < cnt && (p == 0 || (sk[p - 1] >> 13) != (sk[p] >> 13))) {
+                ++heads;
+                if (static_cast<int64_t>(sk[p] >> 13) < r) ++left;
+            }
+        soff[tid] = heads;
+        if (left) atomicAdd(&sleft, left);
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int i = 0; i < kBlock; ++i) {
+                const int h = soff[i];
+                soff[i] = acc;
+                acc += h;
+            }
+            soff[kBlock] = acc;
+        }
+        __syncthreads();
+        const int u = soff[kBlock], nleft = sleft;
+        int rank = soff[tid];
+        for (int p = p0; p < p0 + ch; ++p) {
+            if (!(p < cnt && (p == 0 || (sk[p - 1] >> 13) != (sk[p] >> 13)))) continue;
+            const uint64_t colv = sk[p] >> 13;
+            float s = 0.f, t = 0.f, a = 0.f;
+            for (int q = p; q < cnt && (sk[q] >> 13) == colv; ++q) {
+                const float we = wsorted ? sw[sk[q] & 4095u] : 1.f;
+                s = s + we;
+                t = t + (((sk[q] >> 12) & 1u) ? -we : we);
+                a = a + fabsf(we);
+            }
+            uint4 rec;
+            rec.x = static_cast<uint32_t>(colv) | ((nleft >= 1 && rank == nleft - 1) ? kFlag : 0u);
+            rec.y = __float_as_uint(s / 2.f);
+            rec.z = __float_as_uint(t);
+            rec.w = static_cast<uint32_t>(r) | ((nleft == 0 && rank == 0) ? kFlag : 0u);
+            ent[beg + rank] = rec;
+            sd[rank] = degree_source(s, a, deg_mode);
+            ++rank;
+        }
+        for (int i = u + tid; i < cnt; i += kBlock) ent[beg + i] = make_uint4(0u, 0u, 0u, kNoEntry);
+        __syncthreads();
+        if (tid == 0) {
+            float d = 0.f;
+            for (int k = 0; k < u; ++k) d = d + sd[k];
+            ucnt[r] = u;
+            deg[r] = d;
+        }
+        __syncthreads();
+    }
+}
+
+struct PlusOne {
+    __host__ __device__ int32_t operator()(int32_t v) const { return v + 1; }
+};
+
+// Per-row tables of the second stage, one THREAD per row: deg^-1/2 with 0 -> 0 (get_magnetic_Laplacian.py:69-71; powf is
+// ~150 instructions -- far too many to issue from a wavefront with one live lane per row) and the offset that turns a
+// stream position into a CSR slot (slot = position + shift[row] + (col > row)).
+__global__ void row_tables(const float* __restrict__ deg, const int32_t* __restrict__ rs, const int32_t* __restrict__ rowptr,
+                           int32_t n, int32_t sym, float* __restrict__ dinv, int32_t* __restrict__ shift,
+                           int64_t* __restrict__ info)
+{
+    GRID_STRIDE(r, n)
+    {
+        if (sym) {
+            const float d = deg[r];
+            dinv[r] = d == 0.f ? 0.f : powf(d, -0.5f);
+        }
+        shift[r] = rowptr[r] - rs[r];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) info[0] = static_cast<int64_t>(rowptr[n]) - n;
+}
+
+__device__ __forceinline__ uint4 load_record(const uint4* __restrict__ ent, int64_t p)
+{
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ent) + p);     // touched once
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ float scale_lam(float x, float lam)
+{
+    const float v = (2.0f * x) / lam;
+    return v == INFINITY ? 0.f : v;
+}
+
+// Values of S = 2 L / lambda_max + diag_shift I in the final CSR slots, one thread per record of the stream.
+//   vb_* = S[row, col] (by-source / backward product), vf_* = S[col, row] (by-target / forward product):
+//   Hermitian, so the mirror is the same magnitude multiplied in the mirrored entry's own order with the
+//   conjugate phase (laplacian.hip lap_values / assemble_csr; get_magnetic_Laplacian.py:66-85, MagNetConv.py:100-116).
+// The slots a block produces form one contiguous range [lo, hi) of the CSR (entries of consecutive rows + the
+// diagonals their neighbours place; the single slot of an entry-less row in between is a hole, filled afterwards by
+// diagonal_of_empty_rows), so the five output arrays are staged in LDS and written with aligned 16-byte stores.
+constexpr int kStage = 3 * kBlock;      // slots one block can stage; wider ranges (long runs of entry-less rows) store directly
+
+__global__ __launch_bounds__(256) void values_entries(
+    const uint4* __restrict__ ent, const int32_t* __restrict__ rs, const int32_t* __restrict__ shift,
+    const float* __restrict__ deg, const float* __restrict__ dinv, int32_t n, float two_pi_q, int32_t sym, float lam,
+    float diag_shift, int32_t* __restrict__ ccol, float* __restrict__ vb_re, float* __restrict__ vb_im,
+    float* __restrict__ vf_re, float* __restrict__ vf_im)
+{
+    __shared__ float st[5][kStage];
+    __shared__ int32_t s_lo[4], s_hi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t limit = rs[n];                                   // positions of rows < n (behind: dropped entries)
+    // unit phase arguments (unweighted graphs, +-1 signs): sincos once per thread; sincosf is odd / even in its argument
+    float sn1, cs1;
+    sincosf(two_pi_q, &sn1, &cs1);
+    const bool lam2 = lam == 2.0f;       // the sym default: (2 x) / 2 is x exactly, no division
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + tid;
+    uint4 rec = p < limit ? load_record(ent, p) : make_uint4(0u, 0u, 0u, kNoEntry);
+    for (int64_t base = static_cast<int64_t>(blockIdx.x) * kBlock; base < limit; base += stride) {
+        const uint4 cur = rec;
+        const int64_t pc = p;
+        p += stride;
+        rec = p < limit ? load_record(ent, p) : make_uint4(0u, 0u, 0u, kNoEntry);   // next round, in flight
+        const bool ok = cur.w != kNoEntry;
+        const int32_t row = static_cast<int32_t>(cur.w & ~kFlag), c = static_cast<int32_t>(cur.x & ~kFlag);
+        const bool d_before = ok && (cur.w & kFlag) != 0, d_after = ok && (cur.x & kFlag) != 0;
+        int64_t slot = 0;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, dg = 0.f;
+        if (ok) {
+            slot = pc + shift[row] + (c > row ? 1 : 0);
+            const float th = __uint_as_float(cur.z);
+            float sn, cs;
+            if (fabsf(th) == 1.0f) {
+                cs = cs1;
+                sn = th < 0.f ? -sn1 : sn1;
+            } else {
+                sincosf(two_pi_q * th, &sn, &cs);
+            }
+            float mag = __uint_as_float(cur.y), mmag = mag;
+            if (sym) {
+                const float ir = dinv[row], ic = dinv[c];
+                mag = ir * mag * ic;            // entry (row, col): deg^-1/2[row] * A_s * deg^-1/2[col]
+                mmag = ic * mmag * ir;          // mirrored entry (col, row), multiplied in ITS row/col order
+            }
+            v0 = -(mag * cs);
+            v1 = -(mag * sn);
+            v2 = -(mmag * cs);
+            v3 = mmag * sn;
+            if (!lam2) {
+                v0 = scale_lam(v0, lam);
+                v1 = scale_lam(v1, lam);
+                v2 = scale_lam(v2, lam);
+                v3 = scale_lam(v3, lam);
+            }
+            if (d_before || d_after) dg = scale_lam(sym ? 1.f : deg[row], lam) + diag_shift;
+        }
+        // slot range of the block
+        int32_t lo = ok ? static_cast<int32_t>(slot) - (d_before ? 1 : 0) : INT_MAX;
+        int32_t hi = ok ? static_cast<int32_t>(slot) + (d_after ? 2 : 1) : INT_MIN;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const int32_t ol = __shfl_xor(lo, off), oh = __shfl_xor(hi, off);
+            lo = ol < lo ? ol : lo;
+            hi = oh > hi ? oh : hi;
+        }
+        __syncthreads();                                           // previous round's staging has been drained
+        if (lane == 0) {
+            s_lo[wv] = lo;
+            s_hi[wv] = hi;
+        }
+        __syncthreads();
+        lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        if (hi <= lo) continue;                                    // no entry in this round (block-uniform)
+        const bool staged = hi - lo <= kStage;
+        if (ok) {
+            const int64_t dslot = d_before ? slot - 1 : slot + 1;
+            if (staged) {
+                const int o = static_cast<int>(slot - lo);
+                st[0][o] = __int_as_float(c);
+                st[1][o] = v0;
+                st[2][o] = v1;
+                st[3][o] = v2;
+                st[4][o] = v3;
+                if (d_before || d_after) {
+                    const int od = static_cast<int>(dslot - lo);
+                    st[0][od] = __int_as_float(row);
+                    st[1][od] = dg;
+                    st[2][od] = 0.f;
+                    st[3][od] = dg;
+                    st[4][od] = 0.f;
+                }
+            } else {
+                ccol[slot] = c;
+                vb_re[slot] = v0;
+                vb_im[slot] = v1;
+                vf_re[slot] = v2;
+                vf_im[slot] = v3;
+                if (d_before || d_after) {
+                    ccol[dslot] = row;
+                    vb_re[dslot] = dg;
+                    vb_im[dslot] = 0.f;
+                    vf_re[dslot] = dg;
+                    vf_im[dslot] = 0.f;
+                }
+            }
+        }
+        if (!staged) continue;
+        __syncthreads();
+        // drain: [lo, hi) of each array; the 16-byte aligned middle as dwordx4, the ragged ends as dwords
+        const int32_t a0 = (lo + 3) & ~3, a1 = hi & ~3;
+        float* const outs[5] = {reinterpret_cast<float*>(ccol), vb_re, vb_im, vf_re, vf_im};
+        if (a0 < a1) {
+            const int quads = (a1 - a0) >> 2;
+#pragma unroll
+            for (int arr = 0; arr < 5; ++arr) {
+                for (int g = tid; g < quads; g += kBlock) {
+                    const int o = a0 - lo + 4 * g;
+                    const f32x4 v = {st[arr][o], st[arr][o + 1], st[arr][o + 2], st[arr][o + 3]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(outs[arr] + a0) + g);
+                }
+            }
+            const int ends = (a0 - lo) + (hi - a1);                // <= 6 ragged slots
+            if (tid < 5 * 8) {
+                const int arr = tid >> 3, e = tid & 7;
+                if (e < ends) {
+                    const int32_t sl = e < a0 - lo ? lo + e : a1 + (e - (a0 - lo));
+                    outs[arr][sl] = st[arr][sl - lo];
+                }
+            }
+        } else {                                                   // fewer than 4 aligned slots: all scalar
+#pragma unroll
+            for (int arr = 0; arr < 5; ++arr)
+                for (int sl = lo + tid; sl < hi; sl += kBlock) outs[arr][sl] = st[arr][sl - lo];
+        }
+    }
+}
+
+// diagonal of the rows without any off-diagonal entry (isolated nodes): nobody else writes their single slot
+// (runs AFTER values_entries: a staged slot range that spans such a row carries an unset value there)
+__global__ void diagonal_of_empty_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ucnt,
+                                       const float* __restrict__ deg, int32_t n, int32_t sym, float lam, float diag_shift,
+                                       int32_t* __restrict__ ccol, float* __restrict__ vb_re, float* __restrict__ vb_im,
+                                       float* __restrict__ vf_re, float* __restrict__ vf_im)
+{
+    GRID_STRIDE(r, n)
+    {
+        if (ucnt[r] != 0) continue;
+        const int64_t slot = rowptr[r];
+        const float d = scale_lam(sym ? 1.f : deg[r], lam) + diag_shift;
+        ccol[slot] = static_cast<int32_t>(r);
+        vb_re[slot] = d;
+        vf_re[slot] = d;
+        vb_im[slot] = 0.f;
+        vf_im[slot] = 0.f;
+    }
+}
+
+// rocPRIM's gfx950 default for 64-bit keys sorts 8 bits per pass (3 passes for 20 row bits); 10 bits per pass with
+// 1024-thread blocks needs 2 -- tools/probes/sort_probe.hip, 40 M keys: 0.82 -> 0.64 ms (keys), 1.08 -> 0.85 ms (pairs)
+using RowSortConfig = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 12>, rocprim::kernel_config<1024, 14>, 10,
+                                        rocprim::block_radix_rank_algorithm::match>>;
+
+struct MagopWs {
+    size_t keys_a, keys_b, w_a, w_b, rs, ucnt, dinv, shift, ent, long_rows, n_long, sort_tmp, scan_tmp, sort_tmp_bytes,
+        scan_tmp_bytes, total;
+};
+
+int magop_layout(int64_t e, int32_t n, int weighted, MagopWs* w)
+{
+    const size_t m = static_cast<size_t>(2 * (e > 0 ? e : 1));
+    const size_t nn = static_cast<size_t>(n);
+    size_t sort_tmp = 0, scan_tmp = 0;
+    uint64_t* k = nullptr;
+    float* v = nullptr;
+    int32_t* i32 = nullptr;
+    const unsigned b0 = 32u, b1 = 32u + static_cast<unsigned>(bits_for(static_cast<uint64_t>(n)));
+    if (weighted)
+        PYGSD_HIP_TRY(rocprim::radix_sort_pairs<RowSortConfig>(nullptr, sort_tmp, k, k, v, v, m, b0, b1, hipStream_t(nullptr)));
+    else
+        PYGSD_HIP_TRY(rocprim::radix_sort_keys<RowSortConfig>(nullptr, sort_tmp, k, k, m, b0, b1, hipStream_t(nullptr)));
+    PYGSD_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tmp, rocprim::make_transform_iterator(i32, PlusOne()), i32, 0,
+                                          nn + 1, rocprim::plus<int32_t>(), hipStream_t(nullptr)));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += round_up(bytes, 256); return o; };
+    w->keys_a = take(m * 8);        // edge_keys output; dead after the sort: the records (16 B) reuse keys_a + ent
+    w->ent = take(m * 8);           //   (contiguous with keys_a: take() rounds to 256 B, m * 8 is kept a multiple below)
+    w->keys_b = take(m * 8);
+    w->w_a = take(weighted ? m * 4 : 0);
+    w->w_b = take(weighted ? m * 4 : 0);
+    w->rs = take((nn + 2) * 4);
+    w->ucnt = take((nn + 1) * 4);
+    w->dinv = take((nn + 1) * 4);
+    w->shift = take((nn + 1) * 4);
+    w->long_rows = take((nn + 1) * 4);
+    w->n_long = take(256);
+    w->sort_tmp = take(sort_tmp);
+    w->scan_tmp = take(scan_tmp);
+    w->sort_tmp_bytes = sort_tmp;
+    w->scan_tmp_bytes = scan_tmp;
+    w->total = off + 256;
+    return 0;
+}
+
+inline char* align256(void* p)
+{
+    return reinterpret_cast<char*>(round_up(reinterpret_cast<uintptr_t>(p), 256));
+}
+
+}  // namespace
+}  // namespace pygsd
+
+using namespace pygsd;
+
+extern "C" int pygsd_magop_workspace(int64_t n_edges, int32_t n, int32_t weighted, size_t* bytes)
+{
+    PYGSD_REQUIRE(bytes, "pygsd_magop_workspace: null output");
+    PYGSD_REQUIRE(n >= 0 && n_edges >= 0 && 2 * n_edges < (int64_t(1) << 31), "pygsd_magop_workspace: size out of int32 range");
+    MagopWs w;
+    if (int rc = magop_layout(n_edges, n, weighted, &w)) return rc;
+    *bytes = w.total;
+    return 0;
+}
+
+extern "C" int pygsd_magop_stage1(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
+                                  int32_t is_signed, int32_t absolute_degree, int32_t sym, void* workspace,
+                                  size_t workspace_bytes, int32_t* rowptr, float* deg, int64_t* d_info, void* stream)
+{
+    PYGSD_REQUIRE(n >= 0 && n_edges >= 0 && 2 * n_edges < (int64_t(1) << 31), "pygsd_magop_stage1: size out of int32 range");
+    PYGSD_REQUIRE(workspace && rowptr && d_info && (n == 0 || deg), "pygsd_magop_stage1: null pointer");
+    PYGSD_REQUIRE(n_edges == 0 || (row && col), "pygsd_magop_stage1: null edge list");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_BUILD, s);
+    const int weighted = w != nullptr;
+    MagopWs l;
+    if (int rc = magop_layout(n_edges, n, weighted, &l)) return rc;
+    PYGSD_REQUIRE(workspace_bytes >= l.total, "pygsd_magop_stage1: workspace too small (%zu < %zu)", workspace_bytes, l.total);
+    char* base = align256(workspace);
+    uint64_t* keys_a = reinterpret_cast<uint64_t*>(base + l.keys_a);
+    uint64_t* keys_b = reinterpret_cast<uint64_t*>(base + l.keys_b);
+    float* w_a = weighted ? reinterpret_cast<float*>(base + l.w_a) : nullptr;
+    float* w_b = weighted ? reinterpret_cast<float*>(base + l.w_b) : nullptr;
+    int32_t* rs = reinterpret_cast<int32_t*>(base + l.rs);
+    int32_t* ucnt = reinterpret_cast<int32_t*>(base + l.ucnt);
+    float* dinv = reinterpret_cast<float*>(base + l.dinv);
+    int32_t* shift = reinterpret_cast<int32_t*>(base + l.shift);
+    uint4* ent = reinterpret_cast<uint4*>(base + l.keys_a);       // 16 B x m over keys_a + ent
+    int32_t* long_rows = reinterpret_cast<int32_t*>(base + l.long_rows);
+    int32_t* n_long = reinterpret_cast<int32_t*>(base + l.n_long);
+    const int64_t m = 2 * n_edges;
+    PYGSD_REQUIRE(l.ent == l.keys_a + round_up(static_cast<size_t>(2 * (n_edges > 0 ? n_edges : 1)) * 8, 256),
+                  "pygsd_magop_stage1: record area is not contiguous");
+
+    PYGSD_HIP_TRY(hipMemsetAsync(d_info, 0, 4 * sizeof(int64_t), s));
+    PYGSD_HIP_TRY(hipMemsetAsync(n_long, 0, sizeof(int32_t), s));
+    PYGSD_HIP_TRY(hipMemsetAsync(ucnt + n, 0, sizeof(int32_t), s));
+    if (n_edges > 0) {
+        hipLaunchKernelGGL(edge_keys, dim3(grid_for(n_edges)), dim3(kBlock), 0, s, row, col, w, n_edges, n, keys_a, w_a, d_info);
+        if (int rc = check_launch("edge_keys")) return rc;
+        size_t tb = l.sort_tmp_bytes;
+        const unsigned b0 = 32u, b1 = 32u + static_cast<unsigned>(bits_for(static_cast<uint64_t>(n)));
+        if (weighted)
+            PYGSD_HIP_TRY(rocprim::radix_sort_pairs<RowSortConfig>(base + l.sort_tmp, tb, keys_a, keys_b, w_a, w_b, static_cast<size_t>(m),
+                                                    b0, b1, s));
+        else
+            PYGSD_HIP_TRY(rocprim::radix_sort_keys<RowSortConfig>(base + l.sort_tmp, tb, keys_a, keys_b, static_cast<size_t>(m), b0, b1, s));
+        hipLaunchKernelGGL(key_row_starts, dim3(grid_for(m + 1)), dim3(kBlock), 0, s, keys_b, m, n, rs);
+        if (int rc = check_launch("key_row_starts")) return rc;
+    } else {
+        PYGSD_HIP_TRY(hipMemsetAsync(rs, 0, sizeof(int32_t) * (static_cast<size_t>(n) + 2), s));
+    }
+    const int deg_mode = is_signed ? (absolute_degree ? 2 : 1) : 0;
+    if (n > 0) {
+        const int64_t per_block = 4 * kRowsPerWave;
+        const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n) + per_block - 1) / per_block);
+        if (n <= (1 << 25))
+            hipLaunchKernelGGL(row_merge_wave<uint32_t>, dim3(grid), dim3(kBlock), 0, s, keys_b, w_b, rs, n, m > 0 ? m : 1, deg_mode,
+                               ucnt, deg, ent, long_rows, n_long);
+        else
+            hipLaunchKernelGGL(row_merge_wave<uint64_t>, dim3(grid), dim3(kBlock), 0, s, keys_b, w_b, rs, n, m > 0 ? m : 1, deg_mode,
+                               ucnt, deg, ent, long_rows, n_long);
+        if (int rc = check_launch("row_merge_wave")) return rc;
+        hipLaunchKernelGGL(row_merge_block, dim3(n < 1024 ? 64 : 1024), dim3(kBlock), 0, s, keys_b, w_b, rs, deg_mode, ucnt,
+                           deg, ent, long_rows, n_long, d_info);
+        if (int rc = check_launch("row_merge_block")) return rc;
+    }
+    size_t tb = l.scan_tmp_bytes;
+    PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb, rocprim::make_transform_iterator(ucnt, PlusOne()), rowptr, 0,
+                                          static_cast<size_t>(n) + 1, rocprim::plus<int32_t>(), s));
+    hipLaunchKernelGGL(row_tables, dim3(grid_for(n > 0 ? n : 1)), dim3(kBlock), 0, s, deg, rs, rowptr, n, sym, dinv, shift,
+                       d_info);
+    return check_launch("row_tables");
+}
+
+extern "C" int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, int32_t sym, float lambda_max,
+                                  float diag_shift, void* workspace, size_t workspace_bytes, const int32_t* rowptr,
+                                  const float* deg, int32_t* col, float* vb_real, float* vb_imag, float* vf_real,
+                                  float* vf_imag, void* stream)
+{
+    PYGSD_REQUIRE(n >= 0 && n_edges >= 0 && 2 * n_edges < (int64_t(1) << 31), "pygsd_magop_stage2: size out of int32 range");
+    if (n == 0) return 0;
+    PYGSD_REQUIRE(workspace && rowptr && deg && col && vb_real && vb_imag && vf_real && vf_imag,
+                  "pygsd_magop_stage2: null pointer");
+    PYGSD_REQUIRE(aligned16(col) && aligned16(vb_real) && aligned16(vb_imag) && aligned16(vf_real) && aligned16(vf_imag),
+                  "pygsd_magop_stage2: output arrays must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_BUILD, s);
+    MagopWs l;
+    if (int rc = magop_layout(n_edges, n, weighted, &l)) return rc;
+    PYGSD_REQUIRE(workspace_bytes >= l.total, "pygsd_magop_stage2: workspace too small");
+    char* base = align256(workspace);
+    // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64
+    const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * static_cast<double>(q));
+    const int64_t m = 2 * n_edges;
+    int32_t* rs = reinterpret_cast<int32_t*>(base + l.rs);
+    if (m > 0) {
+        hipLaunchKernelGGL(values_entries, dim3(grid_for(m)), dim3(kBlock), 0, s, reinterpret_cast<uint4*>(base + l.keys_a), rs,
+                           reinterpret_cast<int32_t*>(base + l.shift), deg, reinterpret_cast<float*>(base + l.dinv), n, two_pi_q,
+                           sym, lambda_max, diag_shift, col, vb_real, vb_imag, vf_real, vf_imag);
+        if (int rc = check_launch("values_entries")) return rc;
+    }
+    hipLaunchKernelGGL(diagonal_of_empty_rows, dim3(grid_for(n)), dim3(kBlock), 0, s, rowptr,
+                       reinterpret_cast<int32_t*>(base + l.ucnt), deg, n, sym, lambda_max, diag_shift, col, vb_real, vb_imag,
+                       vf_real, vf_imag);
+    return check_launch("diagonal_of_empty_rows");
+}

@@ -78,7 +78,7 @@ def dsbm(n: int, k: int, p: float, meta: np.ndarray, size_ratio: float = 1.5, se
     labels[relabel] = np.repeat(np.arange(k), sizes)
     ei = np.stack([relabel[rows], relabel[cols]])
     order = rng.permutation(ei.shape[1])  # COO order carries no structure
-    return ei[:, order], labels
+    return np.ascontiguousarray(ei[:, order]), labels                  # (fancy indexing yields F-order: rows strided)
 
 
 def dsbm_for_edges(n: int, e_target: int, k: int = 5, eta: float = 0.1, size_ratio: float = 1.5,
@@ -120,7 +120,7 @@ def ssbm(n: int, k: int, p: float, eta: float, size_ratio: float = 2.0, seed: in
     ei = np.stack([np.concatenate([relabel[lo], relabel[hi]]), np.concatenate([relabel[hi], relabel[lo]])])
     sign = np.concatenate([sign, sign])
     order = rng.permutation(ei.shape[1])
-    return ei[:, order], sign[order], labels
+    return np.ascontiguousarray(ei[:, order]), sign[order], labels
 
 
 def signed_cyclic_meta_graph(k: int = 5, eta: float = 0.1, fill_val: float = 0.5) -> np.ndarray:

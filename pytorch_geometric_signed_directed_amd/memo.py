@@ -79,20 +79,39 @@ class TensorMemo:
     def active(self) -> bool:
         return _enabled if self.on is None else (bool(self.on) and _enabled)
 
+    # A memo is a cache, not state: copying or pickling the module that owns it (copy.deepcopy for best-model
+    # snapshots / swa_utils.AveragedModel, torch.save(model), mp.spawn arguments) yields a fresh, EMPTY memo with the
+    # same capacity and switch -- never the lock, the weak references or another module's operators.
+    def __deepcopy__(self, _memo_dict):
+        return TensorMemo(self.capacity, self.on)
+
+    def __copy__(self):
+        return TensorMemo(self.capacity, self.on)
+
+    def __reduce__(self):
+        return (TensorMemo, (self.capacity, self.on))
+
     def _prune(self, _ref=None):
+        # called from weakref callbacks, possibly re-entrantly on the thread that is inside get() (a cyclic-GC pass
+        # triggered by an allocation there): filter IN PLACE so that a list object held by the caller stays the list
         with self._lock:
-            self._items = [e for e in self._items if all(r is None or r() is not None for r in e.refs)]
+            self._items[:] = [e for e in self._items if all(r is None or r() is not None for r in e.refs)]
 
     def get(self, tensors: Sequence[Optional[torch.Tensor]], extra: Hashable = None) -> Any:
         if not self.active():
             return None
         with self._lock:
-            for k, e in enumerate(self._items):
+            stamps = tuple(_stamp(t) for t in tensors)
+            for e in list(self._items):                      # a snapshot: _prune may shorten the list meanwhile
                 if e.extra != extra or len(e.refs) != len(tensors):
                     continue
                 if all((r is None and t is None) or (r is not None and t is not None and r() is t)
-                       for r, t in zip(e.refs, tensors)) and e.stamps == tuple(_stamp(t) for t in tensors):
-                    self._items.append(self._items.pop(k))
+                       for r, t in zip(e.refs, tensors)) and e.stamps == stamps:
+                    try:                                     # move to the MRU end, by identity (never by a stale index)
+                        self._items.remove(e)
+                    except ValueError:
+                        pass
+                    self._items.append(e)
                     return e.value
         return None
 
@@ -114,7 +133,7 @@ class TensorMemo:
 
     def clear(self) -> None:
         with self._lock:
-            self._items = []
+            self._items[:] = []
 
     def __len__(self) -> int:
         with self._lock:

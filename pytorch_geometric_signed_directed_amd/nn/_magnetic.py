@@ -12,6 +12,7 @@ same slot), so one fused dual-value HIP SpMM per Chebyshev order produces both T
 single traversal; the recurrence 2 S T_{k-1} - T_{k-2} is fused into the kernel epilogue.
 """
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -23,10 +24,21 @@ from ..memo import TensorMemo
 from ..message_passing import MessagePassing
 from ..dense import FixedSpmm2, MagneticConvFunction, dense_supported, tall_linear
 from ..sparse import Pattern, spmm2
-from ..utils._laplacian import (assemble_operator_csr, differentiable_parts, laplacian_parts,
+from ..utils._laplacian import (assemble_operator_csr, differentiable_parts, fused_operator_csr, laplacian_parts,
                                 laplacian_values)
 
 Tensor = torch.Tensor
+
+# PYGSD_GENERIC_OPERATOR_BUILD=1 keeps every build on the generic pipeline (laplacian.hip): the comparison leg of the
+# equivalence tests and of tools/build_probe.py
+_FUSED_BUILD = os.environ.get("PYGSD_GENERIC_OPERATOR_BUILD", "0") != "1"
+
+
+def set_fused_build(on: bool) -> bool:
+    """Switch the fused operator build on / off; returns the previous setting."""
+    global _FUSED_BUILD
+    prev, _FUSED_BUILD = _FUSED_BUILD, bool(on)
+    return prev
 
 
 def glorot(t: Optional[Tensor]):
@@ -51,28 +63,52 @@ class MagneticOperator:
 
     def __init__(self, csr, values_fwd, values_bwd, off_index, off_real, off_imag, diag, lambda_max, n):
         self.csr, self.values_fwd, self.values_bwd = csr, values_fwd, values_bwd
-        # un-scaled Laplacian entries; the COO views below apply 2 x / lambda_max lazily
+        # un-scaled Laplacian entries; the COO views below apply 2 x / lambda_max lazily.  An operator from the fused
+        # build (`from_fused`) has no COO intermediates: off_index is None and the views are read off the CSR.
         self._off_index, self._off_real, self._off_imag, self._diag = off_index, off_real, off_imag, diag
         self._lambda_max, self.n = lambda_max, n
-        self.nnz = int(off_real.numel()) + n
+        self.nnz = csr.nnz if off_real is None else int(off_real.numel()) + n
         self._scaled_cache = None
         self._ref_format = None
         self._coo = None
         self._pattern = None
 
+    @classmethod
+    def from_fused(cls, csr, values_fwd, values_bwd, diag, lambda_max, n):
+        """Operator built by utils._laplacian.fused_operator_csr: only the compute layout exists."""
+        return cls(csr, values_fwd, values_bwd, None, None, None, diag, lambda_max, n)
+
+    def _off_diagonal(self):
+        """(off_index int64 [2, E_s], scaled off_real, off_imag) of an operator that only has its CSR: the slots
+        whose column differs from their row, in CSR order = sorted by (row, col) = the reference's coalesce order;
+        vb_* holds S[row, col] = (2 x) / lambda_max already."""
+        rowptr, col = self.csr.rowptr, self.csr.col.long()
+        counts = (rowptr[1:] - rowptr[:-1]).long()
+        row = torch.repeat_interleave(torch.arange(self.n, dtype=torch.long, device=col.device), counts,
+                                      output_size=col.numel())
+        off = row != col
+        return torch.stack([row[off], col[off]]), self.values_bwd[0][off], self.values_bwd[1][off]
+
     def _scaled(self):
         """(off_real, off_imag, diag) * 2 / lambda_max with +inf -> 0 (MagNetConv.py:106-107,115-116)."""
         if self._scaled_cache is None:
             def sc(t):
-                v = (2.0 * t) / self._lambda_max
+                # tensor / tensor: a true fp32 division like the reference's (its lambda_max is a tensor,
+                # MagNetConv.py:98-107) and like csrc's scale_lam -- torch turns `/ python_scalar` into `* (1 / s)`
+                lam = torch.as_tensor(self._lambda_max, dtype=t.dtype, device=t.device)
+                v = (2.0 * t) / lam
                 return v.masked_fill(v == float("inf"), 0)
-            self._scaled_cache = (sc(self._off_real), sc(self._off_imag), sc(self._diag))
+            if self._off_index is None:
+                self._off_index, off_r, off_i = self._off_diagonal()
+                self._scaled_cache = (off_r, off_i, sc(self._diag))
+            else:
+                self._scaled_cache = (sc(self._off_real), sc(self._off_imag), sc(self._diag))
         return self._scaled_cache
 
     def coo(self):
         """(edge_index [2, E_s + N], values_real, values_imag) with the two reference self-loop sets folded."""
         if self._coo is None:
-            off_r, off_i, diag_s = self._scaled()
+            off_r, off_i, diag_s = self._scaled()          # (also materialises _off_index of a fused operator)
             loops = torch.arange(self.n, dtype=torch.long, device=self._off_index.device).unsqueeze(0).repeat(2, 1)
             self._coo = (torch.cat([self._off_index, loops], dim=1), torch.cat([off_r, diag_s - 1.0]),
                          torch.cat([off_i, torch.zeros_like(diag_s)]))
@@ -89,11 +125,11 @@ class MagneticOperator:
         """(edge_index_real, edge_index_imag, norm_real, norm_imag) exactly as
         MagNetConv.__norm__ returns them (MagNetConv.py:100-120)."""
         if self._ref_format is None:
+            off_r, off_i, diag_s = self._scaled()
             dev = self._off_index.device
             loops = torch.arange(self.n, dtype=torch.long, device=dev).unsqueeze(0).repeat(2, 1)
             ei_imag = torch.cat([self._off_index, loops], dim=1)
             ei_real = torch.cat([ei_imag, loops], dim=1)
-            off_r, off_i, diag_s = self._scaled()
             norm_real = torch.cat([off_r, diag_s, off_r.new_full((self.n,), -1.0)])
             norm_imag = torch.cat([off_i, off_i.new_zeros(self.n)])
             self._ref_format = (ei_real, ei_imag, norm_real, norm_imag)
@@ -184,6 +220,18 @@ class MagneticChebConv(MessagePassing):
         return parts
 
     def _build_operator(self, edge_index, num_nodes, edge_weight, q, normalization, lambda_max, dtype):
+        fixed = not ((isinstance(q, torch.Tensor) and q.requires_grad)
+                     or (edge_weight is not None and edge_weight.requires_grad))
+        if fixed and _FUSED_BUILD:
+            # the case every uncached forward pays for: one fused pass, edge list -> compute layout (csrc/magop.hip)
+            qf = float(q.detach().item()) if isinstance(q, torch.Tensor) else float(q)
+            built = fused_operator_csr(edge_index, edge_weight, num_nodes, q=qf, normalization=normalization,
+                                       lambda_max=float(lambda_max), **self._laplacian_kwargs())
+            if built is not None:
+                csr, vf, vb, deg = built
+                diag = torch.ones_like(deg) if normalization is not None else deg
+                return MagneticOperator.from_fused(csr, vf, vb, diag, lambda_max, num_nodes)
+            # a row with more than 4096 symmetrised entries: the generic pipeline has a path for those
         parts = self._parts_for(edge_index, edge_weight, num_nodes, dtype)
         if (isinstance(q, torch.Tensor) and q.requires_grad) or parts.differentiable:
             # trainable q / edge_weight with gradient: generic differentiable route (edge-value gradients by SDDMM)

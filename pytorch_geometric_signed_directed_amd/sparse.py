@@ -189,6 +189,12 @@ class Pattern:
         self._inv_deg: Optional[Tensor] = None
         self._vcache = {}
 
+    def __getstate__(self):
+        # the per-tensor value cache holds weak references to caller tensors: a copied / pickled pattern starts without
+        st = self.__dict__.copy()
+        st["_vcache"] = {}
+        return st
+
     @property
     def bwd(self) -> CSR:
         if self._bwd is None:

@@ -157,3 +157,83 @@ def laplacian_values(parts: LaplacianParts, q, normalization: Optional[str], mir
     if mirror:
         return off_r, off_i, diag, mir_r, mir_i
     return off_r, off_i, diag
+
+
+_PINNED = {}
+
+
+def _pinned_info(dev):
+    """(pinned int64[4], event) for the device -> host read of the fused build; one per (device, thread)."""
+    import threading
+    key = (dev.index, threading.get_ident())
+    hit = _PINNED.get(key)
+    if hit is None:
+        hit = _PINNED[key] = (torch.empty(4, dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+    return hit
+
+
+def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, signed: bool,
+                       absolute_degree: bool, q: float, normalization: Optional[str], lambda_max: float,
+                       diag_shift: float = -1.0):
+    """Edge list -> compute layout of 2 L / lambda_max + diag_shift I in one pass through csrc/magop.hip
+    (pygsd_magop_stage1 / _stage2): what `laplacian_parts` -> `laplacian_values(mirror=True)` ->
+    `assemble_operator_csr` produce, without their int64 COO intermediates and with the node-id range check and
+    the size read folded into ONE device -> host read.  For a fixed q and weights without gradient (the case the
+    layers rebuild on every uncached forward, MagNetConv.py:157-181).
+
+    Returns (CSR, (vf_real, vf_imag), (vb_real, vb_imag), deg), or None when a node has more than 4096 symmetrised
+    entries (the caller then takes the generic pipeline, which has a path for such rows)."""
+    from ..sparse import CSR
+    _cabi.require_gpu(edge_index, edge_weight)
+    if edge_index.dtype != torch.int64:
+        raise TypeError("edge_index must be int64 (torch.long)")
+    dev = edge_index.device
+    row, col = edge_index[0].contiguous(), edge_index[1].contiguous()
+    e = row.numel()
+    w = None
+    if edge_weight is not None:
+        w = edge_weight.detach().reshape(-1).contiguous()
+        if w.dtype != torch.float32:
+            w = w.float()
+        if w.numel() != e:
+            raise ValueError(f"edge_weight has {w.numel()} entries for {e} edges")
+        if e == 0:
+            w = None                    # an empty tensor has no address: both stages must agree on the layout
+    sym = 1 if normalization is not None else 0
+    lib = _cabi.lib()
+    with torch.cuda.device(dev):
+        need = ctypes.c_size_t(0)
+        check(lib.pygsd_magop_workspace(e, n, 0 if w is None else 1, ctypes.byref(need)), "pygsd_magop_workspace")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        info = torch.empty(4, dtype=torch.int64, device=dev)
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        deg = torch.empty(n, dtype=torch.float32, device=dev)
+        check(lib.pygsd_magop_stage1(ptr(row), ptr(col), ptr(w), e, n, 1 if signed else 0, 1 if absolute_degree else 0,
+                                     sym, ptr(ws), need.value, ptr(rowptr), ptr(deg), ptr(info), stream_ptr()),
+              "pygsd_magop_stage1")
+        host_info, ready = _pinned_info(dev)
+        host_info.copy_(info, non_blocking=True)      # queued behind stage 1; the host waits for THIS, not for stage 2
+        ready.record()
+        # E_s is not known on the host yet -- and is not needed to LAUNCH the second stage: the outputs are allocated
+        # at their upper bound (every listed edge distinct, no self loops: 2 E + n; the bound is tight on the graphs this
+        # is built for) and narrowed after the one host read below, which then overlaps the second stage instead of
+        # draining the device between the two.  A bad id / an over-long row leaves the second stage harmless (such
+        # entries were dropped / marked in the first).
+        cap = 2 * e + n
+        ccol = torch.empty(cap, dtype=torch.int32, device=dev)
+        pad = max((cap + 3) // 4 * 4, 4)              # every value array starts on a 16-byte boundary (dwordx4 stores)
+        vals = torch.empty((4, pad), dtype=torch.float32, device=dev)
+        check(lib.pygsd_magop_stage2(e, n, 0 if w is None else 1, float(q), sym, float(lambda_max), float(diag_shift),
+                                     ptr(ws), need.value, ptr(rowptr), ptr(deg), ptr(ccol), ptr(vals[0]), ptr(vals[1]),
+                                     ptr(vals[2]), ptr(vals[3]), stream_ptr()), "pygsd_magop_stage2")
+        ready.synchronize()                                       # the one host round-trip
+        es, too_long, bad, bad_id = host_info.tolist()
+        if bad:
+            raise IndexError(f"edge_index holds node id {bad_id}, outside [0, {n}); the HIP path gathers and "
+                             "scatters rows by these ids")
+        if too_long:
+            return None
+        nnz = es + n
+        ccol = ccol[:nnz]
+    csr = CSR(n, n, nnz, rowptr, ccol, None)
+    return csr, (vals[2, :nnz], vals[3, :nnz]), (vals[0, :nnz], vals[1, :nnz]), deg

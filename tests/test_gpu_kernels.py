@@ -756,3 +756,128 @@ def test_bf16_gather_with_fp32_partial_products():
         for lo, hi in ((0, 500), (500, n)):
             spmm_rows_into(csr, v, buf, y, lo, hi, 0.5, c > 0)
     close(y, want, what="fp32 partial products of a bf16 gather")
+
+
+# ------------------------------------------------------------------ fused operator build (csrc/magop.hip)
+def _generic_operator(ei, w, n, signed, absdeg, q, norm, lam):
+    from pytorch_geometric_signed_directed_amd.utils._laplacian import (assemble_operator_csr, laplacian_parts,
+                                                                         laplacian_values)
+    parts = laplacian_parts(ei, w, n, signed, absdeg)
+    off_r, off_i, diag, mir_r, mir_i = laplacian_values(parts, q, norm, mirror=True)
+    csr, vf, vb = assemble_operator_csr(parts, off_r, off_i, mir_r, mir_i, diag, lam, -1.0)
+    return csr, vf, vb, parts.deg
+
+
+def _assert_fused_equals_generic(ei, w, n, signed, absdeg, q, norm, lam):
+    from pytorch_geometric_signed_directed_amd.utils._laplacian import fused_operator_csr
+    got = fused_operator_csr(ei, w, n, signed, absdeg, q, norm, lam)
+    assert got is not None
+    csr, vf, vb, deg = got
+    wcsr, wvf, wvb, wdeg = _generic_operator(ei, w, n, signed, absdeg, q, norm, lam)
+    assert csr.nnz == wcsr.nnz
+    assert torch.equal(csr.rowptr, wcsr.rowptr) and torch.equal(csr.col, wcsr.col)
+    assert torch.equal(deg, wdeg)
+    for a, b in zip(vf + vb, wvf + wvb):                 # same formulas in the same order: bit-identical
+        assert torch.equal(a, b)
+    return csr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,e,signed,absdeg,norm,weighted,lam", [
+    (50, 300, False, True, "sym", True, 2.0), (50, 300, False, True, None, False, 3.5),
+    (3000, 40000, False, True, "sym", True, 2.0), (3000, 40000, True, True, "sym", True, 2.0),
+    (3000, 40000, True, False, "sym", True, 1.7), (3000, 40000, True, True, None, True, 2.0),
+    (20000, 400000, False, True, "sym", False, 2.0), (1, 0, False, True, "sym", False, 2.0),
+    (5, 0, False, True, None, True, 2.0)])
+def test_fused_operator_build_is_bitwise_the_generic_pipeline(n, e, signed, absdeg, norm, weighted, lam):
+    if e:
+        ei, w = _messy_graph(n, e, seed=n + e, signed=signed)
+    else:
+        ei, w = torch.zeros(2, 0, dtype=torch.long), torch.zeros(0)
+    d = dev()
+    _assert_fused_equals_generic(ei.to(d), w.to(d) if weighted else None, n, signed, absdeg, 0.2, norm, lam)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weighted", [False, True])
+def test_fused_operator_build_long_rows_and_fallback(weighted):
+    """Rows of 65..4096 symmetrised entries take the block-wide LDS sort; a longer one makes the fused build
+    step aside (None) and the layer falls back to the generic pipeline."""
+    from pytorch_geometric_signed_directed_amd.utils._laplacian import fused_operator_csr
+    n = 6000
+    g = torch.Generator().manual_seed(11)
+    ei, w = _messy_graph(n, 30000, seed=5, signed=True)
+    hubs = []
+    for hub, k in ((7, 65), (8, 64), (100, 300), (2000, 2900), (n - 1, 1500)):     # out- and in-edges of the hubs
+        other = torch.randint(0, n, (k,), generator=g)
+        hubs.append(torch.stack([torch.full((k,), hub), other]))
+        hubs.append(torch.stack([other[: k // 3], torch.full((k // 3,), hub)]))
+    ei = torch.cat([ei] + hubs, dim=1)
+    w = torch.cat([w, torch.rand(ei.size(1) - w.numel(), generator=g) - 0.3])
+    d = dev()
+    wd = w.to(d) if weighted else None
+    csr = _assert_fused_equals_generic(ei.to(d), wd, n, True, True, 0.25, "sym", 2.0)
+    lens = (csr.rowptr[1:] - csr.rowptr[:-1]).cpu()
+    assert int(lens.max()) > 2048 and int((lens > 65).sum()) >= 4
+    # exactly 64 entries (a full wavefront) and exactly 65 (the first row of the block path), with duplicates inside
+    for k in (62, 63):
+        star = torch.stack([torch.zeros(k + 2, dtype=torch.long), torch.cat([torch.arange(1, k + 1), torch.tensor([5, 9])])])
+        sw = (torch.rand(k + 2, generator=g) + 0.5).to(d) if weighted else None
+        scsr = _assert_fused_equals_generic(star.to(d), sw, 200, True, False, 0.1, None, 2.0)
+        assert int(scsr.rowptr[1]) == k + 1
+    # one node above the block limit: not handled here
+    k = 4200
+    big = torch.stack([torch.full((k,), 3), torch.arange(10, 10 + k)])
+    ei2 = torch.cat([ei, big], dim=1).to(d)
+    w2 = None if wd is None else torch.cat([wd, torch.ones(k, device=d)])
+    assert fused_operator_csr(ei2, w2, n, True, True, 0.25, "sym", 2.0) is None
+    # ... and the layer still builds the right operator through the generic pipeline
+    from pytorch_geometric_signed_directed_amd.nn import MSConv
+    conv = MSConv(4, 4, K=1, q=0.25, trainable_q=False, cached=True).to(d)
+    x = torch.randn(n, 4, device=d)
+    conv(x, x, ei2, w2)
+    assert conv._operator.csr.nnz == _generic_operator(ei2, w2, n, True, True, 0.25, "sym", 2.0)[0].nnz
+
+
+@pytest.mark.gpu
+def test_fused_operator_build_rejects_bad_ids_and_wide_id_keys():
+    from pytorch_geometric_signed_directed_amd.utils._laplacian import fused_operator_csr
+    d = dev()
+    ei = torch.tensor([[0, 1, 2], [1, 2, 7]], device=d)
+    with pytest.raises(IndexError, match="node id 7"):
+        fused_operator_csr(ei, None, 5, False, True, 0.25, "sym", 2.0)
+    with pytest.raises(IndexError, match="node id -1"):
+        fused_operator_csr(torch.tensor([[0, -1], [1, 2]], device=d), None, 5, False, True, 0.25, "sym", 2.0)
+    # more than 2^25 nodes: the in-register sort runs on 64-bit keys
+    n = (1 << 25) + 5
+    g = torch.Generator().manual_seed(3)
+    src = torch.randint(0, n, (20000,), generator=g)
+    dst = torch.randint(0, n, (20000,), generator=g)
+    src = torch.cat([src, torch.full((50,), n - 1), dst[:500]])       # a 50-entry row at the top id, reciprocal pairs
+    dst = torch.cat([dst, torch.randint(0, n, (50,), generator=g), src[:500]])
+    _assert_fused_equals_generic(torch.stack([src, dst]).to(d), None, n, False, True, 0.25, "sym", 2.0)
+
+
+@pytest.mark.gpu
+def test_fused_operator_reference_format_matches_generic():
+    """cached_result (the reference's 4-tuple, MagNetConv.py:100-120) read off the fused operator's CSR equals the
+    one the generic pipeline assembles from its COO intermediates."""
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    from pytorch_geometric_signed_directed_amd.nn import _magnetic
+    d = dev()
+    ei, w = _messy_graph(500, 6000, seed=9, signed=False)
+    x = torch.randn(500, 8, device=d)
+    outs = []
+    for fused in (True, False):
+        prev = _magnetic.set_fused_build(fused)
+        try:
+            torch.manual_seed(0)
+            conv = MagNetConv(8, 8, K=2, q=0.2, trainable_q=False, cached=True).to(d)
+            o = conv(x, x, ei.to(d), w.to(d), lambda_max=2.5)
+            outs.append((conv.cached_result, o, conv._operator._off_index is None or fused))
+        finally:
+            _magnetic.set_fused_build(prev)
+    (fa, oa, _), (fb, ob, _) = outs
+    for a, b in zip(fa, fb):
+        assert torch.equal(a, b)
+    assert torch.equal(oa[0], ob[0]) and torch.equal(oa[1], ob[1])
