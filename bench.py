@@ -167,8 +167,13 @@ def main():
                          "above two ranks)")
     ap.add_argument("--phases", type=int, default=None, help="column phases of the pipelined propagate (default 2)")
     ap.add_argument("--return-chunks", type=int, default=None, help="row chunks of the grid's return (default 2)")
+    ap.add_argument("--grid-cols", type=int, default=None,
+                    help="column slices of the grid (default: chosen from the world size); 1 with --layout grid runs the "
+                         "grid SCHEDULE (all-to-all in, row-chunked all-to-all back) on one slice -- with --force-sharded "
+                         "the whole pipeline over RCCL on a single rank")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the node-sharded layer even with one rank (exercises the RCCL path on 1 GPU)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the un-timed parity guard of the sharded mode")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -201,11 +206,17 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
         backend = os.environ.get("PYGSD_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        # the engine keeps its exchange buffers for its own lifetime and orders their reuse with events, so the
+        # allocator need not be told about the communication stream (record_stream would pin blocks until that
+        # stream's events retire); recorded in the `exchange` object
+        os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")
+        limit = datetime.timedelta(seconds=int(os.environ.get("PYGSD_DIST_TIMEOUT_S", "300")))   # a hang becomes an error
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     from pytorch_geometric_signed_directed_amd import _cabi
     from pytorch_geometric_signed_directed_amd.nn import MagNetConv
@@ -229,19 +240,50 @@ def main():
         def op_nnz():
             return layer._operator.nnz
     else:
-        from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv
-        layer_s = ShardedMagNetConv(hidden, hidden, K=1, q=0.25, num_nodes=n, edge_index=edge_index,
-                                    edge_weight=None, device=device, layout=args.layout, phases=args.phases,
-                                    return_chunks=args.return_chunks)
-        xr_loc = layer_s.shard_rows(x_real).requires_grad_()
-        xi_loc = layer_s.shard_rows(x_imag).requires_grad_()
-        del x_real, x_imag, edge_index
+        from pytorch_geometric_signed_directed_amd.parallel import DistExchange, ShardedMagNetConv
+        fallback_note = None
+
+        def make_sharded(layout, phases, chunks, synchronous):
+            ls = ShardedMagNetConv(hidden, hidden, K=1, q=0.25, num_nodes=n, edge_index=edge_index, edge_weight=None,
+                                   device=device, layout=layout, phases=phases, return_chunks=chunks,
+                                   grid_cols=args.grid_cols, exchange=DistExchange(synchronous=synchronous))
+            a = ls.shard_rows(x_real).requires_grad_()
+            b = ls.shard_rows(x_imag).requires_grad_()
+            return ls, a, b
+
+        def sharded_step(ls, a, b):
+            ls.zero_grad(set_to_none=True)
+            a.grad = b.grad = None
+            o_r, o_i = ls(a, b)
+            (o_r.sum() + o_i.sum()).backward()
+
+        def agree(failed: bool) -> bool:
+            """True if ANY rank failed (decided over a gloo side group: it must work when RCCL does not)."""
+            if world == 1:
+                return failed
+            flag = torch.tensor([1.0 if failed else 0.0])
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=control)
+            return bool(flag.item())
+
+        control = dist.new_group(backend="gloo") if (world > 1 and dist.get_backend() != "gloo") else None
+        if world > 1 and control is None:
+            control = dist.group.WORLD
+        err = None
+        try:
+            layer_s, xr_loc, xi_loc = make_sharded(args.layout, args.phases, args.return_chunks, False)
+            sharded_step(layer_s, xr_loc, xi_loc)
+            torch.cuda.synchronize(device)
+        except Exception as exc:  # noqa: BLE001 -- an RCCL failure of the pipelined schedule must not cost the whole run
+            err = f"{type(exc).__name__}: {exc}"
+        if agree(err is not None):
+            # the asynchronous grid schedule failed somewhere: one blocking all-gather per propagate instead, reason kept
+            fallback_note = ("pipelined schedule failed (" + (err or "on another rank") + "); fell back to the row layout, "
+                             "one phase, blocking collectives")
+            sys.stderr.write("bench.py: " + fallback_note + "\n")
+            layer_s, xr_loc, xi_loc = make_sharded("rows", 1, 1, True)
 
         def step():
-            layer_s.zero_grad(set_to_none=True)
-            xr_loc.grad = xi_loc.grad = None
-            o_r, o_i = layer_s(xr_loc, xi_loc)
-            (o_r.sum() + o_i.sum()).backward()
+            sharded_step(layer_s, xr_loc, xi_loc)
 
         def op_nnz():
             return layer_s.global_nnz
@@ -295,40 +337,107 @@ def main():
     if layer_s is not None:
         summary = layer_s.engine.timing_summary() or {}
         layer_s.engine.profile(False)
-        # the exchanges alone (nothing to overlap with): one un-profiled propagate's worth of collectives
+        # the exchanges alone (nothing to overlap with): every collective of one propagate timed on its own -- the
+        # first multi-GPU run calibrates the link rate the single-GPU rehearsal assumed (61 GB/s per direction)
         eng = layer_s.engine
-        alone = []
-        for _ in range(5):
-            sync()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            bufs, works = [], []
-            for c in range(eng.phases):
-                send = eng._pack([xr_loc.detach(), xi_loc.detach()], c)
-                buf = send.new_empty((world, eng.n_sub, send.size(-1)))
-                works.append(eng.ex.all_to_all(buf, send) if eng.grid else eng.ex.all_gather(buf, send))
-                bufs.append(buf)
-            for w_ in works:
-                w_.wait()
-            if eng.grid:
-                fw2 = 2 * (hidden // eng.p_c)
-                back = xr_loc.new_zeros((eng.return_chunks, world, eng.n_rsub, fw2))
-                recv = torch.empty_like(back)
-                for w_ in [eng.ex.all_to_all(recv[r], back[r]) for r in range(eng.return_chunks)]:
-                    w_.wait()
-            b.record()
-            b.synchronize()
-            alone.append(a.elapsed_time(b))
+        esz = xr_loc.element_size()
+
+        def timed_collective(fn):
+            ts = []
+            for _ in range(5):
+                sync()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn().wait()
+                b.record()
+                b.synchronize()
+                ts.append(a.elapsed_time(b))
+            return reduce_max(statistics.median(ts))
+
+        inbound_ms, return_ms = [], []
+        send0 = eng._pack([xr_loc.detach(), xi_loc.detach()], 0)
+        buf0 = send0.new_empty((world, eng.n_sub, send0.size(-1)))
+        for c in range(eng.phases):
+            inbound_ms.append(timed_collective(lambda: eng.ex.all_to_all(buf0, send0) if eng.grid
+                                               else eng.ex.all_gather(buf0, send0)))
+        in_bytes_per_link = (send0[0].numel() if eng.grid else send0.numel()) * esz
+        back_bytes_per_link = 0
+        if eng.grid:
+            fw2 = 2 * (hidden // eng.p_c)
+            back = xr_loc.new_zeros((world, eng.n_rsub, fw2))
+            recv = torch.empty_like(back)
+            back_bytes_per_link = back[0].numel() * esz
+            for r in range(eng.return_chunks):
+                return_ms.append(timed_collective(lambda: eng.ex.all_to_all(recv, back)))
+        alone_total = sum(inbound_ms) + sum(return_ms)
+
+        def rate(nbytes, ms):
+            return nbytes / (ms * 1e-3) / 1e9 if ms and world > 1 else None
         exchange = {"layout": layer_s.layout, "p_r": eng.p_r, "p_c": eng.p_c, "phases": eng.phases,
                     "return_chunks": eng.return_chunks, "propagates_per_step": 2,
                     "propagate_ms": summary.get("total_ms"), "product_ms": summary.get("product_ms"),
                     "pack_ms": summary.get("pack_ms"), "merge_ms": summary.get("merge_ms"),
                     "exposed_exchange_ms": summary.get("exposed_exchange_ms"),
-                    "exchange_alone_ms": reduce_max(statistics.median(alone)),
+                    "exchange_alone_ms": alone_total,
+                    "collectives_alone": {
+                        "inbound_ms_per_phase": inbound_ms, "inbound_bytes_per_link": in_bytes_per_link,
+                        "inbound_GBps_per_link": [rate(in_bytes_per_link, t) for t in inbound_ms],
+                        "return_ms_per_chunk": return_ms, "return_bytes_per_link": back_bytes_per_link,
+                        "return_GBps_per_link": [rate(back_bytes_per_link, t) for t in return_ms],
+                        "assumed_by_the_rehearsal_GBps_per_link": 61.0},
+                    "backend": dist.get_backend(), "blocking_collectives": bool(getattr(layer_s.exchange, "synchronous", False)),
+                    "TORCH_NCCL_AVOID_RECORD_STREAMS": os.environ.get("TORCH_NCCL_AVOID_RECORD_STREAMS"),
+                    "fallback": fallback_note,
                     "node_range_sizes": layer_s.plan.sizes, "n_pad": layer_s.plan.n_pad,
                     "note": "per propagate, compute-stream time of rank 0: product = partial SpMM launches, exposed = "
                             "the compute stream waiting for an inbound phase or the return; exchange_alone = the same "
                             "collectives with nothing to overlap"}
+
+    # ---- un-timed parity guard of the sharded mode: sampled rows of the sharded outputs and input gradients, and the
+    # all-reduced dW / db, against the UN-SHARDED HIP layer run on rank 0 with the same parameters (that layer is held
+    # to a float64 evaluation at this size by tests/test_gpu_fullsize.py).  In the JSON line; rc != 0 above the bar.
+    parity = None
+    if layer_s is not None and not args.no_parity:
+        k_rows = min(1024, n)
+        gen = torch.Generator().manual_seed(12345)
+        rows = torch.sort(torch.randperm(n, generator=gen)[:k_rows]).values
+        layer_s.zero_grad(set_to_none=True)
+        xr_loc.grad = xi_loc.grad = None
+        o_r, o_i = layer_s(xr_loc, xi_loc)
+        (o_r.sum() + o_i.sum()).backward()
+        plan = layer_s.plan
+        mine = (rows >= plan.lo) & (rows < plan.hi)
+        loc = (rows[mine] - plan.lo).to(device)
+        got = torch.zeros((k_rows, 4 * hidden), dtype=torch.float32, device=device)
+        got[mine.to(device)] = torch.cat([t.detach()[loc] for t in (o_r, o_i, xr_loc.grad, xi_loc.grad)], dim=1)
+        layer_s.exchange.all_reduce(got)                  # every sampled row is owned by exactly one rank
+        if rank == 0:
+            ref = MagNetConv(hidden, hidden, K=1, q=0.25, trainable_q=False, cached=True).to(device)
+            with torch.no_grad():
+                ref.weight.copy_(layer_s.weight)
+                ref.bias.copy_(layer_s.bias)
+            a = x_real.detach().clone().requires_grad_()
+            b = x_imag.detach().clone().requires_grad_()
+            w_r, w_i = ref(a, b, edge_index)
+            (w_r.sum() + w_i.sum()).backward()
+            idx = rows.to(device)
+            want = torch.cat([t.detach()[idx] for t in (w_r, w_i, a.grad, b.grad)], dim=1).double()
+            d = (got.double() - want).abs()
+            mixed = float((d / (1.0 + want.abs())).max())
+
+            def norm_err(x, y):
+                return float((x.double() - y.double()).abs().max()) / max(1.0, float(y.abs().max()))
+            dw_err = norm_err(layer_s.weight.grad, ref.weight.grad)
+            db_err = norm_err(layer_s.bias.grad, ref.bias.grad)
+            ok = mixed <= 1e-5 and dw_err <= 1e-5 and db_err <= 1e-5
+            parity = {"ok": ok, "rows": int(k_rows), "max_err_rows": mixed, "max_abs_err_rows": float(d.max()),
+                      "max_abs_want": float(want.abs().max()), "dW_norm_err": dw_err, "db_norm_err": db_err,
+                      "bar": "|d| <= 1e-5 (1 + |want|) per element of out_real / out_imag / dx_real / dx_imag on the "
+                             "sampled rows; max-norm 1e-5 for dW / db", "against": "un-sharded HIP MagNetConv on rank 0, "
+                             "same parameters, same inputs (float64-verified at this size by tests/test_gpu_fullsize.py)",
+                      "operator_nnz_matches": bool(layer_s.global_nnz == ref._operator.nnz)}
+            parity["ok"] = bool(parity["ok"] and parity["operator_nnz_matches"])
+            del ref, a, b, w_r, w_i
 
     if rank == 0:
         nnz = op_nnz()                      # E_s + N (folded diagonal)
@@ -406,6 +515,8 @@ def main():
         }
         if exchange is not None:
             line["exchange"] = exchange
+        if parity is not None:
+            line["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hidden)
         result_out.write(json.dumps(line) + "\n")
@@ -413,6 +524,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        sys.stderr.write("bench.py: PARITY GUARD FAILED: " + json.dumps(parity) + "\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

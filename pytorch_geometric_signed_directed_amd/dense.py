@@ -41,17 +41,27 @@ def dense_fwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, bias: Option
     return out_r, out_i
 
 
-def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor, g_i: Tensor):
-    """-> (da list, db list, dW [k1, f_in, f_out], dbias [f_out])."""
+def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor, g_i: Tensor,
+                  rows: Optional[int] = None):
+    """-> (da list, db list, dW [k1, f_in, f_out], dbias [f_out]).
+    rows: only the first `rows` rows enter (the sharded layer's real rows; the pad rows behind them are not part of
+    the graph): dW / dbias sum over those rows, da / db keep the full height with zero rows behind."""
     k1, f_in, f_out = weight.shape
     a = [t.contiguous() for t in a]
     b = [t.contiguous() for t in b]
     g_r, g_i = g_r.contiguous(), g_i.contiguous()
-    n = a[0].size(0)
+    n_full = a[0].size(0)
+    n = n_full if rows is None else int(rows)
     dev = weight.device
     w = weight.detach().contiguous()
-    da = [torch.empty((n, f_in), dtype=torch.float32, device=dev) for _ in range(k1)]
-    db = [torch.empty((n, f_in), dtype=torch.float32, device=dev) for _ in range(k1)]
+    da = [torch.empty((n_full, f_in), dtype=torch.float32, device=dev) for _ in range(k1)]
+    db = [torch.empty((n_full, f_in), dtype=torch.float32, device=dev) for _ in range(k1)]
+    if n < n_full:
+        for t in da + db:
+            t[n:].zero_()
+    if n == 0:                                     # a shard without real rows contributes nothing
+        return da, db, torch.zeros((k1, f_in, f_out), dtype=torch.float32, device=dev), \
+            torch.zeros(f_out, dtype=torch.float32, device=dev)
     dw = torch.empty((k1, f_in, f_out), dtype=torch.float32, device=dev)
     dbias = torch.empty(f_out, dtype=torch.float32, device=dev)
     lib = _cabi.lib()

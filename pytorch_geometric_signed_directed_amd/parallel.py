@@ -149,10 +149,19 @@ class DistExchange:
     gloo (tests; several ranks sharing one GPU): device tensors are staged through the host, synchronously."""
     emulated = False
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, synchronous: bool = False):
         self.group = group
         self.world_size, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self._staged = dist.get_backend(group) == "gloo"
+        # synchronous: every collective is waited for where it is issued (no overlap) -- the conservative schedule
+        # bench.py falls back to when the pipelined one fails on a machine
+        self.synchronous = bool(synchronous)
+
+    def _issue(self, work):
+        if self.synchronous:
+            work.wait()
+            return _Done()
+        return work
 
     @staticmethod
     def _wire(t: Tensor) -> Tensor:
@@ -176,7 +185,7 @@ class DistExchange:
             else:
                 self._gather_sync(self._wire(out), self._wire(inp.contiguous()))
             return _Done()
-        return dist.all_gather_into_tensor(out, inp.contiguous(), group=self.group, async_op=True)
+        return self._issue(dist.all_gather_into_tensor(out, inp.contiguous(), group=self.group, async_op=True))
 
     def all_to_all(self, out: Tensor, inp: Tensor):
         """chunk d of inp [world, ...] goes to rank d; chunk s of out comes from rank s."""
@@ -188,7 +197,7 @@ class DistExchange:
             else:
                 dist.all_to_all_single(self._wire(out), self._wire(inp.contiguous()), group=self.group)
             return _Done()
-        return dist.all_to_all_single(out, inp.contiguous(), group=self.group, async_op=True)
+        return self._issue(dist.all_to_all_single(out, inp.contiguous(), group=self.group, async_op=True))
 
     def all_reduce(self, t: Tensor) -> Tensor:
         if self.world_size > 1:
@@ -206,12 +215,81 @@ class DistExchange:
         if self.world_size == 1 or self._staged:
             self.all_reduce(t)
             return _Done()
-        return dist.all_reduce(t, group=self.group, async_op=True)
+        return self._issue(dist.all_reduce(t, group=self.group, async_op=True))
 
     def broadcast_list(self, values: list, src: int = 0) -> list:
         box = [values]
         dist.broadcast_object_list(box, src=src, group=self.group)
         return box[0]
+
+
+class ThreadExchange:
+    """The ranks of a job as THREADS of one process that share one device (or the host): every collective is a
+    rendezvous of the threads plus plain tensor copies on the one stream they all enqueue to -- correct values (unlike
+    `EmulatedExchange`), no process group, no second device context.  `ThreadExchange.create(P)` returns the P
+    exchanges; each thread builds its layer / engine with its own one and runs the same SPMD code as a real rank.
+    For checking the sharded path at sizes where several PROCESSES on one GPU are impractical (eight device contexts
+    on the one test GPU made a layer construction at the 20M-edge size take minutes, for reasons of the runtime's
+    queue scheduling, not of this code) and for single-GPU rehearsals with real numbers.
+    Autograd's engine runs every CUDA backward on ONE worker thread per device, so collectives inside a backward
+    would wait for peers that can never run: drive the layers' Function.forward / .backward directly
+    (tests/test_gpu_fullsize.py) or keep to forward-only use."""
+    emulated = False
+    synchronous = True
+
+    class _Shared:
+        def __init__(self, world_size):
+            import threading
+            self.barrier = threading.Barrier(world_size)
+            self.slots = [None] * world_size
+
+    def __init__(self, shared, world_size: int, rank: int):
+        self._sh, self.world_size, self.rank, self.group = shared, int(world_size), int(rank), None
+
+    @classmethod
+    def create(cls, world_size: int):
+        shared = cls._Shared(world_size)
+        return [cls(shared, world_size, r) for r in range(world_size)]
+
+    def _rendezvous(self, payload, consume):
+        sh = self._sh
+        sh.slots[self.rank] = payload
+        sh.barrier.wait()                                # every payload is posted (and its producer enqueued)
+        result = consume(sh.slots)                       # reads of the peers' payloads are enqueued here ...
+        sh.barrier.wait()                                # ... before any owner may enqueue an overwrite
+        return result
+
+    def all_gather(self, out: Tensor, inp: Tensor):
+        def consume(slots):
+            for s, t in enumerate(slots):
+                out[s].copy_(t)
+        self._rendezvous(inp, consume)
+        return _Done()
+
+    def all_to_all(self, out: Tensor, inp: Tensor):
+        def consume(slots):
+            for s, t in enumerate(slots):
+                out[s].copy_(t[self.rank])
+        self._rendezvous(inp, consume)
+        return _Done()
+
+    def all_reduce(self, t: Tensor) -> Tensor:
+        def consume(slots):
+            total = slots[0].clone()                     # fixed order: every rank computes the same sum
+            for other in slots[1:]:
+                total = total + other
+            return total
+        total = self._rendezvous(t, consume)
+        t.copy_(total)
+        self._sh.barrier.wait()
+        return t
+
+    def all_reduce_async(self, t: Tensor):
+        self.all_reduce(t)
+        return _Done()
+
+    def broadcast_list(self, values: list, src: int = 0) -> list:
+        return self._rendezvous(values, lambda slots: list(slots[src]))
 
 
 class _StreamEvent:
@@ -312,21 +390,26 @@ def split_phases(csr: CSR, values: Sequence[Tensor], n_pad: int, phases: int, wo
     if n_pad % phases:
         raise ValueError(f"n_pad = {n_pad} is not a multiple of {phases} phases")
     n_sub = n_pad // phases
+    n_rows, nnz = csr.n_rows, csr.nnz
     col = csr.col.long()
     local = col % n_pad
-    phase = local // n_sub
-    compact = (col // n_pad) * n_sub + local % n_sub
-    rp = csr.rowptr.long()
+    compact = ((col // n_pad) * n_sub + local % n_sub).to(torch.int32)
+    # ONE stable sort by (phase, row) instead of a boolean mask per phase: a handful of launches and a single
+    # device -> host read whatever the number of phases (mask indexing costs a host round trip per mask and array;
+    # with several ranks sharing one GPU those round trips took minutes at the 20M-edge size)
+    key = (local // n_sub) * n_rows + _row_of_slot(csr.rowptr, nnz)
+    skey, order = torch.sort(key, stable=True)
+    edges = torch.arange(phases * n_rows + 1, dtype=torch.long, device=col.device)
+    ptr_all = torch.searchsorted(skey, edges)                      # first sorted entry of every (phase, row)
+    starts = ptr_all[::n_rows].tolist()                            # phase boundaries: the one host read
+    cols = compact[order]
+    vals = [v[order] for v in values]
     out = []
     for c in range(phases):
-        hit = phase == c
-        upto = torch.zeros(csr.nnz + 1, dtype=torch.long, device=col.device)
-        upto[1:] = torch.cumsum(hit.long(), 0)
-        new_ptr = upto[rp]
-        nnz_c = int(upto[-1])
-        sub = CSR(csr.n_rows, world_size * n_sub, nnz_c, new_ptr.to(torch.int32),
-                  compact[hit].to(torch.int32).contiguous(), None)
-        out.append((sub, tuple(v[hit].contiguous() for v in values)))
+        lo, hi = int(starts[c]), int(starts[c + 1])
+        new_ptr = (ptr_all[c * n_rows:(c + 1) * n_rows + 1] - lo).to(torch.int32)
+        sub = CSR(n_rows, world_size * n_sub, hi - lo, new_ptr, cols[lo:hi], None)
+        out.append((sub, tuple(v[lo:hi] for v in vals)))
     return out
 
 
@@ -361,13 +444,15 @@ class PropagateEngine:
     pipelined partial products, exchange back (grid only).  See the module docstring for the schedule."""
 
     def __init__(self, plan: ShardPlan, exchange, p_c: int = 1, phases: int = 1, return_chunks: int = 1,
-                 kernels: Optional[Tuple[Callable, Callable]] = None):
+                 kernels: Optional[Tuple[Callable, Callable]] = None, force_grid: bool = False):
         self.plan, self.ex = plan, exchange
         world = plan.world_size
         if world % p_c:
             raise ValueError(f"{p_c} column slices do not divide {world} ranks")
         self.p_c, self.p_r = int(p_c), world // int(p_c)
-        self.grid = self.p_c > 1
+        # force_grid: the grid schedule (all-to-all in, row-chunked all-to-all back, merge) with ONE column slice --
+        # the degenerate 1 x 1 / p_r x 1 grid, so that a single rank can run the whole schedule over RCCL
+        self.grid = self.p_c > 1 or bool(force_grid)
         self.i, self.j = plan.rank // self.p_c, plan.rank % self.p_c
         self.phases = int(phases)
         self.return_chunks = int(return_chunks) if self.grid else 1
@@ -395,10 +480,10 @@ class PropagateEngine:
         return t
 
     @staticmethod
-    def alignment(world_size: int, p_c: int, phases: int, return_chunks: int) -> int:
+    def alignment(world_size: int, p_c: int, phases: int, return_chunks: int, force_grid: bool = False) -> int:
         p_r = world_size // p_c
         a = phases
-        b = p_r * return_chunks if p_c > 1 else 1
+        b = p_r * return_chunks if (p_c > 1 or force_grid) else 1
         return a * b // math.gcd(a, b)
 
     # ---- which operator rows this rank multiplies, in product order ---------------------------------
@@ -616,14 +701,15 @@ def default_pipeline(world_size: int, grid: bool) -> Tuple[int, int]:
 
 
 def make_plan(num_nodes: int, exchange, edge_index: Optional[Tensor], p_c: int, phases: int, return_chunks: int,
-              balance: bool = True) -> ShardPlan:
+              balance: bool = True, force_grid: bool = False) -> ShardPlan:
     """Equal-work ranges from the edge list (identical on every rank: rank 0's bounds are broadcast)."""
     world, rank = exchange.world_size, exchange.rank
     bounds = None
     if balance and edge_index is not None and world > 1:
         bounds = balanced_bounds(degree_cost(edge_index, num_nodes), world)
         bounds = exchange.broadcast_list(bounds, 0)
-    return ShardPlan(num_nodes, world, rank, bounds, PropagateEngine.alignment(world, p_c, phases, return_chunks))
+    return ShardPlan(num_nodes, world, rank, bounds,
+                     PropagateEngine.alignment(world, p_c, phases, return_chunks, force_grid))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -661,6 +747,12 @@ class _ShardedMagneticFn(torch.autograd.Function):
             ta.append(ya.contiguous())
             tb.append(yb.contiguous())
         out_r, out_i = layer._dense_fwd(ta, tb, weight, bias)
+        n_local = layer.plan.n_local
+        if n_local < layer.plan.n_pad:
+            # pad rows are isolated nodes that do not exist: their outputs are zero (not the bias), so that a stacked
+            # layer sees zero features there again and T_k of a pad row stays zero for every k
+            out_r[n_local:] = 0
+            out_i[n_local:] = 0
         ctx.layer, ctx.k1, ctx.has_bias = layer, k1, bias is not None
         ctx.save_for_backward(weight, *ta, *tb)
         return out_r, out_i
@@ -673,13 +765,10 @@ class _ShardedMagneticFn(torch.autograd.Function):
         weight = saved[0]
         ta, tb = list(saved[1:1 + k1]), list(saved[1 + k1:1 + 2 * k1])
         g_r, g_i = g_r.contiguous(), g_i.contiguous()
-        da, db, dw, dbias = layer._dense_bwd(ta, tb, weight, g_r, g_i)
-        n_local = layer.plan.n_local
-        if n_local < layer.plan.n_pad:
-            # upstream gradient on the PAD rows is not part of the graph.  Their Chebyshev terms are zero (isolated
-            # nodes, zero features), so dW is unaffected and nothing leaks into real rows through S^T; only db
-            # = sum_rows (g_r + g_i) has to lose the pad rows' share
-            dbias = dbias - (g_r[n_local:] + g_i[n_local:]).sum(0)
+        # upstream gradient on the PAD rows is not part of the graph (the forward zeroes those outputs): the dense
+        # backward runs on the real rows only -- dW, db see no pad row whatever the loss or the stacking -- and hands
+        # back zero gradient rows for the pad
+        da, db, dw, dbias = layer._dense_bwd(ta, tb, weight, g_r, g_i, layer.plan.n_local)
         # parameter gradients = sum of the per-shard partials: reduced on the communication stream WHILE the backward
         # propagates below run (they do not depend on it); waited for at the end
         pending = [layer.exchange.all_reduce_async(dw)]
@@ -791,9 +880,10 @@ class ShardedMagNetConv(torch.nn.Module):
         p_c = grid_cols if grid_cols is not None else choose_cols(world, in_channels)
         if layout == "auto":
             layout = "grid" if (p_c > 1 and in_channels % (4 * p_c) == 0) else "rows"
+        force_grid = layout == "grid" and grid_cols == 1     # the grid SCHEDULE on one column slice (RCCL rehearsal on 1 rank)
         if layout == "rows":
             p_c = 1
-        elif p_c <= 1 or world % p_c or in_channels % p_c:
+        elif (p_c <= 1 and not force_grid) or world % p_c or in_channels % p_c:
             raise ValueError(f"grid of {p_c} column slices does not divide world {world} / width {in_channels}")
         self.layout = layout
         d_ph, d_rc = default_pipeline(world, layout == "grid")
@@ -802,8 +892,8 @@ class ShardedMagNetConv(torch.nn.Module):
         device = device or edge_index.device
         edge_index = edge_index.to(device)
         edge_weight = None if edge_weight is None else edge_weight.to(device)
-        self.plan = make_plan(num_nodes, self.exchange, edge_index, p_c, phases, return_chunks, balance)
-        self.engine = PropagateEngine(self.plan, self.exchange, p_c, phases, return_chunks, kernels)
+        self.plan = make_plan(num_nodes, self.exchange, edge_index, p_c, phases, return_chunks, balance, force_grid)
+        self.engine = PropagateEngine(self.plan, self.exchange, p_c, phases, return_chunks, kernels, force_grid)
         proto = (MSConv(in_channels, out_channels, K, q, False, normalization, bias, True, absolute_degree)
                  if signed else MagNetConv(in_channels, out_channels, K, q, False, normalization, True, bias))
         self.weight = proto.weight
@@ -837,15 +927,19 @@ class ShardedMagNetConv(torch.nn.Module):
         b = 0 if bias is None else bias
         return rr - ii + b, rr + ii + b
 
-    def _dense_bwd(self, ta, tb, weight, g_r, g_i):
+    def _dense_bwd(self, ta, tb, weight, g_r, g_i, rows=None):
+        """rows: only the first `rows` rows carry gradient (the rest are pad rows: zero gradient rows come back)."""
         from .dense import dense_bwd_raw, dense_supported
         if ta[0].is_cuda and dense_supported(self.in_channels, self.out_channels, weight.size(0)):
-            return dense_bwd_raw(ta, tb, weight, g_r, g_i)
-        p, m = g_r + g_i, g_i - g_r
+            return dense_bwd_raw(ta, tb, weight, g_r, g_i, rows)
+        n = g_r.size(0)
+        rows = n if rows is None else rows
+        p, m = (g_r + g_i)[:rows], (g_i - g_r)[:rows]
         k1 = weight.size(0)
-        da = [torch.matmul(p, weight[k].t()) for k in range(k1)]
-        db = [torch.matmul(m, weight[k].t()) for k in range(k1)]
-        dw = torch.stack([ta[k].t() @ p + tb[k].t() @ m for k in range(k1)])
+        pad = (0, 0, 0, n - rows)
+        da = [torch.nn.functional.pad(torch.matmul(p, weight[k].t()), pad) for k in range(k1)]
+        db = [torch.nn.functional.pad(torch.matmul(m, weight[k].t()), pad) for k in range(k1)]
+        dw = torch.stack([ta[k][:rows].t() @ p + tb[k][:rows].t() @ m for k in range(k1)])
         return da, db, dw, p.sum(0)
 
     def shard_rows(self, x: Tensor) -> Tensor:
@@ -901,7 +995,35 @@ def _vals(v: Optional[Tensor], csr: CSR) -> Tuple[Tensor]:
     return (v,)
 
 
-class ShardedDiGCNConv(torch.nn.Module):
+class _GradSync:
+    """Parameter gradients of a layer with replicated parameters: every incoming gradient is all-reduced by a tensor
+    hook (so accumulation over several backward calls stays correct).  The hooks fire in the order autograd makes the
+    gradients ready, which is the same on every rank only if the ranks run the same graph; the FIRST backward
+    therefore records that order and compares it across the ranks -- a mismatch (two ranks pairing up different
+    parameters in one all-reduce) raises instead of training on mixed-up sums."""
+
+    def _install_grad_sync(self):
+        self._sync_order, self._sync_checked = [], False
+        self._sync_count = 0
+        for k, prm in enumerate(self.parameters()):
+            self._sync_count += 1
+            prm.register_hook(lambda grad, k=k: self._allreduce(grad, k))
+
+    def _allreduce(self, grad, k):
+        out = self.exchange.all_reduce(grad.contiguous())
+        if not self._sync_checked:
+            self._sync_order.append(k)
+            if len(self._sync_order) == self._sync_count:
+                self._sync_checked = True
+                mine = torch.tensor(self._sync_order, dtype=torch.float64, device=grad.device)
+                total = self.exchange.all_reduce(mine.clone())
+                if not torch.equal(total, mine * self.exchange.world_size):
+                    raise RuntimeError(f"{type(self).__name__}: the ranks all-reduced their parameter gradients in "
+                                       f"different orders (this rank: {self._sync_order}); their autograd graphs differ")
+        return out
+
+
+class ShardedDiGCNConv(_GradSync, torch.nn.Module):
     """DiGCNConv (out = S^T (x W) + b, reference nn/directed/DiGCNConv.py:54-94) over a node-range-sharded
     graph; fp32 or bf16 (`.to(torch.bfloat16)`: BASELINE config "DiGCN_Inception_Block ... bf16, 8xMI355X").
     Parameters are replicated; their gradients are all-reduced by hooks during backward."""
@@ -924,11 +1046,7 @@ class ShardedDiGCNConv(torch.nn.Module):
         self.plan = plan or make_plan(num_nodes, self.exchange, edge_index, 1, phases, 1, balance)
         self.engine = PropagateEngine(self.plan, self.exchange, 1, phases, 1, kernels)
         self.op = ShardedOperator(edge_index, edge_weight.to(device), self.plan, self.engine)
-        for prm in self.parameters():
-            prm.register_hook(self._allreduce)
-
-    def _allreduce(self, grad):
-        return self.exchange.all_reduce(grad.contiguous())
+        self._install_grad_sync()
 
     def shard_rows(self, x: Tensor) -> Tensor:
         return self.plan.shard_rows(x)
@@ -945,14 +1063,16 @@ class ShardedDiGCNConv(torch.nn.Module):
 
 
 def _zero_pad_rows(plan: ShardPlan, t: Tensor) -> Tensor:
-    if plan.n_local == plan.n_pad:
-        return t
+    """Pad rows -> 0.  Applied on EVERY rank, also the one whose range has no pad rows: the ranks' autograd graphs must
+    be the same graph, or their parameter gradients can become ready in different orders and the per-parameter
+    all-reduce hooks of two ranks pair up different parameters (seen at the C5 size: one rank's conv2.weight share
+    summed into conv1.weight, a 12 % error that only showed under load)."""
     mask = torch.zeros((plan.n_pad, 1), dtype=t.dtype, device=t.device)
     mask[:plan.n_local] = 1
     return t * mask
 
 
-class ShardedDiGCNInceptionBlock(torch.nn.Module):
+class ShardedDiGCNInceptionBlock(_GradSync, torch.nn.Module):
     """DiGCN_InceptionBlock (reference nn/directed/DiGCN_Inception_Block.py:9-47: x0 = Linear(x), x1 / x2 =
     DiGCNConv on the first- / second-order proximity operators) over a node-range-sharded graph, fp32 or bf16.
     The two convolutions share ONE exchange per propagate: the projections x W1 and x W2 are packed side by side
@@ -977,11 +1097,7 @@ class ShardedDiGCNInceptionBlock(torch.nn.Module):
         self.engine = PropagateEngine(self.plan, self.exchange, 1, phases, 1, kernels)
         self.op1 = ShardedOperator(edge_index, edge_weight.to(device), self.plan, self.engine)
         self.op2 = ShardedOperator(edge_index2, edge_weight2.to(device), self.plan, self.engine)
-        for prm in self.parameters():
-            prm.register_hook(self._allreduce)
-
-    def _allreduce(self, grad):
-        return self.exchange.all_reduce(grad.contiguous())
+        self._install_grad_sync()
 
     def shard_rows(self, x: Tensor) -> Tensor:
         return self.plan.shard_rows(x)

@@ -84,3 +84,58 @@ def oracle_operator_rows(edge_index, edge_weight, n, q, signed=False, absolute_d
         return sub, (picked[0], picked[1]), (picked[2], picked[3]), fwd.nnz
 
     return build
+
+
+# ------------------------------------------------------------------------------------------------
+# ranks as threads of one process (parallel.ThreadExchange)
+# ------------------------------------------------------------------------------------------------
+class FunctionCtx:
+    """Stand-in for the autograd context of a torch.autograd.Function, to drive forward / backward by hand: the
+    autograd engine runs every CUDA backward on one worker thread per device, so collectives inside a backward cannot
+    rendezvous when the ranks are threads."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = tuple(needs_input_grad)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+def sharded_magnetic_step(layer, x_real, x_imag, g_real, g_imag):
+    """Forward + backward of one ShardedMagNetConv on local rows without the autograd engine:
+    -> (out_real, out_imag, dx_real, dx_imag, dW, db)."""
+    from pytorch_geometric_signed_directed_amd.parallel import _ShardedMagneticFn as Fn
+    ctx = FunctionCtx((True, True, True, layer.bias is not None, False))
+    with torch.no_grad():
+        o_r, o_i = Fn.forward(ctx, x_real, x_imag, layer.weight, layer.bias, layer)
+        gx_r, gx_i, dw, db, _ = Fn.backward(ctx, g_real, g_imag)
+    return o_r, o_i, gx_r, gx_i, dw, db
+
+
+def run_ranks_as_threads(world, body):
+    """body(rank, exchange) in `world` threads sharing ThreadExchange.create(world); -> [result of rank r].  The first
+    exception of any rank is re-raised here (the others are released from their rendezvous)."""
+    import threading
+    from pytorch_geometric_signed_directed_amd.parallel import ThreadExchange
+    exchanges = ThreadExchange.create(world)
+    results, errors = [None] * world, []
+
+    def runner(rank):
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(0)
+            results[rank] = body(rank, exchanges[rank])
+        except threading.BrokenBarrierError:
+            pass
+        except BaseException as exc:  # noqa: BLE001
+            errors.append((rank, exc))
+            exchanges[rank]._sh.barrier.abort()
+    threads = [threading.Thread(target=runner, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0][1]
+    return results

@@ -1,0 +1,211 @@
+"""GPU: the BASELINE configurations at their STATED sizes, on one GPU and node-sharded over 8 ranks, against a float64
+evaluation (VERDICT r2 "sharded correctness at real size").
+
+  north star  MagNetConv K = 1, h = 64, DSBM 1M nodes / 20M edges          (nn/directed/MagNetConv.py:122-249)
+  C4          MSGNN's signed MSConv K = 2, h = 128, SDSBM 1M / 20M          (nn/general/MSConv.py:121-230, MSGNN.py:130-131)
+  C5          DiGCN_InceptionBlock bf16, 2M nodes / ~52M entries / operator  (nn/directed/DiGCN_Inception_Block.py:31-47)
+
+The arbiter is oracle/sparse_f64_torch.py -- the float64 formulas of oracle/sparse_f64.py on torch tensors (pinned to
+the scipy evaluation on the host, tests/test_oracle_sparse_f64.py), evaluated here ON THE DEVICE in float64 with
+coalesce / index_add_ only: the scipy evaluation of C4 needs minutes of one host core.  One GPU: every row is compared.
+Sharded, 8 ranks: plan, distributed operator build, phases, row chunks, packing, both exchanges, merges and the
+parameter all-reduce are the production code at the sizes and with the int32 / padding / alignment arithmetic of the
+real run.  The magnetic configurations run their eight ranks as THREADS of this process (parallel.ThreadExchange: the
+same SPMD code, collectives as rendezvous + copies; forward / backward driven by hand, tests/sharding_cpu.py) and compare
+EVERY local row of every rank: eight PROCESSES sharing the one test GPU took minutes per layer construction at this
+size (runtime queue scheduling between device contexts; measured 1.3 s -> 60..560 s), which the process-per-rank tests of
+tests/test_gpu_sharded.py only tolerate because they are small.  C5 (whose ranks need the autograd engine: parameter hooks)
+runs as eight gloo processes and reports 1024 sampled rows.
+
+Bars: fp32 outputs and input gradients per element |d| <= 1e-5 (1 + |want|); dW / db (row reductions) max-norm 1e-5;
+bf16 (C5) 3 * 2^-8 of the max norm against float64 on bf16-rounded inputs and parameters."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import bigdata
+import fullsize as FS
+import sharding_cpu as C
+from tolerance import RECORDS, TOL
+
+pytestmark = pytest.mark.gpu
+D = torch.device("cuda:0")
+BF16_TOL = FS.BF16_TOL
+WORLD = 8
+
+
+def _record(what, err, tol, norm):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    RECORDS.append(dict(err, test=test, what=what, bar="norm" if norm else "abs", tol=tol))
+    worst = err["max_norm_rel_err"] if norm else err["max_mixed_err"]
+    assert worst <= tol, (f"{what}: {'max-norm relative' if norm else '|d| / (1 + |want|)'} error {worst:.3e} > {tol} "
+                          f"(abs {err['max_abs_err']:.3e}, |want| <= {err['max_abs_want']:.3g})")
+
+
+def _check(got, want, what, tol=TOL, norm=False):
+    """tolerance.close on the device (the arrays are up to 2M x 64): same bar, same record."""
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    _record(what, FS.errors(got.detach(), want.detach()), tol, norm)
+
+
+@pytest.fixture(scope="module", params=list(FS.MAGNETIC))
+def magnetic(request):
+    """Float64 reference of one configuration (all rows, on the device), shared by its tests."""
+    name = request.param
+    want = FS.magnetic_reference(name, D)
+    yield name, want
+    del want
+    torch.cuda.empty_cache()
+
+
+def test_one_gpu_every_row_vs_float64(magnetic):
+    """The un-sharded layer at the stated size, ALL rows of outputs and input gradients, dW, db."""
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv, MSConv
+    name, want = magnetic
+    cfg = FS.MAGNETIC[name]
+    h, k = cfg["h"], cfg["k"]
+    p_ei, p_sign, feats = FS.magnetic_files(name)
+    layer = (MSConv if cfg["signed"] else MagNetConv)(h, h, k, 0.25, False, cached=True).to(D)
+    weight, bias = FS.magnetic_params(name)
+    with torch.no_grad():
+        layer.weight.copy_(weight)
+        layer.bias.copy_(bias)
+    xr, xi, gr, gi = (FS.dev_tensor(p, D) for p in feats)
+    xr.requires_grad_()
+    xi.requires_grad_()
+    o_r, o_i = layer(xr, xi, FS.dev_tensor(p_ei, D), None if p_sign is None else FS.dev_tensor(p_sign, D))
+    ((o_r * gr).sum() + (o_i * gi).sum()).backward()
+    for got, ref, what in ((o_r, want[0], "out_real"), (o_i, want[1], "out_imag"), (xr.grad, want[2], "dx_real"),
+                           (xi.grad, want[3], "dx_imag")):
+        _check(got, ref, f"{name} one GPU {what} (all rows) vs float64")
+    _check(layer.weight.grad, want[4], f"{name} one GPU dW vs float64", norm=True)
+    _check(layer.bias.grad, want[5], f"{name} one GPU db vs float64", norm=True)
+
+
+@pytest.mark.parametrize("layout", ["auto", "rows"])
+def test_sharded_8_ranks_every_row_vs_float64(magnetic, layout):
+    """8 ranks (threads, one device), default pipeline (auto = 2 x 4 grid, 2 phases x 2 return chunks; rows = all-gather
+    layout, 2 phases), distributed operator build: EVERY local row of out_real / out_imag / dx_real / dx_imag of every
+    rank, and the all-reduced dW / db, vs float64."""
+    from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv
+    name, want = magnetic
+    cfg = FS.MAGNETIC[name]
+    n, h, k = cfg["n"], cfg["h"], cfg["k"]
+    p_ei, p_sign, feats = FS.magnetic_files(name)
+    ei = FS.dev_tensor(p_ei, D)                               # read-only, shared by the eight ranks
+    sign = None if p_sign is None else FS.dev_tensor(p_sign, D)
+    weight, bias = FS.magnetic_params(name)
+
+    def body(rank, exchange):
+        layer = ShardedMagNetConv(h, h, k, 0.25, n, ei, sign, device=D, layout=layout, signed=cfg["signed"],
+                                  exchange=exchange)
+        with torch.no_grad():
+            layer.weight.copy_(weight)
+            layer.bias.copy_(bias)
+        plan, eng = layer.plan, layer.engine
+        a, b, ga, gb = (FS.shard(p, plan, h, D) for p in feats)
+        outs = C.sharded_magnetic_step(layer, a, b, ga, gb)
+        return plan, (layer.layout, eng.p_r, eng.p_c, eng.phases, eng.return_chunks), outs, layer.global_nnz
+
+    res = C.run_ranks_as_threads(WORLD, body)
+    shape = res[0][1]
+    assert shape == (("grid", 2, 4, 2, 2) if layout == "auto" else ("rows", 8, 1, 2, 1)), shape
+    tag = f"{name} 8 ranks {shape[0]} {shape[1]}x{shape[2]} C{shape[3]} R{shape[4]}"
+    assert sum(r[0].n_local for r in res) == n and len({r[3] for r in res}) == 1
+    for j, what in enumerate(("out_real", "out_imag", "dx_real", "dx_imag")):
+        got = torch.cat([r[2][j][:r[0].n_local] for r in res])          # contiguous ownership: rank order = row order
+        _check(got, want[j], f"{tag} {what} (all rows) vs float64")
+        assert all(float(r[2][j][r[0].n_local:].abs().sum()) == 0 for r in res)     # pad rows stay out of the graph
+    for r in res:                                                         # all-reduced: the same sums on every rank
+        assert torch.equal(r[2][4], res[0][2][4]) and torch.equal(r[2][5], res[0][2][5])
+    _check(res[0][2][4], want[4], f"{tag} dW vs float64", norm=True)
+    _check(res[0][2][5], want[5], f"{tag} db vs float64", norm=True)
+
+
+# ------------------------------------------------------------------------------------------------ C5
+@pytest.fixture(scope="module")
+def inception():
+    ref = FS.inception_reference(D)
+    yield ref
+    del ref
+    torch.cuda.empty_cache()
+
+
+def test_c5_one_gpu_bf16_every_row_vs_float64(inception):
+    from pytorch_geometric_signed_directed_amd.nn import DiGCN_InceptionBlock
+    outs, dx, grads = inception
+    n, h = FS.C5["n"], FS.C5["h"]
+    ib = DiGCN_InceptionBlock(h, h)
+    ib.load_state_dict(FS.inception_params())
+    ib.to(D).to(torch.bfloat16)
+    p_x, p_g = bigdata.features(n, h, 6, 2)
+    x = FS.dev_tensor(p_x, D).to(torch.bfloat16).requires_grad_()
+    go = FS.dev_tensor(p_g, D)
+    (e1, w1), (e2, w2) = [(FS.dev_tensor(a, D), FS.dev_tensor(b, D)) for a, b in bigdata.digcn_operators(n, FS.C5["e"], seed=3)]
+    got = ib(x, e1, w1, e2, w2)
+    sum(((k + 1.0) * o.float() * go).sum() for k, o in enumerate(got)).backward()
+    for k, (o, ref) in enumerate(zip(got, outs)):
+        _check(o.float(), ref, f"C5 one GPU x{k} (bf16, all rows) vs float64", BF16_TOL, norm=True)
+    _check(x.grad.float(), dx, "C5 one GPU dx (bf16, all rows) vs float64", BF16_TOL, norm=True)
+    for name, prm in ib.named_parameters():
+        _check(prm.grad.float(), grads[name], f"C5 one GPU d {name} (bf16) vs float64", BF16_TOL, norm=True)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _inception_rank(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytorch_geometric_signed_directed_amd.parallel import ShardedDiGCNInceptionBlock
+        n, h = FS.C5["n"], FS.C5["h"]
+        (e1, w1), (e2, w2) = [(FS.dev_tensor(a, D), FS.dev_tensor(b, D)) for a, b in bigdata.digcn_operators(n, FS.C5["e"], seed=3)]
+        layer = ShardedDiGCNInceptionBlock(h, h, n, e1, w1, e2, w2, device=D)
+        layer.load_state_dict(FS.inception_params())
+        layer.to(torch.bfloat16)
+        del e1, w1, e2, w2
+        plan = layer.plan
+        p_x, p_g = bigdata.features(n, h, 6, 2)
+        a = FS.shard(p_x, plan, h, D).to(torch.bfloat16).requires_grad_()
+        go = FS.shard(p_g, plan, h, D)
+        outs = layer(a)
+        sum(((k + 1.0) * o.float() * go).sum() for k, o in enumerate(outs)).backward()
+        rows = FS.sample_rows(n)
+        mine = rows[(rows >= plan.lo) & (rows < plan.hi)]
+        loc = torch.from_numpy(mine - plan.lo).to(D)
+        ret[rank] = dict(rows=mine, vals=[t.detach().float()[loc].cpu().numpy() for t in outs + (a.grad,)],
+                         grads={k: p.grad.float().cpu().numpy() for k, p in layer.named_parameters()},
+                         phases=layer.engine.phases)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c5_sharded_8_ranks_bf16_sampled_rows_vs_float64(inception):
+    """The sharded inception block in bf16 at the stated size, eight gloo processes on the one GPU (row layout, one
+    all-gather shared by both convolutions): 1024 sampled rows and the all-reduced parameter gradients."""
+    outs, dx, grads = inception
+    ret = mp.Manager().dict()
+    mp.spawn(_inception_rank, args=(WORLD, _free_port(), ret), nprocs=WORLD, join=True)
+    assert len(ret) == WORLD
+    rows = np.concatenate([ret[r]["rows"] for r in range(WORLD)])
+    assert np.array_equal(rows, FS.sample_rows(FS.C5["n"]))
+    idx = torch.from_numpy(rows).to(D)
+    for k, ref in enumerate(outs + [dx]):
+        got = torch.from_numpy(np.concatenate([ret[r]["vals"][k] for r in range(WORLD)])).to(D)
+        scale = max(1.0, float(ref.abs().max()))               # relative to the WHOLE matrix's scale, as on one GPU
+        err = float((got.double() - ref[idx]).abs().max())
+        _record(f"C5 8 ranks {'x%d' % k if k < 3 else 'dx'} (bf16, {FS.N_SAMPLE} rows) vs float64",
+                {"max_abs_err": err, "max_mixed_err": err / scale, "max_norm_rel_err": err / scale, "max_abs_want": scale},
+                BF16_TOL, True)
+    for name, ref in grads.items():
+        _check(torch.from_numpy(ret[0]["grads"][name]).to(D), ref, f"C5 8 ranks d {name} (bf16) vs float64", BF16_TOL, norm=True)

@@ -227,8 +227,11 @@ def test_bench_self_launches_its_ranks(gpus):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == gpus and rec["value"] > 0 and rec["scaling"] == "strong"
     assert rec["config"]["nodes"] == 20000 and "exchange" in rec and rec["exchange"]["propagates_per_step"] == 2
-    for key in ("product_ms", "exposed_exchange_ms", "exchange_alone_ms"):
+    for key in ("product_ms", "exposed_exchange_ms", "exchange_alone_ms", "collectives_alone", "fallback"):
         assert key in rec["exchange"], rec["exchange"]
+    assert rec["exchange"]["fallback"] is None
+    # the un-timed parity guard: sampled rows of the sharded run against the un-sharded HIP layer, in the line
+    assert rec["parity"]["ok"] and rec["parity"]["rows"] == 1024 and rec["parity"]["max_err_rows"] <= 1e-5, rec["parity"]
 
 
 
@@ -269,9 +272,26 @@ print("rccl ok")
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(key, None)
+    # the WHOLE pipelined schedule under RCCL at the north-star size (1M nodes / 20M edges, h = 64): with one column
+    # slice forced (--layout grid --grid-cols 1) the single rank runs the grid's asynchronous all-to-all in two phases,
+    # the row-chunked all-to-all back, the merge and the asynchronous dW / db all-reduce on the process group's stream,
+    # and bench.py's parity guard compares sampled rows and dW / db with the un-sharded layer
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--layout", "grid",
+                          "--grid-cols", "1", "--phases", "2", "--return-chunks", "2", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    ex = rec["exchange"]
+    assert rec["n_gpus"] == 1 and rec["config"]["nodes"] == 1000000 and rec["value"] > 0
+    assert (ex["layout"], ex["p_r"], ex["p_c"], ex["phases"], ex["return_chunks"]) == ("grid", 1, 1, 2, 2), ex
+    assert ex["backend"] == "nccl" and ex["fallback"] is None and not ex["blocking_collectives"]
+    assert ex["TORCH_NCCL_AVOID_RECORD_STREAMS"] == "1"
+    assert len(ex["collectives_alone"]["inbound_ms_per_phase"]) == 2 and len(ex["collectives_alone"]["return_ms_per_chunk"]) == 2
+    assert rec["parity"]["ok"] and rec["parity"]["max_err_rows"] <= 1e-5, rec["parity"]
+    # the row layout (stacked all-gather) the same way, small
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "2",
                           "--warmup", "1", "--nodes", "20000", "--edges", "300000", "--no-cpu-baseline"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
-    assert rec["n_gpus"] == 1 and rec["exchange"]["layout"] == "rows" and rec["value"] > 0
+    assert rec["n_gpus"] == 1 and rec["exchange"]["layout"] == "rows" and rec["value"] > 0 and rec["parity"]["ok"]

@@ -60,3 +60,46 @@ def test_sparse_f64_reproduces_the_reference_fixtures(name):
     for arr, key in zip(got, names):
         want = np.asarray(g[key], np.float64)
         assert np.abs(arr - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), key
+
+
+@pytest.mark.parametrize("signed,norm,absdeg", [(False, "sym", True), (False, None, True), (True, "sym", True),
+                                                (True, "sym", False), (True, None, False)])
+def test_torch_restatement_equals_the_scipy_evaluation(signed, norm, absdeg):
+    """oracle/sparse_f64_torch.py (the float64 evaluation that also runs on the device, for the checks at the BASELINE
+    configs' stated sizes) against oracle/sparse_f64.py: operator, outputs and every gradient, K = 1 and 3; its
+    DiGCN product against the reference op sequence of ref_layers.py in float64."""
+    import torch
+    from oracle import ref_layers as R
+    from oracle import sparse_f64_torch as T64
+    rng = np.random.default_rng(8)
+    n, e, f = 90, 900, 6
+    ei = rng.integers(0, n, (2, e))
+    ei[:, :40] = ei[::-1, 40:80]                                 # reciprocal pairs
+    ei[:, 80:100] = ei[:, 100:120]                               # exact duplicates
+    ei[1, 120:130] = ei[0, 120:130]                              # self loops
+    w = rng.uniform(0.5, 1.5, e) * (rng.choice([-1, 1], e) if signed else 1)
+    lam = 2.0 if norm == "sym" else 5.5
+    s = S64.magnetic_operator(ei, w, n, 0.2, norm, lam, signed, absdeg)
+    t = T64.magnetic_operator(torch.from_numpy(ei), torch.from_numpy(w), n, 0.2, norm, lam, signed, absdeg)
+    dense = np.zeros((n, n), np.complex128)
+    np.add.at(dense, (t.row.numpy(), t.col.numpy()), t.real.numpy() + 1j * t.imag.numpy())
+    dense[np.arange(n), np.arange(n)] += t.diag.numpy()
+    assert np.abs(dense - s.toarray()).max() <= 1e-12
+    for k in (1, 3):
+        xr, xi, gr, gi = (rng.normal(size=(n, f)) for _ in range(4))
+        wt, b = rng.normal(size=(k + 1, f, f)), rng.normal(size=f)
+        want = S64.magnet_conv(xr, xi, s, wt, b, gr, gi)
+        got = T64.magnet_conv(*(torch.from_numpy(a) for a in (xr, xi)), t, torch.from_numpy(wt), torch.from_numpy(b),
+                              torch.from_numpy(gr), torch.from_numpy(gi))
+        for a, c in zip(got, want):
+            assert np.abs(a.numpy() - c).max() <= 1e-11
+    x = torch.from_numpy(rng.normal(size=(n, f))).requires_grad_()
+    wt = torch.from_numpy(rng.normal(size=(f, 4))).requires_grad_()
+    bias = torch.from_numpy(rng.normal(size=4)).requires_grad_()
+    go = torch.from_numpy(rng.normal(size=(n, 4)))
+    eit, ew = torch.from_numpy(ei), torch.from_numpy(np.abs(w))
+    want = R.digcn_conv(x, eit, ew, wt, bias)
+    (want * go).sum().backward()
+    got = T64.digcn_conv(x.detach(), eit, ew, wt.detach(), bias.detach(), go)
+    for a, c in zip(got, (want.detach(), x.grad, wt.grad, bias.grad)):
+        assert (a - c).abs().max() <= 1e-11

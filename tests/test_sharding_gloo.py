@@ -195,6 +195,98 @@ def test_sharded_magnetic_layer_equals_unsharded_oracle(world, cfg):
     assert len(ret) == world and max(ret.values()) <= 2e-6, dict(ret)
 
 
+def _stacked_worker(rank, world, port, ret):
+    """Two sharded magnetic layers stacked, uneven ranges (pad rows on most ranks), non-zero biases, a loss that also
+    touches the pad rows of the SECOND layer: outputs on pad rows must be zero (not the bias), and no upstream
+    gradient of a pad row may reach dW / db of either layer."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv, all_gather_rows
+        n, f, k = 53, 8, 2
+        g, ei, w = _graph(n, 77, True)
+        xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+        gr, gi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+        torch.manual_seed(5)
+        layers = [ShardedMagNetConv(f, f, k, 0.25, n, ei, w, layout="rows", phases=1, kernels=C.KERNELS,
+                                    operator_rows=C.oracle_operator_rows(ei, w, n, 0.25)) for _ in range(2)]
+        plan = layers[0].plan
+        assert plan.n_local < plan.n_pad or rank == max(range(world), key=lambda r: plan.sizes[r])
+        with torch.no_grad():
+            for ly in layers:
+                ly.bias.uniform_(0.5, 1.5)
+                dist.broadcast(ly.bias.data, 0)
+                dist.broadcast(ly.weight.data, 0)
+        a, b = plan.shard_rows(xr).requires_grad_(), plan.shard_rows(xi).requires_grad_()
+        h_r, h_i = layers[0](a, b)
+        assert float(h_r[plan.n_local:].abs().sum()) == 0 and float(h_i[plan.n_local:].abs().sum()) == 0
+        o_r, o_i = layers[1](h_r, h_i)
+        assert float(o_r[plan.n_local:].abs().sum()) == 0
+        ((o_r * plan.shard_rows(gr)).sum() + (o_i * plan.shard_rows(gi)).sum() + 3.0 * o_r.sum() - 2.0 * o_i.sum()
+         + 5.0 * h_i[plan.n_local:].sum()).backward()
+        got = [plan.unshard_rows(all_gather_rows(t.detach())) for t in (o_r, o_i, a.grad, b.grad)]
+        c, d = xr.clone().requires_grad_(), xi.clone().requires_grad_()
+        prm = [(ly.weight.detach().clone().requires_grad_(), ly.bias.detach().clone().requires_grad_()) for ly in layers]
+        op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0)
+        m_r, m_i = R.magnet_conv(c, d, op, prm[0][0], prm[0][1], duplicate=False)
+        w_r, w_i = R.magnet_conv(m_r, m_i, op, prm[1][0], prm[1][1], duplicate=False)
+        ((w_r * gr).sum() + (w_i * gi).sum() + 3.0 * w_r.sum() - 2.0 * w_i.sum()).backward()
+        want = [w_r.detach(), w_i.detach(), c.grad, d.grad] + [t.grad for pair in prm for t in pair]
+        have = got + [t for ly in layers for t in (ly.weight.grad, ly.bias.grad)]
+        ret[rank] = max(float((x - y).abs().max()) / max(1.0, float(y.abs().max())) for x, y in zip(have, want))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stacked_sharded_layers_keep_pad_rows_out_of_the_graph():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_stacked_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
+    assert len(ret) == 3 and max(ret.values()) <= 2e-6, dict(ret)
+
+
+@pytest.mark.parametrize("world,layout,k,phases,chunks", [(4, "grid", 2, 2, 2), (8, "grid", 1, 2, 2), (3, "rows", 3, 2, 1)])
+def test_ranks_as_threads_equal_the_unsharded_oracle(world, layout, k, phases, chunks):
+    """parallel.ThreadExchange: the ranks of a sharded layer as threads of ONE process (the form the full-size GPU
+    checks use: several processes on one GPU are impractical there) -- same SPMD code, collectives as rendezvous +
+    copies, forward / backward driven by hand (tests/sharding_cpu.sharded_magnetic_step)."""
+    from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv
+    n, f = 60, 16
+    g, ei, w = _graph(n, 321, True)
+    xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    gr, gi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    torch.manual_seed(3)
+    weight = torch.empty(k + 1, f, f).uniform_(-0.3, 0.3)
+    bias = torch.empty(f).uniform_(-0.5, 0.5)
+
+    def body(rank, exchange):
+        layer = ShardedMagNetConv(f, f, k, 0.25, n, ei, w, layout=layout, phases=phases, return_chunks=chunks,
+                                  exchange=exchange, kernels=C.KERNELS, operator_rows=C.oracle_operator_rows(ei, w, n, 0.25))
+        with torch.no_grad():
+            layer.weight.copy_(weight)
+            layer.bias.copy_(bias)
+        plan = layer.plan
+        outs = C.sharded_magnetic_step(layer, plan.shard_rows(xr), plan.shard_rows(xi), plan.shard_rows(gr), plan.shard_rows(gi))
+        return plan, outs
+
+    res = C.run_ranks_as_threads(world, body)
+    c, d = xr.clone().requires_grad_(), xi.clone().requires_grad_()
+    wt, bs = weight.clone().requires_grad_(), bias.clone().requires_grad_()
+    op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0)
+    w_r, w_i = R.magnet_conv(c, d, op, wt, bs, duplicate=False)
+    ((w_r * gr).sum() + (w_i * gi).sum()).backward()
+    want = [w_r.detach(), w_i.detach(), c.grad, d.grad]
+    for plan, outs in res:
+        for got, ref in zip(outs[:4], want):
+            assert float((got[:plan.n_local] - ref[plan.lo:plan.hi]).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+            assert float(got[plan.n_local:].abs().sum()) == 0
+        assert float((outs[4] - wt.grad).abs().max()) <= 2e-6 * max(1.0, float(wt.grad.abs().max()))
+        assert float((outs[5] - bs.grad).abs().max()) <= 2e-6 * max(1.0, float(bs.grad.abs().max()))
+    with pytest.raises(ZeroDivisionError):                  # a failing rank releases the others and is re-raised
+        C.run_ranks_as_threads(3, lambda rank, ex: (1 // (rank - 1), ex.all_reduce(torch.ones(1)))[1])
+
+
 def _digcn_worker(rank, world, port, n, f, phases, block, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))   # the oracle runs in every rank: no oversubscription
