@@ -44,7 +44,8 @@ const char* pygsd_last_error(void);
  *             + beta * Z[r, :]
  *   scale_r = 1                               (mean == 0)
  *           = 1 / max(rowptr[r+1]-rowptr[r],1) (mean != 0)
- *   val == NULL means all ones; Z == NULL means no beta term.
+ *   val == NULL means all ones; Z == NULL means no beta term; ldz == 0 broadcasts ONE row of Z to every output
+ *   row (a bias vector added in the epilogue: DiGCNConv.update, nn/directed/DiGCNConv.py:90-93).
  *
  * Replaces MessagePassing.propagate(edge_index, x=..., norm=|edge_weight=...) with
  * message() = norm.view(-1,1) * x_j and aggr in {add, mean}:
@@ -346,6 +347,8 @@ int pygsd_complex_relu_bwd_f32(const float* real, const float* g_real, const flo
  * Replaces the four matmuls per Chebyshev order, the out_real = rr - ii / out_imag = ir + ri
  * combination and the in-place bias adds of nn/directed/MagNetConv.py:189-192,198-211,217-247
  * (nn/general/MSConv.py:185-230), and their autograd backward.
+ * ldg (backward): row stride of g_real / g_imag in elements; 0 = ONE row of f_out values broadcast to every node
+ * (the upstream gradient of a loss that sums the outputs over the nodes: nothing [N, f_out] is materialised).
  * pygsd_magnetic_dense_supported: 1 if (f_in, f_out, k1) is covered by the fused kernels
  * (multiples of 16, f_out in {16,32,48,64,128}, f_in < 64 or a multiple of 64, k1 <= 4).
  * ------------------------------------------------------------------------------------------- */
@@ -357,7 +360,7 @@ int pygsd_magnetic_dense_fwd_f32(const float* const* a, const float* const* b, i
 int pygsd_magnetic_dense_bwd_workspace(int32_t n_rows, int32_t f_in, int32_t f_out, int32_t k1,
                                        size_t* bytes);
 int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* const* b, int32_t k1,
-                                 const float* w, const float* g_real, const float* g_imag,
+                                 const float* w, const float* g_real, const float* g_imag, int64_t ldg,
                                  float* const* da, float* const* db, float* dw, float* dbias,
                                  int32_t n_rows, int32_t f_in, int32_t f_out,
                                  void* workspace, size_t workspace_bytes, void* stream);

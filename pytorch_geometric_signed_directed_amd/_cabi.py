@@ -100,7 +100,7 @@ PROTOTYPES = {
                                                c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "pygsd_magnetic_dense_bwd_workspace": (c_int32, [c_int32, c_int32, c_int32, c_int32,
                                                      ctypes.POINTER(c_size_t)]),
-    "pygsd_magnetic_dense_bwd_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+    "pygsd_magnetic_dense_bwd_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                c_int32, c_void_p, c_size_t, c_void_p]),
     "pygsd_id_range_i64": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),

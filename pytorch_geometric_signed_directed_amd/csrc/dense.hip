@@ -124,8 +124,9 @@ struct DenseBwdArgs {
     const float* b[kMaxOrder];
     float* da[kMaxOrder];
     float* db[kMaxOrder];
-    const float* gr;     // [n][f_out]
+    const float* gr;     // [n][f_out], row stride ldg (0: ONE row broadcast to every node -- the gradient of a sum)
     const float* gi;
+    int64_t ldg;
     const float* w;      // [k1][f_in][f_out]
     float* partial;      // [n_partials][k1 * f_in * f_out + f_out]
     int32_t n_rows, f_in, f_out, k1;
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
         //      behind this tile's dA / dB stores -------------------------------------------------------
         const bool lrow_live = r0 + i < p.n_rows;
         const int lrow = lrow_live ? r0 + i : p.n_rows - 1;
-        const float* grp = p.gr + static_cast<int64_t>(lrow) * p.f_out + 4 * g;
-        const float* gip = p.gi + static_cast<int64_t>(lrow) * p.f_out + 4 * g;
+        const float* grp = p.gr + static_cast<int64_t>(lrow) * p.ldg + 4 * g;
+        const float* gip = p.gi + static_cast<int64_t>(lrow) * p.ldg + 4 * g;
         float4 xg[NTO], yg[NTO];
 #pragma unroll
         for (int nt = 0; nt < NTO; ++nt) {
@@ -292,8 +293,8 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
                 const int64_t ro = static_cast<int64_t>(live ? row : 0);
 #pragma unroll
                 for (int nt = 0; nt < NTO; ++nt) {
-                    const float x = live ? p.gr[ro * p.f_out + nt * 16 + i] : 0.f;
-                    const float y = live ? p.gi[ro * p.f_out + nt * 16 + i] : 0.f;
+                    const float x = live ? p.gr[ro * p.ldg + nt * 16 + i] : 0.f;
+                    const float y = live ? p.gi[ro * p.ldg + nt * 16 + i] : 0.f;
                     pb[nt] = x + y;
                     mb[nt] = y - x;
                 }
@@ -507,7 +508,7 @@ extern "C" int pygsd_magnetic_dense_bwd_workspace(int32_t n_rows, int32_t f_in, 
 }
 
 extern "C" int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* const* b, int32_t k1,
-                                            const float* w, const float* g_real, const float* g_imag,
+                                            const float* w, const float* g_real, const float* g_imag, int64_t ldg,
                                             float* const* da, float* const* db, float* dw, float* dbias,
                                             int32_t n_rows, int32_t f_in, int32_t f_out, void* workspace,
                                             size_t workspace_bytes, void* stream)
@@ -518,6 +519,8 @@ extern "C" int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* 
     PYGSD_REQUIRE(a && b && w && g_real && g_imag && da && db && dw && dbias && workspace,
                   "pygsd_magnetic_dense_bwd_f32: null pointer");
     PYGSD_REQUIRE(aligned16(g_real) && aligned16(g_imag), "pygsd_magnetic_dense_bwd_f32: gradients not 16-byte aligned");
+    PYGSD_REQUIRE(ldg == 0 || (ldg >= f_out && ldg % 4 == 0), "pygsd_magnetic_dense_bwd_f32: ldg must be 0 (one broadcast row) "
+                  "or a 16-byte aligned row stride >= f_out (got %lld)", static_cast<long long>(ldg));
     size_t need = 0;
     pygsd_magnetic_dense_bwd_workspace(n_rows, f_in, f_out, k1, &need);
     PYGSD_REQUIRE(workspace_bytes >= need, "pygsd_magnetic_dense_bwd_f32: workspace too small (%zu < %zu)",
@@ -527,7 +530,7 @@ extern "C" int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* 
         PYGSD_REQUIRE(a[k] && b[k] && da[k] && db[k], "pygsd_magnetic_dense_bwd_f32: operand %d null", k);
         args.a[k] = a[k]; args.b[k] = b[k]; args.da[k] = da[k]; args.db[k] = db[k];
     }
-    args.gr = g_real; args.gi = g_imag; args.w = w; args.partial = static_cast<float*>(workspace);
+    args.gr = g_real; args.gi = g_imag; args.ldg = ldg; args.w = w; args.partial = static_cast<float*>(workspace);
     args.n_rows = n_rows; args.f_in = f_in; args.f_out = f_out; args.k1 = k1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_DENSE_BWD, s);

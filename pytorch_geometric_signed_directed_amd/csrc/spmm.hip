@@ -702,7 +702,7 @@ extern "C" int pygsd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, con
     PYGSD_REQUIRE(n_rows >= 0 && n_feat >= 0, "pygsd_spmm_csr_f32: negative size");
     if (n_rows == 0 || n_feat == 0) return 0;
     PYGSD_REQUIRE(rowptr && col && X && Y, "pygsd_spmm_csr_f32: null pointer");
-    PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat),
+    PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat || ldz == 0),
                   "pygsd_spmm_csr_f32: row stride smaller than n_feat");
     SpmmArgs a{rowptr, col, val, nullptr, X, nullptr, Y, nullptr, Z, nullptr,
                ldx, ldy, ldz, n_rows, n_feat, alpha, beta, mean, 0};
@@ -720,7 +720,7 @@ extern "C" int pygsd_spmm_csr_bf16(const int32_t* rowptr, const int32_t* col, co
     PYGSD_REQUIRE(n_feat % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (!Z || ldz % 8 == 0),
                   "pygsd_spmm_csr_bf16: n_feat and row strides must be multiples of 8 (16-byte rows)");
     PYGSD_REQUIRE(aligned16(X) && aligned16(Y) && (!Z || aligned16(Z)), "pygsd_spmm_csr_bf16: pointers must be 16-byte aligned");
-    PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat),
+    PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat || ldz == 0),
                   "pygsd_spmm_csr_bf16: row stride smaller than n_feat");
     SpmmBf16Args a{rowptr, col, val, static_cast<const uint16_t*>(X), static_cast<uint16_t*>(Y),
                    static_cast<const uint16_t*>(Z), ldx, ldy, ldz, n_rows, n_feat, alpha, beta, mean, 0};
@@ -738,7 +738,7 @@ extern "C" int pygsd_spmm_csr_bf16_acc_f32(const int32_t* rowptr, const int32_t*
                   "pygsd_spmm_csr_bf16_acc_f32: n_feat / ldx multiples of 8, fp32 row strides multiples of 4");
     PYGSD_REQUIRE(aligned16(X) && aligned16(Y) && (!Z || aligned16(Z)),
                   "pygsd_spmm_csr_bf16_acc_f32: pointers must be 16-byte aligned");
-    PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat),
+    PYGSD_REQUIRE(ldx >= n_feat && ldy >= n_feat && (!Z || ldz >= n_feat || ldz == 0),
                   "pygsd_spmm_csr_bf16_acc_f32: row stride smaller than n_feat");
     SpmmBf16Args a{rowptr, col, val, static_cast<const uint16_t*>(X), reinterpret_cast<uint16_t*>(Y),
                    reinterpret_cast<const uint16_t*>(Z), ldx, ldy, ldz, n_rows, n_feat, alpha, beta, 0, 1};

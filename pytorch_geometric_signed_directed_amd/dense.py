@@ -49,7 +49,12 @@ def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor,
     k1, f_in, f_out = weight.shape
     a = [t.contiguous() for t in a]
     b = [t.contiguous() for t in b]
-    g_r, g_i = g_r.contiguous(), g_i.contiguous()
+    if g_r.size(0) > 1 and g_r.stride(0) == 0 and g_i.stride(0) == 0:
+        # one row broadcast to every node (the gradient of a loss that sums over the nodes arrives as an expanded
+        # tensor): hand the kernel that row with a zero row stride instead of materialising two [N, F] copies
+        g_r, g_i, ldg = g_r[:1].contiguous(), g_i[:1].contiguous(), 0
+    else:
+        g_r, g_i, ldg = g_r.contiguous(), g_i.contiguous(), f_out
     n_full = a[0].size(0)
     n = n_full if rows is None else int(rows)
     dev = weight.device
@@ -70,7 +75,7 @@ def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor,
         check(lib.pygsd_magnetic_dense_bwd_workspace(n, f_in, f_out, k1, ctypes.byref(need)),
               "pygsd_magnetic_dense_bwd_workspace")
         ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
-        check(lib.pygsd_magnetic_dense_bwd_f32(_ptr_array(a), _ptr_array(b), k1, ptr(w), ptr(g_r), ptr(g_i),
+        check(lib.pygsd_magnetic_dense_bwd_f32(_ptr_array(a), _ptr_array(b), k1, ptr(w), ptr(g_r), ptr(g_i), ldg,
                                                _ptr_array(da), _ptr_array(db), ptr(dw), ptr(dbias), n, f_in,
                                                f_out, ptr(ws), need.value, stream_ptr()),
               "pygsd_magnetic_dense_bwd_f32")
@@ -171,19 +176,24 @@ class _TallLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.matmul(g, weight.t())
         if ctx.needs_input_grad[1]:
-            n, slab = x.size(0), _TallLinear.SLAB
-            s = n // slab
-            if s >= 8:
-                x = x.contiguous()          # column slices of a wider matrix: one copy beats the skinny GEMM
-                head = s * slab
-                gw = torch.bmm(x[:head].view(s, slab, -1).transpose(1, 2), g[:head].view(s, slab, -1)).sum(0)
-                if head < n:
-                    gw = gw + x[head:].t() @ g[head:]
-            else:
-                gw = x.t() @ g
+            gw = tall_gram(x, g)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)
         return gx, gw, gb
+
+
+def tall_gram(x: Tensor, g: Tensor) -> Tensor:
+    """x^T g for tall x [N, F_in], g [N, F_out] (N ~ 10^5..10^6): batched split-K over 4096-row slabs (see _TallLinear)."""
+    n, slab = x.size(0), _TallLinear.SLAB
+    s = n // slab
+    if s < 8:
+        return x.t() @ g
+    x, g = x.contiguous(), g.contiguous()   # column slices of a wider matrix: one copy beats the skinny GEMM
+    head = s * slab
+    gw = torch.bmm(x[:head].view(s, slab, -1).transpose(1, 2), g[:head].view(s, slab, -1)).sum(0)
+    if head < n:
+        gw = gw + x[head:].t() @ g[head:]
+    return gw
 
 
 def tall_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:

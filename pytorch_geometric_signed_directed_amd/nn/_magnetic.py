@@ -118,7 +118,7 @@ class MagneticOperator:
     def pattern(self):
         """Generic COO-based pattern (both CSR orientations by stable sort) -- only built on demand."""
         if self._pattern is None:
-            self._pattern = Pattern(self.coo()[0], self.n, self.n, "source_to_target")
+            self._pattern = Pattern(self.coo()[0], self.n, self.n, "source_to_target", validate=False)   # built here
         return self._pattern
 
     def reference_format(self):

@@ -50,20 +50,21 @@ class DGCNConv(MessagePassing):
                 src_index, src_weight = edge_index, edge_weight
                 edge_index, edge_weight = gcn_norm(edge_index, edge_weight, n, self.improved,
                                                    self.add_self_loops, x.dtype)
+                # gcn_norm range-checked the ids it was given: its output needs no second device -> host read
                 if not self.cached and not (src_weight is not None and src_weight.requires_grad):
-                    pattern = Pattern(edge_index, n, n, self.flow)
+                    pattern = Pattern(edge_index, n, n, self.flow, validate=False)
                     self._memo_store(src_index, src_weight, n, edge_weight, pattern)
                 if self.cached:
                     # one shared instance called with several operators keeps the FIRST one
                     # (DGCNConv.py:71-81)
                     self._cached_edge_index = (edge_index, edge_weight)
-                    self._cached_pattern = Pattern(edge_index, n, n, self.flow)
+                    self._cached_pattern = Pattern(edge_index, n, n, self.flow, validate=False)
                     pattern = self._cached_pattern
             else:
                 edge_index, edge_weight = cache[0], cache[1]
                 pattern = self._cached_pattern
         if pattern is None:
-            pattern = Pattern(edge_index, n, n, self.flow)
+            pattern = Pattern(edge_index, n, n, self.flow, validate=not self.normalize)
         return spmm(pattern, x, edge_weight)
 
     # cached=False (the default) re-normalises and re-sorts on every call in the reference (DGCNConv.py:71-81).

@@ -66,7 +66,9 @@ class Conv_Base(MessagePassing):
                                                        self.add_self_loops, x.dtype)
             else:
                 edge_index, edge_weight = self._normalised(edge_index, edge_weight, n, x.dtype)
-        pattern = GLOBAL_PATTERNS.get(edge_index, n, n, self.flow)
+        # a normalised edge list comes out of conv_norm_rw, which range-checked the ids it was given: no second
+        # device -> host read for the pattern (one synchronisation per uncached call, not two)
+        pattern = GLOBAL_PATTERNS.get(edge_index, n, n, self.flow, validate=not self.normalize)
         return spmm(pattern, x, edge_weight)
 
     def message(self, x_j: Tensor, edge_weight: Optional[Tensor]) -> Tensor:

@@ -15,7 +15,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn import Parameter
 
-from ..dense import tall_linear
+from .. import _cabi
+from ..dense import tall_gram, tall_linear
+from ..sparse import _spmm_raw, spmm_rows_into
 from .directed.complex_relu import complex_relu_layer
 from .directed.DGCNConv import DGCNConv
 from .directed.DiGCNConv import DiGCNConv
@@ -192,6 +194,54 @@ class DiGCN_node_classification(nn.Module):
         return F.log_softmax(self.conv2(x, edge_index, edge_weight), dim=1)
 
 
+class _InceptionBlockFn(torch.autograd.Function):
+    """The whole DiGCN inception block as one autograd node (fixed operator values):
+        forward   P = x [W_ln^T | W_1 | W_2] + [b_ln | 0 | 0]    ONE GEMM (x read once, the Linear's bias in its epilogue)
+                  x0 = P[:, :F] ;  x_k = S_k^T P[:, kF:(k+1)F] + b_k    the HIP SpMM on column slices, the conv bias
+                                                                        added in its epilogue (Z row with stride 0)
+        backward  dP_k = S_k dx_k  written by the SpMM straight into the column halves of ONE [N, 2F] buffer;
+                  dx = dx0 W_ln + [dP_1 | dP_2] [W_1 | W_2]^T   two GEMMs, the second accumulating into the first;
+                  dW_ln = x^T dx0, [dW_1 | dW_2] = x^T [dP_1 | dP_2]   split-K; the three bias gradients are column sums.
+    Replaces three GEMMs + three bias passes forward and three GEMMs + two gradient-accumulation passes + three skinny
+    weight GEMMs backward (reference: DiGCN_Inception_Block.py:44-46, DiGCNConv.py:66,86-93)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ln_t, b_ln, w1, b1, w2, b2, pat1, ew1, pat2, ew2):
+        f = w1.size(1)
+        wcat = torch.cat([w_ln_t, w1, w2], dim=1)
+        if b_ln is not None:
+            bcat = torch.cat([b_ln, b_ln.new_zeros(2 * f)])
+            p = torch.addmm(bcat, x, wcat)
+        else:
+            p = x @ wcat
+        v1, v2 = pat1.values_for(ew1, "fwd"), pat2.values_for(ew2, "fwd")
+        x1 = _spmm_raw(pat1.fwd, v1, p[:, f:2 * f], None, 1.0, 0.0, False, b1)
+        x2 = _spmm_raw(pat2.fwd, v2, p[:, 2 * f:], None, 1.0, 0.0, False, b2)
+        ctx.save_for_backward(x, wcat)
+        ctx.ops = (pat1, ew1, pat2, ew2)
+        ctx.has_bias = (b_ln is not None, b1 is not None, b2 is not None)
+        return p[:, :f], x1, x2
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g0, g1, g2):
+        x, wcat = ctx.saved_tensors
+        pat1, ew1, pat2, ew2 = ctx.ops
+        f = wcat.size(1) // 3
+        g0, g1, g2 = g0.contiguous(), g1.contiguous(), g2.contiguous()
+        dp = torch.empty((x.size(0), 2 * f), dtype=x.dtype, device=x.device)
+        spmm_rows_into(pat1.bwd, pat1.values_for(ew1, "bwd"), g1, dp[:, :f])
+        spmm_rows_into(pat2.bwd, pat2.values_for(ew2, "bwd"), g2, dp[:, f:])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.addmm(g0 @ wcat[:, :f].t(), dp, wcat[:, f:].t())
+        dw_ln_t = tall_gram(x, g0)
+        dw12 = tall_gram(x, dp)
+        hb = ctx.has_bias
+        return (dx, dw_ln_t, g0.sum(0) if hb[0] else None, dw12[:, :f], g1.sum(0) if hb[1] else None,
+                dw12[:, f:], g2.sum(0) if hb[2] else None, None, None, None, None)
+
+
 class DiGCN_InceptionBlock(nn.Module):
     """nn/directed/DiGCN_Inception_Block.py:9-47: x0 = Linear(x), x1 / x2 = DiGCNConv on the first- /
     second-order proximity operators."""
@@ -209,8 +259,20 @@ class DiGCN_InceptionBlock(nn.Module):
         self.conv2.reset_parameters()
 
     def forward(self, x, edge_index, edge_weight, edge_index2, edge_weight2):
-        x0 = tall_linear(x, self.ln.weight.t(), self.ln.bias) if x.dim() == 2 else self.ln(x)
-        return x0, self.conv1(x, edge_index, edge_weight), self.conv2(x, edge_index2, edge_weight2)
+        f = self.conv1.out_channels
+        quantum = 8 if x.dtype == torch.bfloat16 else 4        # 16-byte column slices for the vector SpMM
+        fused = (x.dim() == 2 and x.is_cuda and f % quantum == 0 and edge_weight is not None and edge_weight2 is not None
+                 and not edge_weight.requires_grad and not edge_weight2.requires_grad
+                 and x.dtype in (torch.float32, torch.bfloat16) and x.dtype == self.conv1.weight.dtype)
+        if not fused:
+            x0 = tall_linear(x, self.ln.weight.t(), self.ln.bias) if x.dim() == 2 else self.ln(x)
+            return x0, self.conv1(x, edge_index, edge_weight), self.conv2(x, edge_index2, edge_weight2)
+        _cabi.require_gpu(x, edge_index, edge_weight, edge_index2, edge_weight2)
+        n = x.size(0)
+        pat1, ew1 = self.conv1._operator(edge_index, edge_weight, n)     # (cached-operator semantics of DiGCNConv)
+        pat2, ew2 = self.conv2._operator(edge_index2, edge_weight2, n)
+        return _InceptionBlockFn.apply(x, self.ln.weight.t(), self.ln.bias, self.conv1.weight, self.conv1.bias,
+                                       self.conv2.weight, self.conv2.bias, pat1, ew1, pat2, ew2)
 
 
 class DiGCN_Inception_Block_node_classification(nn.Module):

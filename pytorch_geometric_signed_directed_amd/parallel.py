@@ -764,7 +764,8 @@ class _ShardedMagneticFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         weight = saved[0]
         ta, tb = list(saved[1:1 + k1]), list(saved[1 + k1:1 + 2 * k1])
-        g_r, g_i = g_r.contiguous(), g_i.contiguous()
+        # (an expanded upstream gradient -- the loss summed the outputs -- stays un-materialised: dense_bwd_raw hands the
+        # kernel its one row)
         # upstream gradient on the PAD rows is not part of the graph (the forward zeroes those outputs): the dense
         # backward runs on the real rows only -- dW, db see no pad row whatever the loss or the stacking -- and hands
         # back zero gradient rows for the pad

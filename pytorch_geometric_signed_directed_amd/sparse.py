@@ -171,7 +171,11 @@ class Pattern:
     flow = 'target_to_source': gather = edge_index[1], scatter = edge_index[0]  (Conv_Base)
     """
 
-    def __init__(self, edge_index: Tensor, n_in: int, n_out: int, flow: str = "source_to_target"):
+    def __init__(self, edge_index: Tensor, n_in: int, n_out: int, flow: str = "source_to_target",
+                 validate: bool = True):
+        """validate=False: the caller derived `edge_index` from ids that were range-checked already (the output of
+        gcn_norm / conv_norm_rw / the operator builds) -- skips the device -> host read of the node-id check, the only
+        synchronisation of a pattern build."""
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
         if flow not in ("source_to_target", "target_to_source"):
@@ -183,7 +187,7 @@ class Pattern:
         # The pattern does NOT keep the caller's edge_index (nor views of it) alive: everything later derived
         # from the COO list -- the by-source CSR, the int32 COO operands of the SDDMM, per-entry degrees -- is
         # rebuilt from the by-target CSR (`coo_from_csr`), so a cached Pattern never pins the user's tensor.
-        self.fwd = csr_from_coo(edge_index[s], edge_index[g], self.n_out, self.n_in)
+        self.fwd = csr_from_coo(edge_index[s], edge_index[g], self.n_out, self.n_in, validate=validate)
         self._bwd: Optional[CSR] = None
         self._coo32: Optional[Tuple[Tensor, Tensor]] = None
         self._inv_deg: Optional[Tensor] = None
@@ -250,7 +254,7 @@ class Pattern:
 # raw launches
 # ------------------------------------------------------------------------------------------------
 def _spmm_bf16_raw(csr: CSR, val: Optional[Tensor], x: Tensor, ldx: int, z: Optional[Tensor], alpha: float,
-                   beta: float, mean: bool) -> Tensor:
+                   beta: float, mean: bool, bias: Optional[Tensor] = None) -> Tensor:
     """bf16-storage SpMM (fp32 values / accumulation).  Shapes the 16-byte-row kernel cannot address
     are widened to fp32, run through the fp32 kernel and rounded back -- still the HIP path."""
     f = x.size(1)
@@ -260,8 +264,13 @@ def _spmm_bf16_raw(csr: CSR, val: Optional[Tensor], x: Tensor, ldx: int, z: Opti
         z, ldz = _rows(z.to(torch.bfloat16))
         ok = ok and ldz % 8 == 0 and z.data_ptr() % 16 == 0
         zp = ptr(z)
+    elif bias is not None:                      # one row for every output row: Z with a zero row stride
+        bias = bias.detach().to(torch.bfloat16).contiguous()
+        ok = ok and bias.data_ptr() % 16 == 0
+        zp, beta = ptr(bias), 1.0
     if not ok:
-        y32 = _spmm_raw(csr, val, x.float(), None if z is None else z.float(), alpha, beta, mean)
+        y32 = _spmm_raw(csr, val, x.float(), None if z is None else z.float(), alpha, beta, mean,
+                        None if bias is None else bias.float())
         return y32.to(torch.bfloat16)
     y = torch.empty((csr.n_rows, f), dtype=torch.bfloat16, device=x.device)
     with torch.cuda.device(x.device):
@@ -272,13 +281,17 @@ def _spmm_bf16_raw(csr: CSR, val: Optional[Tensor], x: Tensor, ldx: int, z: Opti
 
 
 def _spmm_raw(csr: CSR, val: Optional[Tensor], x: Tensor, z: Optional[Tensor], alpha: float, beta: float,
-              mean: bool) -> Tensor:
-    _cabi.require_gpu(x, z, val)
+              mean: bool, bias: Optional[Tensor] = None) -> Tensor:
+    """bias: a [F] vector added to every output row in the kernel's epilogue (Z read with a zero row stride);
+    exclusive with z."""
+    _cabi.require_gpu(x, z, val, bias)
+    if bias is not None and z is not None:
+        raise ValueError("spmm: bias and z are exclusive")
     x, ldx = _rows(x)
     if x.dtype == torch.bfloat16 and csr.nnz > 0 and x.size(1) > 0 and csr.n_rows > 0:
         if x.size(0) != csr.n_cols:
             raise ValueError(f"x has {x.size(0)} rows, operator expects {csr.n_cols}")
-        return _spmm_bf16_raw(csr, val, x, ldx, z, alpha, beta, mean)
+        return _spmm_bf16_raw(csr, val, x, ldx, z, alpha, beta, mean, bias)
     if x.size(0) != csr.n_cols:
         raise ValueError(f"x has {x.size(0)} rows, operator expects {csr.n_cols}")
     f = x.size(1)
@@ -289,16 +302,23 @@ def _spmm_raw(csr: CSR, val: Optional[Tensor], x: Tensor, z: Optional[Tensor], a
         # fallback walks a row's neighbours one by one: 2.9 ms against ~1.1 ms at 2M nodes / 52M entries / F = 5)
         pad = (0, 4 - f % 4)
         y = _spmm_raw(csr, val, torch.nn.functional.pad(x, pad), None if z is None else torch.nn.functional.pad(z, pad),
-                      alpha, beta, mean)
+                      alpha, beta, mean, None if bias is None else torch.nn.functional.pad(bias, pad))
         return y[:, :f]
     if csr.nnz == 0 or f == 0 or csr.n_rows == 0:  # edgeless operator: nothing to gather
         y = torch.zeros((csr.n_rows, f), dtype=x.dtype, device=x.device)
+        if bias is not None:
+            return y.add_(bias.to(y.dtype))
         return y if z is None else y.add_(z, alpha=beta)
     y = torch.empty((csr.n_rows, f), dtype=torch.float32, device=x.device)
     zp, ldz = None, 0
     if z is not None:
         z, ldz = _rows(z)
         zp = ptr(z)
+    elif bias is not None:
+        bias = bias.detach().float().contiguous()
+        if bias.data_ptr() % 16:
+            bias = bias.clone()
+        zp, beta = ptr(bias), 1.0
     with torch.cuda.device(x.device):
         hubs, keep = _long_rows_arg(csr, f, False)
         check(_cabi.lib().pygsd_spmm_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(val), ptr(x), ldx, ptr(y),
@@ -609,11 +629,11 @@ class PatternCache:
     def __init__(self, capacity: int = 8):
         self._memo = TensorMemo(capacity)
 
-    def get(self, edge_index: Tensor, n_in: int, n_out: int, flow: str) -> Pattern:
+    def get(self, edge_index: Tensor, n_in: int, n_out: int, flow: str, validate: bool = True) -> Pattern:
         key = (int(n_in), int(n_out), flow)
         pat = self._memo.get((edge_index,), key)
         if pat is None:
-            pat = self._memo.put((edge_index,), key, Pattern(edge_index, n_in, n_out, flow))
+            pat = self._memo.put((edge_index,), key, Pattern(edge_index, n_in, n_out, flow, validate))
         return pat
 
     def clear(self):

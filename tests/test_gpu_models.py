@@ -308,3 +308,52 @@ def test_digcl_model():
     close(m.loss(z1, z2, batch_size=16), g["loss_batched"])
     m.loss(z1, z2).backward()
     assert m.encoder.conv[0].lin.weight.grad.abs().sum() > 0
+
+
+def test_c1_magnet_node_classification_in_its_stated_shape():
+    """BASELINE configs[0] as stated (examples/magnet_node.py:22-29,56-62; MagNet_node_classification.py:66-92):
+    MagNet_node_classification(hidden=16, K=1, layer=2, activation off, dropout off) with `cached=False` (the operator
+    is rebuilt by BOTH layers of every forward -- the fused build), the raw 2879-wide first layer (Clenshaw route) and
+    X_img = X_real (one leaf feeding both inputs), on a DSBM of Cora-ML size (cora_ml.npz itself is not shipped:
+    N = 2995, E = 8416, 7 classes, sparse row-normalised bag-of-words features).  Train-mode forward, NLL on a train
+    mask, backward: log-probabilities and the gradient of every parameter and of the input against the oracle's
+    reference op sequence."""
+    import torch.nn.functional as F
+    from oracle import ref_layers as R
+    from pytorch_geometric_signed_directed_amd import graphs
+    from pytorch_geometric_signed_directed_amd.nn import MagNet_node_classification
+    n, e, f_in, classes, hidden = 2995, 8416, 2879, 7, 16
+    ei_np, labels, _ = graphs.dsbm_for_edges(n, e, k=classes, seed=21)
+    ei = torch.from_numpy(ei_np)
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(n, f_in, generator=g) < 0.0175).float()
+    x = x / x.sum(1, keepdim=True).clamp(min=1.0)
+    y = torch.from_numpy(labels)
+    mask = torch.rand(n, generator=g) < 0.2
+    torch.manual_seed(21)
+    model = MagNet_node_classification(q=0.25, K=1, num_features=f_in, hidden=hidden, label_dim=classes)
+    assert not model.Chebs[0].cached and not model.activation and not model.dropout
+    with torch.no_grad():
+        for cheb in model.Chebs:
+            cheb.bias.uniform_(-0.2, 0.2)
+    # oracle (CPU, reference op sequence)
+    prm = {k: v.detach().clone().requires_grad_() for k, v in model.named_parameters()}
+    xo = x.clone().requires_grad_()
+    op = R.magnet_operator(ei, None, n, 0.25, "sym", 2.0)
+    r1, i1 = R.magnet_conv(xo, xo, op, prm["Chebs.0.weight"], prm["Chebs.0.bias"], duplicate=False)
+    r2, i2 = R.magnet_conv(r1, i1, op, prm["Chebs.1.weight"], prm["Chebs.1.bias"], duplicate=False)
+    logits = torch.cat((r2, i2), dim=-1) @ prm["Conv.weight"][:, :, 0].t() + prm["Conv.bias"]
+    want = F.log_softmax(logits, dim=1)
+    F.nll_loss(want[mask], y[mask]).backward()
+    # the layers on the GPU
+    model.to(D).train()
+    xd = x.to(D).requires_grad_()
+    eid = ei.to(D)
+    got = model(xd, xd, edge_index=eid, edge_weight=None)
+    F.nll_loss(got[mask.to(D)], y.to(D)[mask.to(D)]).backward()
+    close(got, want.detach(), what="C1 log-probabilities")
+    close(xd.grad, xo.grad, what="C1 d loss / d X (real and imaginary inputs share the leaf)")
+    for name, p in model.named_parameters():
+        close(p.grad, prm[name].grad, norm=True, what=f"C1 d {name}")
+    # cached=False: both layers built their operator during the forward, each through the fused build
+    assert all(cheb._operator is not None and cheb._operator._off_index is None for cheb in model.Chebs)

@@ -56,6 +56,26 @@ def close(got, want, tol=TOL, norm=False, what=""):
     return abs_err
 
 
+def close_arbitrated(got, reference_sequence, truth64, tol=TOL, what=""):
+    """For checks whose fp32 REFERENCE sits within a hair of the bar itself: float64 is the arbiter.
+
+        err(got, float64)  <=  max(tol, 1.5 * err(reference sequence in fp32, float64))      (err = |d| / (1 + |want|))
+
+    i.e. the HIP result must be inside the 1e-5 bar around the TRUE value, or -- where fp32 arithmetic itself cannot
+    reach that (long sums of O(10) terms) -- no more than 1.5x as far from the truth as the reference's own fp32 op
+    sequence is.  Both errors are recorded."""
+    abs_err, mixed, rel, top = errors(got, truth64)
+    _, ref_mixed, _, _ = errors(reference_sequence, truth64)
+    bar = max(tol, 1.5 * ref_mixed)
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    RECORDS.append({"test": test, "what": what + " (float64 arbiter)", "max_abs_err": abs_err, "max_mixed_err": mixed,
+                    "max_norm_rel_err": rel, "max_abs_want": top, "bar": "abs", "tol": bar,
+                    "reference_sequence_mixed_err_vs_f64": ref_mixed})
+    assert mixed <= bar, (f"{what} vs float64: {mixed:.3e} > max({tol}, 1.5 x {ref_mixed:.3e} of the fp32 reference "
+                          f"sequence) (max abs err {abs_err:.3e}, |want| <= {top:.3g})")
+    return abs_err
+
+
 def dump(path=None):
     if not RECORDS:
         return
