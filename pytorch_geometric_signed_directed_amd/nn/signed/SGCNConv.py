@@ -9,8 +9,57 @@ from torch import Tensor
 
 from ... import _cabi
 from ...message_passing import MessagePassing
-from ...dense import tall_linear
-from ...sparse import GLOBAL_PATTERNS, spmm
+from ...dense import tall_gram, tall_linear
+from ...sparse import GLOBAL_PATTERNS, spmm, spmm_rows_into
+
+
+class _SgcnFn(torch.autograd.Function):
+    """Both branches of one SGCNConv as ONE autograd node.  y = x W_big + bias with the columns of W_big ordered
+    [own_b | own_u | a_1 | ... | a_m] (o columns each); the output is written IN PLACE, no concatenation:
+        out[:, half_j] = y_own[:, half_j] + sum_j mean_in(pattern_j, a_j)        (half = 0: balanced, 1: unbalanced)
+    -- the first aggregation of a half reads the own block as the SpMM's Z operand, later ones accumulate.  Backward:
+    g_a_j = mean_in(pattern_j)^T g_out[:, half_j] written into ONE [N, m o] buffer, then
+    dx = g_out W_own^T + g_a W_agg^T (two GEMMs, the second accumulating), dW_big = [x^T g_out | x^T g_a] (split-K),
+    d bias = column sums of g_out.  No element-wise passes, no split / cat in either direction
+    (reference order: aggregate, concatenate, Linear -- SGCNConv.py:101-126)."""
+
+    @staticmethod
+    def forward(ctx, x, w_big, bias, o, spec):
+        n = x.size(0)
+        y = torch.addmm(bias, x, w_big) if bias is not None else x @ w_big
+        out = torch.empty((n, 2 * o), dtype=x.dtype, device=x.device)
+        seen = set()
+        for j, (pat, half) in enumerate(spec):
+            a_j = y[:, (2 + j) * o:(3 + j) * o]
+            dst = out[:, half * o:(half + 1) * o]
+            if half in seen:
+                spmm_rows_into(pat.fwd, None, a_j, dst, accumulate=True, mean=True)
+            else:
+                spmm_rows_into(pat.fwd, None, a_j, dst, mean=True, z=y[:, half * o:(half + 1) * o])
+                seen.add(half)
+        ctx.save_for_backward(x, w_big)
+        ctx.o, ctx.spec, ctx.has_bias = o, spec, bias is not None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, w_big = ctx.saved_tensors
+        o, spec = ctx.o, ctx.spec
+        g = g.contiguous()
+        ga = torch.empty((x.size(0), len(spec) * o), dtype=x.dtype, device=x.device)
+        for j, (pat, half) in enumerate(spec):
+            # backward of the mean: every entry weighs 1 / in-degree of its target (cached per pattern)
+            spmm_rows_into(pat.bwd, pat.values_for(pat.mean_values(), "bwd"), g[:, half * o:(half + 1) * o],
+                           ga[:, j * o:(j + 1) * o])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.addmm(g @ w_big[:, :2 * o].t(), ga, w_big[:, 2 * o:].t())
+        dw = torch.cat([tall_gram(x, g), tall_gram(x, ga)], dim=1)
+        dbias = None
+        if ctx.has_bias:
+            dbias = torch.cat([g.sum(0), g.new_zeros(len(spec) * o)])
+        return dx, dw, dbias, None, None
 
 
 class SGCNConv(MessagePassing):
@@ -56,38 +105,32 @@ class SGCNConv(MessagePassing):
     def _fused(self, x: Tensor, pos_edge_index: Tensor, neg_edge_index: Tensor) -> Tensor:
         """Both branches from ONE GEMM when the Linear does not widen (in_dim >= out_dim): every block of
         lin_b / lin_u becomes a column block of one [F_x, 4 or 6 * out_dim] matrix (zero blocks where a block
-        reads the other half of x), the biases ride on the own-feature blocks, and each mean aggregation adds
-        its result onto the previous block through the SpMM's beta * Z epilogue -- no concatenation, no
-        element-wise adds, one weight-gradient GEMM."""
+        reads the other half of x), the biases ride on the own-feature blocks, and the mean aggregations add their
+        results onto the own blocks inside the SpMM's epilogue, written straight into the two halves of the output
+        (`_SgcnFn`: one autograd node, no concatenation, no element-wise passes, one split-K weight gradient)."""
         f, o, n = self.in_dim, self.out_dim, x.size(0)
         wb, wu = self.lin_b.weight, self.lin_u.weight
-        zeros = wb.new_zeros(f, o)
-        if self.first_aggr:             # columns: own_b | agg_b(pos) | own_u | agg_u(neg)
-            w_big = torch.cat([wb[:, f:].t(), wb[:, :f].t(), wu[:, f:].t(), wu[:, :f].t()], dim=1)
-            own = (0, 2)
-        else:                           # x = [lo | hi]; columns: own_b | pos_b | neg_b | own_u | pos_u | neg_u
-            top = torch.cat([wb[:, 2 * f:].t(), wb[:, :f].t(), zeros, zeros, zeros, wu[:, f:2 * f].t()], dim=1)
-            bot = torch.cat([zeros, zeros, wb[:, f:2 * f].t(), wu[:, 2 * f:].t(), wu[:, :f].t(), zeros], dim=1)
-            w_big = torch.cat([top, bot], dim=0)
-            own = (0, 3)
-        bias = None
-        if self.lin_b.bias is not None:
-            z = self.lin_b.bias.new_zeros(o)
-            blocks = [z] * (w_big.size(1) // o)
-            blocks[own[0]], blocks[own[1]] = self.lin_b.bias, self.lin_u.bias
-            bias = torch.cat(blocks)
-        y = tall_linear(x, w_big, bias).split(o, dim=1)
         pos = GLOBAL_PATTERNS.get(pos_edge_index, n, n, self.flow)
         neg = GLOBAL_PATTERNS.get(neg_edge_index, n, n, self.flow)
-        if self.first_aggr:
-            out_b = spmm(pos, y[1], None, z=y[0], beta=1.0, reduce=self.aggr)
-            out_u = spmm(neg, y[3], None, z=y[2], beta=1.0, reduce=self.aggr)
-        else:
-            out_b = spmm(neg, y[2], None, z=spmm(pos, y[1], None, z=y[0], beta=1.0, reduce=self.aggr), beta=1.0,
-                         reduce=self.aggr)
-            out_u = spmm(neg, y[5], None, z=spmm(pos, y[4], None, z=y[3], beta=1.0, reduce=self.aggr), beta=1.0,
-                         reduce=self.aggr)
-        return torch.cat([out_b, out_u], dim=-1)
+        if self.first_aggr:             # columns: own_b | own_u | agg_b(pos) | agg_u(neg)
+            w_big = torch.cat([wb[:, f:].t(), wu[:, f:].t(), wb[:, :f].t(), wu[:, :f].t()], dim=1)
+            spec = ((pos, 0), (neg, 1))
+        else:                           # x = [lo | hi]; columns: own_b | own_u | pos_b | neg_b | pos_u | neg_u
+            zeros = wb.new_zeros(f, o)
+            top = torch.cat([wb[:, 2 * f:].t(), zeros, wb[:, :f].t(), zeros, zeros, wu[:, f:2 * f].t()], dim=1)
+            bot = torch.cat([zeros, wu[:, 2 * f:].t(), zeros, wb[:, f:2 * f].t(), wu[:, :f].t(), zeros], dim=1)
+            w_big = torch.cat([top, bot], dim=0)
+            spec = ((pos, 0), (neg, 0), (pos, 1), (neg, 1))
+        bias = None
+        if self.lin_b.bias is not None:
+            bias = torch.cat([self.lin_b.bias, self.lin_u.bias, self.lin_b.bias.new_zeros(len(spec) * o)])
+        if o % 4 == 0 and x.dtype == torch.float32 and self.aggr == "mean":
+            return _SgcnFn.apply(x, w_big, bias, o, spec)
+        y = tall_linear(x, w_big, bias).split(o, dim=1)    # widths the 16-byte-row kernels do not slice: composed ops
+        halves = [y[0], y[1]]
+        for j, (pat, half) in enumerate(spec):
+            halves[half] = spmm(pat, y[2 + j], None, z=halves[half], beta=1.0, reduce=self.aggr)
+        return torch.cat(halves, dim=-1)
 
     def forward(self, x: Union[Tensor, Tuple[Tensor, Tensor]], pos_edge_index: Tensor,
                 neg_edge_index: Tensor) -> Tensor:

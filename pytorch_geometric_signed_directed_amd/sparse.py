@@ -433,7 +433,7 @@ def spmm2_rows_into(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tens
 
 def spmm_rows_into(csr: CSR, val: Optional[Tensor], x: Tensor, y: Tensor, row_lo: int = 0,
                    row_hi: Optional[int] = None, alpha: float = 1.0, accumulate: bool = False,
-                   mean: bool = False) -> None:
+                   mean: bool = False, z: Optional[Tensor] = None) -> None:
     """Single-operator form of `spmm2_rows_into`; float32 (F % 4 == 0) or bfloat16 storage (F % 8 == 0, fp32
     values and accumulation).  `mean` divides by the row's entry count and is only meaningful for an operator
     that is NOT split into column blocks."""
@@ -460,7 +460,13 @@ def spmm_rows_into(csr: CSR, val: Optional[Tensor], x: Tensor, y: Tensor, row_lo
     esz = 2 if (bf16 and not mixed) else 4
     py = c_void_p(y.data_ptr() + esz * row_lo * ldy)
     rp = c_void_p(csr.rowptr.data_ptr() + 4 * row_lo)
-    z, ldz, beta = (py, ldy, 1.0) if accumulate else (None, 0, 0.0)
+    if z is not None:
+        # y = alpha * S x + z with z ANOTHER matrix of the output's dtype (own row stride; full height, row_lo = 0)
+        if accumulate or row_lo or z.dtype != y.dtype or z.stride(1) != 1 or z.size(0) != y.size(0):
+            raise ValueError("spmm_rows_into: z comes without accumulate / row offsets and has the output's dtype and height")
+        z, ldz, beta = c_void_p(z.data_ptr()), z.stride(0), 1.0
+    else:
+        z, ldz, beta = (py, ldy, 1.0) if accumulate else (None, 0, 0.0)
     with torch.cuda.device(x.device):
         if mixed:
             check(_cabi.lib().pygsd_spmm_csr_bf16_acc_f32(rp, ptr(csr.col), ptr(val), ptr(x), ldx, py, ldy, z, ldz, n_rows, f,

@@ -176,10 +176,22 @@ def digcn_c5(n=2000000, e=25000000, h=64):
     print("C5", json.dumps(out["C5_digcn_inception_block_1gpu"]), flush=True)
 
 
-magnetic("C2_magnetconv_100k_2M_h64", MagNetConv, 100000, 2000000, 64, 1, False)
-signed_c3()
-magnetic("C4_msconv_1M_20M_h128_K2_1gpu", MSConv, 1000000, 20000000, 128, 2, True)
-magnetic("northstar_magnetconv_1M_20M_h64", MagNetConv, 1000000, 20000000, 64, 1, False)
-digcn_c5()
+ONLY = [t for t in os.environ.get("PYGSD_CONFIGS", "").split(",") if t]      # e.g. PYGSD_CONFIGS=C3,C5
+
+
+def want(tag):
+    return not ONLY or tag in ONLY
+
+
+if want("C2"):
+    magnetic("C2_magnetconv_100k_2M_h64", MagNetConv, 100000, 2000000, 64, 1, False)
+if want("C3"):
+    signed_c3()
+if want("C4"):
+    magnetic("C4_msconv_1M_20M_h128_K2_1gpu", MSConv, 1000000, 20000000, 128, 2, True)
+if want("northstar"):
+    magnetic("northstar_magnetconv_1M_20M_h64", MagNetConv, 1000000, 20000000, 64, 1, False)
+if want("C5"):
+    digcn_c5()
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/configs.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/configs.json" if not ONLY else "gpurun_out/configs_partial.json", "w"), indent=1)
