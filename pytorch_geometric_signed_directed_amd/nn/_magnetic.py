@@ -269,9 +269,20 @@ class MagneticChebConv(MessagePassing):
         _cabi.require_gpu(x_real, x_imag, edge_index, edge_weight)
         if x_real.dtype != torch.float32 or x_imag.dtype != torch.float32:
             raise TypeError(f"{type(self).__name__} computes in float32 on the HIP path; got {x_real.dtype}")
+        if x_real.dim() > 2:
+            # [..., N, F] (the reference's node_dim = -2 propagates and broadcasting matmuls accept leading batch
+            # dimensions): one layer evaluation per sample on the SAME operator -- the first builds (or finds) it,
+            # the others hit the layer's operator memo / cache
+            if x_real.shape != x_imag.shape:
+                raise ValueError("x_real and x_imag must have the same shape")
+            lead = x_real.shape[:-2]
+            flat_r, flat_i = x_real.reshape((-1,) + x_real.shape[-2:]), x_imag.reshape((-1,) + x_imag.shape[-2:])
+            outs = [self.forward(flat_r[b], flat_i[b], edge_index, edge_weight, lambda_max) for b in range(flat_r.size(0))]
+            out_r = torch.stack([o[0] for o in outs]).reshape(lead + outs[0][0].shape)
+            out_i = torch.stack([o[1] for o in outs]).reshape(lead + outs[0][1].shape)
+            return out_r, out_i
         if x_real.dim() != 2 or x_imag.dim() != 2:
-            raise NotImplementedError(f"{type(self).__name__}: the HIP path takes 2-D [N, F] inputs, got "
-                                      f"{tuple(x_real.shape)} (batched [B, N, F] is not implemented)")
+            raise ValueError(f"{type(self).__name__}: inputs must be [N, F] or [..., N, F], got {tuple(x_real.shape)}")
         if self.trainable_q:
             self.q = Parameter(torch.clamp(self.q, 0, 0.25))
 

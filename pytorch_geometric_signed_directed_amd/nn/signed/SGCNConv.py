@@ -84,7 +84,7 @@ class SGCNConv(MessagePassing):
         self.lin_u.reset_parameters()
 
     def _mean_in(self, x_src: Tensor, n_dst: int, edge_index: Tensor) -> Tensor:
-        pat = GLOBAL_PATTERNS.get(edge_index, x_src.size(0), n_dst, self.flow)
+        pat = GLOBAL_PATTERNS.get(edge_index, x_src.size(-2), n_dst, self.flow)
         return spmm(pat, x_src, None, reduce=self.aggr)
 
     def _branch(self, lin, aggregated, own, n):
@@ -94,13 +94,14 @@ class SGCNConv(MessagePassing):
         (reference order: aggregate, concatenate, then Linear; SGCNConv.py:101-119)."""
         f = self.in_dim
         w = lin.weight                                  # [out_dim, (len(aggregated) + 1) * in_dim]
+        lin_fn = tall_linear if own.dim() == 2 else (lambda t, wt, b=None: F.linear(t, wt.t(), b))   # [..., N, F]: broadcast
         if self.in_dim > self.out_dim:
-            out = tall_linear(own, w[:, len(aggregated) * f:].t(), lin.bias)
+            out = lin_fn(own, w[:, len(aggregated) * f:].t(), lin.bias)
             for k, (feat, ei) in enumerate(aggregated):
-                out = out + self._mean_in(tall_linear(feat, w[:, k * f:(k + 1) * f].t()), n, ei)
+                out = out + self._mean_in(lin_fn(feat, w[:, k * f:(k + 1) * f].t()), n, ei)
             return out
         parts = [self._mean_in(feat, n, ei) for feat, ei in aggregated] + [own]
-        return tall_linear(torch.cat(parts, dim=-1), w.t(), lin.bias)
+        return lin_fn(torch.cat(parts, dim=-1), w.t(), lin.bias)
 
     def _fused(self, x: Tensor, pos_edge_index: Tensor, neg_edge_index: Tensor) -> Tensor:
         """Both branches from ONE GEMM when the Linear does not widen (in_dim >= out_dim): every block of
@@ -144,7 +145,7 @@ class SGCNConv(MessagePassing):
         if not isinstance(pos_edge_index, Tensor) or not isinstance(neg_edge_index, Tensor):
             raise NotImplementedError("SGCNConv: only the edge_index (Tensor) path exists on the HIP stack")
         _cabi.require_gpu(x[0], x[1], pos_edge_index, neg_edge_index)
-        n = x[1].size(0)
+        n = x[1].size(-2)
         if self.first_aggr:
             out_b = self._branch(self.lin_b, [(x[0], pos_edge_index)], x[1], n)
             out_u = self._branch(self.lin_u, [(x[0], neg_edge_index)], x[1], n)

@@ -34,9 +34,8 @@ Tensor = torch.Tensor
 def _rows(t: Tensor) -> Tuple[Tensor, int]:
     """Return (tensor with unit inner stride, row stride in elements)."""
     if t.dim() != 2:
-        raise NotImplementedError(f"the HIP path takes 2-D [N, F] feature matrices; got shape {tuple(t.shape)} "
-                                  "(batched [B, N, F] inputs, which the reference's node_dim=-2 propagate accepts, "
-                                  "are not implemented: loop over the batch or fold it into F)")
+        raise NotImplementedError(f"the HIP kernels take 2-D [N, F] feature matrices; got shape {tuple(t.shape)} "
+                                  "(sparse.spmm folds leading batch dimensions into F; this raw entry does not)")
     if t.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError(f"the HIP path stores features as float32 or bfloat16 (fp32 accumulate); got {t.dtype}")
     if t.size(1) > 0 and (t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1))):
@@ -573,6 +572,17 @@ def spmm(pat: Pattern, x: Tensor, w: Optional[Tensor] = None, *, z: Optional[Ten
     MessagePassing.propagate for message = w * x_j."""
     if reduce not in ("add", "sum", "mean"):
         raise ValueError(f"unsupported reduce {reduce!r}")
+    if x.dim() > 2:
+        # [..., N, F]: the reference's node_dim = -2 propagate accepts leading batch dimensions (DGCNConv.py:83-97,
+        # SGCNConv.py:101-119).  The operator acts on the node axis only, so the batch folds into the feature axis:
+        # one SpMM at width B * F, gradients (also w.r.t. the edge values: summed over the batch) through the views
+        lead, n, f = x.shape[:-2], x.size(-2), x.size(-1)
+
+        def fold(t):
+            return t.reshape(-1, t.size(-2), f).permute(1, 0, 2).reshape(t.size(-2), -1)
+        y = spmm(pat, fold(x), w, z=None if z is None else fold(z.expand(lead + (pat.n_out, f))), alpha=alpha, beta=beta,
+                 reduce=reduce)
+        return y.reshape(pat.n_out, -1, f).permute(1, 0, 2).reshape(lead + (pat.n_out, f))
     return _Spmm.apply(x, w, z, pat, float(alpha), float(beta), reduce == "mean")
 
 

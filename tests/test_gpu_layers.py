@@ -216,8 +216,12 @@ def test_node_ids_outside_the_graph_raise_index_error():
         with pytest.raises(IndexError, match="outside"):
             DGCNConv()(x, bad.to(D), None)
     Pattern(ei.to(D), n, n)                       # the valid list still builds
-    with pytest.raises(NotImplementedError, match="2-D"):
-        MagNetConv(8, 8, 1, 0.25, False).to(D)(x.unsqueeze(0), x.unsqueeze(0), ei.to(D))
+    # leading batch dimensions are accepted (one evaluation per sample on one operator): [1, N, F] == [N, F]
+    conv = MagNetConv(8, 8, 1, 0.25, False).to(D)
+    o3, o2 = conv(x.unsqueeze(0), x.unsqueeze(0), ei.to(D)), conv(x, x, ei.to(D))
+    assert o3[0].shape == (1, n, 8) and torch.equal(o3[0][0], o2[0]) and torch.equal(o3[1][0], o2[1])
+    with pytest.raises(ValueError, match="N, F"):
+        conv(x[0], x[0], ei.to(D))
 
 
 @pytest.mark.parametrize("name", golden_names("digcn_"))
@@ -1015,3 +1019,53 @@ def test_sgcn_midsize_all_paths_vs_oracle(first, in_dim, out_dim, bias):
     close(xd.grad, xo.grad.numpy())
     for k, p in layer.named_parameters():
         close(p.grad, prm[k].grad.numpy(), tol=3e-5, norm=True)
+
+
+def test_batched_inputs_match_a_loop_over_the_batch():
+    """[B, N, F] inputs (the reference's node_dim = -2 propagates and broadcasting matmuls accept leading batch
+    dimensions: DGCNConv.py:83-97, DiGCNConv.py:66,86, conv_base.py:111, SGCNConv.py:101-126, MagNetConv.py:196-247):
+    outputs and gradients equal the 2-D layer applied to every sample (itself held to the oracle elsewhere)."""
+    from pytorch_geometric_signed_directed_amd.nn import Conv_Base, DGCNConv, DiGCNConv, MagNetConv, SGCNConv
+    g = torch.Generator().manual_seed(31)
+    n, f, b = 300, 16, 3
+    ei = torch.randint(0, n, (2, 2500), generator=g).to(D)
+    ei2 = torch.randint(0, n, (2, 1500), generator=g).to(D)
+    w = (torch.rand(2500, generator=g) + 0.5).to(D)
+    x = torch.randn(b, n, f, generator=g).to(D)
+    go = torch.randn(b, n, f, generator=g).to(D)
+    torch.manual_seed(31)
+    cases = [("DGCNConv", DGCNConv().to(D), lambda m, t: m(t, ei, w)),
+             ("Conv_Base", Conv_Base(0.5).to(D), lambda m, t: m(t, ei, w)),
+             ("DiGCNConv", DiGCNConv(f, f).to(D), lambda m, t: m(t, ei, w)),
+             ("SGCNConv first", SGCNConv(f, f, first_aggr=True).to(D), lambda m, t: m(t, ei, ei2)),
+             ("SGCNConv narrowing", SGCNConv(f, f // 2, first_aggr=True).to(D), lambda m, t: m(t, ei, ei2))]
+    for name, layer, call in cases:
+        xb = x.clone().requires_grad_()
+        out = call(layer, xb)
+        gsel = torch.cat([go, go.flip(-1)], dim=-1)[..., :out.size(-1)]      # SGCNConv returns 2 * out_dim columns
+        (out * gsel).sum().backward()
+        batched = [p.grad.clone() for p in layer.parameters()]
+        layer.zero_grad(set_to_none=True)
+        xs = [x[k].clone().requires_grad_() for k in range(b)]
+        want = [call(layer, t) for t in xs]
+        sum((o * gsel[k]).sum() for k, o in enumerate(want)).backward()
+        assert out.shape == (b, n, want[0].size(-1))
+        close(out, torch.stack([o.detach() for o in want]), what=f"{name} batched output")
+        close(xb.grad, torch.stack([t.grad for t in xs]), what=f"{name} batched dx")
+        for got, p in zip(batched, layer.parameters()):
+            close(got, p.grad, norm=True, what=f"{name} batched parameter gradient")
+    conv = MagNetConv(f, f, K=2, q=0.25, trainable_q=False).to(D)
+    xr, xi = x.clone().requires_grad_(), (x * 0.5 + 1).detach().requires_grad_()
+    o_r, o_i = conv(xr, xi, ei, w)
+    ((o_r * go).sum() + (o_i * go).sum()).backward()
+    batched = [conv.weight.grad.clone(), conv.bias.grad.clone(), xr.grad.clone(), xi.grad.clone()]
+    conv.zero_grad(set_to_none=True)
+    ar, ai = [xr[k].detach().requires_grad_() for k in range(b)], [xi[k].detach().requires_grad_() for k in range(b)]
+    outs = [conv(ar[k], ai[k], ei, w) for k in range(b)]
+    sum((o[0] * go[k]).sum() + (o[1] * go[k]).sum() for k, o in enumerate(outs)).backward()
+    close(o_r, torch.stack([o[0].detach() for o in outs]), what="MagNetConv batched out_real")
+    close(o_i, torch.stack([o[1].detach() for o in outs]), what="MagNetConv batched out_imag")
+    close(batched[2], torch.stack([t.grad for t in ar]), what="MagNetConv batched dx_real")
+    close(batched[3], torch.stack([t.grad for t in ai]), what="MagNetConv batched dx_imag")
+    close(batched[0], conv.weight.grad, norm=True, what="MagNetConv batched dW")
+    close(batched[1], conv.bias.grad, norm=True, what="MagNetConv batched db")
