@@ -997,37 +997,45 @@ def _vals(v: Optional[Tensor], csr: CSR) -> Tuple[Tensor]:
 
 
 class _GradSync:
-    """Parameter gradients of a layer with replicated parameters: every incoming gradient is all-reduced by a tensor
-    hook (so accumulation over several backward calls stays correct).  The hooks fire in the order autograd makes the
-    gradients ready, which is the same on every rank only if the ranks run the same graph; the FIRST backward
-    therefore records that order and compares it across the ranks -- a mismatch (two ranks pairing up different
-    parameters in one all-reduce) raises instead of training on mixed-up sums."""
+    """Parameter gradients of a layer with replicated parameters, summed over the ranks in an order that does NOT
+    depend on autograd.  Per-parameter all-reduce hooks fire in the order autograd makes the gradients ready; that
+    order is the same on every rank only if the ranks run the same graph under the same scheduling, and when it is not,
+    two ranks pair up DIFFERENT parameters in one all-reduce (seen at the C5 size under load: one rank's conv2.weight
+    share summed into conv1.weight, a 12 % error).  Here the hooks only remember each incoming local gradient; a
+    callback that autograd runs at the END of the backward pass all-reduces them in parameter order and corrects
+    `.grad` by (sum over ranks - local share) -- correct under gradient accumulation too, since only the share of THIS
+    backward is exchanged."""
 
     def _install_grad_sync(self):
-        self._sync_order, self._sync_checked = [], False
-        self._sync_count = 0
-        for k, prm in enumerate(self.parameters()):
-            self._sync_count += 1
-            prm.register_hook(lambda grad, k=k: self._allreduce(grad, k))
+        self._sync_params = list(self.parameters())
+        self._sync_local = {}
+        for k, prm in enumerate(self._sync_params):
+            prm.register_hook(lambda grad, k=k: self._remember(grad, k))
 
-    def _allreduce(self, grad, k):
-        out = self.exchange.all_reduce(grad.contiguous())
-        if not self._sync_checked:
-            self._sync_order.append(k)
-            if len(self._sync_order) == self._sync_count:
-                self._sync_checked = True
-                mine = torch.tensor(self._sync_order, dtype=torch.float64, device=grad.device)
-                total = self.exchange.all_reduce(mine.clone())
-                if not torch.equal(total, mine * self.exchange.world_size):
-                    raise RuntimeError(f"{type(self).__name__}: the ranks all-reduced their parameter gradients in "
-                                       f"different orders (this rank: {self._sync_order}); their autograd graphs differ")
-        return out
+    def _remember(self, grad, k):
+        if not self._sync_local:                       # first gradient of this backward pass: arrange the exchange
+            torch.autograd.Variable._execution_engine.queue_callback(self._exchange_gradients)
+        prev = self._sync_local.get(k)
+        self._sync_local[k] = grad if prev is None else prev + grad     # a parameter used twice in one graph
+        return grad
+
+    def _exchange_gradients(self):
+        local, self._sync_local = self._sync_local, {}
+        with torch.no_grad():
+            for k, prm in enumerate(self._sync_params):                  # fixed order on every rank
+                mine = local.get(k)
+                if mine is None:                       # a parameter that got no gradient here still takes part
+                    mine = torch.zeros_like(prm)
+                total = self.exchange.all_reduce(mine.detach().clone().contiguous())
+                if prm.grad is None:                   # (torch.autograd.grad: nothing was accumulated)
+                    continue
+                prm.grad.add_(total - mine)
 
 
 class ShardedDiGCNConv(_GradSync, torch.nn.Module):
     """DiGCNConv (out = S^T (x W) + b, reference nn/directed/DiGCNConv.py:54-94) over a node-range-sharded
     graph; fp32 or bf16 (`.to(torch.bfloat16)`: BASELINE config "DiGCN_Inception_Block ... bf16, 8xMI355X").
-    Parameters are replicated; their gradients are all-reduced by hooks during backward."""
+    Parameters are replicated; their gradients are all-reduced at the end of every backward pass (`_GradSync`)."""
 
     def __init__(self, in_channels: int, out_channels: int, num_nodes: int, edge_index: Tensor,
                  edge_weight: Tensor, bias: bool = True, device=None, group=None, exchange=None,
@@ -1064,10 +1072,9 @@ class ShardedDiGCNConv(_GradSync, torch.nn.Module):
 
 
 def _zero_pad_rows(plan: ShardPlan, t: Tensor) -> Tensor:
-    """Pad rows -> 0.  Applied on EVERY rank, also the one whose range has no pad rows: the ranks' autograd graphs must
-    be the same graph, or their parameter gradients can become ready in different orders and the per-parameter
-    all-reduce hooks of two ranks pair up different parameters (seen at the C5 size: one rank's conv2.weight share
-    summed into conv1.weight, a 12 % error that only showed under load)."""
+    """Pad rows -> 0.  Applied on EVERY rank, also the one whose range has no pad rows, so that the ranks run the same
+    autograd graph (the parameter all-reduce no longer depends on that -- `_GradSync` -- but identical graphs keep the
+    ranks' kernel sequences, and with them their collectives, in step)."""
     mask = torch.zeros((plan.n_pad, 1), dtype=t.dtype, device=t.device)
     mask[:plan.n_local] = 1
     return t * mask

@@ -335,6 +335,54 @@ def _digcn_worker(rank, world, port, n, f, phases, block, ret):
         dist.destroy_process_group()
 
 
+def _grad_sync_worker(rank, world, port, ret):
+    """Ranks whose autograd graphs DIFFER (rank-dependent extra nodes delay one branch), two backward passes without
+    zero_grad: the parameter gradients must still be the un-sharded ones, times two (parallel._GradSync exchanges in
+    parameter order at the end of each backward, whatever order autograd produced the gradients in)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytorch_geometric_signed_directed_amd.parallel import ShardedDiGCNInceptionBlock
+        C.patch_device_builders()
+        n, f = 40, 8
+        g, ei, w = _graph(n, 9, True)
+        _, ei2, w2 = _graph(n, 10, False)
+        w, w2 = w / 8, w2 / 8
+        x, go = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+        torch.manual_seed(3)
+        layer = ShardedDiGCNInceptionBlock(f, f, n, ei, w, ei2, w2, kernels=C.KERNELS)
+        with torch.no_grad():
+            for prm in layer.parameters():
+                prm.uniform_(-0.5, 0.5)
+                dist.broadcast(prm.data, 0)
+        gl = layer.shard_rows(go)
+        for _ in range(2):
+            x0, x1, x2 = layer(layer.shard_rows(x))
+            if rank == 0:                                   # extra nodes on rank 0 only: conv1's branch becomes ready later
+                for _k in range(5):
+                    x1 = x1 * 1.0 + 0.0
+            else:
+                x2 = (x2 + 0.0) * 1.0
+            ((x0 * gl).sum() + 2.0 * (x1 * gl).sum() + 3.0 * (x2 * gl).sum()).backward()
+        xo = x.clone()
+        sd = {k: v.detach().clone().requires_grad_() for k, v in layer.named_parameters()}
+        want = (xo @ sd["ln.weight"].t() + sd["ln.bias"], R.digcn_conv(xo, ei, w, sd["conv1.weight"], sd["conv1.bias"]),
+                R.digcn_conv(xo, ei2, w2, sd["conv2.weight"], sd["conv2.bias"]))
+        ((want[0] * go).sum() + 2.0 * (want[1] * go).sum() + 3.0 * (want[2] * go).sum()).backward()
+        ret[rank] = max(float((prm.grad - 2.0 * sd[k].grad).abs().max()) / max(1.0, float(sd[k].grad.abs().max()))
+                        for k, prm in layer.named_parameters())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_parameter_gradients_do_not_depend_on_the_order_autograd_produces_them_in():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_grad_sync_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert len(ret) == 2 and max(ret.values()) <= 4e-6, dict(ret)
+
+
 @pytest.mark.parametrize("world,n,f,phases,block", [(2, 50, 8, 1, False), (3, 61, 4, 2, False), (2, 50, 8, 1, True),
                                                     (4, 90, 8, 2, True)])
 def test_sharded_digcn_and_inception_block_equal_unsharded_oracle(world, n, f, phases, block):
