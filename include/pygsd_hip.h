@@ -391,6 +391,11 @@ int pygsd_stream_copy_f32(const float* src, float* dst, int64_t n, void* stream)
  * ------------------------------------------------------------------------------------------- */
 int pygsd_pack_slices(const void* const* xs, int32_t groups, int32_t n_rows, int32_t row_bytes, int64_t ld_bytes,
                       int32_t p_r, int32_t p_c, int32_t phases, void* out, void* stream);
+/* out = sum_j weights[j] * xs[j] over n floats, every operand read once: the hop accumulations feat += w[h] * cur of
+ * SIMPA / DIMPA (nn/signed/SIMPA.py:77-93, nn/directed/DIMPA.py:52-57) as one pass instead of one per hop.  xs: HOST array
+ * of k (<= 8) device pointers; weights: HOST array of k floats (they travel by value); n % 4 == 0, 16-byte aligned. */
+int pygsd_weighted_sum_f32(const float* const* xs, const float* weights, int32_t k, int64_t n, float* out,
+                           void* stream);
 
 /* Keeps `stream` busy for `microseconds` (one idle lane polling the constant-rate wall clock).  Measurement
  * only: the single-GPU rehearsal of the sharded propagate (tools/emulate_sharded.py) uses it as the wire time

@@ -108,6 +108,7 @@ PROTOTYPES = {
     "pygsd_spin_us": (c_int32, [c_double, c_void_p]),
     "pygsd_pack_slices": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p,
                                     c_void_p]),
+    "pygsd_weighted_sum_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "pygsd_prof_enable": (c_int32, [c_int32]),
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),

@@ -259,6 +259,50 @@ extern "C" int pygsd_pack_slices(const void* const* xs, int32_t groups, int32_t 
     return check_launch("pack_slices_kernel");
 }
 
+namespace {
+struct WeightedSumArgs {
+    const vec4f* x[8];
+    float w[8];
+    vec4f* out;
+    int64_t n4;
+    int32_t k;
+};
+
+// out = sum_j w[j] * x[j], every operand read once (SIMPA / DIMPA: feat = sum_h w[h] * cur_h, SIMPA.py:77-93)
+__global__ __launch_bounds__(256) void weighted_sum_kernel(WeightedSumArgs a)
+{
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        vec4f acc = a.x[0][i] * a.w[0];
+        for (int j = 1; j < a.k; ++j) acc += a.x[j][i] * a.w[j];       // the reference's accumulation order
+        a.out[i] = acc;
+    }
+}
+}  // namespace
+
+extern "C" int pygsd_weighted_sum_f32(const float* const* xs, const float* weights, int32_t k, int64_t n, float* out,
+                                      void* stream)
+{
+    PYGSD_REQUIRE(k >= 1 && k <= 8 && n >= 0 && n % 4 == 0, "pygsd_weighted_sum_f32: 1..8 operands of a multiple of 4 elements");
+    if (n == 0) return 0;
+    PYGSD_REQUIRE(xs && weights && out && aligned16(out), "pygsd_weighted_sum_f32: null or unaligned pointer");
+    WeightedSumArgs a{};
+    for (int j = 0; j < k; ++j) {
+        PYGSD_REQUIRE(xs[j] && aligned16(xs[j]), "pygsd_weighted_sum_f32: operand %d null or not 16-byte aligned", j);
+        a.x[j] = reinterpret_cast<const vec4f*>(xs[j]);
+        a.w[j] = weights[j];                                           // HOST array: the weights travel by value
+    }
+    a.out = reinterpret_cast<vec4f*>(out);
+    a.n4 = n / 4;
+    a.k = k;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    const int64_t blocks = (a.n4 + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(static_cast<unsigned>(blocks < (1 << 22) ? blocks : (1 << 22))), dim3(kBlock), 0,
+                       s, a);
+    return check_launch("weighted_sum_kernel");
+}
+
 extern "C" int pygsd_spin_us(double microseconds, void* stream)
 {
     PYGSD_REQUIRE(microseconds >= 0.0 && microseconds <= 5e6, "pygsd_spin_us: duration outside [0, 5 s]");

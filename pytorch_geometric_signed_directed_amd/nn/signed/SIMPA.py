@@ -5,7 +5,128 @@ from typing import Optional
 import torch
 from torch.nn import Parameter
 
+from ... import _cabi
+from ...sparse import GLOBAL_PATTERNS, _spmm_raw
 from ..general.conv_base import Conv_Base, flipped_edge_index
+
+
+def weighted_sum(tensors, weights):
+    """sum_j weights[j] * tensors[j] (contiguous fp32 tensors of one shape, Python floats) in ONE pass: pygsd_weighted_sum_f32."""
+    import ctypes
+    k = len(tensors)
+    tensors = [t.contiguous() for t in tensors]        # (a product at an odd width is a column slice of a padded one)
+    out = torch.empty_like(tensors[0])
+    ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors])
+    ws = (ctypes.c_float * k)(*[float(w) for w in weights])
+    with torch.cuda.device(out.device):
+        _cabi.check(_cabi.lib().pygsd_weighted_sum_f32(ptrs, ws, k, out.numel(), _cabi.ptr(out), _cabi.stream_ptr()),
+                    "pygsd_weighted_sum_f32")
+    return out
+
+
+class _StreamFn(torch.autograd.Function):
+    """One (positive, negative) stream of SIMPA as ONE autograd node (fixed operator values).
+
+    Forward: the hop schedule of SIMPA.py:77-93 -- every node of it is a HIP SpMM of an earlier one; feat_p / feat_n are
+    weighted sums of nodes.  Backward: the gradient of a node is  sum_terms w g_feat + sum_consumers S^T grad_consumer ;
+    both kinds of summand ride on the SpMM's own epilogue (Y = alpha S^T X + beta Z: a pending `w g` is consumed as
+    (x = g, alpha = w) when it is propagated and as (z = g, beta = w) when something is added to it), so the chain
+    costs its SpMMs and nothing else -- autograd's composition paid a scale pass, a product-and-reduce pass and an
+    accumulation pass per hop on top.  The hop weights' gradients are dot products <g_feat, node>.  The weights are
+    read to the host once per call (six floats at hop 2)."""
+
+    @staticmethod
+    def forward(ctx, x_pos, x_neg, wp, wn, op_p, op_n, hop):
+        wpl, wnl = wp.detach().reshape(-1).tolist(), wn.detach().reshape(-1).tolist()
+        nodes, ops, terms_p, terms_n = [x_pos.contiguous(), x_neg.contiguous()], [], [(0, 0)], []
+
+        def apply(kind, src):
+            pat, w = op_p if kind == "p" else op_n
+            nodes.append(_spmm_raw(pat.fwd, pat.values_for(w, "fwd"), nodes[src], None, 1.0, 0.0, False))
+            ops.append((len(nodes) - 1, kind, src))
+            return len(nodes) - 1
+
+        cur_p, aux_n, j = 0, 1, 0
+        for h in range(hop + 1):
+            if h > 0:
+                cur_p = apply("p", cur_p)
+                if h != hop:           # the reference also advances aux_n at the last hop, but never reads it again
+                    aux_n = apply("p", aux_n)
+                terms_p.append((h, cur_p))
+            if h != hop:
+                cur_n = apply("n", aux_n)
+                terms_n.append((j, cur_n))
+                j += 1
+                for _ in range(hop - 1 - h):
+                    cur_n = apply("p", cur_n)
+                    terms_n.append((j, cur_n))
+                    j += 1
+
+        def weighted(terms, weights):
+            if not terms:
+                return torch.zeros_like(nodes[0])
+            if nodes[0].numel() % 4 == 0 and len(terms) <= 8:
+                return weighted_sum([nodes[v] for _, v in terms], [weights[wi] for wi, _ in terms])
+            out = nodes[terms[0][1]] * weights[terms[0][0]]
+            for wi, v in terms[1:]:
+                out.add_(nodes[v], alpha=weights[wi])
+            return out
+
+        feat_p, feat_n = weighted(terms_p, wpl), weighted(terms_n, wnl)
+        ctx.save_for_backward(*nodes)
+        ctx.tape = (ops, terms_p, terms_n, wpl, wnl, op_p, op_n, tuple(wp.shape), tuple(wn.shape))
+        return feat_p, feat_n
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_p, g_n):
+        nodes = ctx.saved_tensors
+        ops, terms_p, terms_n, wpl, wnl, op_p, op_n, shape_p, shape_n = ctx.tape
+        g_p, g_n = g_p.contiguous(), g_n.contiguous()
+        grads = {}                                   # node -> tensor | ("pending", w, g): w * g, not materialised
+
+        def add_term(v, w, g):
+            cur = grads.get(v)
+            if cur is None:
+                grads[v] = ("pending", w, g)
+            elif isinstance(cur, tuple):
+                grads[v] = ("pending", cur[1] + w, g) if cur[2] is g else cur[2] * cur[1] + g * w
+            else:
+                cur.add_(g, alpha=w)
+
+        for wi, v in terms_p:
+            add_term(v, wpl[wi], g_p)
+        for wi, v in terms_n:
+            add_term(v, wnl[wi], g_n)
+        for dst, kind, src in reversed(ops):         # every consumer of `dst` was created later: its gradient is complete
+            gd = grads.pop(dst, None)
+            if gd is None:
+                continue
+            pat, w = op_p if kind == "p" else op_n
+            x, alpha = (gd[2], gd[1]) if isinstance(gd, tuple) else (gd, 1.0)
+            cs = grads.get(src)
+            if cs is None:
+                z, beta = None, 0.0
+            elif isinstance(cs, tuple):
+                z, beta = cs[2], cs[1]
+            else:
+                z, beta = cs, 1.0
+            grads[src] = _spmm_raw(pat.bwd, pat.values_for(w, "bwd"), x, z, alpha, beta, False)
+
+        def materialise(v):
+            cur = grads.get(v)
+            if cur is None:
+                return torch.zeros_like(nodes[v])
+            return cur[2] * cur[1] if isinstance(cur, tuple) else cur
+
+        def dots(terms, g, shape):
+            out = g.new_zeros(shape)
+            flat = out.view(-1)
+            for wi, v in terms:
+                flat[wi] = torch.dot(g.reshape(-1), nodes[v].reshape(-1))
+            return out
+
+        return (materialise(0), materialise(1), dots(terms_p, g_p, shape_p), dots(terms_n, g_n, shape_n), None, None, None)
 
 
 class SIMPA(torch.nn.Module):
@@ -35,9 +156,23 @@ class SIMPA(torch.nn.Module):
         for name in ("_w_sp", "_w_sn", "_w_tp", "_w_tn"):
             getattr(self, name).data.fill_(1.0)
 
+    def _fusable(self, w_p, w_n, x_pos, x_neg):
+        return (x_pos.dim() == 2 and x_pos.is_cuda and x_pos.dtype == torch.float32 and x_neg.dtype == torch.float32
+                and x_pos.shape == x_neg.shape and not (w_p is not None and w_p.requires_grad)
+                and not (w_n is not None and w_n.requires_grad)
+                and all(c.normalize for c in (self.conv_layer_p, self.conv_layer_n)))
+
     def _stream(self, ei_p, w_p, ei_n, w_n, x_pos, x_neg, wp, wn):
         """One (positive, negative) feature pair: feat_p = sum_h wp[h] Ap^h x_pos and the mixed
         paths Ap^m An Ap^h x_neg, in the reference's accumulation order (SIMPA.py:77-93)."""
+        if self._fusable(w_p, w_n, x_pos, x_neg):
+            _cabi.require_gpu(x_pos, x_neg, ei_p, ei_n, w_p, w_n)
+            n = x_pos.size(0)
+            handles = []
+            for conv, ei, w in ((self.conv_layer_p, ei_p, w_p), (self.conv_layer_n, ei_n, w_n)):
+                nei, nw = conv._normalised(ei, w, n, x_pos.dtype)          # conv_norm_rw, memoised on the graph tensors
+                handles.append((GLOBAL_PATTERNS.get(nei, n, n, conv.flow, validate=False), nw))
+            return _StreamFn.apply(x_pos, x_neg, wp, wn, handles[0], handles[1], self._hop_p - 1)
         feat_p = wp[0] * x_pos
         feat_n = None
         cur_p, aux_n = x_pos, x_neg

@@ -921,3 +921,15 @@ def test_fused_operator_reference_format_matches_generic():
     for a, b in zip(fa, fb):
         assert torch.equal(a, b)
     assert torch.equal(oa[0], ob[0]) and torch.equal(oa[1], ob[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,shape", [(1, (5, 4)), (3, (1000, 64)), (8, (333, 12))])
+def test_weighted_sum_kernel(k, shape):
+    """sum_j w[j] * x[j] in one pass (SIMPA / DIMPA hop accumulations) against float64."""
+    from pytorch_geometric_signed_directed_amd.nn.signed.SIMPA import weighted_sum
+    g = torch.Generator().manual_seed(k)
+    xs = [torch.randn(shape, generator=g) for _ in range(k)]
+    ws = [float(v) for v in torch.randn(k, generator=g)]
+    want = sum(w * x.double() for w, x in zip(ws, xs))
+    close(weighted_sum([x.to(dev()) for x in xs], ws), want, 1e-6)
