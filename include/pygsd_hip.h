@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 8
+#define PYGSD_ABI_VERSION 9
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -396,6 +396,36 @@ int pygsd_pack_slices(const void* const* xs, int32_t groups, int32_t n_rows, int
  * of k (<= 8) device pointers; weights: HOST array of k floats (they travel by value); n % 4 == 0, 16-byte aligned. */
 int pygsd_weighted_sum_f32(const float* const* xs, const float* weights, int32_t k, int64_t n, float* out,
                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tall-skinny linear maps of the non-magnetic layers on the matrix cores (csrc/tall.hip).
+ *
+ *   Y[n_rows, f_out] = [X_0 | X_1 | ... | X_{n_seg-1}] W (+ bias)
+ *
+ * One pass over tall operands (n_rows ~ 10^5..10^7): every segment row is read once and every output row written once.
+ * Replaces the Linear / weight products around the aggregations -- x W of DiGCNConv (nn/directed/DiGCNConv.py:66), the
+ * Linear of the inception block (nn/directed/DiGCN_Inception_Block.py:44-46), the Linear over [aggregated | own] features
+ * of SGCNConv (nn/signed/SGCNConv.py:121-126) -- and, with the upstream gradient and the back-propagated aggregates as the
+ * segments and w_transposed != 0, their input gradients [g | dP] W^T in one product instead of one GEMM per block plus
+ * accumulation passes.
+ * dtype: 0 = fp32 (exact: v_mfma_f32_16x16x4_f32), 1 = bf16 storage with fp32 accumulation (v_mfma_f32_16x16x32_bf16), for
+ * X, W, bias and Y alike.  xs / ldx / widths: HOST arrays over the n_seg (<= 4) column segments -- device pointer
+ * (16-byte aligned), row stride in elements (a multiple of 16 bytes) and width (a multiple of 32 columns for bf16, 16 for
+ * fp32).  W[k][n] (k over the concatenated segment columns) sits at w[k * ldw + n], or at w[n * ldw + k] when w_transposed.
+ * bias: f_out elements or NULL.  Shapes: pygsd_tall_linear_supported(dtype, K = sum of widths, f_out) -- K, f_out <= 256 in
+ * the multiples above with K * f_out <= 32768 (bf16) / 16384 (fp32) (W lives in 64 KB of LDS); the host falls back to
+ * library GEMMs otherwise.
+ * ------------------------------------------------------------------------------------------- */
+int pygsd_tall_linear_supported(int32_t dtype, int32_t k_total, int32_t f_out);
+int pygsd_tall_linear(const void* const* xs, const int64_t* ldx, const int32_t* widths, int32_t n_seg, const void* w,
+                      int64_t ldw, int32_t w_transposed, const void* bias, void* y, int64_t ldy, int64_t n_rows,
+                      int32_t f_out, int32_t dtype, void* stream);
+/* out[c] = sum_r x[r * ldx + c], c < f, accumulated in fp32 in a fixed order (deterministic): the bias gradients of the
+ * layers above (the reference's autograd reduces dY over the nodes for DiGCNConv.py:90-93 / torch.nn.Linear biases).
+ * dtype as above; f a multiple of 4 (fp32) / 8 (bf16), at most 1024 / 2048; workspace from pygsd_column_sums_workspace. */
+int pygsd_column_sums_workspace(int64_t n_rows, int32_t f, int32_t dtype, size_t* bytes);
+int pygsd_column_sums(const void* x, int64_t ldx, int64_t n_rows, int32_t f, int32_t dtype, float* out, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* Keeps `stream` busy for `microseconds` (one idle lane polling the constant-rate wall clock).  Measurement
  * only: the single-GPU rehearsal of the sharded propagate (tools/emulate_sharded.py) uses it as the wire time

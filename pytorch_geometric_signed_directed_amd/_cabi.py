@@ -109,11 +109,17 @@ PROTOTYPES = {
     "pygsd_pack_slices": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p,
                                     c_void_p]),
     "pygsd_weighted_sum_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "pygsd_tall_linear_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "pygsd_tall_linear": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
+                                    c_int64, c_int64, c_int32, c_int32, c_void_p]),
+    "pygsd_column_sums_workspace": (c_int32, [c_int64, c_int32, c_int32, ctypes.POINTER(ctypes.c_size_t)]),
+    "pygsd_column_sums": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p, ctypes.c_size_t,
+                                    c_void_p]),
     "pygsd_prof_enable": (c_int32, [c_int32]),
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def lib_path():

@@ -5,7 +5,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpygsd_hip.so")
-SOURCES = ["runtime.hip", "spmm.hip", "dense.hip", "build.hip", "laplacian.hip", "magop.hip", "attention.hip"]
+SOURCES = ["runtime.hip", "spmm.hip", "dense.hip", "tall.hip", "build.hip", "laplacian.hip", "magop.hip", "attention.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 

@@ -1,0 +1,434 @@
+// Tall-skinny linear maps of the non-magnetic layers on the matrix cores (bf16: v_mfma_f32_16x16x32_bf16, fp32 accumulate;
+// fp32: the exact v_mfma_f32_16x16x4_f32) and the column sums their bias gradients need.
+//
+//   Y[n, f_out] = [X_0 | X_1 | ...] W (+ bias)          n ~ 10^5..10^7 rows, K = sum of the segment widths <= 256, f_out <= 256
+//
+// One pass: every operand row is read once, every output row written once, whatever the number of column segments --
+// the segments are what the layers would otherwise concatenate or multiply one GEMM at a time and accumulate:
+//   x W                        DiGCNConv.py:66, the Linear of DiGCN_Inception_Block.py:44, SGCNConv.py:121-126
+//   [g_0 | dP_1 | dP_2] W^T    their input gradient in ONE product (two library GEMMs + an accumulation pass before)
+//
+// Tiling (as csrc/dense.hip): one wavefront owns 16 rows.  The MFMA is issued TRANSPOSED -- A operand = a fragment of W
+// (its 16 rows are OUTPUT columns), B operand = the lane's own 16-byte row load (lane l: row l & 15, k-slots of quarter
+// l >> 4), so activations never pass through LDS and the C/D layout (col = lane & 15, row = 4 (lane >> 4) + reg) hands every
+// lane consecutive output columns of ONE row.  W is laid out in LDS once per block IN FRAGMENT ORDER ([k-block][tile][lane],
+// 16 B per lane for bf16, 4 B for fp32): every A fragment is one conflict-free ds_read.  For bf16 the output columns of two
+// neighbouring tiles are interleaved (column 32 m + 8 q + 4 (t & 1) + r for tile t = 2 m + (t & 1), quarter q, register r) so
+// that a lane's 8 results form one 16-byte store.  The next tile's rows are loaded before the current tile's MFMAs.
+#include "common.hpp"
+
+namespace pygsd {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kMaxKB = 16;     // k-blocks: 32 bf16 / 16 fp32 columns each (one 16-byte load per lane)
+constexpr int kMaxSeg = 4;
+
+struct TallArgs {
+    const void* x[kMaxKB];     // first element of k-block kb in row 0 of its segment
+    int64_t ld[kMaxKB];        // that segment's row stride in elements
+    const void* w;             // W[k][n] at w[k * ldw + n]  (w_t == 0)  or  w[n * ldw + k]  (w_t != 0)
+    int64_t ldw;
+    const void* bias;          // f_out elements of the storage type, or null
+    void* y;
+    int64_t ldy;
+    int32_t n_rows, f_out, w_t;
+};
+
+__device__ __forceinline__ float bf16_value(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t bf16_bits(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;                   // round to nearest even
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return bf16_bits(lo) | (bf16_bits(hi) << 16); }
+
+// ---- bf16 storage, fp32 accumulation -----------------------------------------------------------
+template <int KB, int NT>
+__global__ __launch_bounds__(256) void tall_linear_bf16_kernel(TallArgs p)
+{
+    static_assert(NT % 2 == 0, "output tiles come in interleaved pairs");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* frag = reinterpret_cast<uint4*>(smem);                                   // [KB][NT][64] x 8 bf16
+    float* bias = reinterpret_cast<float*>(smem + static_cast<size_t>(KB) * NT * 64 * 16);   // [NT * 16]
+    const int tid = threadIdx.x;
+    const uint16_t* w = static_cast<const uint16_t*>(p.w);
+    for (int idx = tid; idx < KB * NT * 64; idx += 256) {
+        const int lane = idx & 63, t = (idx >> 6) % NT, kb = (idx >> 6) / NT;
+        const int i = lane & 15, q = lane >> 4;
+        const int64_t n = 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
+        const int64_t k0 = kb * 32 + 8 * q;
+        uint32_t h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = p.w_t ? w[n * p.ldw + k0 + e] : w[(k0 + e) * p.ldw + n];
+        frag[idx] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    }
+    for (int c = tid; c < NT * 16; c += 256)
+        bias[c] = p.bias ? bf16_value(static_cast<const uint16_t*>(p.bias)[c]) : 0.f;
+    __syncthreads();
+
+    const int lane = tid & 63, j = lane & 15, q = lane >> 4;
+    const int n_tiles = (p.n_rows + 15) >> 4;
+    const int stride = static_cast<int>(gridDim.x) * 4;
+    int tile = static_cast<int>(blockIdx.x) * 4 + (tid >> 6);
+    uint4 cur[KB], nxt[KB];
+    if (tile < n_tiles) {
+        const int64_t row = (tile * 16 + j < p.n_rows) ? tile * 16 + j : p.n_rows - 1;   // clamped: stores are masked
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+            cur[kb] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.x[kb]) + row * p.ld[kb] + 8 * q);
+    }
+    for (; tile < n_tiles; tile += stride) {
+        const int next = tile + stride;
+        if (next < n_tiles) {
+            const int64_t row = (next * 16 + j < p.n_rows) ? next * 16 + j : p.n_rows - 1;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                nxt[kb] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.x[kb]) + row * p.ld[kb] + 8 * q);
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, cur[kb]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, frag[(kb * NT + t) * 64 + lane]);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        // lane (j, q): tiles 2 m and 2 m + 1 hold columns [32 m + 8 q, 32 m + 8 q + 8) of row 16 tile + j
+        if (tile * 16 + j < p.n_rows) {
+            uint16_t* yrow = static_cast<uint16_t*>(p.y) + static_cast<int64_t>(tile * 16 + j) * p.ldy + 8 * q;
+#pragma unroll
+            for (int m = 0; m < NT / 2; ++m) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bias + 32 * m + 8 * q);
+                const float4 b1 = *reinterpret_cast<const float4*>(bias + 32 * m + 8 * q + 4);
+                const f32x4 lo = acc[2 * m], hi = acc[2 * m + 1];
+                uint4 o;
+                o.x = pack2(lo[0] + b0.x, lo[1] + b0.y);
+                o.y = pack2(lo[2] + b0.z, lo[3] + b0.w);
+                o.z = pack2(hi[0] + b1.x, hi[1] + b1.y);
+                o.w = pack2(hi[2] + b1.z, hi[3] + b1.w);
+                *reinterpret_cast<uint4*>(yrow + 32 * m) = o;
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) cur[kb] = nxt[kb];
+    }
+}
+
+// ---- fp32, exact (an fmaf chain per output) ----------------------------------------------------
+template <int KB, int NT>
+__global__ __launch_bounds__(256) void tall_linear_f32_kernel(TallArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* frag = reinterpret_cast<float*>(smem);                  // [KB][4][NT][64]
+    float* bias = frag + static_cast<size_t>(KB) * 4 * NT * 64;    // [NT * 16]
+    const int tid = threadIdx.x;
+    const float* w = static_cast<const float*>(p.w);
+    for (int idx = tid; idx < KB * 4 * NT * 64; idx += 256) {
+        const int lane = idx & 63, t = (idx >> 6) % NT, m = ((idx >> 6) / NT) & 3, kb = (idx >> 6) / NT / 4;
+        const int64_t n = 16 * t + (lane & 15);
+        const int64_t k = kb * 16 + 4 * (lane >> 4) + m;
+        frag[idx] = p.w_t ? w[n * p.ldw + k] : w[k * p.ldw + n];
+    }
+    for (int c = tid; c < NT * 16; c += 256) bias[c] = p.bias ? static_cast<const float*>(p.bias)[c] : 0.f;
+    __syncthreads();
+
+    const int lane = tid & 63, j = lane & 15, q = lane >> 4;
+    const int n_tiles = (p.n_rows + 15) >> 4;
+    const int stride = static_cast<int>(gridDim.x) * 4;
+    int tile = static_cast<int>(blockIdx.x) * 4 + (tid >> 6);
+    float4 cur[KB], nxt[KB];
+    if (tile < n_tiles) {
+        const int64_t row = (tile * 16 + j < p.n_rows) ? tile * 16 + j : p.n_rows - 1;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+            cur[kb] = *reinterpret_cast<const float4*>(static_cast<const float*>(p.x[kb]) + row * p.ld[kb] + 4 * q);
+    }
+    for (; tile < n_tiles; tile += stride) {
+        const int next = tile + stride;
+        if (next < n_tiles) {
+            const int64_t row = (next * 16 + j < p.n_rows) ? next * 16 + j : p.n_rows - 1;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                nxt[kb] = *reinterpret_cast<const float4*>(static_cast<const float*>(p.x[kb]) + row * p.ld[kb] + 4 * q);
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const float xs[4] = {cur[kb].x, cur[kb].y, cur[kb].z, cur[kb].w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[((kb * 4 + m) * NT + t) * 64 + lane], xs[m], acc[t],
+                                                                  0, 0, 0);
+            }
+        }
+        if (tile * 16 + j < p.n_rows) {
+            float* yrow = static_cast<float*>(p.y) + static_cast<int64_t>(tile * 16 + j) * p.ldy + 4 * q;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + 16 * t + 4 * q);
+                *reinterpret_cast<float4*>(yrow + 16 * t) =
+                    make_float4(acc[t][0] + b.x, acc[t][1] + b.y, acc[t][2] + b.z, acc[t][3] + b.w);
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) cur[kb] = nxt[kb];
+    }
+}
+
+template <typename Kern>
+int launch_tall(Kern kern, const TallArgs& a, int kb, int nt, hipStream_t s)
+{
+    const size_t lds = static_cast<size_t>(kb) * nt * 1024 + static_cast<size_t>(nt) * 16 * sizeof(float);
+    if (lds > 64 * 1024)
+        PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          static_cast<int>(lds)));
+    size_t per_cu = (160 * 1024) / lds;        // resident blocks per CU by LDS
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t n_tiles = (static_cast<int64_t>(a.n_rows) + 15) / 16;
+    int64_t grid = (n_tiles + 3) / 4;
+    if (grid > static_cast<int64_t>(256 * per_cu)) grid = static_cast<int64_t>(256 * per_cu);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, s, a);
+    return check_launch("tall_linear_kernel");
+}
+
+// K = 32 kb (bf16) / 16 kb (fp32); f_out = 16 nt; kb * nt <= 64 (64 KB of W fragments per block)
+bool shape_ok(int dtype, int k_total, int f_out)
+{
+    if (dtype == 1) {
+        if (k_total % 32 || f_out % 32) return false;
+        const int kb = k_total / 32, nt = f_out / 16;
+        const bool kb_ok = kb == 1 || kb == 2 || kb == 3 || kb == 4 || kb == 6 || kb == 8;
+        const bool nt_ok = nt == 2 || nt == 4 || nt == 6 || nt == 8 || nt == 12 || nt == 16;
+        return kb_ok && nt_ok && kb * nt <= 64;
+    }
+    if (dtype == 0) {
+        if (k_total % 16 || f_out % 16) return false;
+        const int kb = k_total / 16, nt = f_out / 16;
+        const bool kb_ok = kb == 1 || kb == 2 || kb == 4 || kb == 6 || kb == 8 || kb == 12 || kb == 16;
+        const bool nt_ok = nt == 1 || nt == 2 || nt == 4 || nt == 6 || nt == 8 || nt == 12 || nt == 16;
+        return kb_ok && nt_ok && kb * nt <= 64;
+    }
+    return false;
+}
+
+template <int KB>
+int dispatch_bf16(const TallArgs& a, int nt, hipStream_t s)
+{
+    switch (nt) {
+        case 2: return launch_tall(tall_linear_bf16_kernel<KB, 2>, a, KB, 2, s);
+        case 4: return launch_tall(tall_linear_bf16_kernel<KB, 4>, a, KB, 4, s);
+        case 6: return launch_tall(tall_linear_bf16_kernel<KB, 6>, a, KB, 6, s);
+        case 8: return launch_tall(tall_linear_bf16_kernel<KB, 8>, a, KB, 8, s);
+        case 12: if constexpr (KB <= 4) return launch_tall(tall_linear_bf16_kernel<KB, 12>, a, KB, 12, s); break;
+        case 16: if constexpr (KB <= 4) return launch_tall(tall_linear_bf16_kernel<KB, 16>, a, KB, 16, s); break;
+        default: break;
+    }
+    return fail("pygsd_tall_linear: unsupported bf16 shape (%d k-blocks x %d tiles)", KB, nt);
+}
+
+template <int KB>
+int dispatch_f32(const TallArgs& a, int nt, hipStream_t s)
+{
+    switch (nt) {
+        case 1: return launch_tall(tall_linear_f32_kernel<KB, 1>, a, KB, 1, s);
+        case 2: return launch_tall(tall_linear_f32_kernel<KB, 2>, a, KB, 2, s);
+        case 4: return launch_tall(tall_linear_f32_kernel<KB, 4>, a, KB, 4, s);
+        case 6: if constexpr (KB <= 8) return launch_tall(tall_linear_f32_kernel<KB, 6>, a, KB, 6, s); break;
+        case 8: if constexpr (KB <= 8) return launch_tall(tall_linear_f32_kernel<KB, 8>, a, KB, 8, s); break;
+        case 12: if constexpr (KB <= 4) return launch_tall(tall_linear_f32_kernel<KB, 12>, a, KB, 12, s); break;
+        case 16: if constexpr (KB <= 4) return launch_tall(tall_linear_f32_kernel<KB, 16>, a, KB, 16, s); break;
+        default: break;
+    }
+    return fail("pygsd_tall_linear: unsupported fp32 shape (%d k-blocks x %d tiles)", KB, nt);
+}
+
+// ---- column sums -------------------------------------------------------------------------------
+struct ColumnSumArgs {
+    const void* x;
+    int64_t ldx, n_rows;
+    int32_t f;
+    float* partial;      // [gridDim.x][f]
+};
+
+// 16-byte loads (8 bf16 / 4 fp32 columns per thread, f / that threads per row, as many rows per pass as fit 256 threads);
+// per-thread fp32 sums, combined per block through LDS -> one partial row per block; fixed order (deterministic).
+template <bool BF16>
+__global__ __launch_bounds__(256) void column_sums_kernel(ColumnSumArgs p)
+{
+    constexpr int V = BF16 ? 8 : 4;
+    __shared__ float sm[256 * V];
+    const int tid = threadIdx.x;
+    const int tpr = p.f / V, rpp = 256 / tpr;
+    const int cv = tid % tpr, rl = tid / tpr;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    if (rl < rpp) {
+        for (int64_t row = static_cast<int64_t>(blockIdx.x) * rpp + rl; row < p.n_rows;
+             row += static_cast<int64_t>(gridDim.x) * rpp) {
+            if constexpr (BF16) {
+                const uint4 u = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.x) + row * p.ldx + cv * V);
+                acc[0] += bf16_value(u.x & 0xffffu); acc[1] += bf16_value(u.x >> 16);
+                acc[2] += bf16_value(u.y & 0xffffu); acc[3] += bf16_value(u.y >> 16);
+                acc[4] += bf16_value(u.z & 0xffffu); acc[5] += bf16_value(u.z >> 16);
+                acc[6] += bf16_value(u.w & 0xffffu); acc[7] += bf16_value(u.w >> 16);
+            } else {
+                const float4 u = *reinterpret_cast<const float4*>(static_cast<const float*>(p.x) + row * p.ldx + cv * V);
+                acc[0] += u.x; acc[1] += u.y; acc[2] += u.z; acc[3] += u.w;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) sm[rl * p.f + cv * V + v] = acc[v];
+    }
+    __syncthreads();
+    for (int c = tid; c < p.f; c += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rpp; ++r) s += sm[r * p.f + c];
+        p.partial[static_cast<int64_t>(blockIdx.x) * p.f + c] = s;
+    }
+}
+
+// out[c] = sum_b partial[b][c]: 64 columns per block, 4 groups of partial rows per column combined through LDS
+__global__ __launch_bounds__(256) void column_sums_finish_kernel(const float* __restrict__ partial, int n_partials, int f,
+                                                                 float* __restrict__ out)
+{
+    __shared__ float sm[256];
+    const int tid = threadIdx.x;
+    const int c = static_cast<int>(blockIdx.x) * 64 + (tid & 63), grp = tid >> 6;
+    float acc = 0.f;
+    if (c < f)
+        for (int b = grp; b < n_partials; b += 4) acc += partial[static_cast<int64_t>(b) * f + c];
+    sm[tid] = acc;
+    __syncthreads();
+    if (grp == 0 && c < f) out[c] = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
+}
+
+unsigned column_sum_blocks(int64_t n_rows, int f, int v)
+{
+    const int rpp = 256 / (f / v);
+    int64_t b = (n_rows + rpp - 1) / rpp;
+    if (b > 1024) b = 1024;
+    return static_cast<unsigned>(b < 1 ? 1 : b);
+}
+}  // namespace
+}  // namespace pygsd
+
+using namespace pygsd;
+
+extern "C" int pygsd_tall_linear_supported(int32_t dtype, int32_t k_total, int32_t f_out)
+{
+    return (k_total > 0 && f_out > 0 && shape_ok(dtype, k_total, f_out)) ? 1 : 0;
+}
+
+extern "C" int pygsd_tall_linear(const void* const* xs, const int64_t* ldx, const int32_t* widths, int32_t n_seg,
+                                 const void* w, int64_t ldw, int32_t w_transposed, const void* bias, void* y, int64_t ldy,
+                                 int64_t n_rows, int32_t f_out, int32_t dtype, void* stream)
+{
+    PYGSD_REQUIRE(dtype == 0 || dtype == 1, "pygsd_tall_linear: dtype must be 0 (fp32) or 1 (bf16), got %d", dtype);
+    PYGSD_REQUIRE(n_seg >= 1 && n_seg <= kMaxSeg && xs && ldx && widths, "pygsd_tall_linear: 1..%d column segments", kMaxSeg);
+    PYGSD_REQUIRE(n_rows >= 0 && n_rows < (1ll << 31) - 16, "pygsd_tall_linear: row count outside [0, 2^31)");
+    const int kw = dtype == 1 ? 32 : 16;          // columns per k-block
+    const int vec = dtype == 1 ? 8 : 4;           // elements per 16 bytes
+    const size_t esz = dtype == 1 ? 2 : 4;
+    int k_total = 0;
+    for (int g = 0; g < n_seg; ++g) {
+        PYGSD_REQUIRE(widths[g] > 0 && widths[g] % kw == 0, "pygsd_tall_linear: segment %d is %d columns wide (multiples of %d)",
+                      g, widths[g], kw);
+        k_total += widths[g];
+    }
+    PYGSD_REQUIRE(shape_ok(dtype, k_total, f_out), "pygsd_tall_linear: unsupported shape K=%d f_out=%d (see "
+                  "pygsd_tall_linear_supported)", k_total, f_out);
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(w && y && aligned16(y) && ldy >= f_out && ldy % vec == 0, "pygsd_tall_linear: output null, unaligned or "
+                  "row stride %lld not a multiple of 16 bytes >= f_out", static_cast<long long>(ldy));
+    PYGSD_REQUIRE(ldw >= (w_transposed ? k_total : f_out), "pygsd_tall_linear: ldw = %lld too small",
+                  static_cast<long long>(ldw));
+    TallArgs a{};
+    int kb = 0;
+    for (int g = 0; g < n_seg; ++g) {
+        PYGSD_REQUIRE(xs[g] && aligned16(xs[g]) && ldx[g] >= widths[g] && ldx[g] % vec == 0,
+                      "pygsd_tall_linear: segment %d null, not 16-byte aligned, or row stride %lld not a multiple of 16 bytes "
+                      ">= its width", g, static_cast<long long>(ldx[g]));
+        for (int c = 0; c < widths[g]; c += kw, ++kb) {
+            a.x[kb] = static_cast<const unsigned char*>(xs[g]) + static_cast<size_t>(c) * esz;
+            a.ld[kb] = ldx[g];
+        }
+    }
+    a.w = w; a.ldw = ldw; a.w_t = w_transposed ? 1 : 0; a.bias = bias; a.y = y; a.ldy = ldy;
+    a.n_rows = static_cast<int32_t>(n_rows); a.f_out = f_out;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_DENSE, s);
+    const int nt = f_out / 16;
+    if (dtype == 1) {
+        switch (kb) {
+            case 1: return dispatch_bf16<1>(a, nt, s);
+            case 2: return dispatch_bf16<2>(a, nt, s);
+            case 3: return dispatch_bf16<3>(a, nt, s);
+            case 4: return dispatch_bf16<4>(a, nt, s);
+            case 6: return dispatch_bf16<6>(a, nt, s);
+            case 8: return dispatch_bf16<8>(a, nt, s);
+            default: break;
+        }
+    } else {
+        switch (kb) {
+            case 1: return dispatch_f32<1>(a, nt, s);
+            case 2: return dispatch_f32<2>(a, nt, s);
+            case 4: return dispatch_f32<4>(a, nt, s);
+            case 6: return dispatch_f32<6>(a, nt, s);
+            case 8: return dispatch_f32<8>(a, nt, s);
+            case 12: return dispatch_f32<12>(a, nt, s);
+            case 16: return dispatch_f32<16>(a, nt, s);
+            default: break;
+        }
+    }
+    return fail("pygsd_tall_linear: unsupported shape K=%d f_out=%d", k_total, f_out);
+}
+
+extern "C" int pygsd_column_sums_workspace(int64_t n_rows, int32_t f, int32_t dtype, size_t* bytes)
+{
+    PYGSD_REQUIRE(bytes, "pygsd_column_sums_workspace: null output");
+    PYGSD_REQUIRE(dtype == 0 || dtype == 1, "pygsd_column_sums_workspace: dtype must be 0 (fp32) or 1 (bf16)");
+    const int v = dtype == 1 ? 8 : 4;
+    PYGSD_REQUIRE(f > 0 && f % v == 0 && f / v <= 256, "pygsd_column_sums_workspace: f = %d must be a multiple of %d, at most %d",
+                  f, v, 256 * v);
+    *bytes = static_cast<size_t>(column_sum_blocks(n_rows < 0 ? 0 : n_rows, f, v)) * f * sizeof(float);
+    return 0;
+}
+
+extern "C" int pygsd_column_sums(const void* x, int64_t ldx, int64_t n_rows, int32_t f, int32_t dtype, float* out,
+                                 void* workspace, size_t workspace_bytes, void* stream)
+{
+    size_t need = 0;
+    if (int rc = pygsd_column_sums_workspace(n_rows, f, dtype, &need)) return rc;
+    PYGSD_REQUIRE(n_rows >= 0, "pygsd_column_sums: negative size");
+    PYGSD_REQUIRE(out && workspace && workspace_bytes >= need, "pygsd_column_sums: null output or workspace too small "
+                  "(%zu < %zu)", workspace_bytes, need);
+    const int v = dtype == 1 ? 8 : 4;
+    PYGSD_REQUIRE(n_rows == 0 || (x && aligned16(x) && ldx >= f && ldx % v == 0),
+                  "pygsd_column_sums: input null, not 16-byte aligned, or row stride not a multiple of 16 bytes >= f");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    const unsigned blocks = column_sum_blocks(n_rows, f, v);
+    ColumnSumArgs a{x, ldx, n_rows, f, static_cast<float*>(workspace)};
+    if (dtype == 1)
+        hipLaunchKernelGGL(column_sums_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(column_sums_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+    if (int rc = check_launch("column_sums_kernel")) return rc;
+    hipLaunchKernelGGL(column_sums_finish_kernel, dim3((static_cast<unsigned>(f) + 63u) / 64u), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), static_cast<int>(blocks), f, out);
+    return check_launch("column_sums_finish_kernel");
+}

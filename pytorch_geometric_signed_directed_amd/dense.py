@@ -1,6 +1,7 @@
 """Host wrappers of the fused MFMA dense stage (csrc/dense.hip; include/pygsd_hip.h
 pygsd_magnetic_dense_*) and the single autograd node of a whole MagNetConv / MSConv layer."""
 import ctypes
+import os
 from ctypes import c_void_p
 from typing import List, Optional, Sequence, Tuple
 
@@ -153,6 +154,109 @@ class MagneticConvFunction(torch.autograd.Function):
         return gx_r, gx_i, dw, (dbias if ctx.has_bias else None), None
 
 
+# ------------------------------------------------------------------------------------------------
+# tall-skinny linear maps of the non-magnetic layers (csrc/tall.hip)
+# ------------------------------------------------------------------------------------------------
+_TALL_DTYPES = {torch.float32: 0, torch.bfloat16: 1}
+_TALL_KERNELS = os.environ.get("PYGSD_LIBRARY_GEMMS", "0") != "1"
+
+
+def set_tall_kernels(on: bool) -> bool:
+    """Route the tall linear maps / column sums through csrc/tall.hip (default) or through library GEMMs and torch
+    reductions (measurement, A/B).  Returns the previous setting."""
+    global _TALL_KERNELS
+    prev, _TALL_KERNELS = _TALL_KERNELS, bool(on)
+    return prev
+
+
+def _row_major16(t: Tensor) -> Tensor:
+    """t as the kernels address it: unit column stride, 16-byte aligned rows (column slices of a wider matrix qualify)."""
+    vec = 16 // t.element_size()
+    if t.stride(1) == 1 and t.stride(0) % vec == 0 and t.stride(0) >= t.size(1) and t.data_ptr() % 16 == 0:
+        return t
+    return t.contiguous()
+
+
+def tall_product(segments: Sequence[Tensor], w: Tensor, transposed: bool = False, bias: Optional[Tensor] = None) -> Tensor:
+    """[X_0 | X_1 | ...] @ W (+ bias) for tall segments [N, K_s] in ONE pass (pygsd_tall_linear), without concatenating.
+    W: [K, F_out] with K = sum of the segment widths, or [F_out, K] with transposed=True (the input gradient
+    [g | dP] W^T of a layer whose forward weight is W).  Shapes the kernel does not take run as library GEMMs."""
+    x0 = segments[0]
+    n, dtype = x0.size(0), x0.dtype
+    k_total = sum(int(t.size(1)) for t in segments)
+    f_out = int(w.size(0) if transposed else w.size(1))
+    if (w.size(1) if transposed else w.size(0)) != k_total:
+        raise ValueError(f"segments are {k_total} columns wide in total, W is {tuple(w.shape)} (transposed={transposed})")
+    code = _TALL_DTYPES.get(dtype)
+    kw = 32 if dtype == torch.bfloat16 else 16
+    fused = (_TALL_KERNELS and code is not None and x0.is_cuda and len(segments) <= 4 and w.dtype == dtype
+             and all(t.dim() == 2 and t.dtype == dtype and t.size(0) == n and t.size(1) % kw == 0 for t in segments)
+             and (bias is None or bias.dtype == dtype)
+             and bool(_cabi.lib().pygsd_tall_linear_supported(code, k_total, f_out)))
+    if not fused:
+        y, at = None, 0
+        for t in segments:
+            blk = w[:, at:at + t.size(1)].t() if transposed else w[at:at + t.size(1)]
+            if y is None:
+                y = torch.addmm(bias, t, blk) if bias is not None else t @ blk
+            else:
+                y.addmm_(t, blk)
+            at += t.size(1)
+        return y
+    segs = [_row_major16(t.detach()) for t in segments]
+    wd = w.detach()
+    if wd.stride(1) != 1:
+        wd = wd.contiguous()
+    bd = None if bias is None else bias.detach().contiguous()
+    y = torch.empty((n, f_out), dtype=dtype, device=x0.device)
+    k = len(segs)
+    xs = (c_void_p * k)(*[t.data_ptr() for t in segs])
+    lds = (ctypes.c_int64 * k)(*[t.stride(0) for t in segs])
+    wid = (ctypes.c_int32 * k)(*[t.size(1) for t in segs])
+    with torch.cuda.device(x0.device):
+        check(_cabi.lib().pygsd_tall_linear(xs, lds, wid, k, ptr(wd), wd.stride(0), 1 if transposed else 0, ptr(bd), ptr(y),
+                                            f_out, n, f_out, code, stream_ptr()), "pygsd_tall_linear")
+    return y
+
+
+def column_sums(x: Tensor) -> Tensor:
+    """x.sum(0) of a tall [N, F] matrix, accumulated in fp32 (pygsd_column_sums); result in x.dtype.  A row broadcast to
+    every node (stride 0: the gradient of a sum over the nodes) is N times that row."""
+    code = _TALL_DTYPES.get(x.dtype)
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    if not (_TALL_KERNELS and code is not None and x.is_cuda and x.dim() == 2 and x.size(1) % vec == 0
+            and 0 < x.size(1) <= 256 * vec // 2 and x.size(0) > 0):
+        return x.sum(0)
+    if x.size(0) > 1 and x.stride(0) == 0:
+        return (x[0].float() * x.size(0)).to(x.dtype)
+    xd = _row_major16(x.detach())
+    n, f = xd.shape
+    out = torch.empty(f, dtype=torch.float32, device=x.device)
+    lib = _cabi.lib()
+    with torch.cuda.device(x.device):
+        need = ctypes.c_size_t(0)
+        check(lib.pygsd_column_sums_workspace(n, f, code, ctypes.byref(need)), "pygsd_column_sums_workspace")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
+        check(lib.pygsd_column_sums(ptr(xd), xd.stride(0), n, f, code, ptr(out), ptr(ws), need.value, stream_ptr()),
+              "pygsd_column_sums")
+    return out if x.dtype == torch.float32 else out.to(x.dtype)
+
+
+def column_sums_of(tensors: Sequence[Optional[Tensor]]) -> List[Optional[Tensor]]:
+    """column_sums of each tensor, computing ONE reduction for tensors that are the same memory (the three branches of an
+    inception block summed by the model receive one upstream gradient)."""
+    done, out = {}, []
+    for t in tensors:
+        if t is None:
+            out.append(None)
+            continue
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
+        if key not in done:
+            done[key] = column_sums(t)
+        out.append(done[key])
+    return out
+
+
 class _TallLinear(torch.autograd.Function):
     """y = x @ W (+ b) for a tall x [N, F_in] (N ~ 10^5..10^6, F ~ 10^1..10^2) with library GEMMs.
     Forward and dX are ordinary GEMMs; the weight gradient dW = x^T g has a reduction dimension of N and
@@ -165,8 +269,7 @@ class _TallLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        y = torch.matmul(x, weight)
-        return y if bias is None else y + bias
+        return tall_product([x], weight, False, bias)
 
     @staticmethod
     def backward(ctx, g):
@@ -174,11 +277,11 @@ class _TallLinear(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.matmul(g, weight.t())
+            gx = tall_product([g], weight, True)
         if ctx.needs_input_grad[1]:
             gw = tall_gram(x, g)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0)
+            gb = column_sums(g)
         return gx, gw, gb
 
 

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch.nn import Parameter
 
 from .. import _cabi
-from ..dense import tall_gram, tall_linear
+from ..dense import column_sums_of, tall_gram, tall_linear, tall_product
 from ..sparse import _spmm_raw, spmm_rows_into
 from .directed.complex_relu import complex_relu_layer
 from .directed.DGCNConv import DGCNConv
@@ -209,11 +209,8 @@ class _InceptionBlockFn(torch.autograd.Function):
     def forward(ctx, x, w_ln_t, b_ln, w1, b1, w2, b2, pat1, ew1, pat2, ew2):
         f = w1.size(1)
         wcat = torch.cat([w_ln_t, w1, w2], dim=1)
-        if b_ln is not None:
-            bcat = torch.cat([b_ln, b_ln.new_zeros(2 * f)])
-            p = torch.addmm(bcat, x, wcat)
-        else:
-            p = x @ wcat
+        bcat = None if b_ln is None else torch.cat([b_ln, b_ln.new_zeros(2 * f)])
+        p = tall_product([x], wcat, False, bcat)
         v1, v2 = pat1.values_for(ew1, "fwd"), pat2.values_for(ew2, "fwd")
         x1 = _spmm_raw(pat1.fwd, v1, p[:, f:2 * f], None, 1.0, 0.0, False, b1)
         x2 = _spmm_raw(pat2.fwd, v2, p[:, 2 * f:], None, 1.0, 0.0, False, b2)
@@ -234,12 +231,12 @@ class _InceptionBlockFn(torch.autograd.Function):
         spmm_rows_into(pat2.bwd, pat2.values_for(ew2, "bwd"), g2, dp[:, f:])
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.addmm(g0 @ wcat[:, :f].t(), dp, wcat[:, f:].t())
+            dx = tall_product([g0, dp], wcat, True)         # g0 W_ln + [dP_1 | dP_2] [W_1 | W_2]^T in one pass
         dw_ln_t = tall_gram(x, g0)
         dw12 = tall_gram(x, dp)
         hb = ctx.has_bias
-        return (dx, dw_ln_t, g0.sum(0) if hb[0] else None, dw12[:, :f], g1.sum(0) if hb[1] else None,
-                dw12[:, f:], g2.sum(0) if hb[2] else None, None, None, None, None)
+        db0, db1, db2 = column_sums_of([g0 if hb[0] else None, g1 if hb[1] else None, g2 if hb[2] else None])
+        return (dx, dw_ln_t, db0, dw12[:, :f], db1, dw12[:, f:], db2, None, None, None, None)
 
 
 class DiGCN_InceptionBlock(nn.Module):

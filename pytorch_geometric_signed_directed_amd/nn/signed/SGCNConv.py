@@ -9,7 +9,7 @@ from torch import Tensor
 
 from ... import _cabi
 from ...message_passing import MessagePassing
-from ...dense import tall_gram, tall_linear
+from ...dense import column_sums, tall_gram, tall_linear, tall_product
 from ...sparse import GLOBAL_PATTERNS, spmm, spmm_rows_into
 
 
@@ -26,7 +26,7 @@ class _SgcnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_big, bias, o, spec):
         n = x.size(0)
-        y = torch.addmm(bias, x, w_big) if bias is not None else x @ w_big
+        y = tall_product([x], w_big, False, bias)
         out = torch.empty((n, 2 * o), dtype=x.dtype, device=x.device)
         seen = set()
         for j, (pat, half) in enumerate(spec):
@@ -54,11 +54,11 @@ class _SgcnFn(torch.autograd.Function):
                            ga[:, j * o:(j + 1) * o])
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.addmm(g @ w_big[:, :2 * o].t(), ga, w_big[:, 2 * o:].t())
+            dx = tall_product([g, ga], w_big, True)          # g W_own^T + g_a W_agg^T in one pass
         dw = torch.cat([tall_gram(x, g), tall_gram(x, ga)], dim=1)
         dbias = None
         if ctx.has_bias:
-            dbias = torch.cat([g.sum(0), g.new_zeros(len(spec) * o)])
+            dbias = torch.cat([column_sums(g), g.new_zeros(len(spec) * o)])
         return dx, dw, dbias, None, None
 
 

@@ -933,3 +933,101 @@ def test_weighted_sum_kernel(k, shape):
     ws = [float(v) for v in torch.randn(k, generator=g)]
     want = sum(w * x.double() for w, x in zip(ws, xs))
     close(weighted_sum([x.to(dev()) for x in xs], ws), want, 1e-6)
+
+
+# ------------------------------------------------------------------ tall linear maps (csrc/tall.hip)
+TALL_CASES = [
+    # (dtype, rows, segment widths, f_out, transposed W, bias, segments are column slices of a wider matrix)
+    ("f32", 1000, (64,), 192, False, True, False),       # DiGCN inception block forward, fp32
+    ("f32", 777, (64, 128), 64, True, False, True),      # its input gradient [g0 | dP] W^T (rows not a multiple of 16)
+    ("f32", 50, (64,), 256, False, True, False),         # SGCNConv layer 1: [own_b | own_u | a_pos | a_neg]
+    ("f32", 4099, (128, 128), 64, True, False, False),   # its input gradient, K = 256
+    ("f32", 33, (16,), 16, False, True, False),          # the smallest shape
+    ("f32", 300, (32, 64), 96, False, False, True),
+    ("bf16", 1000, (64,), 192, False, True, False),      # C5: bf16 inception block forward
+    ("bf16", 777, (64, 128), 64, True, False, True),     # C5: its input gradient
+    ("bf16", 4099, (128, 64, 64), 64, True, False, False),
+    ("bf16", 17, (32,), 32, False, True, False),
+    ("bf16", 513, (256,), 128, False, True, False),
+]
+
+
+@pytest.mark.parametrize("dtype,n,widths,f_out,transposed,with_bias,sliced", TALL_CASES)
+def test_tall_product_matches_float64(dtype, n, widths, f_out, transposed, with_bias, sliced):
+    """[X_0 | X_1 | ...] W (+ bias) in one pass on the matrix cores against float64 on the SAME (already rounded) inputs.
+    W is asymmetric and every output column has its own scale, so a transposed or permuted C/D write cannot pass.
+    fp32: the 1e-5 bar; bf16 storage: the result is the fp32-accumulated product rounded once (half an ulp, 2^-8)."""
+    from pytorch_geometric_signed_directed_amd.dense import set_tall_kernels, tall_product
+    from pytorch_geometric_signed_directed_amd import _cabi
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    k = sum(widths)
+    assert _cabi.lib().pygsd_tall_linear_supported(0 if dtype == "f32" else 1, k, f_out) == 1
+    g = torch.Generator().manual_seed(n + k + f_out)
+    scale = torch.linspace(0.25, 2.0, f_out)
+    w = (torch.randn(k, f_out, generator=g) / k ** 0.5 * scale).to(td)
+    if sliced:          # segments are column ranges of one wider row-major matrix (row stride != width)
+        wide = torch.randn(n, k + 32, generator=g).to(td).to(dev())
+        segs, at = [], 0
+        for wd in widths:
+            segs.append(wide[:, at:at + wd])
+            at += wd
+    else:
+        segs = [torch.randn(n, wd, generator=g).to(td).to(dev()) for wd in widths]
+    bias = torch.randn(f_out, generator=g).to(td) if with_bias else None
+    wdev = (w.t().contiguous() if transposed else w).to(dev())
+    got = tall_product(segs, wdev, transposed, None if bias is None else bias.to(dev()))
+    assert got.dtype == td and got.shape == (n, f_out)
+    want = torch.cat([s.double().cpu() for s in segs], dim=1) @ w.double()
+    if bias is not None:
+        want = want + bias.double()
+    if dtype == "f32":
+        close(got, want, TOL, what="tall product fp32")
+    else:
+        close(got, want, 2.0 ** -8, what="tall product bf16 (one rounding of the fp32 sum)")
+    prev = set_tall_kernels(False)      # the library route computes the same thing
+    try:
+        lib = tall_product(segs, wdev, transposed, None if bias is None else bias.to(dev()))
+    finally:
+        set_tall_kernels(prev)
+    close(lib, want, TOL if dtype == "f32" else 2.0 ** -6, what="library route")
+
+
+@pytest.mark.parametrize("dtype,n,f,sliced", [("f32", 1000, 64, False), ("f32", 5, 4, False), ("f32", 70001, 192, True),
+                                              ("bf16", 1000, 64, False), ("bf16", 70001, 128, True), ("bf16", 3, 8, False)])
+def test_column_sums_match_float64(dtype, n, f, sliced):
+    """Bias gradients: column sums accumulated in fp32 in a fixed order, against float64 (max-norm bar: a reduction over
+    the rows, tests/tolerance.py)."""
+    from pytorch_geometric_signed_directed_amd.dense import column_sums, column_sums_of
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(n + f)
+    x = (torch.randn(n, f + (16 if sliced else 0), generator=g) + 0.25).to(td).to(dev())
+    view = x[:, 8:8 + f] if sliced else x
+    got = column_sums(view)
+    assert got.dtype == td and got.shape == (f,)
+    want = view.double().sum(0)
+    close(got, want, TOL if dtype == "f32" else 2.0 ** -8, norm=True, what="column sums")
+    assert torch.equal(column_sums(view), got)                                   # deterministic
+    a, b, c = column_sums_of([view, None, view])
+    assert b is None and a is c
+    row = torch.randn(1, f, generator=g).to(td).to(dev())
+    close(column_sums(row.expand(n, f)), row[0].double() * n, 2.0 ** -8 if dtype == "bf16" else TOL, norm=True,
+          what="column sums of a broadcast row")
+
+
+def test_tall_linear_autograd_matches_float64():
+    """tall_linear (forward, dX through the transposed product, dW split-K, db column sums) against float64 autograd."""
+    from pytorch_geometric_signed_directed_amd.dense import tall_linear
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(5000, 64, generator=g)
+    w = torch.randn(64, 128, generator=g) / 8
+    b = torch.randn(128, generator=g)
+    gy = torch.randn(5000, 128, generator=g)
+    xd, wd, bd = (t.to(dev()).requires_grad_() for t in (x, w, b))
+    y = tall_linear(xd, wd, bd)
+    y.backward(gy.to(dev()))
+    x64, w64, b64 = (t.double().requires_grad_() for t in (x, w, b))
+    (x64 @ w64 + b64).backward(gy.double())
+    close(y, x64 @ w64 + b64, TOL, what="tall_linear forward")
+    close(xd.grad, x64.grad, TOL, what="tall_linear dX")
+    close(wd.grad, w64.grad, TOL, norm=True, what="tall_linear dW")
+    close(bd.grad, b64.grad, TOL, norm=True, what="tall_linear db")
