@@ -391,12 +391,19 @@ int pygsd_stream_copy_f32(const float* src, float* dst, int64_t n, void* stream)
  * ------------------------------------------------------------------------------------------- */
 int pygsd_pack_slices(const void* const* xs, int32_t groups, int32_t n_rows, int32_t row_bytes, int64_t ld_bytes,
                       int32_t p_r, int32_t p_c, int32_t phases, void* out, void* stream);
-/* out = sum_j weights[j] * xs[j] over n floats, every operand read once: the hop accumulations feat += w[h] * cur of
- * SIMPA / DIMPA (nn/signed/SIMPA.py:77-93, nn/directed/DIMPA.py:52-57) as one pass instead of one per hop.  xs: HOST array
- * of k (<= 8) device pointers; weights: HOST array of k floats (they travel by value); n % 4 == 0, 16-byte aligned. */
-int pygsd_weighted_sum_f32(const float* const* xs, const float* weights, int32_t k, int64_t n, float* out,
-                           void* stream);
-
+/* out = sum_j weights[j] * xs[j], every operand read once: the hop accumulations feat += w[h] * cur of SIMPA / DIMPA
+ * (nn/signed/SIMPA.py:77-93, nn/directed/DIMPA.py:52-57) as one pass instead of one per hop.  xs: HOST array of k (<= 8)
+ * device pointers to contiguous [n_rows, n_cols] matrices; weights: HOST array of k floats (they travel by value);
+ * n_cols % 4 == 0, 16-byte aligned.  out has the row stride ldo (elements, a multiple of 4): it may be a column block of a
+ * wider matrix -- SIMPA's cat([feat_p, feat_n], dim=1) (SIMPA.py:95) written in place. */
+int pygsd_weighted_sum_f32(const float* const* xs, const float* weights, int32_t k, int64_t n_rows, int32_t n_cols,
+                           float* out, int64_t ldo, void* stream);
+/* out[j] = <g, xs[j]>, j < k (<= 8): the gradients of SIMPA's hop weights (autograd's reduction of g * cur_h for
+ * SIMPA.py:77-93), g read ONCE for all k products.  g: [n_rows, n_cols] with row stride ldg (a column block of the
+ * upstream gradient of the concatenated output); xs: HOST array of device pointers to contiguous [n_rows, n_cols]
+ * matrices; out: k floats on the device; workspace >= 32 KiB.  fp32 accumulation in a fixed order (deterministic). */
+int pygsd_dots_f32(const float* g, int64_t ldg, const float* const* xs, int32_t k, int64_t n_rows, int32_t n_cols,
+                   float* out, void* workspace, size_t workspace_bytes, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * Tall-skinny linear maps of the non-magnetic layers on the matrix cores (csrc/tall.hip).
  *
@@ -412,14 +419,16 @@ int pygsd_weighted_sum_f32(const float* const* xs, const float* weights, int32_t
  * X, W, bias and Y alike.  xs / ldx / widths: HOST arrays over the n_seg (<= 4) column segments -- device pointer
  * (16-byte aligned), row stride in elements (a multiple of 16 bytes) and width (a multiple of 32 columns for bf16, 16 for
  * fp32).  W[k][n] (k over the concatenated segment columns) sits at w[k * ldw + n], or at w[n * ldw + k] when w_transposed.
- * bias: f_out elements or NULL.  Shapes: pygsd_tall_linear_supported(dtype, K = sum of widths, f_out) -- K, f_out <= 256 in
+ * The f_out = sum of out_widths output columns are written to n_out (<= 8) column segments ys / ldy / out_widths of the same
+ * form (one [n_rows, f_out] matrix, or one matrix per consumer so that each is gathered from contiguous rows).
+ * bias: f_out elements (over the concatenated output columns) or NULL.  Shapes: pygsd_tall_linear_supported(dtype, K = sum of widths, f_out) -- K, f_out <= 256 in
  * the multiples above with K * f_out <= 32768 (bf16) / 16384 (fp32) (W lives in 64 KB of LDS); the host falls back to
  * library GEMMs otherwise.
  * ------------------------------------------------------------------------------------------- */
 int pygsd_tall_linear_supported(int32_t dtype, int32_t k_total, int32_t f_out);
 int pygsd_tall_linear(const void* const* xs, const int64_t* ldx, const int32_t* widths, int32_t n_seg, const void* w,
-                      int64_t ldw, int32_t w_transposed, const void* bias, void* y, int64_t ldy, int64_t n_rows,
-                      int32_t f_out, int32_t dtype, void* stream);
+                      int64_t ldw, int32_t w_transposed, const void* bias, void* const* ys, const int64_t* ldy,
+                      const int32_t* out_widths, int32_t n_out, int64_t n_rows, int32_t dtype, void* stream);
 /* out[c] = sum_r x[r * ldx + c], c < f, accumulated in fp32 in a fixed order (deterministic): the bias gradients of the
  * layers above (the reference's autograd reduces dY over the nodes for DiGCNConv.py:90-93 / torch.nn.Linear biases).
  * dtype as above; f a multiple of 4 (fp32) / 8 (bf16), at most 1024 / 2048; workspace from pygsd_column_sums_workspace. */

@@ -108,10 +108,12 @@ PROTOTYPES = {
     "pygsd_spin_us": (c_int32, [c_double, c_void_p]),
     "pygsd_pack_slices": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p,
                                     c_void_p]),
-    "pygsd_weighted_sum_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "pygsd_weighted_sum_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
+    "pygsd_dots_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_size_t,
+                                 c_void_p]),
     "pygsd_tall_linear_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "pygsd_tall_linear": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
-                                    c_int64, c_int64, c_int32, c_int32, c_void_p]),
+                                    c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "pygsd_column_sums_workspace": (c_int32, [c_int64, c_int32, c_int32, ctypes.POINTER(ctypes.c_size_t)]),
     "pygsd_column_sums": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p, ctypes.c_size_t,
                                     c_void_p]),

@@ -264,28 +264,92 @@ struct WeightedSumArgs {
     const vec4f* x[8];
     float w[8];
     vec4f* out;
-    int64_t n4;
-    int32_t k;
+    int64_t n4, ldo4;    // float4 units: elements in total, output row stride
+    int32_t k, c4;       // operands, float4 units per row
 };
 
-// out = sum_j w[j] * x[j], every operand read once (SIMPA / DIMPA: feat = sum_h w[h] * cur_h, SIMPA.py:77-93)
+// out = sum_j w[j] * x[j], every operand read once (SIMPA / DIMPA: feat = sum_h w[h] * cur_h, SIMPA.py:77-93); the output
+// may be a column block of a wider matrix (SIMPA's cat([feat_p, feat_n]) written in place)
 __global__ __launch_bounds__(256) void weighted_sum_kernel(WeightedSumArgs a)
 {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n4;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         vec4f acc = a.x[0][i] * a.w[0];
         for (int j = 1; j < a.k; ++j) acc += a.x[j][i] * a.w[j];       // the reference's accumulation order
-        a.out[i] = acc;
+        const int64_t r = i / a.c4;
+        a.out[r * a.ldo4 + (i - r * a.c4)] = acc;
     }
+}
+
+constexpr int kDotBlocks = 1024;
+
+struct DotsArgs {
+    const vec4f* g;
+    const vec4f* x[8];
+    float* partial;      // [gridDim.x][k]
+    int64_t n4, ldg4;
+    int32_t k, c4;
+};
+
+// partial[b][j] = this block's share of <g, x_j>, j < k: g (possibly a column block of a wider matrix) is read ONCE for all
+// k products.  Fixed grid and a fixed combination order: deterministic.
+__global__ __launch_bounds__(256) void dots_kernel(DotsArgs a)
+{
+    __shared__ float sm[4][8];
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t r = i / a.c4;
+        const vec4f g = a.g[r * a.ldg4 + (i - r * a.c4)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < a.k) {
+                const vec4f x = a.x[j][i];
+                acc[j] += (g[0] * x[0] + g[1] * x[1]) + (g[2] * x[2] + g[3] * x[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = acc[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < static_cast<unsigned>(a.k))
+        a.partial[static_cast<int64_t>(blockIdx.x) * a.k + threadIdx.x] =
+            (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// out[j] = sum_b partial[b][j]: one block, 32 threads per product
+__global__ __launch_bounds__(256) void dots_finish_kernel(const float* __restrict__ partial, int n_partials, int k,
+                                                          float* __restrict__ out)
+{
+    __shared__ float sm[256];
+    const int j = threadIdx.x >> 5, t = threadIdx.x & 31;
+    float acc = 0.f;
+    if (j < k)
+        for (int b = t; b < n_partials; b += 32) acc += partial[static_cast<int64_t>(b) * k + j];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 16; off > 0; off >>= 1) {
+        if (t < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (t == 0 && j < k) out[j] = sm[threadIdx.x];
 }
 }  // namespace
 
-extern "C" int pygsd_weighted_sum_f32(const float* const* xs, const float* weights, int32_t k, int64_t n, float* out,
-                                      void* stream)
+extern "C" int pygsd_weighted_sum_f32(const float* const* xs, const float* weights, int32_t k, int64_t n_rows, int32_t n_cols,
+                                      float* out, int64_t ldo, void* stream)
 {
-    PYGSD_REQUIRE(k >= 1 && k <= 8 && n >= 0 && n % 4 == 0, "pygsd_weighted_sum_f32: 1..8 operands of a multiple of 4 elements");
-    if (n == 0) return 0;
-    PYGSD_REQUIRE(xs && weights && out && aligned16(out), "pygsd_weighted_sum_f32: null or unaligned pointer");
+    PYGSD_REQUIRE(k >= 1 && k <= 8 && n_rows >= 0 && n_cols >= 0 && n_cols % 4 == 0,
+                  "pygsd_weighted_sum_f32: 1..8 operands of rows that are multiples of 4 elements");
+    if (n_rows == 0 || n_cols == 0) return 0;
+    PYGSD_REQUIRE(xs && weights && out && aligned16(out) && ldo >= n_cols && ldo % 4 == 0,
+                  "pygsd_weighted_sum_f32: null or unaligned pointer, or output row stride not a multiple of 16 bytes >= n_cols");
     WeightedSumArgs a{};
     for (int j = 0; j < k; ++j) {
         PYGSD_REQUIRE(xs[j] && aligned16(xs[j]), "pygsd_weighted_sum_f32: operand %d null or not 16-byte aligned", j);
@@ -293,7 +357,9 @@ extern "C" int pygsd_weighted_sum_f32(const float* const* xs, const float* weigh
         a.w[j] = weights[j];                                           // HOST array: the weights travel by value
     }
     a.out = reinterpret_cast<vec4f*>(out);
-    a.n4 = n / 4;
+    a.c4 = n_cols / 4;
+    a.n4 = n_rows * a.c4;
+    a.ldo4 = ldo / 4;
     a.k = k;
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_ELEMENTWISE, s);
@@ -301,6 +367,41 @@ extern "C" int pygsd_weighted_sum_f32(const float* const* xs, const float* weigh
     hipLaunchKernelGGL(weighted_sum_kernel, dim3(static_cast<unsigned>(blocks < (1 << 22) ? blocks : (1 << 22))), dim3(kBlock), 0,
                        s, a);
     return check_launch("weighted_sum_kernel");
+}
+
+extern "C" int pygsd_dots_f32(const float* g, int64_t ldg, const float* const* xs, int32_t k, int64_t n_rows, int32_t n_cols,
+                              float* out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    PYGSD_REQUIRE(k >= 1 && k <= 8 && n_rows >= 0 && n_cols >= 0 && n_cols % 4 == 0,
+                  "pygsd_dots_f32: 1..8 operands of rows that are multiples of 4 elements");
+    PYGSD_REQUIRE(out && workspace && workspace_bytes >= sizeof(float) * kDotBlocks * 8,
+                  "pygsd_dots_f32: null output or workspace smaller than %zu bytes", sizeof(float) * kDotBlocks * 8);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_rows == 0 || n_cols == 0) {
+        PYGSD_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * k, s));
+        return 0;
+    }
+    PYGSD_REQUIRE(g && xs && aligned16(g) && ldg >= n_cols && ldg % 4 == 0,
+                  "pygsd_dots_f32: g null, not 16-byte aligned, or its row stride not a multiple of 16 bytes >= n_cols");
+    DotsArgs a{};
+    for (int j = 0; j < k; ++j) {
+        PYGSD_REQUIRE(xs[j] && aligned16(xs[j]), "pygsd_dots_f32: operand %d null or not 16-byte aligned", j);
+        a.x[j] = reinterpret_cast<const vec4f*>(xs[j]);
+    }
+    a.g = reinterpret_cast<const vec4f*>(g);
+    a.partial = static_cast<float*>(workspace);
+    a.c4 = n_cols / 4;
+    a.n4 = n_rows * a.c4;
+    a.ldg4 = ldg / 4;
+    a.k = k;
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    int64_t blocks = (a.n4 + kBlock - 1) / kBlock;
+    if (blocks > kDotBlocks) blocks = kDotBlocks;
+    hipLaunchKernelGGL(dots_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a);
+    if (int rc = check_launch("dots_kernel")) return rc;
+    hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, s, static_cast<const float*>(workspace),
+                       static_cast<int>(blocks), k, out);
+    return check_launch("dots_finish_kernel");
 }
 
 extern "C" int pygsd_spin_us(double microseconds, void* stream)

@@ -24,7 +24,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kMaxKB = 16;     // k-blocks: 32 bf16 / 16 fp32 columns each (one 16-byte load per lane)
-constexpr int kMaxSeg = 4;
+constexpr int kMaxSeg = 4;      // input column segments
+constexpr int kMaxOut = 8;      // output column segments
 
 struct TallArgs {
     const void* x[kMaxKB];     // first element of k-block kb in row 0 of its segment
@@ -32,8 +33,8 @@ struct TallArgs {
     const void* w;             // W[k][n] at w[k * ldw + n]  (w_t == 0)  or  w[n * ldw + k]  (w_t != 0)
     int64_t ldw;
     const void* bias;          // f_out elements of the storage type, or null
-    void* y;
-    int64_t ldy;
+    void* y[kMaxKB];           // first element of output block b (32 bf16 / 16 fp32 columns) in row 0 of its segment
+    int64_t ldy[kMaxKB];       // that segment's row stride in elements
     int32_t n_rows, f_out, w_t;
 };
 
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void tall_linear_bf16_kernel(TallArgs p)
         }
         // lane (j, q): tiles 2 m and 2 m + 1 hold columns [32 m + 8 q, 32 m + 8 q + 8) of row 16 tile + j
         if (tile * 16 + j < p.n_rows) {
-            uint16_t* yrow = static_cast<uint16_t*>(p.y) + static_cast<int64_t>(tile * 16 + j) * p.ldy + 8 * q;
+            const int64_t row = tile * 16 + j;
 #pragma unroll
             for (int m = 0; m < NT / 2; ++m) {
                 const float4 b0 = *reinterpret_cast<const float4*>(bias + 32 * m + 8 * q);
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void tall_linear_bf16_kernel(TallArgs p)
                 o.y = pack2(lo[2] + b0.z, lo[3] + b0.w);
                 o.z = pack2(hi[0] + b1.x, hi[1] + b1.y);
                 o.w = pack2(hi[2] + b1.z, hi[3] + b1.w);
-                *reinterpret_cast<uint4*>(yrow + 32 * m) = o;
+                *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.y[m]) + row * p.ldy[m] + 8 * q) = o;
             }
         }
 #pragma unroll
@@ -174,11 +175,11 @@ __global__ __launch_bounds__(256) void tall_linear_f32_kernel(TallArgs p)
             }
         }
         if (tile * 16 + j < p.n_rows) {
-            float* yrow = static_cast<float*>(p.y) + static_cast<int64_t>(tile * 16 + j) * p.ldy + 4 * q;
+            const int64_t row = tile * 16 + j;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float4 b = *reinterpret_cast<const float4*>(bias + 16 * t + 4 * q);
-                *reinterpret_cast<float4*>(yrow + 16 * t) =
+                *reinterpret_cast<float4*>(static_cast<float*>(p.y[t]) + row * p.ldy[t] + 4 * q) =
                     make_float4(acc[t][0] + b.x, acc[t][1] + b.y, acc[t][2] + b.z, acc[t][3] + b.w);
             }
         }
@@ -334,27 +335,33 @@ extern "C" int pygsd_tall_linear_supported(int32_t dtype, int32_t k_total, int32
 }
 
 extern "C" int pygsd_tall_linear(const void* const* xs, const int64_t* ldx, const int32_t* widths, int32_t n_seg,
-                                 const void* w, int64_t ldw, int32_t w_transposed, const void* bias, void* y, int64_t ldy,
-                                 int64_t n_rows, int32_t f_out, int32_t dtype, void* stream)
+                                 const void* w, int64_t ldw, int32_t w_transposed, const void* bias, void* const* ys,
+                                 const int64_t* ldy, const int32_t* out_widths, int32_t n_out, int64_t n_rows, int32_t dtype,
+                                 void* stream)
 {
     PYGSD_REQUIRE(dtype == 0 || dtype == 1, "pygsd_tall_linear: dtype must be 0 (fp32) or 1 (bf16), got %d", dtype);
-    PYGSD_REQUIRE(n_seg >= 1 && n_seg <= kMaxSeg && xs && ldx && widths, "pygsd_tall_linear: 1..%d column segments", kMaxSeg);
+    PYGSD_REQUIRE(n_seg >= 1 && n_seg <= kMaxSeg && xs && ldx && widths, "pygsd_tall_linear: 1..%d input segments", kMaxSeg);
+    PYGSD_REQUIRE(n_out >= 1 && n_out <= kMaxOut && ys && ldy && out_widths, "pygsd_tall_linear: 1..%d output segments",
+                  kMaxOut);
     PYGSD_REQUIRE(n_rows >= 0 && n_rows < (1ll << 31) - 16, "pygsd_tall_linear: row count outside [0, 2^31)");
-    const int kw = dtype == 1 ? 32 : 16;          // columns per k-block
+    const int kw = dtype == 1 ? 32 : 16;          // columns per block (inputs and outputs alike)
     const int vec = dtype == 1 ? 8 : 4;           // elements per 16 bytes
     const size_t esz = dtype == 1 ? 2 : 4;
-    int k_total = 0;
+    int k_total = 0, f_out = 0;
     for (int g = 0; g < n_seg; ++g) {
-        PYGSD_REQUIRE(widths[g] > 0 && widths[g] % kw == 0, "pygsd_tall_linear: segment %d is %d columns wide (multiples of %d)",
-                      g, widths[g], kw);
+        PYGSD_REQUIRE(widths[g] > 0 && widths[g] % kw == 0, "pygsd_tall_linear: input segment %d is %d columns wide "
+                      "(multiples of %d)", g, widths[g], kw);
         k_total += widths[g];
+    }
+    for (int g = 0; g < n_out; ++g) {
+        PYGSD_REQUIRE(out_widths[g] > 0 && out_widths[g] % kw == 0, "pygsd_tall_linear: output segment %d is %d columns wide "
+                      "(multiples of %d)", g, out_widths[g], kw);
+        f_out += out_widths[g];
     }
     PYGSD_REQUIRE(shape_ok(dtype, k_total, f_out), "pygsd_tall_linear: unsupported shape K=%d f_out=%d (see "
                   "pygsd_tall_linear_supported)", k_total, f_out);
     if (n_rows == 0) return 0;
-    PYGSD_REQUIRE(w && y && aligned16(y) && ldy >= f_out && ldy % vec == 0, "pygsd_tall_linear: output null, unaligned or "
-                  "row stride %lld not a multiple of 16 bytes >= f_out", static_cast<long long>(ldy));
-    PYGSD_REQUIRE(ldw >= (w_transposed ? k_total : f_out), "pygsd_tall_linear: ldw = %lld too small",
+    PYGSD_REQUIRE(w && ldw >= (w_transposed ? k_total : f_out), "pygsd_tall_linear: W null or ldw = %lld too small",
                   static_cast<long long>(ldw));
     TallArgs a{};
     int kb = 0;
@@ -367,7 +374,17 @@ extern "C" int pygsd_tall_linear(const void* const* xs, const int64_t* ldx, cons
             a.ld[kb] = ldx[g];
         }
     }
-    a.w = w; a.ldw = ldw; a.w_t = w_transposed ? 1 : 0; a.bias = bias; a.y = y; a.ldy = ldy;
+    int ob = 0;
+    for (int g = 0; g < n_out; ++g) {
+        PYGSD_REQUIRE(ys[g] && aligned16(ys[g]) && ldy[g] >= out_widths[g] && ldy[g] % vec == 0,
+                      "pygsd_tall_linear: output segment %d null, not 16-byte aligned, or row stride %lld not a multiple of "
+                      "16 bytes >= its width", g, static_cast<long long>(ldy[g]));
+        for (int c = 0; c < out_widths[g]; c += kw, ++ob) {
+            a.y[ob] = static_cast<unsigned char*>(ys[g]) + static_cast<size_t>(c) * esz;
+            a.ldy[ob] = ldy[g];
+        }
+    }
+    a.w = w; a.ldw = ldw; a.w_t = w_transposed ? 1 : 0; a.bias = bias;
     a.n_rows = static_cast<int32_t>(n_rows); a.f_out = f_out;
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_DENSE, s);

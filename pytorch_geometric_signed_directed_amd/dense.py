@@ -177,21 +177,27 @@ def _row_major16(t: Tensor) -> Tensor:
     return t.contiguous()
 
 
-def tall_product(segments: Sequence[Tensor], w: Tensor, transposed: bool = False, bias: Optional[Tensor] = None) -> Tensor:
+def tall_product(segments: Sequence[Tensor], w: Tensor, transposed: bool = False, bias: Optional[Tensor] = None,
+                 splits: Optional[Sequence[int]] = None):
     """[X_0 | X_1 | ...] @ W (+ bias) for tall segments [N, K_s] in ONE pass (pygsd_tall_linear), without concatenating.
     W: [K, F_out] with K = sum of the segment widths, or [F_out, K] with transposed=True (the input gradient
-    [g | dP] W^T of a layer whose forward weight is W).  Shapes the kernel does not take run as library GEMMs."""
+    [g | dP] W^T of a layer whose forward weight is W).  splits: column widths summing to F_out -- the result comes back
+    as one CONTIGUOUS matrix per width (each consumer then gathers whole rows) instead of one [N, F_out] matrix.
+    Shapes the kernel does not take run as library GEMMs."""
     x0 = segments[0]
     n, dtype = x0.size(0), x0.dtype
     k_total = sum(int(t.size(1)) for t in segments)
     f_out = int(w.size(0) if transposed else w.size(1))
     if (w.size(1) if transposed else w.size(0)) != k_total:
         raise ValueError(f"segments are {k_total} columns wide in total, W is {tuple(w.shape)} (transposed={transposed})")
+    if splits is not None and sum(splits) != f_out:
+        raise ValueError(f"splits {tuple(splits)} do not add up to {f_out} output columns")
     code = _TALL_DTYPES.get(dtype)
     kw = 32 if dtype == torch.bfloat16 else 16
     fused = (_TALL_KERNELS and code is not None and x0.is_cuda and len(segments) <= 4 and w.dtype == dtype
              and all(t.dim() == 2 and t.dtype == dtype and t.size(0) == n and t.size(1) % kw == 0 for t in segments)
              and (bias is None or bias.dtype == dtype)
+             and (splits is None or (len(splits) <= 8 and all(c > 0 and c % kw == 0 for c in splits)))
              and bool(_cabi.lib().pygsd_tall_linear_supported(code, k_total, f_out)))
     if not fused:
         y, at = None, 0
@@ -202,21 +208,24 @@ def tall_product(segments: Sequence[Tensor], w: Tensor, transposed: bool = False
             else:
                 y.addmm_(t, blk)
             at += t.size(1)
-        return y
+        return y if splits is None else list(y.split(list(splits), dim=1))
     segs = [_row_major16(t.detach()) for t in segments]
     wd = w.detach()
     if wd.stride(1) != 1:
         wd = wd.contiguous()
     bd = None if bias is None else bias.detach().contiguous()
-    y = torch.empty((n, f_out), dtype=dtype, device=x0.device)
-    k = len(segs)
+    outs = [torch.empty((n, c), dtype=dtype, device=x0.device) for c in (splits if splits is not None else (f_out,))]
+    k, m = len(segs), len(outs)
     xs = (c_void_p * k)(*[t.data_ptr() for t in segs])
     lds = (ctypes.c_int64 * k)(*[t.stride(0) for t in segs])
     wid = (ctypes.c_int32 * k)(*[t.size(1) for t in segs])
+    ys = (c_void_p * m)(*[t.data_ptr() for t in outs])
+    ldy = (ctypes.c_int64 * m)(*[t.stride(0) for t in outs])
+    owid = (ctypes.c_int32 * m)(*[t.size(1) for t in outs])
     with torch.cuda.device(x0.device):
-        check(_cabi.lib().pygsd_tall_linear(xs, lds, wid, k, ptr(wd), wd.stride(0), 1 if transposed else 0, ptr(bd), ptr(y),
-                                            f_out, n, f_out, code, stream_ptr()), "pygsd_tall_linear")
-    return y
+        check(_cabi.lib().pygsd_tall_linear(xs, lds, wid, k, ptr(wd), wd.stride(0), 1 if transposed else 0, ptr(bd), ys, ldy,
+                                            owid, m, n, code, stream_ptr()), "pygsd_tall_linear")
+    return outs[0] if splits is None else outs
 
 
 def column_sums(x: Tensor) -> Tensor:

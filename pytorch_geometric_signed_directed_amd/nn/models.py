@@ -196,11 +196,12 @@ class DiGCN_node_classification(nn.Module):
 
 class _InceptionBlockFn(torch.autograd.Function):
     """The whole DiGCN inception block as one autograd node (fixed operator values):
-        forward   P = x [W_ln^T | W_1 | W_2] + [b_ln | 0 | 0]    ONE GEMM (x read once, the Linear's bias in its epilogue)
-                  x0 = P[:, :F] ;  x_k = S_k^T P[:, kF:(k+1)F] + b_k    the HIP SpMM on column slices, the conv bias
+        forward   [x0 | P_1 | P_2] = x [W_ln^T | W_1 | W_2] + [b_ln | 0 | 0]    ONE product (csrc/tall.hip: x read once, the
+                  Linear's bias in its epilogue, the three blocks written as three contiguous matrices)
+                  x_k = S_k^T P_k + b_k                                 the HIP SpMM, the conv bias
                                                                         added in its epilogue (Z row with stride 0)
         backward  dP_k = S_k dx_k  written by the SpMM straight into the column halves of ONE [N, 2F] buffer;
-                  dx = dx0 W_ln + [dP_1 | dP_2] [W_1 | W_2]^T   two GEMMs, the second accumulating into the first;
+                  dx = [dx0 | dP_1 | dP_2] [W_ln^T | W_1 | W_2]^T   ONE product over the three column segments;
                   dW_ln = x^T dx0, [dW_1 | dW_2] = x^T [dP_1 | dP_2]   split-K; the three bias gradients are column sums.
     Replaces three GEMMs + three bias passes forward and three GEMMs + two gradient-accumulation passes + three skinny
     weight GEMMs backward (reference: DiGCN_Inception_Block.py:44-46, DiGCNConv.py:66,86-93)."""
@@ -210,14 +211,15 @@ class _InceptionBlockFn(torch.autograd.Function):
         f = w1.size(1)
         wcat = torch.cat([w_ln_t, w1, w2], dim=1)
         bcat = None if b_ln is None else torch.cat([b_ln, b_ln.new_zeros(2 * f)])
-        p = tall_product([x], wcat, False, bcat)
+        # three contiguous matrices: x0 as the caller gets it, and the two the aggregations gather whole rows from
+        x0, p1, p2 = tall_product([x], wcat, False, bcat, splits=(f, f, f))
         v1, v2 = pat1.values_for(ew1, "fwd"), pat2.values_for(ew2, "fwd")
-        x1 = _spmm_raw(pat1.fwd, v1, p[:, f:2 * f], None, 1.0, 0.0, False, b1)
-        x2 = _spmm_raw(pat2.fwd, v2, p[:, 2 * f:], None, 1.0, 0.0, False, b2)
+        x1 = _spmm_raw(pat1.fwd, v1, p1, None, 1.0, 0.0, False, b1)
+        x2 = _spmm_raw(pat2.fwd, v2, p2, None, 1.0, 0.0, False, b2)
         ctx.save_for_backward(x, wcat)
         ctx.ops = (pat1, ew1, pat2, ew2)
         ctx.has_bias = (b_ln is not None, b1 is not None, b2 is not None)
-        return p[:, :f], x1, x2
+        return x0, x1, x2
 
     @staticmethod
     @torch.autograd.function.once_differentiable

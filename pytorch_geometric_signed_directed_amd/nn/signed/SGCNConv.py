@@ -19,23 +19,24 @@ class _SgcnFn(torch.autograd.Function):
         out[:, half_j] = y_own[:, half_j] + sum_j mean_in(pattern_j, a_j)        (half = 0: balanced, 1: unbalanced)
     -- the first aggregation of a half reads the own block as the SpMM's Z operand, later ones accumulate.  Backward:
     g_a_j = mean_in(pattern_j)^T g_out[:, half_j] written into ONE [N, m o] buffer, then
-    dx = g_out W_own^T + g_a W_agg^T (two GEMMs, the second accumulating), dW_big = [x^T g_out | x^T g_a] (split-K),
+    dx = [g_out | g_a] W_big^T (one product over the two column segments), dW_big = [x^T g_out | x^T g_a] (split-K),
     d bias = column sums of g_out.  No element-wise passes, no split / cat in either direction
     (reference order: aggregate, concatenate, Linear -- SGCNConv.py:101-126)."""
 
     @staticmethod
     def forward(ctx, x, w_big, bias, o, spec):
         n = x.size(0)
-        y = tall_product([x], w_big, False, bias)
+        # the own block [own_b | own_u] and one contiguous matrix per aggregated block (gathered by whole rows)
+        parts = tall_product([x], w_big, False, bias, splits=(2 * o,) + (o,) * len(spec))
+        own = parts[0]
         out = torch.empty((n, 2 * o), dtype=x.dtype, device=x.device)
         seen = set()
         for j, (pat, half) in enumerate(spec):
-            a_j = y[:, (2 + j) * o:(3 + j) * o]
             dst = out[:, half * o:(half + 1) * o]
             if half in seen:
-                spmm_rows_into(pat.fwd, None, a_j, dst, accumulate=True, mean=True)
+                spmm_rows_into(pat.fwd, None, parts[1 + j], dst, accumulate=True, mean=True)
             else:
-                spmm_rows_into(pat.fwd, None, a_j, dst, mean=True, z=y[:, half * o:(half + 1) * o])
+                spmm_rows_into(pat.fwd, None, parts[1 + j], dst, mean=True, z=own[:, half * o:(half + 1) * o])
                 seen.add(half)
         ctx.save_for_backward(x, w_big)
         ctx.o, ctx.spec, ctx.has_bias = o, spec, bias is not None

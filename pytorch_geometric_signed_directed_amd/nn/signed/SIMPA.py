@@ -10,17 +10,42 @@ from ...sparse import GLOBAL_PATTERNS, _spmm_raw
 from ..general.conv_base import Conv_Base, flipped_edge_index
 
 
-def weighted_sum(tensors, weights):
-    """sum_j weights[j] * tensors[j] (contiguous fp32 tensors of one shape, Python floats) in ONE pass: pygsd_weighted_sum_f32."""
+def weighted_sum(tensors, weights, out=None):
+    """sum_j weights[j] * tensors[j] (fp32 matrices of one shape, Python floats) in ONE pass: pygsd_weighted_sum_f32.
+    out: where to write it -- a column block of a wider matrix qualifies (unit column stride, 16-byte aligned rows)."""
     import ctypes
     k = len(tensors)
     tensors = [t.contiguous() for t in tensors]        # (a product at an odd width is a column slice of a padded one)
-    out = torch.empty_like(tensors[0])
+    shape = tensors[0].shape
+    rows, cols = (1, tensors[0].numel()) if tensors[0].dim() != 2 else (shape[0], shape[1])
+    if out is None:
+        out = torch.empty_like(tensors[0])
+        ldo = cols
+    else:
+        if tuple(out.shape) != tuple(shape) or out.dim() != 2 or out.stride(1) != 1 or out.dtype != torch.float32:
+            raise ValueError("weighted_sum: `out` must be an fp32 [rows, cols] matrix with unit column stride")
+        ldo = out.stride(0)
     ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors])
     ws = (ctypes.c_float * k)(*[float(w) for w in weights])
     with torch.cuda.device(out.device):
-        _cabi.check(_cabi.lib().pygsd_weighted_sum_f32(ptrs, ws, k, out.numel(), _cabi.ptr(out), _cabi.stream_ptr()),
+        _cabi.check(_cabi.lib().pygsd_weighted_sum_f32(ptrs, ws, k, rows, cols, _cabi.ptr(out), ldo, _cabi.stream_ptr()),
                     "pygsd_weighted_sum_f32")
+    return out
+
+
+def dots(g, tensors):
+    """[<g, t> for t in tensors] as one fp32 device vector, g read once (pygsd_dots_f32); at most 8 tensors of g's shape."""
+    import ctypes
+    k = len(tensors)
+    g = g.contiguous()
+    tensors = [t.contiguous() for t in tensors]
+    rows, cols = (1, g.numel()) if g.dim() != 2 else (g.size(0), g.size(1))
+    out = torch.empty(k, dtype=torch.float32, device=g.device)
+    ws = torch.empty(8192, dtype=torch.float32, device=g.device)
+    ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors])
+    with torch.cuda.device(g.device):
+        _cabi.check(_cabi.lib().pygsd_dots_f32(_cabi.ptr(g), cols, ptrs, k, rows, cols, _cabi.ptr(out), _cabi.ptr(ws),
+                                               ws.numel() * 4, _cabi.stream_ptr()), "pygsd_dots_f32")
     return out
 
 
@@ -32,8 +57,9 @@ class _StreamFn(torch.autograd.Function):
     both kinds of summand ride on the SpMM's own epilogue (Y = alpha S^T X + beta Z: a pending `w g` is consumed as
     (x = g, alpha = w) when it is propagated and as (z = g, beta = w) when something is added to it), so the chain
     costs its SpMMs and nothing else -- autograd's composition paid a scale pass, a product-and-reduce pass and an
-    accumulation pass per hop on top.  The hop weights' gradients are dot products <g_feat, node>.  The weights are
-    read to the host once per call (six floats at hop 2)."""
+    accumulation pass per hop on top.  The hop weights' gradients are dot products <g_feat, node>, one pass per stream
+    half (pygsd_dots_f32).  feat_p / feat_n are written side by side into ONE [N, 2F] matrix (the reference's cat,
+    SIMPA.py:95).  The weights are read to the host once per call (six floats at hop 2)."""
 
     @staticmethod
     def forward(ctx, x_pos, x_neg, wp, wn, op_p, op_n, hop):
@@ -62,27 +88,33 @@ class _StreamFn(torch.autograd.Function):
                     terms_n.append((j, cur_n))
                     j += 1
 
-        def weighted(terms, weights):
-            if not terms:
-                return torch.zeros_like(nodes[0])
-            if nodes[0].numel() % 4 == 0 and len(terms) <= 8:
-                return weighted_sum([nodes[v] for _, v in terms], [weights[wi] for wi, _ in terms])
-            out = nodes[terms[0][1]] * weights[terms[0][0]]
-            for wi, v in terms[1:]:
-                out.add_(nodes[v], alpha=weights[wi])
-            return out
+        n, f = nodes[0].shape
+        feat = torch.empty((n, 2 * f), dtype=nodes[0].dtype, device=nodes[0].device)   # [feat_p | feat_n], SIMPA.py:95
 
-        feat_p, feat_n = weighted(terms_p, wpl), weighted(terms_n, wnl)
+        def weighted(terms, weights, out):
+            if not terms:
+                out.zero_()
+            elif f % 4 == 0 and len(terms) <= 8:
+                weighted_sum([nodes[v] for _, v in terms], [weights[wi] for wi, _ in terms], out)
+            else:
+                torch.mul(nodes[terms[0][1]], weights[terms[0][0]], out=out)
+                for wi, v in terms[1:]:
+                    out.add_(nodes[v], alpha=weights[wi])
+
+        weighted(terms_p, wpl, feat[:, :f])
+        weighted(terms_n, wnl, feat[:, f:])
         ctx.save_for_backward(*nodes)
         ctx.tape = (ops, terms_p, terms_n, wpl, wnl, op_p, op_n, tuple(wp.shape), tuple(wn.shape))
-        return feat_p, feat_n
+        return feat
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_p, g_n):
+    def backward(ctx, g):
         nodes = ctx.saved_tensors
         ops, terms_p, terms_n, wpl, wnl, op_p, op_n, shape_p, shape_n = ctx.tape
-        g_p, g_n = g_p.contiguous(), g_n.contiguous()
+        f = nodes[0].size(1)
+        # contiguous halves: most of the backward products gather their rows straight from these
+        g_p, g_n = g[:, :f].contiguous(), g[:, f:].contiguous()
         grads = {}                                   # node -> tensor | ("pending", w, g): w * g, not materialised
 
         def add_term(v, w, g):
@@ -119,14 +151,24 @@ class _StreamFn(torch.autograd.Function):
                 return torch.zeros_like(nodes[v])
             return cur[2] * cur[1] if isinstance(cur, tuple) else cur
 
-        def dots(terms, g, shape):
+        def weight_grads(terms, g, shape):
             out = g.new_zeros(shape)
+            if not terms:
+                return out
             flat = out.view(-1)
-            for wi, v in terms:
-                flat[wi] = torch.dot(g.reshape(-1), nodes[v].reshape(-1))
+            if g.size(1) % 4 == 0 and len(terms) <= 8:
+                res = dots(g, [nodes[v] for _, v in terms])             # g read once for all of the stream's hop weights
+                which = [wi for wi, _ in terms]
+                if which == list(range(flat.numel())):
+                    return res.view(shape)
+                flat.index_copy_(0, torch.tensor(which, device=g.device), res)
+            else:
+                for wi, v in terms:
+                    flat[wi] = torch.dot(g.reshape(-1), nodes[v].reshape(-1))
             return out
 
-        return (materialise(0), materialise(1), dots(terms_p, g_p, shape_p), dots(terms_n, g_n, shape_n), None, None, None)
+        return (materialise(0), materialise(1), weight_grads(terms_p, g_p, shape_p), weight_grads(terms_n, g_n, shape_n),
+                None, None, None)
 
 
 class SIMPA(torch.nn.Module):
@@ -164,7 +206,7 @@ class SIMPA(torch.nn.Module):
 
     def _stream(self, ei_p, w_p, ei_n, w_n, x_pos, x_neg, wp, wn):
         """One (positive, negative) feature pair: feat_p = sum_h wp[h] Ap^h x_pos and the mixed
-        paths Ap^m An Ap^h x_neg, in the reference's accumulation order (SIMPA.py:77-93)."""
+        paths Ap^m An Ap^h x_neg, in the reference's accumulation order (SIMPA.py:77-93).  -> [feat_p | feat_n]."""
         if self._fusable(w_p, w_n, x_pos, x_neg):
             _cabi.require_gpu(x_pos, x_neg, ei_p, ei_n, w_p, w_n)
             n = x_pos.size(0)
@@ -172,7 +214,7 @@ class SIMPA(torch.nn.Module):
             for conv, ei, w in ((self.conv_layer_p, ei_p, w_p), (self.conv_layer_n, ei_n, w_n)):
                 nei, nw = conv._normalised(ei, w, n, x_pos.dtype)          # conv_norm_rw, memoised on the graph tensors
                 handles.append((GLOBAL_PATTERNS.get(nei, n, n, conv.flow, validate=False), nw))
-            return _StreamFn.apply(x_pos, x_neg, wp, wn, handles[0], handles[1], self._hop_p - 1)
+            return _StreamFn.apply(x_pos, x_neg, wp, wn, handles[0], handles[1], self._hop_p - 1)    # [feat_p | feat_n]
         feat_p = wp[0] * x_pos
         feat_n = None
         cur_p, aux_n = x_pos, x_neg
@@ -192,7 +234,7 @@ class SIMPA(torch.nn.Module):
                     cur_n = self.conv_layer_p(cur_n, ei_p, w_p)
                     feat_n = torch.addcmul(feat_n, wn[j], cur_n)
                     j += 1
-        return feat_p, (torch.zeros_like(feat_p) if feat_n is None else feat_n)
+        return torch.cat([feat_p, torch.zeros_like(feat_p) if feat_n is None else feat_n], dim=1)
 
     def forward(self, edge_index_p: torch.LongTensor, edge_weight_p: torch.FloatTensor,
                 edge_index_n: torch.LongTensor, edge_weight_n: torch.FloatTensor,
@@ -200,12 +242,9 @@ class SIMPA(torch.nn.Module):
                 x_pt: Optional[torch.FloatTensor] = None,
                 x_nt: Optional[torch.FloatTensor] = None) -> torch.FloatTensor:
         if self._undirected:
-            fp, fn = self._stream(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, x_p, x_n,
-                                  self._w_p, self._w_n)
-            return torch.cat([fp, fn], dim=1)
-        sp, sn = self._stream(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, x_p, x_n,
-                              self._w_sp, self._w_sn)
-        tp, tn = self._stream(flipped_edge_index(edge_index_p), edge_weight_p,
+            return self._stream(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, x_p, x_n, self._w_p, self._w_n)
+        source = self._stream(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, x_p, x_n, self._w_sp, self._w_sn)
+        target = self._stream(flipped_edge_index(edge_index_p), edge_weight_p,
                               flipped_edge_index(edge_index_n), edge_weight_n,
                               x_pt, x_nt, self._w_tp, self._w_tn)
-        return torch.cat([sp, sn, tp, tn], dim=1)
+        return torch.cat([source, target], dim=1)               # [sp | sn | tp | tn], SIMPA.py:142

@@ -933,6 +933,25 @@ def test_weighted_sum_kernel(k, shape):
     ws = [float(v) for v in torch.randn(k, generator=g)]
     want = sum(w * x.double() for w, x in zip(ws, xs))
     close(weighted_sum([x.to(dev()) for x in xs], ws), want, 1e-6)
+    wide = torch.full((shape[0], 2 * shape[1] + 4), 7.0, device=dev())           # into a column block of a wider matrix
+    weighted_sum([x.to(dev()) for x in xs], ws, wide[:, shape[1]:2 * shape[1]])
+    close(wide[:, shape[1]:2 * shape[1]], want, 1e-6)
+    assert bool((wide[:, :shape[1]] == 7.0).all()) and bool((wide[:, 2 * shape[1]:] == 7.0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,shape", [(1, (5, 4)), (3, (100000, 64)), (8, (333, 12))])
+def test_dots_kernel(k, shape):
+    """<g, x_j> for all j in one pass over g (the gradients of SIMPA's hop weights) against float64; a reduction over all
+    N F elements: max-norm bar."""
+    from pytorch_geometric_signed_directed_amd.nn.signed.SIMPA import dots
+    g = torch.Generator().manual_seed(k)
+    gg = torch.randn(shape, generator=g)
+    xs = [torch.randn(shape, generator=g) + (0.5 - 0.2 * j) * gg for j in range(k)]    # correlated: the sums do not cancel
+    want = torch.stack([(gg.double() * x.double()).sum() for x in xs])
+    got = dots(gg.to(dev()), [x.to(dev()) for x in xs])
+    close(got, want, TOL, norm=True, what="dots")
+    assert torch.equal(dots(gg.to(dev()), [x.to(dev()) for x in xs]), got)       # deterministic
 
 
 # ------------------------------------------------------------------ tall linear maps (csrc/tall.hip)
