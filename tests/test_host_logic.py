@@ -159,3 +159,27 @@ def test_digcn_operator_preprocessing_matches_reference():
     dense = A._perron_left_vector(p, 0.1, 40)
     power = A._perron_left_vector(p, 0.1, 40, dense_limit=0)             # force the sparse power iteration
     assert np.abs(power / power.sum() - dense / dense.sum()).max() < 1e-6
+
+
+def test_tall_product_and_column_sums_library_route_on_cpu():
+    """dense.tall_product / column_sums off the GPU are plain torch (the HIP kernels take CUDA tensors only): segments are
+    multiplied block by block and accumulated, W^T for the input gradient, split outputs are column views."""
+    import torch
+    from pytorch_geometric_signed_directed_amd.dense import column_sums, column_sums_of, tall_product
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randn(50, 32, generator=g), torch.randn(50, 64, generator=g)
+    w, bias = torch.randn(96, 48, generator=g), torch.randn(48, generator=g)
+    want = torch.cat([a, b], 1).double() @ w.double() + bias.double()
+    assert torch.allclose(tall_product([a, b], w, False, bias).double(), want, atol=1e-4)
+    assert torch.allclose(tall_product([a, b], w.t().contiguous(), True, bias).double(), want, atol=1e-4)
+    parts = tall_product([a, b], w, False, bias, splits=(16, 32))
+    assert [tuple(p.shape) for p in parts] == [(50, 16), (50, 32)]
+    assert torch.allclose(torch.cat(parts, 1).double(), want, atol=1e-4)
+    import pytest
+    with pytest.raises(ValueError):
+        tall_product([a, b], w[:90], False)
+    with pytest.raises(ValueError):
+        tall_product([a, b], w, False, None, splits=(16, 16))
+    assert torch.equal(column_sums(a), a.sum(0))
+    x, y, z = column_sums_of([a, None, a])
+    assert y is None and x is z
