@@ -39,13 +39,14 @@ struct TallArgs {
 };
 
 __device__ __forceinline__ float bf16_value(uint32_t h) { return __uint_as_float(h << 16); }
-__device__ __forceinline__ uint32_t bf16_bits(float f)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> two bf16 in one dword, round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t pack2(float lo, float hi)
 {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN stays NaN
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;                   // round to nearest even
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return bf16_bits(lo) | (bf16_bits(hi) << 16); }
 
 // ---- bf16 storage, fp32 accumulation -----------------------------------------------------------
 template <int KB, int NT>
