@@ -1008,7 +1008,8 @@ def test_tall_product_matches_float64(dtype, n, widths, f_out, transposed, with_
         lib = tall_product(segs, wdev, transposed, None if bias is None else bias.to(dev()))
     finally:
         set_tall_kernels(prev)
-    close(lib, want, TOL if dtype == "f32" else 2.0 ** -6, what="library route")
+    # (bf16: the library route rounds to bf16 once per segment it accumulates, the kernel once in total)
+    close(lib, want, TOL if dtype == "f32" else 2.0 ** -7 * (1 + len(widths)), what="library route")
 
 
 @pytest.mark.parametrize("dtype,n,f,sliced", [("f32", 1000, 64, False), ("f32", 5, 4, False), ("f32", 70001, 192, True),
