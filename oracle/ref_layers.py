@@ -1,6 +1,7 @@
 """ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
-CPU restatement ("port") of the sparse message-passing hot path of
+CPU restatement ("port"; device-agnostic torch ops, so the tests at the stated sizes can also run the same op
+sequence in fp32 on the test device) of the sparse message-passing hot path of
 SherylHYX/pytorch_geometric_signed_directed, written as plain functions over
 explicit parameter tensors.  It executes the SAME ATen op sequence the
 reference executes through PyG on CPU -- per propagate
@@ -124,7 +125,7 @@ def magnetic_laplacian(edge_index: Tensor, edge_weight: Optional[Tensor], n: int
     """
     edge_index, edge_weight = drop_self_loops(edge_index, edge_weight)
     if edge_weight is None:
-        edge_weight = torch.ones(edge_index.size(1), dtype=dtype)
+        edge_weight = torch.ones(edge_index.size(1), dtype=dtype, device=edge_index.device)
     r, c = edge_index[0], edge_index[1]
     both = torch.stack([torch.cat([r, c]), torch.cat([c, r])])
     cols = [torch.cat([edge_weight, edge_weight]), torch.cat([edge_weight, -edge_weight])]
@@ -248,7 +249,7 @@ def gcn_norm(edge_index, edge_weight, n, improved=False, add_self_loops=True,
         edge_index, edge_weight = append_remaining_self_loops(
             edge_index, edge_weight, 2.0 if improved else 1.0, n)
     if edge_weight is None:
-        edge_weight = torch.ones(edge_index.size(1), dtype=dtype)
+        edge_weight = torch.ones(edge_index.size(1), dtype=dtype, device=edge_index.device)
     row, col = edge_index[0], edge_index[1]
     deg = scatter_rows(edge_weight, col, n)
     dis = deg.pow(-0.5)
@@ -268,7 +269,7 @@ def conv_norm_rw(edge_index, edge_weight, n, fill_value=0.5, add_self_loops=True
                  dtype=torch.float32):
     """conv_base.py:12-31: row-normalised D^-1 (A + fill I)."""
     if edge_weight is None:
-        edge_weight = torch.ones(edge_index.size(1), dtype=dtype)
+        edge_weight = torch.ones(edge_index.size(1), dtype=dtype, device=edge_index.device)
     if add_self_loops:
         edge_index, edge_weight = append_remaining_self_loops(edge_index, edge_weight,
                                                               fill_value, n)
@@ -373,9 +374,9 @@ def segment_softmax(e: Tensor, index: Tensor, n: int) -> Tensor:
     """torch_geometric.utils.softmax: per-target max-shifted exp / (segment sum + 1e-16)."""
     shape = (n,) + tuple(e.shape[1:])
     idx = index.view((-1,) + (1,) * (e.dim() - 1)).expand_as(e)
-    mx = torch.full(shape, float("-inf"), dtype=e.dtype).scatter_reduce(0, idx, e.detach(), "amax", include_self=True)
+    mx = torch.full(shape, float("-inf"), dtype=e.dtype, device=e.device).scatter_reduce(0, idx, e.detach(), "amax", include_self=True)
     out = (e - mx.index_select(0, index)).exp()
-    den = torch.zeros(shape, dtype=e.dtype).scatter_add_(0, idx, out) + 1e-16
+    den = torch.zeros(shape, dtype=e.dtype, device=e.device).scatter_add_(0, idx, out) + 1e-16
     return out / den.index_select(0, index)
 
 

@@ -133,3 +133,137 @@ def digcn_conv(x, edge_index, edge_weight, weight, bias, g=None):
     g = g.double()
     dh = spmm(edge_index[0], edge_index[1], ew, g, x.size(0))
     return out, dh @ w.t(), x.t() @ dh, g.sum(0)
+
+
+# --------------------------------------------------------------------------------------------------
+# Signed scatter-aggregate layers (BASELINE config C3: SSSNET / SGCN on an SSBM graph) in float64.
+# Reference formulas: nn/general/conv_base.py:12-31 (conv_norm_rw: add_remaining_self_loops, row sums, D^-1) and
+# :98-114 (flow = target_to_source: aggregation at edge_index[0]); nn/signed/SIMPA.py:77-139 (hop schedule);
+# nn/directed/DIMPA.py:32-59; nn/signed/SGCNConv.py:94-126 (mean over incoming edges, cat, Linear);
+# nn/signed/SSSNET_node_clustering.py:90-160 (two-layer MLPs -> SIMPA -> linear head, softmax, normalize).
+# Gradients come from torch autograd through `_Apply` (a fixed linear operator and its transpose), in float64.
+# --------------------------------------------------------------------------------------------------
+class _Apply(torch.autograd.Function):
+    """y = A x for a fixed COO operator A (rows, cols, vals): chunked index_add_, adjoint = A^T g."""
+
+    @staticmethod
+    def forward(ctx, x, rows, cols, vals, n_rows):
+        ctx.op = (rows, cols, vals, x.size(0))
+        return spmm(rows, cols, vals, x, n_rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, cols, vals, n_cols = ctx.op
+        return spmm(cols, rows, vals, g.contiguous(), n_cols), None, None, None, None
+
+
+class RowOperator:
+    """out[rows[e]] += vals[e] * x[cols[e]] (float64), differentiable in x."""
+
+    def __init__(self, rows, cols, vals, n):
+        self.rows, self.cols, self.vals, self.n = rows, cols, vals, n
+
+    def __call__(self, x):
+        return _Apply.apply(x, self.rows, self.cols, self.vals, self.n)
+
+
+def rw_operator(edge_index, edge_weight, n, fill, flip=False):
+    """D^-1 (A - listed loops + diag(loop weight if listed (last one wins) else fill)), aggregated at edge_index[0]
+    (conv_base.py:12-31, :98-114).  flip: on edge_index[[1, 0]] (the target streams of directed SIMPA / DIMPA)."""
+    ei = edge_index[[1, 0]] if flip else edge_index
+    dev = ei.device
+    w = torch.ones(ei.size(1), dtype=torch.float64, device=dev) if edge_weight is None else edge_weight.double()
+    off = ei[0] != ei[1]
+    diag = torch.full((n,), float(fill), dtype=torch.float64, device=dev)
+    pos = (~off).nonzero(as_tuple=True)[0]
+    if pos.numel():
+        last = torch.full((n,), -1, dtype=torch.long, device=dev).scatter_reduce(0, ei[0][pos], pos, "amax",
+                                                                                 include_self=True)
+        diag = torch.where(last >= 0, w[last.clamp(min=0)], diag)
+    loops = torch.arange(n, device=dev)
+    rows, cols, vals = torch.cat([ei[0][off], loops]), torch.cat([ei[1][off], loops]), torch.cat([w[off], diag])
+    deg = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, rows, vals)
+    inv = torch.where(deg != 0, 1.0 / deg, torch.zeros_like(deg))
+    return RowOperator(rows, cols, inv[rows] * vals, n)
+
+
+def mean_operator(edge_index, n):
+    """Row i = mean of x[j] over the listed edges j -> i (a multi-edge counts twice; no edge: 0)."""
+    src, dst = edge_index[0], edge_index[1]
+    cnt = torch.zeros(n, dtype=torch.float64, device=src.device).index_add_(
+        0, dst, torch.ones(dst.numel(), dtype=torch.float64, device=src.device))
+    return RowOperator(dst, src, (1.0 / cnt.clamp(min=1.0))[dst], n)
+
+
+def simpa_stream(a_p, a_n, x_pos, x_neg, wp, wn, hop):
+    """(feat_p, feat_n): feat_p = sum_h wp[h] Ap^h x_pos; feat_n = sum_{h < hop} sum_{m < hop - h} wn[j] Ap^m An Ap^h x_neg,
+    j counting h-major (SIMPA.py:77-93)."""
+    wp, wn = wp.reshape(-1), wn.reshape(-1)
+    feat_p = wp[0] * x_pos
+    cur = x_pos
+    for h in range(1, hop + 1):
+        cur = a_p(cur)
+        feat_p = feat_p + wp[h] * cur
+    feat_n = torch.zeros_like(feat_p)
+    base, j = x_neg, 0
+    for h in range(hop):
+        cur = a_n(base)
+        for m in range(hop - h):
+            if m:
+                cur = a_p(cur)
+            feat_n = feat_n + wn[j] * cur
+            j += 1
+        base = a_p(base)
+    return feat_p, feat_n
+
+
+def simpa(ei_p, w_p, ei_n, w_n, x_p, x_n, params, hop, fill, directed=False, x_pt=None, x_nt=None):
+    """SIMPA.forward in float64 (params: the module's weights as float64 tensors, possibly requiring grad)."""
+    n = x_p.size(0)
+    a_p, a_n = rw_operator(ei_p, w_p, n, fill), rw_operator(ei_n, w_n, n, 0.0)
+    if not directed:
+        return torch.cat(simpa_stream(a_p, a_n, x_p, x_n, params["_w_p"], params["_w_n"], hop), dim=1)
+    t_p, t_n = rw_operator(ei_p, w_p, n, fill, flip=True), rw_operator(ei_n, w_n, n, 0.0, flip=True)
+    return torch.cat(simpa_stream(a_p, a_n, x_p, x_n, params["_w_sp"], params["_w_sn"], hop)
+                     + simpa_stream(t_p, t_n, x_pt, x_nt, params["_w_tp"], params["_w_tn"], hop), dim=1)
+
+
+def dimpa(x_s, x_t, edge_index, edge_weight, w_s, w_t, hop, fill=0.5):
+    """DIMPA.forward in float64 (DIMPA.py:32-59)."""
+    n = x_s.size(0)
+    a, a_t = rw_operator(edge_index, edge_weight, n, fill), rw_operator(edge_index, edge_weight, n, fill, flip=True)
+    w_s, w_t = w_s.reshape(-1), w_t.reshape(-1)
+    feat_s, feat_t, cur_s, cur_t = w_s[0] * x_s, w_t[0] * x_t, x_s, x_t
+    for h in range(1, hop + 1):
+        cur_s, cur_t = a(cur_s), a_t(cur_t)
+        feat_s, feat_t = feat_s + w_s[h] * cur_s, feat_t + w_t[h] * cur_t
+    return torch.cat([feat_s, feat_t], dim=1)
+
+
+def sgcn_conv(x, pos_ei, neg_ei, lin_b, lin_u, first_aggr, in_dim):
+    """SGCNConv.forward in float64 (SGCNConv.py:94-126); lin_* = (weight [out, k in], bias or None)."""
+    n = x.size(0)
+    m_pos, m_neg = mean_operator(pos_ei, n), mean_operator(neg_ei, n)
+
+    def lin(z, wb):
+        out = z @ wb[0].t()
+        return out if wb[1] is None else out + wb[1]
+
+    if first_aggr:
+        return torch.cat([lin(torch.cat([m_pos(x), x], 1), lin_b), lin(torch.cat([m_neg(x), x], 1), lin_u)], dim=1)
+    lo, hi = x[:, :in_dim].contiguous(), x[:, in_dim:].contiguous()
+    return torch.cat([lin(torch.cat([m_pos(lo), m_neg(hi), lo], 1), lin_b),
+                      lin(torch.cat([m_pos(hi), m_neg(lo), hi], 1), lin_u)], dim=1)
+
+
+def sssnet(ei_p, w_p, ei_n, w_n, features, sd, hop, fill, directed=False):
+    """SSSNET_node_clustering.forward in eval mode (dropout = identity), float64; sd = its state_dict in float64.
+    -> (normalize(z), log_softmax(output), softmax(output))."""
+    streams = ("sp", "sn", "tp", "tn") if directed else ("p", "n")
+    xs = [torch.relu(features @ sd[f"_w_{s}0"]) @ sd[f"_w_{s}1"] for s in streams]
+    hop_weights = {k[len("_simpa."):]: v for k, v in sd.items() if k.startswith("_simpa.")}
+    z = simpa(ei_p, w_p, ei_n, w_n, xs[0], xs[1], hop_weights, hop, fill, directed, *(xs[2:] if directed else ()))
+    out = z @ sd["_W_prob"]
+    if sd.get("_bias") is not None:
+        out = out + sd["_bias"]
+    return torch.nn.functional.normalize(z), torch.log_softmax(out, dim=1), torch.softmax(out, dim=1)

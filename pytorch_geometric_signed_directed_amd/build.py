@@ -1,21 +1,33 @@
-"""Build recipe for csrc/libpygsd_hip.so (hipcc, gfx950 only).  Used by __graft_entry__.build()."""
+"""Build recipe for csrc/libpygsd_hip.so (hipcc, gfx950 only).  Used by __graft_entry__.build().
+
+Every .hip source is compiled to its own object (in parallel; only the ones older than their inputs) and the objects are
+linked into the one shared library -- a change to one kernel file costs that file's compile, not all of them."""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpygsd_hip.so")
+OBJ = os.path.join(CSRC, "build")
 SOURCES = ["runtime.hip", "spmm.hip", "dense.hip", "tall.hip", "build.hip", "laplacian.hip", "magop.hip", "attention.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+HEADER = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "pygsd_hip.h")
+
+
+def _shared_deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [HEADER, os.path.abspath(__file__)]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
-    deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "pygsd_hip.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _newer(LIB, [os.path.join(CSRC, f) for f in SOURCES] + _shared_deps())
 
 
 def build_library(force=False, verbose=False):
@@ -23,8 +35,22 @@ def build_library(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+    os.makedirs(OBJ, exist_ok=True)
+    shared = _shared_deps()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, src[:-4] + ".o")
+        if force or _newer(obj, [os.path.join(CSRC, src)] + shared):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, cwd=CSRC, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, cwd=CSRC, check=True)
     return LIB

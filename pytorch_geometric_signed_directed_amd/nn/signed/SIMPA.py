@@ -6,6 +6,7 @@ import torch
 from torch.nn import Parameter
 
 from ... import _cabi
+from ...memo import TensorMemo
 from ...sparse import GLOBAL_PATTERNS, _spmm_raw
 from ..general.conv_base import Conv_Base, flipped_edge_index
 
@@ -49,6 +50,19 @@ def dots(g, tensors):
     return out
 
 
+_HOST_WEIGHTS = TensorMemo(16)
+
+
+def _host_weights(w):
+    """The hop weights as Python floats (they become alpha / beta kernel arguments).  One device -> host read per
+    in-place VERSION of the parameter, not per call (memo.TensorMemo: weakly held, same opt-outs): an optimiser step
+    bumps the version, inference re-uses the copy -- no synchronisation in a forward whose weights did not change."""
+    hit = _HOST_WEIGHTS.get((w,), "hop weights")
+    if hit is None:
+        hit = _HOST_WEIGHTS.put((w,), "hop weights", tuple(w.detach().reshape(-1).tolist()))
+    return list(hit)
+
+
 class _StreamFn(torch.autograd.Function):
     """One (positive, negative) stream of SIMPA as ONE autograd node (fixed operator values).
 
@@ -59,11 +73,11 @@ class _StreamFn(torch.autograd.Function):
     costs its SpMMs and nothing else -- autograd's composition paid a scale pass, a product-and-reduce pass and an
     accumulation pass per hop on top.  The hop weights' gradients are dot products <g_feat, node>, one pass per stream
     half (pygsd_dots_f32).  feat_p / feat_n are written side by side into ONE [N, 2F] matrix (the reference's cat,
-    SIMPA.py:95).  The weights are read to the host once per call (six floats at hop 2)."""
+    SIMPA.py:95).  The weights are read to the host once per parameter version (`_host_weights`; six floats at hop 2)."""
 
     @staticmethod
     def forward(ctx, x_pos, x_neg, wp, wn, op_p, op_n, hop):
-        wpl, wnl = wp.detach().reshape(-1).tolist(), wn.detach().reshape(-1).tolist()
+        wpl, wnl = _host_weights(wp), _host_weights(wn)
         nodes, ops, terms_p, terms_n = [x_pos.contiguous(), x_neg.contiguous()], [], [(0, 0)], []
 
         def apply(kind, src):
@@ -130,7 +144,9 @@ class _StreamFn(torch.autograd.Function):
             add_term(v, wpl[wi], g_p)
         for wi, v in terms_n:
             add_term(v, wnl[wi], g_n)
-        for dst, kind, src in reversed(ops):         # every consumer of `dst` was created later: its gradient is complete
+        need = ctx.needs_input_grad
+        chain = ops if (need[0] or need[1]) else ()   # frozen inputs (a first layer on fixed features): no product at all
+        for dst, kind, src in reversed(chain):       # every consumer of `dst` was created later: its gradient is complete
             gd = grads.pop(dst, None)
             if gd is None:
                 continue
@@ -167,8 +183,9 @@ class _StreamFn(torch.autograd.Function):
                     flat[wi] = torch.dot(g.reshape(-1), nodes[v].reshape(-1))
             return out
 
-        return (materialise(0), materialise(1), weight_grads(terms_p, g_p, shape_p), weight_grads(terms_n, g_n, shape_n),
-                None, None, None)
+        return (materialise(0) if need[0] else None, materialise(1) if need[1] else None,
+                weight_grads(terms_p, g_p, shape_p) if need[2] else None,
+                weight_grads(terms_n, g_n, shape_n) if need[3] else None, None, None, None)
 
 
 class SIMPA(torch.nn.Module):

@@ -384,13 +384,18 @@ def split_phases(csr: CSR, values: Sequence[Tensor], n_pad: int, phases: int, wo
     """Column blocks of an operator whose columns are PADDED node ids: block c holds the entries whose column
     falls in sub-range c (of `phases`) of ITS rank's range, with the column re-based into phase c's exchange
     buffer [world, n_pad / phases, ...] viewed as rows: (col // n_pad) * n_sub + (col % n_pad) % n_sub.
-    A row's entries keep their order inside a block."""
+    A row's entries keep their order inside a block.  The blocks' col / value arrays are VIEWS into one buffer sorted
+    by (phase, row): they keep all phases' memory alive together and are 4-byte aligned only."""
     if phases == 1:
         return [(csr, tuple(values))]
     if n_pad % phases:
         raise ValueError(f"n_pad = {n_pad} is not a multiple of {phases} phases")
     n_sub = n_pad // phases
     n_rows, nnz = csr.n_rows, csr.nnz
+    if n_rows == 0 or nnz == 0:                    # an empty shard: every phase is an empty block of the same shape
+        empty_ptr = torch.zeros(n_rows + 1, dtype=torch.int32, device=csr.rowptr.device)
+        return [(CSR(n_rows, world_size * n_sub, 0, empty_ptr, csr.col[:0], None), tuple(v[:0] for v in values))
+                for _ in range(phases)]
     col = csr.col.long()
     local = col % n_pad
     compact = ((col // n_pad) * n_sub + local % n_sub).to(torch.int32)
@@ -1009,27 +1014,50 @@ class _GradSync:
     def _install_grad_sync(self):
         self._sync_params = list(self.parameters())
         self._sync_local = {}
+        self._sync_seen = {}           # k -> (the .grad object, its version) found when this pass's first share arrived
+        self._sync_task = None         # autograd graph task the pending shares belong to
         for k, prm in enumerate(self._sync_params):
             prm.register_hook(lambda grad, k=k: self._remember(grad, k))
 
     def _remember(self, grad, k):
-        if not self._sync_local:                       # first gradient of this backward pass: arrange the exchange
+        task = torch._C._current_graph_task_id()
+        if task != self._sync_task:
+            # a new backward pass.  Shares left over from a pass that aborted after its first hook (OOM, an exception
+            # in a later node: the engine never ran that pass's callback) are dropped here instead of blocking every
+            # later exchange; the callback is queued once per graph task, whatever state the last one ended in.
+            self._sync_task, self._sync_local, self._sync_seen = task, {}, {}
             torch.autograd.Variable._execution_engine.queue_callback(self._exchange_gradients)
+        if k not in self._sync_seen:
+            held = self._sync_params[k].grad
+            self._sync_seen[k] = (held, None if held is None else held._version)
         prev = self._sync_local.get(k)
         self._sync_local[k] = grad if prev is None else prev + grad     # a parameter used twice in one graph
         return grad
 
     def _exchange_gradients(self):
-        local, self._sync_local = self._sync_local, {}
+        local, seen = self._sync_local, self._sync_seen
+        self._sync_local, self._sync_seen, self._sync_task = {}, {}, None
         with torch.no_grad():
+            stale = None
             for k, prm in enumerate(self._sync_params):                  # fixed order on every rank
                 mine = local.get(k)
                 if mine is None:                       # a parameter that got no gradient here still takes part
-                    mine = torch.zeros_like(prm)
+                    total = self.exchange.all_reduce(torch.zeros_like(prm))
+                    if prm.grad is not None:
+                        prm.grad.add_(total)           # other ranks' shares of a parameter this rank's graph skipped
+                    continue
                 total = self.exchange.all_reduce(mine.detach().clone().contiguous())
-                if prm.grad is None:                   # (torch.autograd.grad: nothing was accumulated)
+                held, version = seen[k]
+                if prm.grad is None or (prm.grad is held and prm.grad._version == version):
+                    stale = k                          # nothing was accumulated into .grad: torch.autograd.grad(...)
                     continue
                 prm.grad.add_(total - mine)
+            if stale is not None:
+                # every rank reaches this after the same collectives, so raising cannot leave a peer inside one
+                raise RuntimeError(
+                    "sharded layers all-reduce parameter gradients into `.grad` at the end of `.backward()`; "
+                    "torch.autograd.grad(...) would hand back this rank's share only -- use .backward() "
+                    f"(parameter #{stale} received a gradient that was not accumulated)")
 
 
 class ShardedDiGCNConv(_GradSync, torch.nn.Module):

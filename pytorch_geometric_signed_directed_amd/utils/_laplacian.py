@@ -11,6 +11,7 @@ One host round-trip is inherent: the number of distinct symmetrised entries size
 """
 import ctypes
 import math
+import threading
 from typing import Optional
 
 import torch
@@ -159,16 +160,18 @@ def laplacian_values(parts: LaplacianParts, q, normalization: Optional[str], mir
     return off_r, off_i, diag
 
 
-_PINNED = {}
+_PINNED = threading.local()
 
 
 def _pinned_info(dev):
-    """(pinned int64[4], event) for the device -> host read of the fused build; one per (device, thread)."""
-    import threading
-    key = (dev.index, threading.get_ident())
-    hit = _PINNED.get(key)
+    """(pinned int64[4], event) for the device -> host read of the fused build; one per (thread, device) -- thread-local,
+    so the buffers of a pool's worker threads die with their threads."""
+    table = getattr(_PINNED, "table", None)
+    if table is None:
+        table = _PINNED.table = {}
+    hit = table.get(dev.index)
     if hit is None:
-        hit = _PINNED[key] = (torch.empty(4, dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+        hit = table[dev.index] = (torch.empty(4, dtype=torch.int64, pin_memory=True), torch.cuda.Event())
     return hit
 
 
@@ -234,6 +237,14 @@ def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int
         if too_long:
             return None
         nnz = es + n
-        ccol = ccol[:nnz]
+        if nnz < 0.9 * cap:
+            # many duplicates / self loops: the operator is memoised / cached by the layers, so views into the
+            # upper-bound allocations would pin up to twice the memory it needs for its lifetime -- right-size them
+            ccol = ccol[:nnz].clone()
+            tight = torch.empty((4, max((nnz + 3) // 4 * 4, 4)), dtype=torch.float32, device=dev)   # rows stay 16-byte aligned
+            tight[:, :nnz] = vals[:, :nnz]
+            vals = tight
+        else:
+            ccol = ccol[:nnz]
     csr = CSR(n, n, nnz, rowptr, ccol, None)
     return csr, (vals[2, :nnz], vals[3, :nnz]), (vals[0, :nnz], vals[1, :nnz]), deg

@@ -106,6 +106,8 @@ def gcn_norm(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, 
     n = int(num_nodes)
     fill = 2.0 if improved else 1.0
     if _differentiable(edge_weight):
+        # the tensor-op route below never reaches a checked kernel: range-check here, the callers skip theirs
+        _cabi.check_node_ids((n, edge_index[0]), (n, edge_index[1]))
         if add_self_loops:
             edge_index, edge_weight = _loops_torch(edge_index, edge_weight, fill, n)
         row, col = edge_index[0], edge_index[1]
@@ -130,6 +132,8 @@ def conv_norm_rw(edge_index: Tensor, fill_value: float = 0.5, edge_weight: Optio
     _cabi.require_gpu(edge_index, edge_weight)
     n = maybe_num_nodes(edge_index, num_nodes)
     if _differentiable(edge_weight):
+        # the tensor-op route below never reaches a checked kernel: range-check here, the callers skip theirs
+        _cabi.check_node_ids((n, edge_index[0]), (n, edge_index[1]))
         if add_self_loops:
             edge_index, edge_weight = _loops_torch(edge_index, edge_weight, fill_value, n)
         row = edge_index[0]

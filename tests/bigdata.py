@@ -51,6 +51,21 @@ def sdsbm_graph(n, e, seed=1):
     return pe, ps
 
 
+def ssbm_graph(n, entries, seed=2):
+    """-> (path of the [2, M] edge list holding both orientations, path of the float32 signs): graphs.ssbm with p chosen
+    for `entries` stored entries (BASELINE config C3: 500k nodes / 10M +- entries)."""
+    from pytorch_geometric_signed_directed_amd import graphs
+    pe, ps = _path(f"ssbm_{n}_{entries}_{seed}_ei"), _path(f"ssbm_{n}_{entries}_{seed}_sign")
+    if not (os.path.exists(pe) and os.path.exists(ps)):
+        p = (entries / 2) / (n * (n - 1) / 2)
+        ei, sign, _ = graphs.ssbm(n, 5, p, 0.1, 2.0, seed=seed)
+        for path, arr in ((pe, ei), (ps, sign.astype(np.float32))):
+            tmp = path + f".{os.getpid()}.tmp.npy"
+            np.save(tmp, arr)
+            os.replace(tmp, path)
+    return pe, ps
+
+
 def features(n, f, seed, count):
     """-> paths of `count` N(0, 1) float32 [n, f] matrices drawn from one torch generator."""
     names = [f"feat_{n}_{f}_{seed}_{k}" for k in range(count)]

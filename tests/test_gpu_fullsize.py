@@ -209,3 +209,185 @@ def test_c5_sharded_8_ranks_bf16_sampled_rows_vs_float64(inception):
                 BF16_TOL, True)
     for name, ref in grads.items():
         _check(torch.from_numpy(ret[0]["grads"][name]).to(D), ref, f"C5 8 ranks d {name} (bf16) vs float64", BF16_TOL, norm=True)
+
+
+# ------------------------------------------------------------------------------------------------ C3
+# BASELINE config 3: "SSSNET / SGCN signed scatter-aggregate on synthetic SSBM 500k nodes / 10M +- edges, h = 64".
+# The arbiter is the float64 evaluation of oracle/sparse_f64_torch.py (pinned on the host against the dense formulas, the
+# reference op sequence in float64 and the fixtures recorded from the reference: tests/test_oracle_sparse_f64.py); every
+# check also runs the reference's own fp32 op sequence (oracle/ref_layers.py: index_select -> mul -> scatter_add_) on the
+# device and records ITS distance from float64 -- the HIP result must be inside the 1e-5 bar around the float64 value, or
+# no further from it than 1.5x the reference sequence is (tolerance.close_arbitrated's rule, evaluated on the device).
+C3 = dict(n=500000, entries=10000000, h=64, hop=2, fill=0.5)
+
+
+def _check_arbitrated(got, ref32, truth, what, norm=False):
+    assert got.shape == truth.shape, (what, got.shape, truth.shape)
+    err, ref = FS.errors(got.detach(), truth.detach()), FS.errors(ref32.detach(), truth.detach())
+    key = "max_norm_rel_err" if norm else "max_mixed_err"
+    bar = max(TOL, 1.5 * ref[key])
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    RECORDS.append(dict(err, test=test, what=what + " (float64 arbiter)", bar="norm" if norm else "abs", tol=bar,
+                        reference_sequence_err_vs_f64=ref[key]))
+    assert err[key] <= bar, (f"{what} vs float64: {err[key]:.3e} > max({TOL}, 1.5 x {ref[key]:.3e} of the fp32 reference "
+                             f"sequence) (abs {err['max_abs_err']:.3e}, |want| <= {err['max_abs_want']:.3g})")
+
+
+@pytest.fixture(scope="module")
+def ssbm_c3():
+    p_ei, p_sign = bigdata.ssbm_graph(C3["n"], C3["entries"], seed=2)
+    ei, sign = FS.dev_tensor(p_ei, D), FS.dev_tensor(p_sign, D)
+    pos, neg = ei[:, sign > 0].contiguous(), ei[:, sign < 0].contiguous()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    w_pos = torch.rand(pos.size(1), device=D, generator=g) + 0.5
+    w_neg = torch.rand(neg.size(1), device=D, generator=g) + 0.5
+    yield pos, neg, w_pos, w_neg
+    torch.cuda.empty_cache()
+
+
+def _randn(*shape, seed):
+    return torch.randn(*shape, device=D, generator=torch.Generator(device="cuda").manual_seed(seed))
+
+
+@pytest.mark.parametrize("directed", [False, True])
+def test_c3_simpa_hop2_every_row_vs_float64(ssbm_c3, directed):
+    """SIMPA (SSSNET's aggregation, nn/signed/SIMPA.py:77-139) at C3's stated size, weighted operators: every row of the
+    output and of the input gradients, and the hop-weight gradients (pygsd_dots_f32) -- the one-node _StreamFn with its
+    backward summands folded into the SpMM epilogues, on the low-degree kernel variant the 5-entry rows select."""
+    from oracle import ref_layers as R
+    from oracle import sparse_f64_torch as T64
+    from pytorch_geometric_signed_directed_amd.nn import SIMPA
+    pos, neg, w_pos, w_neg = ssbm_c3
+    n, h, hop, fill = C3["n"], C3["h"], C3["hop"], C3["fill"]
+    k = 4 if directed else 2
+    xs = [_randn(n, h, seed=30 + j) for j in range(k)]
+    go = _randn(n, k * h, seed=40)
+    layer = SIMPA(hop, fill, directed).to(D)
+    with torch.no_grad():
+        for j, prm in enumerate(layer.parameters()):
+            prm.copy_(torch.rand(prm.shape, generator=torch.Generator().manual_seed(50 + j)) + 0.5)
+    names = [nm for nm, _ in layer.named_parameters()]
+
+    def run(fn, dtype):
+        ins = [x.to(dtype).requires_grad_() for x in xs]
+        prm = {nm: p.detach().to(dtype).requires_grad_() for nm, p in layer.named_parameters()}
+        out = fn(pos, w_pos.to(dtype), neg, w_neg.to(dtype), ins[0], ins[1], prm, hop, fill, directed, *ins[2:])
+        (out * go.to(dtype)).sum().backward()
+        return [out.detach()] + [x.grad for x in ins] + [prm[nm].grad for nm in names]
+
+    truth, ref32 = run(T64.simpa, torch.float64), run(R.simpa, torch.float32)
+    ins = [x.clone().requires_grad_() for x in xs]
+    out = layer(pos, w_pos, neg, w_neg, *ins)
+    (out * go).sum().backward()
+    got = [out] + [x.grad for x in ins] + [p.grad for p in layer.parameters()]
+    tag = f"C3 SIMPA hop {hop} {'directed' if directed else 'undirected'}"
+    labels = ["feat"] + ["dx_" + s for s in ("p", "n", "pt", "nt")[:k]] + ["d" + nm for nm in names]
+    for a, r, t, what in zip(got, ref32, truth, labels):
+        _check_arbitrated(a, r, t, f"{tag} {what} (all rows)", norm=what.startswith("d_"))
+
+
+def test_c3_dimpa_hop2_every_row_vs_float64():
+    """DIMPA (nn/directed/DIMPA.py:32-59) on a DSBM graph of C3's size (500k nodes / 10M weighted directed edges)."""
+    from oracle import ref_layers as R
+    from oracle import sparse_f64_torch as T64
+    from pytorch_geometric_signed_directed_amd.nn import DIMPA
+    n, h, hop, fill = C3["n"], C3["h"], C3["hop"], C3["fill"]
+    ei = FS.dev_tensor(bigdata.dsbm_graph(n, C3["entries"], seed=5), D)
+    w = torch.rand(ei.size(1), device=D, generator=torch.Generator(device="cuda").manual_seed(22)) + 0.5
+    x_s, x_t, go = _randn(n, h, seed=31), _randn(n, h, seed=32), _randn(n, 2 * h, seed=41)
+    layer = DIMPA(hop, fill).to(D)
+    with torch.no_grad():
+        for j, prm in enumerate(layer.parameters()):
+            prm.copy_(torch.rand(prm.shape, generator=torch.Generator().manual_seed(60 + j)) + 0.5)
+
+    def run(fn, dtype):
+        a, b = x_s.to(dtype).requires_grad_(), x_t.to(dtype).requires_grad_()
+        ws, wt = (p.detach().to(dtype).requires_grad_() for p in (layer._w_s, layer._w_t))
+        out = fn(a, b, ei, w.to(dtype), ws, wt, hop, fill)
+        (out * go.to(dtype)).sum().backward()
+        return out.detach(), a.grad, b.grad, ws.grad, wt.grad
+
+    truth, ref32 = run(T64.dimpa, torch.float64), run(R.dimpa, torch.float32)
+    a, b = x_s.clone().requires_grad_(), x_t.clone().requires_grad_()
+    out = layer(a, b, ei, w)
+    (out * go).sum().backward()
+    got = (out, a.grad, b.grad, layer._w_s.grad, layer._w_t.grad)
+    for g_, r, t, what in zip(got, ref32, truth, ("feat", "dx_s", "dx_t", "d_w_s", "d_w_t")):
+        _check_arbitrated(g_, r, t, f"C3-size DIMPA hop {hop} {what} (all rows)", norm=what.startswith("d_"))
+
+
+def test_c3_sssnet_model_every_row_vs_float64(ssbm_c3):
+    """SSSNET_node_clustering (nn/signed/SSSNET_node_clustering.py:90-160; 64 features, hidden 64, 5 clusters, hop 2) in
+    eval mode on C3's SSBM with unit weights: normalised embedding, log-probabilities, probabilities (every row), the
+    gradient of the features and of EVERY parameter (MLP weights through the tall products, hop weights, head)."""
+    from oracle import sparse_f64_torch as T64
+    from pytorch_geometric_signed_directed_amd.nn import SSSNET_node_clustering
+    pos, neg, _, _ = ssbm_c3
+    n, h, hop, fill = C3["n"], C3["h"], C3["hop"], C3["fill"]
+    torch.manual_seed(17)
+    model = SSSNET_node_clustering(h, h, 5, 0.5, hop, fill).to(D).eval()
+    with torch.no_grad():
+        model._bias.uniform_(-0.5, 0.5)
+    feats = _randn(n, h, seed=33)
+    gz, gl, gp = _randn(n, 2 * h, seed=42), _randn(n, 5, seed=43), _randn(n, 5, seed=44)
+    w_pos, w_neg = torch.ones(pos.size(1), device=D), torch.ones(neg.size(1), device=D)
+
+    x64 = feats.double().requires_grad_()
+    sd64 = {k: v.detach().double().requires_grad_() for k, v in model.state_dict().items()}
+    z64, lp64, pr64 = T64.sssnet(pos, w_pos, neg, w_neg, x64, sd64, hop, fill)
+    ((z64 * gz.double()).sum() + (lp64 * gl.double()).sum() + (pr64 * gp.double()).sum()).backward()
+
+    # the reference's own op sequence in fp32 on the device (torch.mm MLPs, ref_layers.simpa, torch.mm head)
+    from oracle import ref_layers as R
+    x32 = feats.clone().requires_grad_()
+    sd32 = {k: v.detach().clone().requires_grad_() for k, v in model.state_dict().items()}
+    xs32 = [torch.mm(torch.relu(torch.mm(x32, sd32[f"_w_{s}0"])), sd32[f"_w_{s}1"]) for s in ("p", "n")]
+    z32 = R.simpa(pos, w_pos, neg, w_neg, xs32[0], xs32[1], {"_w_p": sd32["_simpa._w_p"], "_w_n": sd32["_simpa._w_n"]},
+                  hop, fill)
+    o32 = torch.mm(z32, sd32["_W_prob"]) + sd32["_bias"]
+    zn32, lp32, pr32 = torch.nn.functional.normalize(z32), torch.log_softmax(o32, 1), torch.softmax(o32, 1)
+    ((zn32 * gz).sum() + (lp32 * gl).sum() + (pr32 * gp).sum()).backward()
+
+    x = feats.clone().requires_grad_()
+    z, logp, pred, prob = model(pos, w_pos, neg, w_neg, x)
+    ((z * gz).sum() + (logp * gl).sum() + (prob * gp).sum()).backward()
+    _check_arbitrated(z, zn32, z64.detach(), "C3 SSSNET normalised embedding (all rows)")
+    _check_arbitrated(logp, lp32, lp64.detach(), "C3 SSSNET log-probabilities (all rows)")
+    _check_arbitrated(prob, pr32, pr64.detach(), "C3 SSSNET probabilities (all rows)")
+    assert float((pred != lp64.argmax(1)).float().mean()) <= 1e-4           # ties within rounding only
+    _check_arbitrated(x.grad, x32.grad, x64.grad, "C3 SSSNET d features (all rows)")
+    for name, prm in model.named_parameters():
+        _check_arbitrated(prm.grad, sd32[name].grad, sd64[name].grad, f"C3 SSSNET d {name}", norm=True)
+
+
+def test_c3_sgcn_every_row_and_parameter_gradients_vs_float64(ssbm_c3):
+    """SGCNConv first (64 -> 32) and deep (32 + 32 -> 32) aggregation at C3's size: every row of the output and of dx, and
+    the lin_b / lin_u weight and bias gradients (the products over the 500k rows; nn/signed/SGCNConv.py:94-126)."""
+    from oracle import ref_layers as R
+    from oracle import sparse_f64_torch as T64
+    from pytorch_geometric_signed_directed_amd.nn import SGCNConv
+    pos, neg, _, _ = ssbm_c3
+    n, h = C3["n"], C3["h"]
+    for first in (True, False):
+        in_dim, o = (h, h // 2) if first else (h // 2, h // 2)
+        torch.manual_seed(5 if first else 6)
+        conv = SGCNConv(in_dim, o, first_aggr=first).to(D)
+        x, go = _randn(n, h, seed=34 + first), _randn(n, 2 * o, seed=45 + first)
+        names = ("lin_b.weight", "lin_b.bias", "lin_u.weight", "lin_u.bias")
+        sd = conv.state_dict()
+
+        def run(fn, dtype):
+            a = x.to(dtype).requires_grad_()
+            prm = [sd[nm].detach().to(dtype).requires_grad_() for nm in names]
+            out = fn(a, pos, neg, (prm[0], prm[1]), (prm[2], prm[3]), first, in_dim)
+            (out * go.to(dtype)).sum().backward()
+            return [out.detach(), a.grad] + [p.grad for p in prm]
+
+        truth, ref32 = run(T64.sgcn_conv, torch.float64), run(R.sgcn_conv, torch.float32)
+        b = x.clone().requires_grad_()
+        out = conv(b, pos, neg)
+        (out * go).sum().backward()
+        got = [out, b.grad] + [dict(conv.named_parameters())[nm].grad for nm in names]
+        tag = f"C3 SGCNConv {'first' if first else 'deep'}"
+        for a, r, t, what in zip(got, ref32, truth, ("out", "dx") + tuple("d " + nm for nm in names)):
+            _check_arbitrated(a, r, t, f"{tag} {what}", norm=what.startswith("d "))

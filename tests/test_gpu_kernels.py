@@ -256,7 +256,14 @@ def test_fullsize_linearity_and_adjoint():
     pat = Pattern(ei, n, n)
     sx, sy = spmm(pat, x, w), spmm(pat, y, w)
     lin = spmm(pat, 0.75 * x - 1.5 * y, w)
-    close(lin, 0.75 * sx - 1.5 * sy, 2e-5)
+    # S (0.75 x - 1.5 y) against the float64 value of 0.75 S x - 1.5 S y, at the standard bar
+
+    def s64(v):
+        return torch.zeros(n, f, dtype=torch.float64, device=d).index_add_(0, ei[1], w.double()[:, None] * v.double()[ei[0]])
+
+    sx64, sy64 = s64(x), s64(y)
+    close(sx, sx64, what="S x vs float64")
+    close(lin, 0.75 * sx64 - 1.5 * sy64, what="S (0.75 x - 1.5 y) vs float64 of 0.75 S x - 1.5 S y")
     xg = x.clone().requires_grad_()
     (spmm(pat, xg, w) * y).sum().backward()           # xg.grad = S^T y via the by-source CSR
     lhs = float((y.double() * sx.double()).sum())
@@ -264,7 +271,8 @@ def test_fullsize_linearity_and_adjoint():
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
     ones = torch.ones(n, 4, device=d)
     rowsum = torch.zeros(n, device=d, dtype=torch.float64).index_add_(0, ei[1], w.double())
-    close(spmm(pat, ones, w)[:, 0], rowsum.float(), 2e-5)
+    rowsum32 = torch.zeros(n, device=d).index_add_(0, ei[1], w)          # the reference's scatter in fp32
+    close_arbitrated(spmm(pat, ones, w)[:, 0], rowsum32, rowsum, what="S 1 = row sums")
 
 
 # ------------------------------------------------------------------ fused MFMA dense stage
@@ -303,8 +311,10 @@ def test_dense_stage_matches_reference_formula(f_in, f_out, k1, n):
     for k in range(k1):
         close_arbitrated(da[k], p32 @ w[k].t(), ad[k].grad, what="dense dA")
         close_arbitrated(db[k], m32 @ w[k].t(), bd[k].grad, what="dense dB")
-    close(dw, wd.grad, 2e-5, norm=True)          # reductions over the n rows (tests/tolerance.py)
-    close(dbias, bbd.grad, 2e-5, norm=True)
+    # reductions over the n rows (tests/tolerance.py): the reference's own fp32 formula arbitrated by float64
+    dw32 = torch.stack([a[k].t() @ p32 + b[k].t() @ m32 for k in range(k1)])
+    close_arbitrated(dw, dw32, wd.grad, norm=True, what="dense dW")
+    close_arbitrated(dbias, p32.sum(0), bbd.grad, norm=True, what="dense db")
     # no-bias forward
     o_r, o_i = dense_fwd_raw([t.to(d) for t in a], [t.to(d) for t in b], w.to(d), None)
     close(o_r, want_r - bbd)
@@ -601,10 +611,16 @@ def test_hub_row_gradients_through_the_layer_api():
     out.backward(gout.to(d))
     A = torch.zeros(n, n, dtype=torch.float64)
     A.index_put_((ei[1], ei[0]), w.double(), accumulate=True)
-    assert torch.allclose(out.detach().cpu().double(), A @ x.double(), atol=2e-3, rtol=1e-4)
-    assert torch.allclose(xd.grad.cpu().double(), A.T @ gout.double(), atol=2e-3, rtol=1e-4)
+    # float64 arbitrates between the HIP result and the reference's own fp32 op sequence (index_select -> mul ->
+    # scatter_add_ over the 6000- / 7000-entry hub rows, oracle/ref_layers.py)
+    from oracle import ref_layers as R
+    x32, w32 = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = R.propagate(x32, ei, w32, n)
+    ref.backward(gout)
+    close_arbitrated(out, ref.detach(), A @ x.double(), what="hub rows: product")
+    close_arbitrated(xd.grad, x32.grad, A.T @ gout.double(), what="hub rows: dX")
     gw = (gout.double()[ei[1]] * x.double()[ei[0]]).sum(1)
-    assert torch.allclose(wd.grad.cpu().double(), gw, atol=1e-4, rtol=1e-4)
+    close_arbitrated(wd.grad, w32.grad, gw, what="hub rows: d edge values")
 
 
 @pytest.mark.gpu
@@ -627,13 +643,15 @@ def test_wide_dual_spmm_column_blocks_match_single_pass(monkeypatch):
     one = _spmm2_raw(pat.fwd, va, vb, xa, xb, za, zb, 2.0, -1.0)
     monkeypatch.setattr(sparse, "_COLBLOCK_BYTES", 0)
     blocked = _spmm2_raw(pat.fwd, va, vb, xa, xb, za, zb, 2.0, -1.0)
-    for a, b in zip(one, blocked):
-        assert torch.allclose(a, b, atol=2e-5, rtol=1e-5)
-    dense = torch.zeros(n, n, dtype=torch.float64)
     rows = torch.repeat_interleave(torch.arange(n), (pat.fwd.rowptr[1:] - pat.fwd.rowptr[:-1]).cpu().long())
-    dense.index_put_((rows, pat.fwd.col.cpu().long()), va.cpu().double(), accumulate=True)
-    want = 2.0 * (dense @ xa.cpu().double()) - za.cpu().double()
-    assert torch.allclose(blocked[0].cpu().double(), want, atol=1e-4, rtol=1e-5)
+    for k, (v, xk, zk) in enumerate(((va, xa, za), (vb, xb, zb))):
+        dense = torch.zeros(n, n, dtype=torch.float64)
+        dense.index_put_((rows, pat.fwd.col.cpu().long()), v.cpu().double(), accumulate=True)
+        want = 2.0 * (dense @ xk.cpu().double()) - zk.cpu().double()
+        # the column-blocked passes (16 lanes per gathered row) and the single pass (64 lanes) add a row's entries in
+        # different orders: both are held to float64, the blocked one no further from it than 1.5x the single pass
+        close(one[k], want, what=f"single-pass dual product {k} vs float64")
+        close_arbitrated(blocked[k], one[k], want, what=f"column-blocked dual product {k}")
 
 
 @pytest.mark.gpu
@@ -656,7 +674,8 @@ def test_gather_rows_backward_is_the_segment_sum(f):
             assert torch.equal(out, b[ei[row]])
             (out * w).sum().backward()
             (b[ei[row]] * w).sum().backward()
-            assert torch.allclose(a.grad, b.grad, atol=1e-4, rtol=1e-5)
+            t64 = torch.zeros(n, f, dtype=torch.float64, device=d).index_add_(0, ei[row], w.double())
+            close_arbitrated(a.grad, b.grad, t64, what="gather_rows backward (segment sum)")
             assert float(a.grad[n - 5:].abs().sum()) == 0.0
 
 
@@ -680,7 +699,10 @@ def test_scalar_fallback_kernel_through_the_raw_abi():
     _cabi.check(lib.pygsd_spmm_csr_f32(P(csr.rowptr), P(csr.col), P(v), P(x), f, P(y), f, P(z), f, n, f, 2.0, -1.0, 0, nnz,
                                        None, _cabi.stream_ptr()), "spmm scalar")
     want = _spmm_raw(csr, v, x, z, 2.0, -1.0, False)          # padded -> vector kernel
-    assert want.shape == (n, f) and torch.allclose(y, want, atol=1e-4, rtol=1e-5)
+    assert want.shape == (n, f)
+    rows = torch.repeat_interleave(torch.arange(n, device=d), (csr.rowptr[1:] - csr.rowptr[:-1]).long())
+    t64 = torch.zeros(n, f, dtype=torch.float64, device=d).index_add_(0, rows, v.double()[:, None] * x.double()[csr.col.long()])
+    close_arbitrated(y, want, 2.0 * t64 - z.double(), what="scalar fallback kernel (float64 arbiter, vector kernel as the fp32 reference)")
 
 
 

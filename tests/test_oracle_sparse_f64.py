@@ -103,3 +103,105 @@ def test_torch_restatement_equals_the_scipy_evaluation(signed, norm, absdeg):
     got = T64.digcn_conv(x.detach(), eit, ew, wt.detach(), bias.detach(), go)
     for a, c in zip(got, (want.detach(), x.grad, wt.grad, bias.grad)):
         assert (a - c).abs().max() <= 1e-11
+
+
+def _signed_graph(rng, n, e_pos, e_neg):
+    """Positive / negative edge lists with reciprocal pairs, exact duplicates and listed self loops (twice on one node)."""
+    def part(e):
+        ei = rng.integers(0, n, (2, e))
+        ei[:, :10] = ei[::-1, 10:20]
+        ei[:, 20:26] = ei[:, 26:32]
+        ei[1, 32:38] = ei[0, 32:38]
+        ei[:, 38] = ei[:, 37]                     # the same loop listed twice: the LAST weight wins
+        return ei, rng.uniform(0.5, 1.5, e)
+    return part(e_pos), part(e_neg)
+
+
+@pytest.mark.parametrize("directed,hop", [(False, 2), (False, 3), (True, 2)])
+def test_torch_signed_layers_equal_the_dense_formulas_and_the_reference_sequence(directed, hop):
+    """oracle/sparse_f64_torch.py's SIMPA / DIMPA / SGCNConv / SSSNET (the float64 arbiter of the C3 checks at the stated
+    size): forward against the independent dense formulas of oracle/dense_f64.py, gradients against autograd through
+    the reference op sequence (oracle/ref_layers.py) evaluated in float64."""
+    import torch
+    from oracle import ref_layers as R
+    from oracle import sparse_f64_torch as T64
+    rng = np.random.default_rng(12)
+    n, f = 70, 5
+    (ei_p, w_p), (ei_n, w_n) = _signed_graph(rng, n, 400, 250)
+    tp, tn = torch.from_numpy(ei_p), torch.from_numpy(ei_n)
+    twp, twn = torch.from_numpy(w_p), torch.from_numpy(w_n)
+    names = ("_w_sp", "_w_sn", "_w_tp", "_w_tn") if directed else ("_w_p", "_w_n")
+    rows = {True: hop + 1, False: (hop + 1) * hop // 2}
+    xs_np = [rng.normal(size=(n, f)) for _ in range(4 if directed else 2)]
+    prm_np = {k: rng.uniform(0.5, 1.5, (rows[k.endswith("p")], 1)) for k in names}
+    go = torch.from_numpy(rng.normal(size=(n, f * len(xs_np))))
+    want = D64.simpa(ei_p, w_p, ei_n, w_n, xs_np[0], xs_np[1], prm_np, hop, 0.5, directed, *xs_np[2:])
+
+    def run(mod):
+        xs = [torch.from_numpy(a).requires_grad_() for a in xs_np]
+        prm = {k: torch.from_numpy(v).requires_grad_() for k, v in prm_np.items()}
+        out = mod.simpa(tp, twp, tn, twn, xs[0], xs[1], prm, hop, 0.5, directed, *xs[2:])
+        (out * go).sum().backward()
+        return [out.detach()] + [x.grad for x in xs] + [prm[k].grad for k in names]
+
+    got, ref = run(T64), run(R)
+    assert np.abs(got[0].numpy() - want).max() <= 1e-11
+    for a, c in zip(got, ref):
+        assert (a - c).abs().max() <= 1e-11
+    if directed:
+        return
+    # DIMPA
+    x_s, x_t = rng.normal(size=(n, f)), rng.normal(size=(n, f))
+    w_s, w_t = rng.uniform(0.5, 1.5, (hop + 1, 1)), rng.uniform(0.5, 1.5, (hop + 1, 1))
+    want = D64.dimpa(x_s, x_t, ei_p, w_p, w_s, w_t, hop, 0.5)
+    god = torch.from_numpy(rng.normal(size=(n, 2 * f)))
+
+    def run_d(fn):
+        a, b = torch.from_numpy(x_s).requires_grad_(), torch.from_numpy(x_t).requires_grad_()
+        ws, wt = torch.from_numpy(w_s).requires_grad_(), torch.from_numpy(w_t).requires_grad_()
+        out = fn(a, b, tp, twp, ws, wt, hop, 0.5)
+        (out * god).sum().backward()
+        return out.detach(), a.grad, b.grad, ws.grad, wt.grad
+
+    got, ref = run_d(T64.dimpa), run_d(R.dimpa)
+    assert np.abs(got[0].numpy() - want).max() <= 1e-11
+    for a, c in zip(got, ref):
+        assert (a - c).abs().max() <= 1e-11
+    # SGCNConv, first and deep aggregation
+    for first in (True, False):
+        in_dim, o = 6, 4
+        x_np = rng.normal(size=(n, in_dim if first else 2 * in_dim))
+        k = 2 if first else 3
+        lb = (rng.normal(size=(o, k * in_dim)), rng.normal(size=o))
+        lu = (rng.normal(size=(o, k * in_dim)), rng.normal(size=o))
+        want = D64.sgcn_conv(x_np, ei_p, ei_n, lb, lu, first, in_dim)
+        gos = torch.from_numpy(rng.normal(size=(n, 2 * o)))
+
+        def run_s(fn):
+            x = torch.from_numpy(x_np).requires_grad_()
+            prm = [torch.from_numpy(a).requires_grad_() for a in lb + lu]
+            out = fn(x, tp, tn, (prm[0], prm[1]), (prm[2], prm[3]), first, in_dim)
+            (out * gos).sum().backward()
+            return [out.detach(), x.grad] + [p.grad for p in prm]
+
+        got, ref = run_s(T64.sgcn_conv), run_s(R.sgcn_conv)
+        assert np.abs(got[0].numpy() - want).max() <= 1e-11
+        for a, c in zip(got, ref):
+            assert (a - c).abs().max() <= 1e-11
+
+
+@pytest.mark.parametrize("name", ["model_sssnet_undirected", "model_sssnet_directed"])
+def test_torch_sssnet_reproduces_the_reference_model_fixtures(name):
+    """The float64 SSSNET restatement against the outputs recorded from the reference's own model (fp32, eval mode)."""
+    import torch
+    from oracle import sparse_f64_torch as T64
+    g = load_golden(name)
+    sd = {k[3:]: torch.from_numpy(np.asarray(g[k], np.float64)) for k in g if k.startswith("sd.")}
+    directed = bool(g["directed"])
+    hop = sd["_simpa._w_sp" if directed else "_simpa._w_p"].numel() - 1
+    fill = float(g["fill_value"]) if "fill_value" in g else 0.5
+    z, logp, prob = T64.sssnet(g.t("edge_index_p"), g.t("edge_weight_p"), g.t("edge_index_n"), g.t("edge_weight_n"),
+                               g.t("x").double(), sd, hop, fill, directed)
+    for got, key in ((z, "out0"), (logp, "out1"), (prob, "out3")):
+        want = np.asarray(g[key], np.float64)
+        assert np.abs(got.numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), key

@@ -99,6 +99,20 @@ def test_take_rows_and_split_phases_preserve_the_product():
     assert torch.allclose(acc, want, atol=1e-5)
 
 
+def test_split_phases_of_an_empty_shard():
+    """A rank that multiplies no rows (or rows without entries) still takes part in every phase: empty blocks of the
+    phase buffers' shape instead of a zero slice step."""
+    from pytorch_geometric_signed_directed_amd.sparse import CSR
+    world, n_pad, phases = 2, 8, 2
+    for n_rows in (0, 3):
+        csr = CSR(n_rows, world * n_pad, 0, torch.zeros(n_rows + 1, dtype=torch.int32), torch.zeros(0, dtype=torch.int32), None)
+        blocks = split_phases(csr, (torch.zeros(0),), n_pad, phases, world)
+        assert len(blocks) == phases
+        for blk, (v,) in blocks:
+            assert (blk.n_rows, blk.n_cols, blk.nnz) == (n_rows, world * n_pad // phases, 0)
+            assert blk.rowptr.numel() == n_rows + 1 and int(blk.rowptr.abs().sum()) == 0 and v.numel() == 0
+
+
 @pytest.mark.parametrize("world,p_c,phases,chunks", [(8, 4, 2, 2), (4, 4, 1, 3), (8, 2, 3, 1), (4, 1, 2, 1), (6, 2, 2, 2)])
 def test_row_blocks_cover_every_padded_row_exactly_once(world, p_c, phases, chunks):
     align = PropagateEngine.alignment(world, p_c, phases, chunks)
@@ -357,6 +371,22 @@ def _grad_sync_worker(rank, world, port, ret):
                 prm.uniform_(-0.5, 0.5)
                 dist.broadcast(prm.data, 0)
         gl = layer.shard_rows(go)
+
+        class _Boom(torch.autograd.Function):              # identity whose backward raises: an aborted backward pass
+            @staticmethod
+            def forward(ctx, t):
+                return t.clone()
+
+            @staticmethod
+            def backward(ctx, g_):
+                raise ValueError("boom")
+
+        # the input's gradient is the LAST node of the pass: every parameter hook has fired when it raises, and the
+        # engine drops the queued end-of-pass callback -- the next passes must exchange as if nothing had happened
+        x0, x1, x2 = layer(_Boom.apply(layer.shard_rows(x).requires_grad_()))
+        with pytest.raises(ValueError, match="boom"):
+            ((x0 * gl).sum() + (x1 * gl).sum() + (x2 * gl).sum()).backward()
+        layer.zero_grad(set_to_none=(rank == 0))            # the aborted pass left rank-local sums behind
         for _ in range(2):
             x0, x1, x2 = layer(layer.shard_rows(x))
             if rank == 0:                                   # extra nodes on rank 0 only: conv1's branch becomes ready later
@@ -372,6 +402,10 @@ def _grad_sync_worker(rank, world, port, ret):
         ((want[0] * go).sum() + 2.0 * (want[1] * go).sum() + 3.0 * (want[2] * go).sum()).backward()
         ret[rank] = max(float((prm.grad - 2.0 * sd[k].grad).abs().max()) / max(1.0, float(sd[k].grad.abs().max()))
                         for k, prm in layer.named_parameters())
+        # torch.autograd.grad would return this rank's share only: refused (after the same collectives on every rank)
+        x0, x1, x2 = layer(layer.shard_rows(x))
+        with pytest.raises(RuntimeError, match="use .backward"):
+            torch.autograd.grad((x0 * gl).sum() + (x1 * gl).sum() + (x2 * gl).sum(), list(layer.parameters()))
     finally:
         dist.destroy_process_group()
 
