@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 9
+#define PYGSD_ABI_VERSION 10
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -435,6 +435,33 @@ int pygsd_tall_linear(const void* const* xs, const int64_t* ldx, const int32_t* 
 int pygsd_column_sums_workspace(int64_t n_rows, int32_t f, int32_t dtype, size_t* bytes);
 int pygsd_column_sums(const void* x, int64_t ldx, int64_t n_rows, int32_t f, int32_t dtype, float* out, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* Weight gradients of the tall linear maps above (csrc/gram.hip):
+ *
+ *   out[K, F] (fp32, row-major, ld = F) = [X_0 | X_1 | ...]^T [G_0 | G_1 | ...]        reduction over the n_rows rows
+ *
+ * -- what autograd's `mm` backward computes for the reference's x W products (nn/directed/DiGCNConv.py:66,
+ * nn/directed/DiGCN_Inception_Block.py:44-46, nn/signed/SGCNConv.py:121-126): dW = x^T dY.  Every operand row is read once
+ * per column chunk of the other side (coalesced 16-byte row loads), transposed through a wavefront-private LDS image
+ * (bf16: ds_read_b64_tr_b16) and multiplied on the matrix cores (fp32: exact v_mfma_f32_16x16x4_f32; bf16:
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation); per-block partials are added in a fixed order (deterministic).
+ * dtype, xs / ldx / x_widths and gs / ldg / g_widths as for pygsd_tall_linear (HOST arrays over up to 8 segments a side;
+ * widths multiples of 16 columns; at most 16 column chunks a side -- X in chunks of <= 64 columns, G of <= 128).  The result is fp32 for both dtypes.  workspace from pygsd_tall_gram_workspace. */
+int pygsd_tall_gram_workspace(int64_t n_rows, int32_t k_total, int32_t f_total, int32_t dtype, size_t* bytes);
+int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const int32_t* x_widths, int32_t n_x, const void* const* gs,
+                    const int64_t* ldg, const int32_t* g_widths, int32_t n_g, int64_t n_rows, int32_t dtype, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* C[m, n] (+)= A[m, k] B[k, n] (+ bias[n]) in exact fp32 for ANY shapes and strides (csrc/gemm.hip): the catch-all behind
+ * the MFMA kernels above for the dense products they do not tile -- odd widths, reductions deeper than 256, transposed
+ * views: torch.mm / torch.matmul of the reference's layers at such shapes (e.g. the 2879-wide first MagNetConv of
+ * examples/magnet_node.py through nn/directed/MagNetConv.py:217-247, the 10-class Conv1d head of MagNet_node_classification)
+ * and their autograd gradients.  A[i][j] sits at a[i * sa_m + j * sa_k], B[i][j] at b[i * sb_k + j * sb_n] (element
+ * strides: a transpose is a stride swap), C row-major with row stride ldc.  accumulate != 0: C += ...  A reduction that is
+ * long against the output is split into k-ranges added in a fixed order (workspace from pygsd_gemm_f32_workspace; 0 bytes
+ * otherwise).  Deterministic. */
+int pygsd_gemm_f32_workspace(int64_t m, int64_t n, int64_t k, size_t* bytes);
+int pygsd_gemm_f32(const float* a, int64_t sa_m, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_n, const float* bias,
+                   float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, int32_t accumulate, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* Keeps `stream` busy for `microseconds` (one idle lane polling the constant-rate wall clock).  Measurement
  * only: the single-GPU rehearsal of the sharded propagate (tools/emulate_sharded.py) uses it as the wire time

@@ -5,8 +5,11 @@ hipStream_t of torch's current stream.
 The library is REQUIRED: there is no CPU or eager-PyTorch fallback behind these functions.  If the
 shared object is missing or fails to load, importing an op raises immediately.
 """
+import collections
 import ctypes
 import os
+import threading
+import warnings
 from ctypes import c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 import torch
@@ -117,11 +120,17 @@ PROTOTYPES = {
     "pygsd_column_sums_workspace": (c_int32, [c_int64, c_int32, c_int32, ctypes.POINTER(ctypes.c_size_t)]),
     "pygsd_column_sums": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p, ctypes.c_size_t,
                                     c_void_p]),
+    "pygsd_tall_gram_workspace": (c_int32, [c_int64, c_int32, c_int32, c_int32, ctypes.POINTER(ctypes.c_size_t)]),
+    "pygsd_tall_gram": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
+                                  c_int32, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    "pygsd_gemm_f32_workspace": (c_int32, [c_int64, c_int64, c_int64, ctypes.POINTER(ctypes.c_size_t)]),
+    "pygsd_gemm_f32": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                 c_int64, c_int64, c_int32, c_void_p, ctypes.c_size_t, c_void_p]),
     "pygsd_prof_enable": (c_int32, [c_int32]),
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 def lib_path():
@@ -203,6 +212,39 @@ def check_node_ids(*bounded_lists, what="edge_index"):
         if lo < 0 or hi >= bound:
             raise IndexError(f"{what} holds node id {lo if lo < 0 else hi}, outside [0, {bound}); the HIP path "
                              "gathers and scatters rows by these ids")
+
+
+# ---- library routes ---------------------------------------------------------------------------
+# The path is hand-written HIP; where a shape falls outside what the kernels tile, the host may still route a DENSE
+# product or reduction through a library (hipBLASLt / rocBLAS behind torch.mm, a torch reduction).  Every such route is
+# counted here and announced once per (site, shape): "hand-written on the hot path" is an invariant the GPU tests assert
+# (zero routes for the BASELINE configurations with default switches), not a claim.
+_LIBRARY_ROUTES = collections.Counter()
+_LIBRARY_WARNED = set()
+_library_lock = threading.Lock()
+
+
+def note_library_route(site, detail=""):
+    """Record one library-routed dense product / reduction at `site` (warns once per (site, detail))."""
+    key = (site, str(detail))
+    with _library_lock:
+        _LIBRARY_ROUTES[site] += 1
+        first = key not in _LIBRARY_WARNED
+        _LIBRARY_WARNED.add(key)
+    if first:
+        warnings.warn(f"pytorch_geometric_signed_directed_amd: {site} runs through a library (not the HIP kernels): {detail}",
+                      RuntimeWarning, stacklevel=3)
+
+
+def library_routes():
+    """{site: count} of the library-routed products / reductions since the last reset."""
+    with _library_lock:
+        return dict(_LIBRARY_ROUTES)
+
+
+def reset_library_routes():
+    with _library_lock:
+        _LIBRARY_ROUTES.clear()
 
 
 # ---- kernel-timing recorder (bench.py) --------------------------------------------------------

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpygsd_hip.so")
 OBJ = os.path.join(CSRC, "build")
-SOURCES = ["runtime.hip", "spmm.hip", "dense.hip", "tall.hip", "build.hip", "laplacian.hip", "magop.hip", "attention.hip"]
+SOURCES = ["runtime.hip", "spmm.hip", "dense.hip", "tall.hip", "gram.hip", "gemm.hip", "build.hip", "laplacian.hip", "magop.hip", "attention.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 HEADER = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "pygsd_hip.h")
 

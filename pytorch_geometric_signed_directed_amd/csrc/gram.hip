@@ -1,0 +1,377 @@
+// Weight gradients of the tall linear maps on the matrix cores:  dW[K, F] = [X_0 | X_1 | ...]^T [G_0 | G_1 | ...]
+// for tall operands (n ~ 10^5..10^7 rows, K and F a few tens to a few hundreds of columns): the reduction runs over the
+// ROWS, i.e. both MFMA operands are needed column-major while they sit row-major in HBM.
+//
+//   x^T g   DiGCNConv.py:66 (x W), DiGCN_Inception_Block.py:44-46, SGCNConv.py:121-126 (the Linear over
+//           [aggregated | own]) -- what autograd's mm backward computes for the reference; library GEMMs ran these
+//           K = 10^6-deep, 64 x 128 products on a handful of CUs (split-K bmm + a reduction pass: 0.19 of the 1.22 ms
+//           SGCNConv step, 0.33 of the 5.88 ms inception block)
+//
+// One wavefront owns a tile of 16 (fp32) / 32 (bf16) rows.  Every global load is a coalesced 16-byte row load (a
+// row's columns sit on adjacent lanes); the tile goes through a wavefront-private LDS image once and comes back as
+// column fragments:
+//   fp32: image [16][cols + 4] (ds_write_b128 rows, conflict-free ds_read_b32 columns), v_mfma_f32_16x16x4_f32 (exact)
+//   bf16: image [col block][32 rows][16 cols] (32-byte rows), read with ds_read_b64_tr_b16 -- the LDS transpose read
+//         of gfx950: lane (i, q) of a 16-lane group receives column i of rows 4 q .. 4 q + 3 of the group's block --
+//         v_mfma_f32_16x16x32_bf16, fp32 accumulation.  The row <-> k-slot assignment of an MFMA is free (a sum), so the
+//         two reads of an operand take rows 4 q + j and 16 + 4 q + j: a 32-lane half then touches 8 consecutive 32-byte
+//         rows = all 64 banks once.
+// The operands are cut into column CHUNKS (host side, along segment boundaries: X 16 / 32 / 64 columns, G up to 128); block
+// (chunk pair, x) accumulates the [chunk cx of X]^T [chunk cg of G] block of dW over a persistent row loop in MFMA registers,
+// the four wavefronts of a block are combined through LDS in wave order, one partial per block, and a second kernel adds
+// the partials in block order: no atomics, deterministic.
+#include "common.hpp"
+
+namespace pygsd {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kMaxChunks = 16;
+
+struct GramChunk {
+    const void* p;     // first element of the chunk in row 0
+    int64_t ld;        // row stride in elements
+    int32_t tiles;     // 16-column tiles: 1, 2, 4 (X and G) or 8 (G)
+    int32_t at;        // first row (X chunks) / column (G chunks) of this chunk in dW
+};
+
+struct GramArgs {
+    GramChunk x[kMaxChunks];
+    GramChunk g[kMaxChunks];
+    float* partial;          // [gridDim.y][k_total * f_total]
+    int64_t n_rows;
+    int32_t k_total, f_total, n_g;
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- fp32 ---------------------------------------------------------------------------------------
+// rows of one 16-row tile -> the wavefront's image: NT float4 loads per lane, a row's 16 NT floats on 4 NT adjacent lanes
+template <int NT>
+__device__ __forceinline__ void stage_rows_f32(const GramChunk& c, int64_t r0, int64_t n_rows, int lane, float* img, int rs)
+{
+    constexpr int LPR = NT * 4;            // 16-byte pieces (lanes) per row
+    const float* base = static_cast<const float*>(c.p);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int piece = t * 64 + lane;                      // piece-major over the 16 x LPR pieces of the tile
+        const int row = piece / LPR, col = (piece % LPR) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + row < n_rows) v = *reinterpret_cast<const float4*>(base + (r0 + row) * c.ld + col);
+        *reinterpret_cast<float4*>(img + row * rs + col) = v;
+    }
+}
+
+template <int NTK, int NTF>
+__device__ __forceinline__ void gram_block_f32(const GramArgs& p, const GramChunk& cx, const GramChunk& cg, float* lds)
+{
+    constexpr int rsx = NTK * 16 + 4, rsg = NTF * 16 + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    float* imx = lds + wave * 16 * (rsx + rsg);
+    float* img = imx + 16 * rsx;
+    f32x4 acc[NTK][NTF];
+#pragma unroll
+    for (int a = 0; a < NTK; ++a)
+#pragma unroll
+        for (int b = 0; b < NTF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t n_tiles = (p.n_rows + 15) >> 4;
+    for (int64_t tile = static_cast<int64_t>(blockIdx.y) * 4 + wave; tile < n_tiles; tile += static_cast<int64_t>(gridDim.y) * 4) {
+        stage_rows_f32<NTK>(cx, tile << 4, p.n_rows, lane, imx, rsx);
+        stage_rows_f32<NTF>(cg, tile << 4, p.n_rows, lane, img, rsg);
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // MFMA k-slot q of step s <-> tile row 4 q + s; lane (i, q) supplies column i of both operands
+            float xa[NTK], gb[NTF];
+#pragma unroll
+            for (int a = 0; a < NTK; ++a) xa[a] = imx[(4 * q + s) * rsx + a * 16 + i];
+#pragma unroll
+            for (int b = 0; b < NTF; ++b) gb[b] = img[(4 * q + s) * rsg + b * 16 + i];
+#pragma unroll
+            for (int a = 0; a < NTK; ++a)
+#pragma unroll
+                for (int b = 0; b < NTF; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[a], gb[b], acc[a][b], 0, 0, 0);
+        }
+        wave_sync();
+    }
+    // C/D layout: lane (i, q), register r -> dW[16 a + 4 q + r][16 b + i]; the four wavefronts add in wave order
+    __syncthreads();
+    constexpr int fo = NTF * 16;
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int a = 0; a < NTK; ++a)
+#pragma unroll
+                for (int b = 0; b < NTF; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = (a * 16 + 4 * q + r) * fo + b * 16 + i;
+                        lds[e] = (turn == 0 ? 0.f : lds[e]) + acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* part = p.partial + static_cast<int64_t>(blockIdx.y) * p.k_total * p.f_total;
+    for (int e = tid; e < NTK * 16 * fo; e += 256) {
+        const int row = e / fo, col = e - row * fo;
+        part[static_cast<int64_t>(cx.at + row) * p.f_total + cg.at + col] = lds[e];
+    }
+}
+
+template <int NTK>
+__device__ __forceinline__ void gram_pick_f32(const GramArgs& p, const GramChunk& cx, const GramChunk& cg, float* lds)
+{
+    if (cg.tiles == 8) gram_block_f32<NTK, 8>(p, cx, cg, lds);
+    else if (cg.tiles == 4) gram_block_f32<NTK, 4>(p, cx, cg, lds);
+    else if (cg.tiles == 2) gram_block_f32<NTK, 2>(p, cx, cg, lds);
+    else gram_block_f32<NTK, 1>(p, cx, cg, lds);
+}
+
+__global__ __launch_bounds__(256, 2) void tall_gram_f32_kernel(GramArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_f32[];
+    const GramChunk cx = p.x[blockIdx.x / p.n_g], cg = p.g[blockIdx.x % p.n_g];
+    if (cx.tiles == 4) gram_pick_f32<4>(p, cx, cg, lds_f32);
+    else if (cx.tiles == 2) gram_pick_f32<2>(p, cx, cg, lds_f32);
+    else gram_pick_f32<1>(p, cx, cg, lds_f32);
+}
+
+// ---- bf16 storage, fp32 accumulation ------------------------------------------------------------
+// rows of one 32-row tile -> image [tile][32 rows][16 cols]: NT 16-byte loads per lane, a row's 16 NT columns on 2 NT lanes
+template <int NT>
+__device__ __forceinline__ void stage_rows_bf16(const GramChunk& c, int64_t r0, int64_t n_rows, int lane, unsigned char* img)
+{
+    constexpr int LPR = NT * 2;            // 16-byte pieces (lanes) per row
+    const uint16_t* base = static_cast<const uint16_t*>(c.p);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int piece = t * 64 + lane;                      // piece-major over the 32 x LPR pieces of the tile
+        const int row = piece / LPR, c8 = piece % LPR;        // 8-column piece c8 of the row
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + row < n_rows) v = *reinterpret_cast<const uint4*>(base + (r0 + row) * c.ld + c8 * 8);
+        *reinterpret_cast<uint4*>(img + (c8 >> 1) * 1024 + row * 32 + (c8 & 1) * 16) = v;
+    }
+}
+
+// column i (= lane & 15) of rows {4 q + j} and {16 + 4 q + j}, j < 4, of one [32][16] block: the 8 k-slots of lane (i, q)
+__device__ __forceinline__ bf16x8 column_fragment(uint32_t block_addr, int lane)
+{
+    const int t = lane & 15, q = lane >> 4;
+    const uint32_t a = block_addr + static_cast<uint32_t>((4 * q + (t >> 2)) * 32 + (t & 3) * 8);
+    uint64_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(a)
+                 : "memory");
+    const uint4 u = make_uint4(static_cast<uint32_t>(lo), static_cast<uint32_t>(lo >> 32), static_cast<uint32_t>(hi),
+                               static_cast<uint32_t>(hi >> 32));
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+template <int NTK, int NTF>
+__device__ __forceinline__ void gram_block_bf16(const GramArgs& p, const GramChunk& cx, const GramChunk& cg, unsigned char* lds)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    unsigned char* imx = lds + wave * (NTK + NTF) * 1024;
+    unsigned char* img = imx + NTK * 1024;
+    const uint32_t ax = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(imx));      // LDS offsets: the low 32 bits
+    const uint32_t ag = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(img));
+    f32x4 acc[NTK][NTF];
+#pragma unroll
+    for (int a = 0; a < NTK; ++a)
+#pragma unroll
+        for (int b = 0; b < NTF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t n_tiles = (p.n_rows + 31) >> 5;
+    for (int64_t tile = static_cast<int64_t>(blockIdx.y) * 4 + wave; tile < n_tiles; tile += static_cast<int64_t>(gridDim.y) * 4) {
+        stage_rows_bf16<NTK>(cx, tile << 5, p.n_rows, lane, imx);
+        stage_rows_bf16<NTF>(cg, tile << 5, p.n_rows, lane, img);
+        wave_sync();
+        bf16x8 xa[NTK], gb[NTF];
+#pragma unroll
+        for (int a = 0; a < NTK; ++a) xa[a] = column_fragment(ax + a * 1024, lane);
+#pragma unroll
+        for (int b = 0; b < NTF; ++b) gb[b] = column_fragment(ag + b * 1024, lane);
+#pragma unroll
+        for (int a = 0; a < NTK; ++a)
+#pragma unroll
+            for (int b = 0; b < NTF; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[a], gb[b], acc[a][b], 0, 0, 0);
+        wave_sync();
+    }
+    __syncthreads();
+    float* sum = reinterpret_cast<float*>(lds);
+    constexpr int fo = NTF * 16;
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int a = 0; a < NTK; ++a)
+#pragma unroll
+                for (int b = 0; b < NTF; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = (a * 16 + 4 * q + r) * fo + b * 16 + i;
+                        sum[e] = (turn == 0 ? 0.f : sum[e]) + acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* part = p.partial + static_cast<int64_t>(blockIdx.y) * p.k_total * p.f_total;
+    for (int e = tid; e < NTK * 16 * fo; e += 256) {
+        const int row = e / fo, col = e - row * fo;
+        part[static_cast<int64_t>(cx.at + row) * p.f_total + cg.at + col] = sum[e];
+    }
+}
+
+template <int NTK>
+__device__ __forceinline__ void gram_pick_bf16(const GramArgs& p, const GramChunk& cx, const GramChunk& cg, unsigned char* lds)
+{
+    if (cg.tiles == 8) gram_block_bf16<NTK, 8>(p, cx, cg, lds);
+    else if (cg.tiles == 4) gram_block_bf16<NTK, 4>(p, cx, cg, lds);
+    else if (cg.tiles == 2) gram_block_bf16<NTK, 2>(p, cx, cg, lds);
+    else gram_block_bf16<NTK, 1>(p, cx, cg, lds);
+}
+
+__global__ __launch_bounds__(256, 2) void tall_gram_bf16_kernel(GramArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_b16[];
+    const GramChunk cx = p.x[blockIdx.x / p.n_g], cg = p.g[blockIdx.x % p.n_g];
+    if (cx.tiles == 4) gram_pick_bf16<4>(p, cx, cg, lds_b16);
+    else if (cx.tiles == 2) gram_pick_bf16<2>(p, cx, cg, lds_b16);
+    else gram_pick_bf16<1>(p, cx, cg, lds_b16);
+}
+
+// out[e] = sum_b partial[b][e] in block order: 64 elements per block, 4 groups of partials combined through LDS
+__global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ partial, int n_partials, int64_t n_elem,
+                                                          float* __restrict__ out)
+{
+    __shared__ float sm[256];
+    const int tid = threadIdx.x;
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * 64 + (tid & 63);
+    const int grp = tid >> 6;
+    float acc = 0.f;
+    if (e < n_elem) {
+#pragma unroll 8
+        for (int b = grp; b < n_partials; b += 4) acc += partial[static_cast<int64_t>(b) * n_elem + e];
+    }
+    sm[tid] = acc;
+    __syncthreads();
+    if (grp == 0 && e < n_elem) out[e] = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
+}
+
+unsigned gram_blocks(int64_t n_rows, int rows_per_tile)
+{
+    const int64_t tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
+    int64_t b = (tiles + 3) / 4;
+    if (b > 512) b = 512;                       // 2 blocks per CU; every block walks >= 1 tile per wavefront
+    return static_cast<unsigned>(b < 1 ? 1 : b);
+}
+
+// a width (multiple of 16) as chunks of 8 / 4 / 2 / 1 tiles, none above `cap`
+int cut_chunks(const void* base, int64_t ld, int width, size_t esz, int at, int cap, GramChunk* out, int have)
+{
+    int col = 0;
+    while (col < width) {
+        const int left = (width - col) / 16;
+        const int tiles = (left >= 8 && cap >= 8) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
+        if (have >= kMaxChunks) return -1;
+        out[have++] = GramChunk{static_cast<const unsigned char*>(base) + static_cast<size_t>(col) * esz, ld, tiles, at + col};
+        col += tiles * 16;
+    }
+    return have;
+}
+}  // namespace
+}  // namespace pygsd
+
+using namespace pygsd;
+
+extern "C" int pygsd_tall_gram_workspace(int64_t n_rows, int32_t k_total, int32_t f_total, int32_t dtype, size_t* bytes)
+{
+    PYGSD_REQUIRE(bytes, "pygsd_tall_gram_workspace: null output");
+    PYGSD_REQUIRE(dtype == 0 || dtype == 1, "pygsd_tall_gram_workspace: dtype must be 0 (fp32) or 1 (bf16)");
+    PYGSD_REQUIRE(n_rows >= 0 && k_total > 0 && f_total > 0, "pygsd_tall_gram_workspace: sizes must be positive");
+    *bytes = static_cast<size_t>(gram_blocks(n_rows, dtype == 1 ? 32 : 16)) * k_total * f_total * sizeof(float);
+    return 0;
+}
+
+extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const int32_t* x_widths, int32_t n_x,
+                               const void* const* gs, const int64_t* ldg, const int32_t* g_widths, int32_t n_g, int64_t n_rows,
+                               int32_t dtype, float* out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    PYGSD_REQUIRE(dtype == 0 || dtype == 1, "pygsd_tall_gram: dtype must be 0 (fp32) or 1 (bf16), got %d", dtype);
+    PYGSD_REQUIRE(n_x >= 1 && n_x <= 8 && xs && ldx && x_widths && n_g >= 1 && n_g <= 8 && gs && ldg && g_widths,
+                  "pygsd_tall_gram: 1..8 column segments on either side");
+    PYGSD_REQUIRE(n_rows >= 0 && out, "pygsd_tall_gram: negative row count or null output");
+    const size_t esz = dtype == 1 ? 2 : 4;
+    const int vec = dtype == 1 ? 8 : 4;
+    GramArgs a{};
+    int nx = 0, ng = 0, k_total = 0, f_total = 0;
+    for (int s = 0; s < n_x; ++s) {
+        PYGSD_REQUIRE(x_widths[s] > 0 && x_widths[s] % 16 == 0, "pygsd_tall_gram: X segment %d is %d columns wide (multiples "
+                      "of 16)", s, x_widths[s]);
+        PYGSD_REQUIRE(n_rows == 0 || (xs[s] && aligned16(xs[s]) && ldx[s] >= x_widths[s] && ldx[s] % vec == 0),
+                      "pygsd_tall_gram: X segment %d null, not 16-byte aligned, or row stride not a multiple of 16 bytes >= its "
+                      "width", s);
+        nx = cut_chunks(xs[s], ldx[s], x_widths[s], esz, k_total, 4, a.x, nx);
+        PYGSD_REQUIRE(nx > 0, "pygsd_tall_gram: more than %d column chunks in X", kMaxChunks);
+        k_total += x_widths[s];
+    }
+    for (int s = 0; s < n_g; ++s) {
+        PYGSD_REQUIRE(g_widths[s] > 0 && g_widths[s] % 16 == 0, "pygsd_tall_gram: G segment %d is %d columns wide (multiples "
+                      "of 16)", s, g_widths[s]);
+        PYGSD_REQUIRE(n_rows == 0 || (gs[s] && aligned16(gs[s]) && ldg[s] >= g_widths[s] && ldg[s] % vec == 0),
+                      "pygsd_tall_gram: G segment %d null, not 16-byte aligned, or row stride not a multiple of 16 bytes >= its "
+                      "width", s);
+        ng = cut_chunks(gs[s], ldg[s], g_widths[s], esz, f_total, 8, a.g, ng);
+        PYGSD_REQUIRE(ng > 0, "pygsd_tall_gram: more than %d column chunks in G", kMaxChunks);
+        f_total += g_widths[s];
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n_elem = static_cast<int64_t>(k_total) * f_total;
+    if (n_rows == 0) {
+        PYGSD_HIP_TRY(hipMemsetAsync(out, 0, static_cast<size_t>(n_elem) * sizeof(float), s));
+        return 0;
+    }
+    const unsigned blocks = gram_blocks(n_rows, dtype == 1 ? 32 : 16);
+    PYGSD_REQUIRE(workspace && workspace_bytes >= static_cast<size_t>(blocks) * n_elem * sizeof(float),
+                  "pygsd_tall_gram: workspace null or too small (pygsd_tall_gram_workspace)");
+    a.partial = static_cast<float*>(workspace);
+    a.n_rows = n_rows;
+    a.k_total = k_total;
+    a.f_total = f_total;
+    ProfScope prof(PYGSD_K_DENSE_BWD, s);
+    // chunk pair fastest: the blocks that re-read a row range for another column chunk run side by side (the re-read is an
+    // Infinity-Cache hit, not a second trip to HBM)
+    a.n_g = ng;
+    const dim3 grid(static_cast<unsigned>(ng * nx), blocks);
+    int tk = 1, tf = 1;                           // widest chunk on either side sizes the LDS region
+    for (int c = 0; c < nx; ++c) tk = a.x[c].tiles > tk ? a.x[c].tiles : tk;
+    for (int c = 0; c < ng; ++c) tf = a.g[c].tiles > tf ? a.g[c].tiles : tf;
+    const size_t combine = static_cast<size_t>(tk) * 16 * tf * 16 * sizeof(float);     // the block's dW chunk, wave-order sum
+    if (dtype == 1) {
+        size_t lds = static_cast<size_t>(4) * (tk + tf) * 1024;                        // 4 wavefronts x [tile][32][16] bf16
+        if (lds < combine) lds = combine;
+        if (lds > 64 * 1024)
+            PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram_bf16_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL(tall_gram_bf16_kernel, grid, dim3(256), lds, s, a);
+    } else {
+        size_t lds = static_cast<size_t>(4) * 16 * ((tk * 16 + 4) + (tf * 16 + 4)) * sizeof(float);   // 4 x [16][cols + 4]
+        if (lds < combine) lds = combine;
+        if (lds > 64 * 1024)
+            PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram_f32_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL(tall_gram_f32_kernel, grid, dim3(256), lds, s, a);
+    }
+    if (int rc = check_launch("tall_gram_kernel")) return rc;
+    hipLaunchKernelGGL(gram_finish_kernel, dim3(static_cast<unsigned>((n_elem + 63) / 64)), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), static_cast<int>(blocks), n_elem, out);
+    return check_launch("gram_finish_kernel");
+}

@@ -200,14 +200,7 @@ def tall_product(segments: Sequence[Tensor], w: Tensor, transposed: bool = False
              and (splits is None or (len(splits) <= 8 and all(c > 0 and c % kw == 0 for c in splits)))
              and bool(_cabi.lib().pygsd_tall_linear_supported(code, k_total, f_out)))
     if not fused:
-        y, at = None, 0
-        for t in segments:
-            blk = w[:, at:at + t.size(1)].t() if transposed else w[at:at + t.size(1)]
-            if y is None:
-                y = torch.addmm(bias, t, blk) if bias is not None else t @ blk
-            else:
-                y.addmm_(t, blk)
-            at += t.size(1)
+        y = _gemm_fallback(segments, w, transposed, bias, k_total, f_out)
         return y if splits is None else list(y.split(list(splits), dim=1))
     segs = [_row_major16(t.detach()) for t in segments]
     wd = w.detach()
@@ -235,6 +228,13 @@ def column_sums(x: Tensor) -> Tensor:
     vec = 8 if x.dtype == torch.bfloat16 else 4
     if not (_TALL_KERNELS and code is not None and x.is_cuda and x.dim() == 2 and x.size(1) % vec == 0
             and 0 < x.size(1) <= 256 * vec // 2 and x.size(0) > 0):
+        if _TALL_KERNELS and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(0) > 0 and x.size(1) > 0:
+            # widths the 16-byte-row kernel does not take (a 10-class head): 1^T x through the generic HIP GEMM, whose
+            # split reduction adds the row ranges in a fixed order (the row of ones is a stride-0 view, never materialised)
+            ones = torch.ones(1, dtype=torch.float32, device=x.device).expand(1, x.size(0))
+            return gemm(ones, x).view(-1)
+        if x.is_cuda and x.dim() == 2 and x.size(0) >= 4096:          # a tall reduction outside the kernels' shapes
+            _cabi.note_library_route("column_sums", f"{tuple(x.shape)} {x.dtype}")
         return x.sum(0)
     if x.size(0) > 1 and x.stride(0) == 0:
         return (x[0].float() * x.size(0)).to(x.dtype)
@@ -267,11 +267,11 @@ def column_sums_of(tensors: Sequence[Optional[Tensor]]) -> List[Optional[Tensor]
 
 
 class _TallLinear(torch.autograd.Function):
-    """y = x @ W (+ b) for a tall x [N, F_in] (N ~ 10^5..10^6, F ~ 10^1..10^2) with library GEMMs.
-    Forward and dX are ordinary GEMMs; the weight gradient dW = x^T g has a reduction dimension of N and
-    only F_in x F_out outputs, which rocBLAS runs on a handful of CUs (measured 1.8 ms at N = 10^6,
-    F = 64).  Here it is a batched split-K: N is cut into 4096-row slabs, one GEMM per slab (bmm), and
-    the [S, F_in, F_out] partials are summed -- every CU gets work, ~10x faster."""
+    """y = x @ W (+ b) for a tall x [N, F_in] (N ~ 10^5..10^6, F ~ 10^1..10^2): forward and dX by tall_product
+    (csrc/tall.hip), the weight gradient dW = x^T g by tall_gram (csrc/gram.hip) -- a reduction over N with only
+    F_in x F_out outputs, which rocBLAS runs on a handful of CUs (measured 1.8 ms at N = 10^6, F = 64).  Shapes the MFMA
+    kernels do not tile take the generic HIP GEMM (fp32) or, counted and announced, library GEMMs (batched split-K over
+    4096-row slabs for the weight gradient)."""
     SLAB = 4096
 
     @staticmethod
@@ -294,9 +294,125 @@ class _TallLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
-def tall_gram(x: Tensor, g: Tensor) -> Tensor:
-    """x^T g for tall x [N, F_in], g [N, F_out] (N ~ 10^5..10^6): batched split-K over 4096-row slabs (see _TallLinear)."""
-    n, slab = x.size(0), _TallLinear.SLAB
+def _gemm_fallback(segments, w, transposed, bias, k_total, f_out):
+    """[X_0 | X_1 | ...] W (+ bias) for shapes pygsd_tall_linear does not tile: the generic HIP GEMM (fp32, any shape),
+    else -- counted and announced (_cabi.note_library_route) -- library GEMMs."""
+    x0 = segments[0]
+    if _TALL_KERNELS and x0.is_cuda and x0.dtype == torch.float32 and w.dtype == torch.float32 \
+            and all(t.dim() == 2 and t.dtype == torch.float32 for t in segments) and (bias is None or bias.dtype == torch.float32):
+        y, at = None, 0
+        for t in segments:
+            blk = w[:, at:at + t.size(1)].t() if transposed else w[at:at + t.size(1)]
+            y = gemm(t, blk, bias=bias if y is None else None, out=y, accumulate=y is not None)
+            at += t.size(1)
+        return y
+    _cabi.note_library_route("tall_product", f"{tuple(x0.shape)} {x0.dtype} x K={k_total} -> {f_out}")
+    y, at = None, 0
+    for t in segments:
+        blk = w[:, at:at + t.size(1)].t() if transposed else w[at:at + t.size(1)]
+        if y is None:
+            y = torch.addmm(bias, t, blk) if bias is not None else t @ blk
+        else:
+            y.addmm_(t, blk)
+        at += t.size(1)
+    return y
+
+
+def gemm(a: Tensor, b: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """a [M, K] @ b [K, N] (+ bias [N]) in exact fp32 (fmaf chains) for ANY shapes and strides (views, transposes):
+    pygsd_gemm_f32, the generic tiled kernel behind the shapes the MFMA kernels do not take (odd widths, K > 256, the
+    2879-wide first layer of BASELINE config 1).  accumulate: add onto `out`.  A tall reduction (K >> M, N: a weight
+    gradient) is split over the blocks and summed in a fixed order."""
+    m, k = a.shape
+    n = b.size(1)
+    a, b = a.detach(), b.detach()
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if m == 0 or n == 0:
+        return out
+    lib = _cabi.lib()
+    with torch.cuda.device(a.device):
+        need = ctypes.c_size_t(0)
+        check(lib.pygsd_gemm_f32_workspace(m, n, k, ctypes.byref(need)), "pygsd_gemm_f32_workspace")
+        ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=a.device)
+        check(lib.pygsd_gemm_f32(ptr(a), a.stride(0), a.stride(1), ptr(b), b.stride(0), b.stride(1),
+                                 ptr(None if bias is None else bias.detach().contiguous()), ptr(out), out.stride(0), m, n, k,
+                                 1 if accumulate else 0, ptr(ws), need.value, stream_ptr()), "pygsd_gemm_f32")
+    return out
+
+
+class _Matmul(torch.autograd.Function):
+    """a @ b through the generic HIP GEMM, with its two gradient products."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return gemm(a, b)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = gemm(g, b.t()) if ctx.needs_input_grad[0] else None
+        gb = gemm(a.t(), g) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def matmul(a: Tensor, b: Tensor) -> Tensor:
+    """a [M, K] @ b [K, N] for fp32 device matrices of any shape / stride through pygsd_gemm_f32 (differentiable): the
+    small or odd-shaped products around the path -- cluster flows P^T (A P), volumes, 1..6-column read-outs -- that the
+    libraries run at ~100 GB/s (rocBLAS gemv on a 5 * 10^5 x 32 operand: 4.5 ms).  Other inputs: torch.matmul, counted."""
+    if (_TALL_KERNELS and a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and b.dtype == torch.float32):
+        return _Matmul.apply(a, b)
+    if a.is_cuda and max(a.size(-2), a.size(-1)) >= 4096:
+        _cabi.note_library_route("matmul", f"{tuple(a.shape)} @ {tuple(b.shape)} {a.dtype}")
+    return torch.matmul(a, b)
+
+
+def _gram_chunks(width: int, cap: int) -> int:
+    """Column chunks pygsd_tall_gram cuts a segment into (8 / 4 / 2 / 1 tiles of 16 columns, none above `cap`)."""
+    left, count = width // 16, 0
+    while left > 0:
+        left -= 8 if (left >= 8 and cap >= 8) else 4 if left >= 4 else 2 if left >= 2 else 1
+        count += 1
+    return count
+
+
+def tall_gram(xs, gs) -> Tensor:
+    """[X_0 | X_1 | ...]^T [G_0 | G_1 | ...] for tall segments (N ~ 10^5..10^7 rows): the weight gradients dW = x^T dY of
+    the tall linear maps in ONE pass over the operands (pygsd_tall_gram: coalesced row loads, LDS transposition, MFMA,
+    deterministic partial sums) -- every segment pair's block of the result side by side.  Tensors or lists of tensors."""
+    xs = [xs] if isinstance(xs, Tensor) else list(xs)
+    gs = [gs] if isinstance(gs, Tensor) else list(gs)
+    x0 = xs[0]
+    n, dtype = x0.size(0), x0.dtype
+    code = _TALL_DTYPES.get(dtype)
+    k_total, f_total = sum(int(t.size(1)) for t in xs), sum(int(t.size(1)) for t in gs)
+    fused = (_TALL_KERNELS and code is not None and x0.is_cuda and len(xs) <= 8 and len(gs) <= 8
+             and all(t.dim() == 2 and t.dtype == dtype and t.size(0) == n and t.size(1) % 16 == 0 and t.size(1) > 0
+                     for t in xs + gs)
+             and sum(_gram_chunks(t.size(1), 4) for t in xs) <= 16 and sum(_gram_chunks(t.size(1), 8) for t in gs) <= 16)
+    if fused:
+        xd, gd = [_row_major16(t.detach()) for t in xs], [_row_major16(t.detach()) for t in gs]
+        out = torch.empty((k_total, f_total), dtype=torch.float32, device=x0.device)
+        arr = lambda ts, fn, ct: (ct * len(ts))(*[fn(t) for t in ts])  # noqa: E731
+        lib = _cabi.lib()
+        with torch.cuda.device(x0.device):
+            need = ctypes.c_size_t(0)
+            check(lib.pygsd_tall_gram_workspace(n, k_total, f_total, code, ctypes.byref(need)), "pygsd_tall_gram_workspace")
+            ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=x0.device)
+            check(lib.pygsd_tall_gram(arr(xd, lambda t: t.data_ptr(), c_void_p), arr(xd, lambda t: t.stride(0), ctypes.c_int64),
+                                      arr(xd, lambda t: t.size(1), ctypes.c_int32), len(xd),
+                                      arr(gd, lambda t: t.data_ptr(), c_void_p), arr(gd, lambda t: t.stride(0), ctypes.c_int64),
+                                      arr(gd, lambda t: t.size(1), ctypes.c_int32), len(gd), n, code, ptr(out), ptr(ws),
+                                      need.value, stream_ptr()), "pygsd_tall_gram")
+        return out if dtype == torch.float32 else out.to(dtype)
+    x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=1)
+    g = gs[0] if len(gs) == 1 else torch.cat(gs, dim=1)
+    if _TALL_KERNELS and x.is_cuda and dtype == torch.float32 and g.dtype == torch.float32:
+        return gemm(x.t(), g)                       # generic HIP GEMM, reduction over the rows split over the blocks
+    _cabi.note_library_route("tall_gram", f"{tuple(x.shape)}^T {tuple(g.shape)} {dtype}")
+    slab = _TallLinear.SLAB
     s = n // slab
     if s < 8:
         return x.t() @ g

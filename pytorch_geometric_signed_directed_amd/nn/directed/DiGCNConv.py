@@ -66,7 +66,12 @@ class DiGCNConv(MessagePassing):
     def forward(self, x: torch.FloatTensor, edge_index: torch.LongTensor,
                 edge_weight: torch.FloatTensor = None) -> torch.FloatTensor:
         _cabi.require_gpu(x, edge_index, edge_weight)
-        projected = tall_linear(x, self.weight) if x.dim() == 2 else torch.matmul(x, self.weight)
+        if x.dim() == 2:
+            projected = tall_linear(x, self.weight)
+        else:                                   # [..., N, F] batches: a broadcasting library product, counted
+            if x.is_cuda:
+                _cabi.note_library_route("DiGCNConv batched x W", f"{tuple(x.shape)} {x.dtype}")
+            projected = torch.matmul(x, self.weight)
         return self.aggregate_projected(projected, edge_index, edge_weight)
 
     # -- MessagePassing hooks (generic propagate path) -------------------------------------------------

@@ -202,7 +202,7 @@ class _InceptionBlockFn(torch.autograd.Function):
                                                                         added in its epilogue (Z row with stride 0)
         backward  dP_k = S_k dx_k  written by the SpMM straight into the column halves of ONE [N, 2F] buffer;
                   dx = [dx0 | dP_1 | dP_2] [W_ln^T | W_1 | W_2]^T   ONE product over the three column segments;
-                  dW_ln = x^T dx0, [dW_1 | dW_2] = x^T [dP_1 | dP_2]   split-K; the three bias gradients are column sums.
+                  [dW_ln | dW_1 | dW_2] = x^T [dx0 | dP_1 | dP_2]   ONE pass (csrc/gram.hip); the bias gradients are column sums.
     Replaces three GEMMs + three bias passes forward and three GEMMs + two gradient-accumulation passes + three skinny
     weight GEMMs backward (reference: DiGCN_Inception_Block.py:44-46, DiGCNConv.py:66,86-93)."""
 
@@ -234,8 +234,8 @@ class _InceptionBlockFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = tall_product([g0, dp], wcat, True)         # g0 W_ln + [dP_1 | dP_2] [W_1 | W_2]^T in one pass
-        dw_ln_t = tall_gram(x, g0)
-        dw12 = tall_gram(x, dp)
+        dw = tall_gram([x], [g0, dp])                       # x^T [dx0 | dP_1 | dP_2]: x, dx0 and dP read once
+        dw_ln_t, dw12 = dw[:, :f], dw[:, f:]
         hb = ctx.has_bias
         db0, db1, db2 = column_sums_of([g0 if hb[0] else None, g1 if hb[1] else None, g2 if hb[2] else None])
         return (dx, dw_ln_t, db0, dw12[:, :f], db1, dw12[:, f:], db2, None, None, None, None)

@@ -19,7 +19,7 @@ class _SgcnFn(torch.autograd.Function):
         out[:, half_j] = y_own[:, half_j] + sum_j mean_in(pattern_j, a_j)        (half = 0: balanced, 1: unbalanced)
     -- the first aggregation of a half reads the own block as the SpMM's Z operand, later ones accumulate.  Backward:
     g_a_j = mean_in(pattern_j)^T g_out[:, half_j] written into ONE [N, m o] buffer, then
-    dx = [g_out | g_a] W_big^T (one product over the two column segments), dW_big = [x^T g_out | x^T g_a] (split-K),
+    dx = [g_out | g_a] W_big^T (one product over the two column segments), dW_big = x^T [g_out | g_a] (csrc/gram.hip),
     d bias = column sums of g_out.  No element-wise passes, no split / cat in either direction
     (reference order: aggregate, concatenate, Linear -- SGCNConv.py:101-126)."""
 
@@ -56,7 +56,7 @@ class _SgcnFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = tall_product([g, ga], w_big, True)          # g W_own^T + g_a W_agg^T in one pass
-        dw = torch.cat([tall_gram(x, g), tall_gram(x, ga)], dim=1)
+        dw = tall_gram([x], [g, ga])                         # [x^T g_out | x^T g_a] in one pass over x, g and g_a
         dbias = None
         if ctx.has_bias:
             dbias = torch.cat([column_sums(g), g.new_zeros(len(spec) * o)])
@@ -95,7 +95,13 @@ class SGCNConv(MessagePassing):
         (reference order: aggregate, concatenate, then Linear; SGCNConv.py:101-119)."""
         f = self.in_dim
         w = lin.weight                                  # [out_dim, (len(aggregated) + 1) * in_dim]
-        lin_fn = tall_linear if own.dim() == 2 else (lambda t, wt, b=None: F.linear(t, wt.t(), b))   # [..., N, F]: broadcast
+        if own.dim() == 2:
+            lin_fn = tall_linear
+        else:                                           # [..., N, F] batches: a broadcasting library product, counted
+            def lin_fn(t, wt, b=None):
+                if t.is_cuda:
+                    _cabi.note_library_route("SGCNConv batched Linear", f"{tuple(t.shape)} {t.dtype}")
+                return F.linear(t, wt.t(), b)
         if self.in_dim > self.out_dim:
             out = lin_fn(own, w[:, len(aggregated) * f:].t(), lin.bias)
             for k, (feat, ei) in enumerate(aggregated):

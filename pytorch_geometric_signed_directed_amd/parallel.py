@@ -928,8 +928,9 @@ class ShardedMagNetConv(torch.nn.Module):
         from .dense import dense_fwd_raw, dense_supported
         if ta[0].is_cuda and dense_supported(self.in_channels, self.out_channels, weight.size(0)):
             return dense_fwd_raw(ta, tb, weight, bias)
-        rr = sum(torch.matmul(ta[k], weight[k]) for k in range(weight.size(0)))
-        ii = sum(torch.matmul(tb[k], weight[k]) for k in range(weight.size(0)))
+        mm = _dense_mm(ta[0])
+        rr = sum(mm(ta[k], weight[k]) for k in range(weight.size(0)))
+        ii = sum(mm(tb[k], weight[k]) for k in range(weight.size(0)))
         b = 0 if bias is None else bias
         return rr - ii + b, rr + ii + b
 
@@ -943,9 +944,10 @@ class ShardedMagNetConv(torch.nn.Module):
         p, m = (g_r + g_i)[:rows], (g_i - g_r)[:rows]
         k1 = weight.size(0)
         pad = (0, 0, 0, n - rows)
-        da = [torch.nn.functional.pad(torch.matmul(p, weight[k].t()), pad) for k in range(k1)]
-        db = [torch.nn.functional.pad(torch.matmul(m, weight[k].t()), pad) for k in range(k1)]
-        dw = torch.stack([ta[k][:rows].t() @ p + tb[k][:rows].t() @ m for k in range(k1)])
+        mm = _dense_mm(p)
+        da = [torch.nn.functional.pad(mm(p, weight[k].t()), pad) for k in range(k1)]
+        db = [torch.nn.functional.pad(mm(m, weight[k].t()), pad) for k in range(k1)]
+        dw = torch.stack([mm(ta[k][:rows].t(), p) + mm(tb[k][:rows].t(), m) for k in range(k1)])
         return da, db, dw, p.sum(0)
 
     def shard_rows(self, x: Tensor) -> Tensor:
@@ -1097,6 +1099,15 @@ class ShardedDiGCNConv(_GradSync, torch.nn.Module):
         out = self.aggregate(tall_linear(x_local, self.weight))
         out = out if self.bias is None else out + self.bias
         return _zero_pad_rows(self.plan, out)
+
+
+def _dense_mm(like: Tensor):
+    """The product routine of the sharded layers' dense stage for shapes the MFMA kernels do not tile: the generic HIP GEMM
+    on the device, torch.matmul for the CPU restatements the gloo tests run."""
+    if like.is_cuda and like.dtype == torch.float32:
+        from .dense import gemm
+        return lambda a, b: gemm(a.detach(), b.detach())
+    return torch.matmul
 
 
 def _zero_pad_rows(plan: ShardPlan, t: Tensor) -> Tensor:

@@ -12,6 +12,7 @@ from typing import Optional, Union
 import numpy as np
 import torch
 
+from ...dense import matmul
 from ...sparse import Pattern, spmm
 
 
@@ -58,8 +59,8 @@ class Prob_Imbalance_Loss(torch.nn.Module):
         eps = 1e-8
         pat, val, deg = self._operator(A)
         prob = P[:, :K]
-        flow = torch.matmul(prob.t(), spmm(pat, prob.contiguous(), val))          # flow[k, l] = P_k^T A P_l
-        vol = torch.matmul(deg, prob)                                             # probabilistic cluster volumes
+        flow = matmul(prob.t(), spmm(pat, prob.contiguous(), val))                # flow[k, l] = P_k^T A P_l
+        vol = matmul(deg.unsqueeze(0), prob).squeeze(0)                           # probabilistic cluster volumes
         # all cluster pairs k < l at once (the reference loops over them with a host read per pair)
         k_idx, l_idx = torch.triu_indices(K, K, offset=1, device=device)
         forth, back = flow[k_idx, l_idx], flow[l_idx, k_idx]

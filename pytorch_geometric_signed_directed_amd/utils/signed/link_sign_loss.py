@@ -15,19 +15,17 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...dense import matmul
 from ...memo import TensorMemo
 
 Tensor = torch.Tensor
 
 
 def _project(z: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
-    """z @ weight^T (+ bias) for a tall z [N, d] and a weight with only a few output rows: the library's GEMMs
-    for 1..6 output columns run at ~100 GB/s (1.2 ms at N = 5 * 10^5, d = 64), so the weight is zero-padded to
-    16 output columns and the result sliced."""
-    k = weight.size(0)
-    if z.is_cuda and k < 16:
-        weight = F.pad(weight, (0, 0, 0, 16 - k))
-    out = (z @ weight.t())[:, :k]
+    """z @ weight^T (+ bias) for a tall z [N, d] and a weight with only a few output rows: the libraries' GEMMs for
+    1..6 output columns run at ~100 GB/s (1.2 ms at N = 5 * 10^5, d = 64); on the device the product goes through the
+    generic HIP GEMM (dense.matmul), which takes any shape."""
+    out = matmul(z, weight.t()) if z.is_cuda else z @ weight.t()
     return out if bias is None else out + bias
 
 

@@ -269,8 +269,8 @@ def test_c3_simpa_hop2_every_row_vs_float64(ssbm_c3, directed):
     names = [nm for nm, _ in layer.named_parameters()]
 
     def run(fn, dtype):
-        ins = [x.to(dtype).requires_grad_() for x in xs]
-        prm = {nm: p.detach().to(dtype).requires_grad_() for nm, p in layer.named_parameters()}
+        ins = [x.detach().clone().to(dtype).requires_grad_() for x in xs]
+        prm = {nm: p.detach().clone().to(dtype).requires_grad_() for nm, p in layer.named_parameters()}
         out = fn(pos, w_pos.to(dtype), neg, w_neg.to(dtype), ins[0], ins[1], prm, hop, fill, directed, *ins[2:])
         (out * go.to(dtype)).sum().backward()
         return [out.detach()] + [x.grad for x in ins] + [prm[nm].grad for nm in names]
@@ -301,8 +301,8 @@ def test_c3_dimpa_hop2_every_row_vs_float64():
             prm.copy_(torch.rand(prm.shape, generator=torch.Generator().manual_seed(60 + j)) + 0.5)
 
     def run(fn, dtype):
-        a, b = x_s.to(dtype).requires_grad_(), x_t.to(dtype).requires_grad_()
-        ws, wt = (p.detach().to(dtype).requires_grad_() for p in (layer._w_s, layer._w_t))
+        a, b = (t.detach().clone().to(dtype).requires_grad_() for t in (x_s, x_t))
+        ws, wt = (p.detach().clone().to(dtype).requires_grad_() for p in (layer._w_s, layer._w_t))
         out = fn(a, b, ei, w.to(dtype), ws, wt, hop, fill)
         (out * go.to(dtype)).sum().backward()
         return out.detach(), a.grad, b.grad, ws.grad, wt.grad
@@ -377,8 +377,8 @@ def test_c3_sgcn_every_row_and_parameter_gradients_vs_float64(ssbm_c3):
         sd = conv.state_dict()
 
         def run(fn, dtype):
-            a = x.to(dtype).requires_grad_()
-            prm = [sd[nm].detach().to(dtype).requires_grad_() for nm in names]
+            a = x.detach().clone().to(dtype).requires_grad_()
+            prm = [sd[nm].detach().clone().to(dtype).requires_grad_() for nm in names]
             out = fn(a, pos, neg, (prm[0], prm[1]), (prm[2], prm[3]), first, in_dim)
             (out * go.to(dtype)).sum().backward()
             return [out.detach(), a.grad] + [p.grad for p in prm]

@@ -1073,3 +1073,109 @@ def test_tall_linear_autograd_matches_float64():
     close(xd.grad, x64.grad, TOL, what="tall_linear dX")
     close(wd.grad, w64.grad, TOL, norm=True, what="tall_linear dW")
     close(bd.grad, b64.grad, TOL, norm=True, what="tall_linear db")
+
+
+# ------------------------------------------------------------------ weight gradients of the tall maps (csrc/gram.hip), generic GEMM
+GRAM_CASES = [
+    # dtype, rows, X segment widths, G segment widths, column slices of wider matrices
+    ("f32", 70001, (64,), (64, 64), False),            # C3 SGCNConv: x^T [g | g_a]
+    ("f32", 1000, (64,), (64, 128), True),             # fp32 inception block: x^T [dx0 | dP_1 | dP_2]
+    ("f32", 1, (16,), (16,), False),
+    ("f32", 37, (32, 16), (16, 128, 48), False),       # every chunk size on both sides, ragged tail
+    ("f32", 5000, (128,), (32,), True),
+    ("bf16", 70001, (64,), (64, 128), False),          # C5: bf16 inception block
+    ("bf16", 1, (16,), (16,), False),
+    ("bf16", 33, (32, 16), (16, 128, 48), True),       # a partial 32-row tile
+    ("bf16", 4099, (64, 64), (192,), False),
+    ("bf16", 1000, (16,), (32,), True),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,n,xw,gw,sliced", GRAM_CASES)
+def test_tall_gram_matches_float64(dtype, n, xw, gw, sliced):
+    """[X_0 | ...]^T [G_0 | ...] (dW = x^T dY of the tall linear maps; autograd's mm backward for DiGCNConv.py:66,
+    DiGCN_Inception_Block.py:44-46, SGCNConv.py:121-126) against float64 on the same (already rounded) inputs.  Every
+    column of either operand has its own scale and the operands differ, so a transposed, permuted or mis-chunked result
+    cannot pass.  Row reductions: the max-norm bar, float64 arbitrating against the plain fp32 product x^T g."""
+    from pytorch_geometric_signed_directed_amd import _cabi
+    from pytorch_geometric_signed_directed_amd.dense import tall_gram
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(n + sum(xw) * 7 + sum(gw))
+
+    def make(widths, lo, hi):
+        total = sum(widths)
+        scale = torch.linspace(lo, hi, total)
+        if sliced:
+            wide = (torch.randn(n, total + 16, generator=g) * torch.cat([scale, torch.ones(16)])).to(td).to(dev())
+            segs, at = [], 0
+            for wd in widths:
+                segs.append(wide[:, at:at + wd])
+                at += wd
+            return segs
+        full = (torch.randn(n, total, generator=g) * scale).to(td)
+        return [full[:, a:a + wd].contiguous().to(dev()) for a, wd in zip(np.cumsum((0,) + widths[:-1]), widths)]
+
+    xs, gs = make(xw, 0.5, 1.5), make(gw, 0.25, 2.0)
+    _cabi.reset_library_routes()
+    got = tall_gram(xs, gs)
+    assert _cabi.library_routes() == {}, _cabi.library_routes()
+    assert got.dtype == td and got.shape == (sum(xw), sum(gw))
+    x64 = torch.cat([t.double() for t in xs], dim=1)
+    g64 = torch.cat([t.double() for t in gs], dim=1)
+    want = x64.t() @ g64
+    ref32 = x64.float().t() @ g64.float()
+    if dtype == "f32":
+        close_arbitrated(got, ref32, want, norm=True, what="tall gram fp32")
+    else:
+        # fp32 accumulation of exact bf16 products, rounded to bf16 once: half an ulp of the result's scale
+        close(got.float(), want, 2.0 ** -8, norm=True, what="tall gram bf16 (one rounding of the fp32 sum)")
+    again = tall_gram(xs, gs)
+    assert torch.equal(again, got)                      # fixed summation order: run-to-run deterministic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k,ta,tb,bias,acc", [(1000, 10, 2879, False, False, True, False),     # C1: x W at the raw width
+                                                    (2879, 16, 3000, True, False, False, False),     # C1: dW = x^T g (split)
+                                                    (64, 10, 100000, True, False, False, False),      # a deep split reduction
+                                                    (300, 2879, 16, False, True, False, False),       # C1: dx = g W^T
+                                                    (5, 3, 7, False, False, True, True),
+                                                    (129, 65, 33, True, True, True, True),
+                                                    (70001, 5, 128, False, False, False, False)])     # a 5-class read-out
+def test_generic_gemm_matches_float64(m, n, k, ta, tb, bias, acc):
+    """pygsd_gemm_f32 (the catch-all behind the MFMA kernels) for odd shapes, transposed views, bias, accumulation and the
+    split reduction, against float64; float64 arbitrates against torch's own fp32 product."""
+    from pytorch_geometric_signed_directed_amd.dense import gemm
+    g = torch.Generator().manual_seed(m + 3 * n + 5 * k)
+    scale = torch.linspace(0.5, 1.5, k)                              # column scales: a transposed operand cannot pass
+    a = ((torch.randn(k, m, generator=g) * scale[:, None]).to(dev()).t() if ta
+         else (torch.randn(m, k, generator=g) * scale).to(dev()))
+    b = (torch.randn(n, k, generator=g).to(dev()).t() if tb else torch.randn(k, n, generator=g).to(dev()))
+    assert a.shape == (m, k) and b.shape == (k, n) and (a.stride(0) == 1) == (ta and m > 1) and (b.stride(1) != 1) == (tb and k > 1)
+    bv = torch.randn(n, generator=g).to(dev()) if bias else None
+    c0 = torch.randn(m, n, generator=g).to(dev()) if acc else None
+    got = gemm(a, b, bias=bv, out=None if c0 is None else c0.clone(), accumulate=acc)
+    want = a.double() @ b.double()
+    ref32 = a @ b
+    if bias:
+        want, ref32 = want + bv.double(), ref32 + bv
+    if acc:
+        want, ref32 = want + c0.double(), ref32 + c0
+    close_arbitrated(got, ref32, want, norm=k >= 2048, what=f"generic gemm {m}x{n}x{k}")
+    assert torch.equal(gemm(a, b, bias=bv, out=None if c0 is None else c0.clone(), accumulate=acc), got)
+
+
+@pytest.mark.gpu
+def test_hip_matmul_is_differentiable():
+    from pytorch_geometric_signed_directed_amd.dense import matmul
+    g = torch.Generator().manual_seed(77)
+    a0, b0, go = torch.randn(5000, 7, generator=g), torch.randn(7, 5, generator=g), torch.randn(5000, 5, generator=g)
+    a, b = a0.to(dev()).requires_grad_(), b0.to(dev()).requires_grad_()
+    (matmul(a, b) * go.to(dev())).sum().backward()
+    a64, b64 = a0.double().requires_grad_(), b0.double().requires_grad_()
+    ((a64 @ b64) * go.double()).sum().backward()
+    close(a.grad, a64.grad, what="d a")
+    close(b.grad, b64.grad, norm=True, what="d b (a reduction over the rows)")
+    pt = a0.to(dev()).t().requires_grad_()                          # a transposed view as the left operand: P^T (A P)
+    (matmul(pt, go.to(dev())) * b0.to(dev())).sum().backward()
+    close(pt.grad, (go.double() @ b0.double().t()).t(), what="d (transposed view)")

@@ -1124,3 +1124,68 @@ def test_batched_inputs_match_a_loop_over_the_batch():
     close(batched[3], torch.stack([t.grad for t in ai]), what="MagNetConv batched dx_imag")
     close(batched[0], conv.weight.grad, norm=True, what="MagNetConv batched dW")
     close(batched[1], conv.bias.grad, norm=True, what="MagNetConv batched db")
+
+
+def test_baseline_configs_take_no_library_route():
+    """'Hand-written HIP on the hot path' as an invariant: one training step of every BASELINE configuration at its
+    stated WIDTHS, dtypes and layer arguments (graphs of 6000 nodes -- a route depends on shapes and dtypes, not on N, and
+    the tall-reduction routes only count from 4096 rows) takes ZERO library-routed dense products or reductions with the
+    default switches (_cabi.library_routes: hipBLASLt / rocBLAS GEMMs, torch reductions behind the dense stages)."""
+    import warnings
+    from pytorch_geometric_signed_directed_amd import _cabi, graphs
+    from pytorch_geometric_signed_directed_amd.nn import (DiGCN_InceptionBlock, MagNet_node_classification, MagNetConv,
+                                                          MSConv, SGCNConv, SIMPA, SSSNET_node_clustering)
+    n = 6000
+    g = torch.Generator().manual_seed(3)
+    ei = torch.from_numpy(graphs.dsbm_for_edges(n, 20 * n, seed=1)[0]).to(D)
+    sign = (torch.rand(ei.size(1), generator=g) < 0.7).float().mul(2).sub(1).to(D)
+    pos, neg = ei[:, sign > 0].contiguous(), ei[:, sign < 0].contiguous()
+    ones_p, ones_n = torch.ones(pos.size(1), device=D), torch.ones(neg.size(1), device=D)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).to(D)  # noqa: E731
+
+    def magnetic(cls, h, k, w=None):
+        layer = cls(h, h, k, 0.25, False).to(D)
+        xr, xi = rnd(n, h).requires_grad_(), rnd(n, h).requires_grad_()
+        o_r, o_i = layer(xr, xi, ei, w)
+        ((o_r * rnd(n, h)).sum() + (o_i * rnd(n, h)).sum()).backward()
+
+    def c1():
+        model = MagNet_node_classification(q=0.25, K=1, num_features=2879, hidden=16, label_dim=10).to(D)
+        out = model(rnd(n, 2879), rnd(n, 2879), ei)
+        torch.nn.functional.nll_loss(out, torch.randint(0, 10, (n,), generator=g).to(D)).backward()
+
+    def c3_sgcn():
+        for first in (True, False):
+            conv = SGCNConv(64 if first else 32, 32, first_aggr=first).to(D)
+            x = rnd(n, 64).requires_grad_()
+            (conv(x, pos, neg) * rnd(n, 64)).sum().backward()
+
+    def c3_sssnet():
+        model = SSSNET_node_clustering(64, 64, 5, 0.5, 2, 0.5).to(D)
+        z, logp, _, prob = model(pos, ones_p, neg, ones_n, rnd(n, 64).requires_grad_())
+        ((z * rnd(n, 128)).sum() + (logp * rnd(n, 5)).sum() + (prob * rnd(n, 5)).sum()).backward()
+        simpa = SIMPA(2, 0.5, True).to(D)
+        xs = [rnd(n, 64).requires_grad_() for _ in range(4)]
+        (simpa(pos, ones_p, neg, ones_n, *xs) * rnd(n, 256)).sum().backward()
+
+    def c5(dtype):
+        loops = torch.arange(n, device=D)
+        e2 = torch.stack([torch.cat([ei[0], ei[1], loops]), torch.cat([ei[1], ei[0], loops])])
+        w2 = torch.rand(e2.size(1), generator=g).to(D) * 0.1
+        ib = DiGCN_InceptionBlock(64, 64).to(D).to(dtype)
+        x = rnd(n, 64).to(dtype).requires_grad_()
+        outs = ib(x, e2, w2, e2, w2)
+        sum((o.float() * rnd(n, 64)).sum() for o in outs).backward()
+
+    steps = [("C1 MagNet_node_classification 2879 -> 16 -> 10", c1),
+             ("C2 / north star MagNetConv h = 64, K = 1", lambda: magnetic(MagNetConv, 64, 1)),
+             ("C3 SGCNConv first + deep", c3_sgcn), ("C3 SSSNET model + directed SIMPA", c3_sssnet),
+             ("C4 MSConv h = 128, K = 2, signed", lambda: magnetic(MSConv, 128, 2, sign)),
+             ("C5 inception block fp32", lambda: c5(torch.float32)), ("C5 inception block bf16", lambda: c5(torch.bfloat16))]
+    for name, step in steps:
+        _cabi.reset_library_routes()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            step()
+        torch.cuda.synchronize()
+        assert _cabi.library_routes() == {}, (name, _cabi.library_routes())

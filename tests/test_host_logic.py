@@ -183,3 +183,19 @@ def test_tall_product_and_column_sums_library_route_on_cpu():
     assert torch.equal(column_sums(a), a.sum(0))
     x, y, z = column_sums_of([a, None, a])
     assert y is None and x is z
+
+
+def test_library_routes_are_counted_and_announced_once():
+    """_cabi.note_library_route: every library-routed dense product is counted; the warning fires once per (site, shape)."""
+    import warnings
+    from pytorch_geometric_signed_directed_amd import _cabi
+    _cabi.reset_library_routes()
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        _cabi.note_library_route("unit-test site", "(3, 5) float32")
+        _cabi.note_library_route("unit-test site", "(3, 5) float32")
+        _cabi.note_library_route("unit-test site", "(4, 5) float32")
+    assert _cabi.library_routes() == {"unit-test site": 3}
+    assert len([w for w in seen if "unit-test site" in str(w.message)]) == 2
+    _cabi.reset_library_routes()
+    assert _cabi.library_routes() == {}

@@ -15,6 +15,15 @@ from pytorch_geometric_signed_directed_amd.nn import (Conv_Base, DiGCN_Inception
 
 dev = torch.device("cuda:0")
 out = {}
+# e.g. PYGSD_CONFIGS=C3,C5 -- or one step alone for a profile whose kernel averages belong to ONE configuration:
+# C3a (SGCNConv), C3b (SIMPA), C5a (inception block fp32), C5b (bf16)
+ONLY = [t for t in os.environ.get("PYGSD_CONFIGS", "").split(",") if t]
+
+
+def want(tag):
+    return not ONLY or tag in ONLY or tag[:2] in ONLY
+
+
 
 
 def timed(step, iters=10, warm=3):
@@ -28,7 +37,7 @@ def timed(step, iters=10, warm=3):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
     _cabi.prof_enable(False)
-    prof = {k: _cabi.prof_collect(k) for k in ("spmm", "spmm2", "dense", "dense_bwd", "build")}
+    prof = {k: _cabi.prof_collect(k) for k in ("spmm", "spmm2", "dense", "dense_bwd", "build", "elementwise")}
     _cabi.prof_reset()
     return ms, {k: {"launches_per_step": n / iters, "ms_per_launch": (t / n if n else 0.0)} for k, (n, t) in prof.items()}
 
@@ -111,15 +120,22 @@ def signed_c3(n=500000, entries=10000000, h=64):
     def step():
         conv.zero_grad(set_to_none=True); x.grad = None
         conv(x, pos, neg).sum().backward()
-    ms, prof = timed(step)
+    if not want("C3a"):
+        ms, prof = None, None
+    else:
+        ms, prof = timed(step)
     # the layer applies its Linear blocks BEFORE the aggregation, so the value-less mean SpMMs run at width h / 2
-    b = spmm_bytes(pos.size(1), n, h // 2, val=False) + spmm_bytes(neg.size(1), n, h // 2, val=False)
-    k = prof["spmm"]
-    out["C3_sgcnconv_first"] = {"nodes": n, "pos_entries": int(pos.size(1)), "neg_entries": int(neg.size(1)),
-                                "hidden": h, "ms_per_step": ms, "entries_per_s": ei.size(1) / ms * 1e3, "kernels": prof,
-                                "spmm_alg_GBps_fwd_pair": b / (2 * k["ms_per_launch"]) / 1e6 if k["ms_per_launch"] else None}
-    out["C3_sgcnconv_first"].update(residency(n * (h // 2) * 4, out["C3_sgcnconv_first"]["spmm_alg_GBps_fwd_pair"]))
-    print("C3_sgcnconv_first", json.dumps(out["C3_sgcnconv_first"]), flush=True)
+    if prof is not None:
+        b = spmm_bytes(pos.size(1), n, h // 2, val=False) + spmm_bytes(neg.size(1), n, h // 2, val=False)
+        k = prof["spmm"]
+        out["C3_sgcnconv_first"] = {"nodes": n, "pos_entries": int(pos.size(1)), "neg_entries": int(neg.size(1)),
+                                    "hidden": h, "ms_per_step": ms, "entries_per_s": ei.size(1) / ms * 1e3, "kernels": prof,
+                                    "spmm_alg_GBps_fwd_pair": b / (2 * k["ms_per_launch"]) / 1e6 if k["ms_per_launch"] else None}
+        out["C3_sgcnconv_first"].update(residency(n * (h // 2) * 4, out["C3_sgcnconv_first"]["spmm_alg_GBps_fwd_pair"]))
+        print("C3_sgcnconv_first", json.dumps(out["C3_sgcnconv_first"]), flush=True)
+    if not want("C3b"):
+        torch.cuda.empty_cache()
+        return
     simpa = SIMPA(2, 0.5).to(dev)
     wp = torch.ones(pos.size(1), device=dev)
     wn = torch.ones(neg.size(1), device=dev)
@@ -142,6 +158,8 @@ def digcn_c5(n=2000000, e=25000000, h=64):
     loops = torch.arange(n, device=dev)
     res = {}
     for dtype in (torch.float32, torch.bfloat16):
+        if not want("C5a" if dtype == torch.float32 else "C5b"):
+            continue
         ops = []
         for k in range(2):           # two symmetric, positively weighted, sym-normalised operators
             g = torch.Generator(device="cuda").manual_seed(10 + k)
@@ -157,16 +175,28 @@ def digcn_c5(n=2000000, e=25000000, h=64):
         torch.manual_seed(0)
         ib = DiGCN_InceptionBlock(h, h).to(dev).to(dtype)
 
+        # the loss is NOT part of the block: three pre-built upstream gradients (one row broadcast over the nodes each, as a
+        # sum-type loss would hand them over) go straight into autograd -- the round-3 figure included 0.58 ms of
+        # (x0 + x1 + x2).float().sum() and its materialised gradient, reported separately below
+        grow = [torch.ones(1, h, device=dev, dtype=dtype).expand(n, h) for _ in range(3)]
+
         def step():
+            ib.zero_grad(set_to_none=True); x.grad = None
+            outs = ib(x, ops[0][0], ops[0][1], ops[1][0], ops[1][1])
+            torch.autograd.backward(outs, grow)
+
+        def step_with_loss():
             ib.zero_grad(set_to_none=True); x.grad = None
             x0, x1, x2 = ib(x, ops[0][0], ops[0][1], ops[1][0], ops[1][1])
             (x0 + x1 + x2).float().sum().backward()
+        ms_loss, _ = timed(step_with_loss, iters=5, warm=2)
         ms, prof = timed(step, iters=5, warm=2)
         nnz = ops[0][0].size(1)
         s_el = 2 if dtype == torch.bfloat16 else 4
         b = spmm_bytes(nnz, n, h, s=s_el)
         k = prof["spmm"]
-        res[str(dtype).split(".")[-1]] = {"ms_per_block_step": ms, "nnz_per_operator": nnz, "kernels": prof,
+        res[str(dtype).split(".")[-1]] = {"ms_per_block_step": ms, "ms_per_block_step_incl_sum_loss": ms_loss,
+                                          "nnz_per_operator": nnz, "kernels": prof,
                                           "spmm_alg_GBps": b / k["ms_per_launch"] / 1e6 if k["ms_per_launch"] else None,
                                           "nnz_per_s": 2 * nnz / ms * 1e3}
         res[str(dtype).split(".")[-1]].update(residency(n * h * s_el, res[str(dtype).split(".")[-1]]["spmm_alg_GBps"]))
@@ -176,22 +206,15 @@ def digcn_c5(n=2000000, e=25000000, h=64):
     print("C5", json.dumps(out["C5_digcn_inception_block_1gpu"]), flush=True)
 
 
-ONLY = [t for t in os.environ.get("PYGSD_CONFIGS", "").split(",") if t]      # e.g. PYGSD_CONFIGS=C3,C5
-
-
-def want(tag):
-    return not ONLY or tag in ONLY
-
-
 if want("C2"):
     magnetic("C2_magnetconv_100k_2M_h64", MagNetConv, 100000, 2000000, 64, 1, False)
-if want("C3"):
+if want("C3") or want("C3a") or want("C3b"):
     signed_c3()
 if want("C4"):
     magnetic("C4_msconv_1M_20M_h128_K2_1gpu", MSConv, 1000000, 20000000, 128, 2, True)
 if want("northstar"):
     magnetic("northstar_magnetconv_1M_20M_h64", MagNetConv, 1000000, 20000000, 64, 1, False)
-if want("C5"):
+if want("C5") or want("C5a") or want("C5b"):
     digcn_c5()
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/configs.json" if not ONLY else "gpurun_out/configs_partial.json", "w"), indent=1)

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Run ON THE GPU BOX from the repo root: round 4, second capture -- GPU tests, then ONE rocprofv3 kernel-stats run and two PMC
+# passes (FETCH_SIZE, WRITE_SIZE; counters only) per configuration step, each step alone in its process so that a kernel's
+# average belongs to one configuration: C3a SGCNConv, C3b SIMPA, C5a inception block fp32, C5b bf16 (tools/bench_configs.py).
+set -u
+O=gpurun_out
+T=${TAG:-r4b}
+mkdir -p $O
+export TMPDIR=/tmp
+rm -f $O/parity_errors_*.json
+( timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 > $O/${T}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/${T}_pytest_gpu.log )
+tail -5 $O/${T}_pytest_gpu.log
+C="python tools/bench_configs.py"
+for cfg in C3a C3b C5a C5b; do
+  export PYGSD_CONFIGS=$cfg
+  rm -rf $O/${T}_prof_$cfg $O/${T}_pmc_${cfg}_*
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof_$cfg -o k -- $C > $O/${T}_prof_$cfg.log 2>&1
+  cp $O/configs_partial.json $O/${T}_configs_$cfg.json
+  rm -f $O/${T}_prof_$cfg/k_kernel_trace.csv
+  for grp in "FETCH_SIZE" "WRITE_SIZE" ${EXTRA_PMC:-}; do
+    timeout 300 rocprofv3 --pmc $grp --output-format csv -d $O/${T}_pmc_${cfg}_$grp -o k -- $C > $O/${T}_pmc_${cfg}_$grp.log 2>&1
+  done
+done
+for cfg in ${SQ_CONFIGS:-C3a C5b}; do
+  export PYGSD_CONFIGS=$cfg
+  for grp in "SQ_INSTS_VALU SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_WAVES" "TCC_HIT_sum TCC_MISS_sum"; do
+    tag=$(echo $grp | tr ' ' '_')
+    rm -rf $O/${T}_pmc_${cfg}_$tag
+    timeout 300 rocprofv3 --pmc $grp --output-format csv -d $O/${T}_pmc_${cfg}_$tag -o k -- $C > $O/${T}_pmc_${cfg}_$tag.log 2>&1
+  done
+done
+unset PYGSD_CONFIGS
+ls $O | grep ${T}_ | head -60
