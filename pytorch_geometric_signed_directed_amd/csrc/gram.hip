@@ -55,7 +55,7 @@ __device__ __forceinline__ void wave_sync()
 // ---- fp32 ---------------------------------------------------------------------------------------
 // rows of one 16-row tile -> the wavefront's image: NT float4 loads per lane, a row's 16 NT floats on 4 NT adjacent lanes
 template <int NT>
-__device__ __forceinline__ void stage_rows_f32(const GramChunk& c, int64_t r0, int64_t n_rows, int lane, float* img, int rs)
+__device__ __forceinline__ void load_rows_f32(const GramChunk& c, int64_t r0, int64_t n_rows, int lane, float4 (&v)[NT])
 {
     constexpr int LPR = NT * 4;            // 16-byte pieces (lanes) per row
     const float* base = static_cast<const float*>(c.p);
@@ -63,9 +63,19 @@ __device__ __forceinline__ void stage_rows_f32(const GramChunk& c, int64_t r0, i
     for (int t = 0; t < NT; ++t) {
         const int piece = t * 64 + lane;                      // piece-major over the 16 x LPR pieces of the tile
         const int row = piece / LPR, col = (piece % LPR) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + row < n_rows) v = *reinterpret_cast<const float4*>(base + (r0 + row) * c.ld + col);
-        *reinterpret_cast<float4*>(img + row * rs + col) = v;
+        v[t] = make_float4(0.f, 0.f, 0.f, 0.f);               // rows past the end contribute nothing
+        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const float4*>(base + (r0 + row) * c.ld + col);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void store_rows_f32(const float4 (&v)[NT], int lane, float* img, int rs)
+{
+    constexpr int LPR = NT * 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int piece = t * 64 + lane;
+        *reinterpret_cast<float4*>(img + (piece / LPR) * rs + (piece % LPR) * 4) = v[t];
     }
 }
 
@@ -82,9 +92,21 @@ __device__ __forceinline__ void gram_block_f32(const GramArgs& p, const GramChun
 #pragma unroll
         for (int b = 0; b < NTF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t n_tiles = (p.n_rows + 15) >> 4;
-    for (int64_t tile = static_cast<int64_t>(blockIdx.y) * 4 + wave; tile < n_tiles; tile += static_cast<int64_t>(gridDim.y) * 4) {
-        stage_rows_f32<NTK>(cx, tile << 4, p.n_rows, lane, imx, rsx);
-        stage_rows_f32<NTF>(cg, tile << 4, p.n_rows, lane, img, rsg);
+    const int64_t stride = static_cast<int64_t>(gridDim.y) * 4;
+    int64_t tile = static_cast<int64_t>(blockIdx.y) * 4 + wave;
+    // the NEXT tile's rows are in flight (in registers) while the current tile is multiplied out of the LDS image
+    float4 rx[NTK], rg[NTF];
+    if (tile < n_tiles) {
+        load_rows_f32<NTK>(cx, tile << 4, p.n_rows, lane, rx);
+        load_rows_f32<NTF>(cg, tile << 4, p.n_rows, lane, rg);
+    }
+    for (; tile < n_tiles; tile += stride) {
+        store_rows_f32<NTK>(rx, lane, imx, rsx);
+        store_rows_f32<NTF>(rg, lane, img, rsg);
+        if (tile + stride < n_tiles) {
+            load_rows_f32<NTK>(cx, (tile + stride) << 4, p.n_rows, lane, rx);
+            load_rows_f32<NTF>(cg, (tile + stride) << 4, p.n_rows, lane, rg);
+        }
         wave_sync();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -147,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void tall_gram_f32_kernel(GramArgs p)
 // ---- bf16 storage, fp32 accumulation ------------------------------------------------------------
 // rows of one 32-row tile -> image [tile][32 rows][16 cols]: NT 16-byte loads per lane, a row's 16 NT columns on 2 NT lanes
 template <int NT>
-__device__ __forceinline__ void stage_rows_bf16(const GramChunk& c, int64_t r0, int64_t n_rows, int lane, unsigned char* img)
+__device__ __forceinline__ void load_rows_bf16(const GramChunk& c, int64_t r0, int64_t n_rows, int lane, uint4 (&v)[NT])
 {
     constexpr int LPR = NT * 2;            // 16-byte pieces (lanes) per row
     const uint16_t* base = static_cast<const uint16_t*>(c.p);
@@ -155,25 +177,46 @@ __device__ __forceinline__ void stage_rows_bf16(const GramChunk& c, int64_t r0, 
     for (int t = 0; t < NT; ++t) {
         const int piece = t * 64 + lane;                      // piece-major over the 32 x LPR pieces of the tile
         const int row = piece / LPR, c8 = piece % LPR;        // 8-column piece c8 of the row
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (r0 + row < n_rows) v = *reinterpret_cast<const uint4*>(base + (r0 + row) * c.ld + c8 * 8);
-        *reinterpret_cast<uint4*>(img + (c8 >> 1) * 1024 + row * 32 + (c8 & 1) * 16) = v;
+        v[t] = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const uint4*>(base + (r0 + row) * c.ld + c8 * 8);
     }
 }
 
-// column i (= lane & 15) of rows {4 q + j} and {16 + 4 q + j}, j < 4, of one [32][16] block: the 8 k-slots of lane (i, q)
-__device__ __forceinline__ bf16x8 column_fragment(uint32_t block_addr, int lane)
+template <int NT>
+__device__ __forceinline__ void store_rows_bf16(const uint4 (&v)[NT], int lane, unsigned char* img)
+{
+    constexpr int LPR = NT * 2;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int piece = t * 64 + lane;
+        const int row = piece / LPR, c8 = piece % LPR;
+        *reinterpret_cast<uint4*>(img + (c8 >> 1) * 1024 + row * 32 + (c8 & 1) * 16) = v[t];
+    }
+}
+
+// column i (= lane & 15) of rows {4 q + j} and {16 + 4 q + j}, j < 4, of N consecutive [32][16] blocks: the 8 k-slots of lane
+// (i, q) for each.  All 2 N transpose reads are issued back to back; ONE s_waitcnt covers them (the empty asm statements tie
+// every result register to that wait, so that no use can be scheduled in front of it).
+template <int N>
+__device__ __forceinline__ void column_fragments(uint32_t first_block_addr, int lane, bf16x8 (&out)[N])
 {
     const int t = lane & 15, q = lane >> 4;
-    const uint32_t a = block_addr + static_cast<uint32_t>((4 * q + (t >> 2)) * 32 + (t & 3) * 8);
-    uint64_t lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(lo), "=&v"(hi)
-                 : "v"(a)
-                 : "memory");
-    const uint4 u = make_uint4(static_cast<uint32_t>(lo), static_cast<uint32_t>(lo >> 32), static_cast<uint32_t>(hi),
-                               static_cast<uint32_t>(hi >> 32));
-    return __builtin_bit_cast(bf16x8, u);
+    const uint32_t a = first_block_addr + static_cast<uint32_t>((4 * q + (t >> 2)) * 32 + (t & 3) * 8);
+    uint64_t lo[N], hi[N];
+#pragma unroll
+    for (int b = 0; b < N; ++b)
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512"
+                     : "=&v"(lo[b]), "=&v"(hi[b])
+                     : "v"(a + static_cast<uint32_t>(b) * 1024u)
+                     : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+        asm volatile("" : "+v"(lo[b]), "+v"(hi[b]));
+        const uint4 u = make_uint4(static_cast<uint32_t>(lo[b]), static_cast<uint32_t>(lo[b] >> 32), static_cast<uint32_t>(hi[b]),
+                                   static_cast<uint32_t>(hi[b] >> 32));
+        out[b] = __builtin_bit_cast(bf16x8, u);
+    }
 }
 
 template <int NTK, int NTF>
@@ -190,20 +233,34 @@ __device__ __forceinline__ void gram_block_bf16(const GramArgs& p, const GramChu
 #pragma unroll
         for (int b = 0; b < NTF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t n_tiles = (p.n_rows + 31) >> 5;
-    for (int64_t tile = static_cast<int64_t>(blockIdx.y) * 4 + wave; tile < n_tiles; tile += static_cast<int64_t>(gridDim.y) * 4) {
-        stage_rows_bf16<NTK>(cx, tile << 5, p.n_rows, lane, imx);
-        stage_rows_bf16<NTF>(cg, tile << 5, p.n_rows, lane, img);
+    const int64_t stride = static_cast<int64_t>(gridDim.y) * 4;
+    int64_t tile = static_cast<int64_t>(blockIdx.y) * 4 + wave;
+    uint4 rx[NTK], rg[NTF];                       // the next tile's rows, in flight while the current one is multiplied
+    if (tile < n_tiles) {
+        load_rows_bf16<NTK>(cx, tile << 5, p.n_rows, lane, rx);
+        load_rows_bf16<NTF>(cg, tile << 5, p.n_rows, lane, rg);
+    }
+    for (; tile < n_tiles; tile += stride) {
+        store_rows_bf16<NTK>(rx, lane, imx);
+        store_rows_bf16<NTF>(rg, lane, img);
+        if (tile + stride < n_tiles) {
+            load_rows_bf16<NTK>(cx, (tile + stride) << 5, p.n_rows, lane, rx);
+            load_rows_bf16<NTF>(cg, (tile + stride) << 5, p.n_rows, lane, rg);
+        }
         wave_sync();
-        bf16x8 xa[NTK], gb[NTF];
+        bf16x8 xa[NTK];
+        column_fragments<NTK>(ax, lane, xa);
+        constexpr int GB = NTF < 4 ? NTF : 4;          // G fragments live at a time (registers: the accumulators take 16 NTK NTF)
 #pragma unroll
-        for (int a = 0; a < NTK; ++a) xa[a] = column_fragment(ax + a * 1024, lane);
+        for (int b0 = 0; b0 < NTF; b0 += GB) {
+            bf16x8 gb[GB];
+            column_fragments<GB>(ag + b0 * 1024, lane, gb);
 #pragma unroll
-        for (int b = 0; b < NTF; ++b) gb[b] = column_fragment(ag + b * 1024, lane);
+            for (int a = 0; a < NTK; ++a)
 #pragma unroll
-        for (int a = 0; a < NTK; ++a)
-#pragma unroll
-            for (int b = 0; b < NTF; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[a], gb[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < GB; ++b)
+                    acc[a][b0 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[a], gb[b], acc[a][b0 + b], 0, 0, 0);
+        }
         wave_sync();
     }
     __syncthreads();

@@ -295,14 +295,97 @@ __global__ __launch_bounds__(256) void spmm_long_finish_kernel(SpmmArgs p, const
 // Low-degree rows at narrow widths.  One wavefront per row wastes the machine when a row has fewer entries than
 // one wave-wide load fetches (NPW = 64 / LPR neighbours: 16 at F = 16, 8 at F = 32, 4 at F = 64): the signed SBM
 // parts (5-15 entries per row, SGCNConv / SIMPA) and the column blocks of the sharded grid product (10-20 entries
-// per row and phase at 16 + 16 packed floats).  Here every LPR-lane group owns its OWN row -- NPW rows per
-// wavefront -- and walks that row's entries in CSR order with UN gathers in flight; no cross-lane hand-off, no
-// butterfly: a group's accumulator IS the row's result, summed in the row's CSR (= the reference's scatter) order.
-// The loop runs to the longest row of the wavefront; lanes of finished rows idle.  The host picks this variant
-// from entries per row (launch_spmm).
+// per row and phase at 16 + 16 packed floats).  Here every LPR-lane group owns its OWN row -- NPW consecutive rows per
+// wavefront -- and a group's accumulator IS the row's result, summed in the row's CSR (= the reference's scatter) order:
+// no butterfly.
+//
+// Round 4: the rows of a wavefront are consecutive, so their entries are ONE contiguous range of the CSR: the
+// wavefront reads it 64 entries at a time with one coalesced load per stream (as the row kernel does) and hands entry
+// (pos_g + k) to group g through the LDS crossbar.  The first version had every group read its own col / val with
+// 4-byte loads inside its loop: a dependent chain rowptr -> col -> gather -> col -> gather (5 memory latencies for a
+// 6-entry row; SQ_WAVE_CYCLES showed wavefronts resident for ~9 us each and the kernel at 5.4 TB/s of a cache-resident
+// set, profiles/r4a counters) where this one has rowptr -> entries -> all gathers.  Rows the long-row path takes are holes in the
+// range and are jumped over.  The host picks this variant from entries per row (launch_spmm).
 // ------------------------------------------------------------------------------------------
 template <int LPR, bool DUAL>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_packed_kernel(SpmmArgs p)
+{
+    constexpr int NPW = 64 / LPR;
+    constexpr int UN = 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int fl = (lane % LPR) * 4;
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t row0 = wave * NPW;
+    if (row0 >= p.n_rows) return;                                   // wave-uniform
+    const int64_t row = row0 + sub;
+    const bool fact = fl < p.n_feat;
+    const bool mine_row = row < p.n_rows;
+    const int beg = p.rowptr[mine_row ? row : p.n_rows];
+    const int end = mine_row ? p.rowptr[row + 1] : beg;
+    const bool mine = mine_row && !(p.skip_longer_than > 0 && end - beg > p.skip_longer_than);   // hub row: spmm_long_kernel
+    const int wave_end = __shfl(end, 63);                            // end of the wavefront's last row
+    const int deg = end - beg;
+    int pos = mine ? beg : 0;                                        // next entry of this group's row
+    const int stop = mine ? end : 0;
+    float4 acc_a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xa = p.xa + fl;
+    const float* xb = DUAL ? p.xb + fl : nullptr;
+    while (true) {
+        const unsigned long long work = __ballot(pos < stop);
+        if (work == 0) break;
+        // rows are consecutive: the first group with entries left holds the lowest one
+        const int base = __shfl(pos, __ffsll(static_cast<long long>(work)) - 1);
+        int c = 0;
+        float wa = 0.f, wb = 0.f;
+        if (base + lane < wave_end) {
+            c = __builtin_nontemporal_load(p.col + base + lane);
+            wa = p.va ? __builtin_nontemporal_load(p.va + base + lane) : 1.f;
+            if (DUAL) wb = __builtin_nontemporal_load(p.vb + base + lane);
+        }
+        const int hi = stop < base + 64 ? stop : base + 64;          // this group's entries inside the chunk: [pos, hi)
+        for (int e = pos; __any(e < hi); e += UN) {
+            float4 ga[UN], gb[UN];
+            float sa[UN], sb[UN];
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                const int idx = e + k - base;
+                const bool ok = fact && e + k < hi;
+                const int cj = __shfl(c, idx & 63);
+                const float ta = __shfl(wa, idx & 63);
+                sa[k] = ok ? ta : 0.f;
+                ga[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (DUAL) {
+                    const float tb = __shfl(wb, idx & 63);
+                    sb[k] = ok ? tb : 0.f;
+                    gb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (ok) {
+                    const int64_t off = static_cast<int64_t>(cj) * p.ldx;
+                    ga[k] = ld4(xa + off);
+                    if (DUAL) gb[k] = ld4(xb + off);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                fma4(acc_a, sa[k], ga[k]);
+                if (DUAL) fma4(acc_b, sb[k], gb[k]);
+            }
+        }
+        if (pos < hi) pos = hi;
+    }
+    if (mine && fact) {
+        const int64_t yo = row * p.ldy + fl;
+        const int64_t zo = row * p.ldz + fl;
+        st4(p.ya + yo, finish(acc_a, p.alpha, p.beta, p.mean != 0, deg, p.za ? p.za + zo : nullptr));
+        if (DUAL) st4(p.yb + yo, finish(acc_b, p.alpha, p.beta, false, deg, p.zb ? p.zb + zo : nullptr));
+    }
+}
+
+// The first version (kept for A/B probes, PYGSD_SPMM_PACKED_V1=1): every group loads its own row's col / val inside its loop.
+template <int LPR, bool DUAL>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_packed_v1_kernel(SpmmArgs p)
 {
     constexpr int NPW = 64 / LPR;
     constexpr int UN = 4;
@@ -427,16 +510,18 @@ int64_t long_workspace_bytes(int32_t n_long, int32_t max_entries, int32_t n_feat
 }
 
 // Entries per row below which the rows-per-wavefront variant is used.  Measured (tools/packed_probe.py ->
-// profiles/r2_packed_probe.json; 20 M entries, Poisson row lengths, 1 M source rows; speed-up of the packed variant):
-//   single, F = 16 / 32: x2.8 / x2.0 at 4 entries per row, x1.7 / x1.6 at 6, x1.3 at 8, x0.85 at 12
-//   single, F = 64     : x1.24 at 4, x1.05 at 6, x0.92 at 8
-//   dual,   F = 16 / 32: x1.9 / x1.6 at 4, x1.2 / x1.07 at 6, x0.88 at 8;   dual, F = 64: x1.05 at 4, x0.90 at 6
-// (beyond the crossover one wavefront per row wins by up to 2.5x: it keeps 4-16 gathers in flight per lane where a
-// lane group walking its own row has 4).
+// profiles/r4_packed_probe.json; 20 M entries, Poisson row lengths, 1 M source rows; speed-up of the packed variant over one
+// wavefront per row, round 4's kernel -- round 3's in brackets):
+//   single, F = 16 / 32: x3.2 / x2.7 at 4 entries per row (2.8 / 2.0), x1.66 / x1.54 at 8 (1.3), x1.19 / x1.17 at 12 (0.85),
+//                        x1.00 / x1.02 at 16, x0.98 / x0.97 at 24, x0.72 / x0.77 at 48
+//   single, F = 64     : x1.74 at 4 (1.24), x1.37 at 6, x1.11 at 8 (0.92), x0.97 at 12
+//   dual,   F = 16 / 32: x2.2 / x1.9 at 4, x1.17 / x1.08 at 8 (0.88), x0.98 at 12;   dual, F = 64: x1.19 at 4, x1.03 at 6, x0.97 at 8
+// (with the coalesced entry chunks the variant no longer collapses on longer rows -- it ties with one wavefront per row up to
+// ~32 entries -- but it does not win there either: a row's accumulation is sequential inside its lane group.)
 inline int64_t packed_threshold(int lpr, bool dual)
 {
-    if (dual) return lpr <= 8 ? 7 : lpr == 16 ? 5 : 0;
-    return lpr <= 8 ? 10 : lpr == 16 ? 7 : 4;
+    if (dual) return lpr <= 8 ? 10 : lpr == 16 ? 7 : 0;
+    return lpr <= 8 ? 20 : lpr == 16 ? 10 : 4;
 }
 
 template <bool DUAL>
@@ -475,14 +560,23 @@ int launch_spmm(SpmmArgs a, int64_t nnz_hint, const pygsd_long_rows* hubs, hipSt
     bool packed = false;
     if (lpr <= 32) {
         const char* force = getenv("PYGSD_SPMM_PACKED");
+        const char* upto = getenv("PYGSD_SPMM_PACKED_BELOW");       // probes: entries per row below which rows are packed
+        const int64_t thr = upto ? atoll(upto) : packed_threshold(lpr, DUAL);
         if (force) packed = force[0] == '1';
-        else packed = nnz_hint > 0 && nnz_hint < packed_threshold(lpr, DUAL) * static_cast<int64_t>(a.n_rows);
+        else packed = nnz_hint > 0 && nnz_hint < thr * static_cast<int64_t>(a.n_rows);
     }
     if (packed) {
         const int npw = 64 / lpr;
         const int64_t waves = (static_cast<int64_t>(a.n_rows) + npw - 1) / npw;
         const dim3 pg(static_cast<unsigned>((waves + kWavesPerBlock - 1) / kWavesPerBlock));
-        if (lpr == 4) hipLaunchKernelGGL((spmm_packed_kernel<4, DUAL>), pg, block, 0, stream, a);
+        const char* v1env = getenv("PYGSD_SPMM_PACKED_V1");
+        const bool v1 = v1env && v1env[0] == '1';
+        if (v1) {
+            if (lpr == 4) hipLaunchKernelGGL((spmm_packed_v1_kernel<4, DUAL>), pg, block, 0, stream, a);
+            else if (lpr == 8) hipLaunchKernelGGL((spmm_packed_v1_kernel<8, DUAL>), pg, block, 0, stream, a);
+            else if (lpr == 16) hipLaunchKernelGGL((spmm_packed_v1_kernel<16, DUAL>), pg, block, 0, stream, a);
+            else hipLaunchKernelGGL((spmm_packed_v1_kernel<32, DUAL>), pg, block, 0, stream, a);
+        } else if (lpr == 4) hipLaunchKernelGGL((spmm_packed_kernel<4, DUAL>), pg, block, 0, stream, a);
         else if (lpr == 8) hipLaunchKernelGGL((spmm_packed_kernel<8, DUAL>), pg, block, 0, stream, a);
         else if (lpr == 16) hipLaunchKernelGGL((spmm_packed_kernel<16, DUAL>), pg, block, 0, stream, a);
         else hipLaunchKernelGGL((spmm_packed_kernel<32, DUAL>), pg, block, 0, stream, a);
@@ -548,11 +642,41 @@ __device__ __forceinline__ void unpack8(const uint4& q, float (&v)[8])
     v[6] = bf16_to_f32(q.w & 0xffffu); v[7] = bf16_to_f32(q.w >> 16);
 }
 
+// Cross-group reduction of the bf16 kernel.  The butterfly of the fp32 kernel would move all 8 accumulators of a lane through
+// every stage (24 exchanges + 24 adds at F = 64, where 8 lane groups share a row): this kernel is instruction-issue bound
+// on short rows (SQ_INSTS_VALU: 294 VALU instructions per 26-entry row = 0.96 ms of issue at 2M rows against 1.10 ms
+// measured), so the reduction is a REDUCE-SCATTER instead -- every stage halves the values a lane carries:
+//   lane bit 3 (inside a 16-lane DPP row): keep one half, add the partner's copy of it (row_ror:8 on the add itself)
+//   lane bit 4 / bit 5: v_permlane16_swap / v_permlane32_swap exchange the halves of two registers between the partner
+//                       rows, so ONE swap + ONE add reduce two values at once
+// after which every lane owns ONE output column of the row: 7 adds instead of 24, one conversion and one 2-byte store per
+// lane (the 64 lanes of a wavefront still write one contiguous 128-byte row).
+__device__ __forceinline__ float add_ror8(float keep, float send)
+{
+    // keep + (send rotated by 8 lanes inside its 16-lane row)
+    return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128 /* row_ror:8 */,
+                                                                        0xf, 0xf, false));
+}
+// (inline asm, not __builtin_amdgcn_permlane{16,32}_swap: this compiler folds the builtin's two results into one register when
+// they are added -- it emitted v_add_f32 v2, v2, v2 after the swap, found in the disassembly after the C5 parity test failed.
+// The s_nop pair covers the VALU-write -> permlane-swap-read and swap -> VALU-read wait states the compiler would have inserted.)
+__device__ __forceinline__ float add_swap16(float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float add_swap32(float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 template <int LPR>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_bf16_kernel(SpmmBf16Args p)
 {
     constexpr int NPW = 64 / LPR;
     constexpr int UNROLL = 4;
+    constexpr bool SCATTER = LPR == 8;           // F = 64 (BASELINE config C5): three halving stages -> one column per lane
     const int lane = threadIdx.x & 63;
     const int row = __builtin_amdgcn_readfirstlane(
         static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
@@ -562,15 +686,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_bf16_kernel(Spmm
     const bool fact = fl < p.n_feat;
     const int beg = p.rowptr[row];
     const int end = p.rowptr[row + 1];
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x2_t acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // packed fp32: one v_pk_fma_f32 per column pair
     const uint16_t* xb = p.x + fl;
     for (int base = beg; base < end; base += 64) {
         const int cnt = (end - base) < 64 ? (end - base) : 64;
         int c = 0;
         float w = 0.f;
         if (lane < cnt) {
-            c = p.col[base + lane];
-            w = p.val ? p.val[base + lane] : 1.f;
+            c = __builtin_nontemporal_load(p.col + base + lane);
+            w = p.val ? __builtin_nontemporal_load(p.val + base + lane) : 1.f;
         }
         for (int u = 0; u < cnt; u += NPW * UNROLL) {
             uint4 g[UNROLL];
@@ -587,28 +711,59 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_bf16_kernel(Spmm
             }
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k) {
-                float v[8];
-                unpack8(g[k], v);
+                const f32x2_t s2 = {sc[k], sc[k]};
+                const uint32_t q[4] = {g[k].x, g[k].y, g[k].z, g[k].w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(sc[k], v[j], acc[j]);
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2_t v = {__uint_as_float(q[j] << 16), __uint_as_float(q[j] & 0xffff0000u)};
+                    acc[j] = __builtin_elementwise_fma(s2, v, acc[j]);
+                }
             }
         }
     }
+    const int deg = end - beg;
+    const float d = p.mean ? static_cast<float>(deg > 1 ? deg : 1) : 1.f;
+    if constexpr (SCATTER) {
+        // columns of this lane: fl + 0..7 = acc[0].x, acc[0].y, acc[1].x, ...; lane bits 3 / 4 / 5 = the row's lane group
+        const bool b3 = (lane & 8) != 0;
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                       // bit 3: columns {0..3} stay on b3 = 0, {4..7} on b3 = 1
+            const float lo0 = acc[j].x, lo1 = acc[j].y, hi0 = acc[j + 2].x, hi1 = acc[j + 2].y;
+            r[2 * j] = add_ror8(b3 ? hi0 : lo0, b3 ? lo0 : hi0);
+            r[2 * j + 1] = add_ror8(b3 ? hi1 : lo1, b3 ? lo1 : hi1);
+        }
+        // bit 4: of the 4 columns a lane carries, {0, 1} stay on the even 16-lane rows, {2, 3} on the odd ones
+        const float s0 = add_swap16(r[0], r[2]), s1 = add_swap16(r[1], r[3]);
+        // bit 5: {0} stays on lanes 0..31, {1} on lanes 32..63
+        float v = add_swap32(s0, s1);
+        const int col = fl + ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + (lane >> 5);
+        if (fact) {
+            v = (p.mean ? v / d : v) * p.alpha;
+            if (p.acc_f32) {
+                // partial products of a phased (sharded) product stay in fp32: the bf16 rounding happens ONCE, at the caller
+                const float* zf = reinterpret_cast<const float*>(p.z);
+                if (zf) v = fmaf(p.beta, zf[static_cast<int64_t>(row) * p.ldz + col], v);
+                reinterpret_cast<float*>(p.y)[static_cast<int64_t>(row) * p.ldy + col] = v;
+            } else {
+                const float zz = p.z ? bf16_to_f32(p.z[static_cast<int64_t>(row) * p.ldz + col]) : 0.f;
+                p.y[static_cast<int64_t>(row) * p.ldy + col] = static_cast<uint16_t>(pack_bf16x2(fmaf(p.beta, zz, v), 0.f));
+            }
+        }
+        return;
+    }
+    float accs[8] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y, acc[2].x, acc[2].y, acc[3].x, acc[3].y};
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off);
+        for (int j = 0; j < 8; ++j) accs[j] += __shfl_xor(accs[j], off);
     if (sub == 0 && fact) {
-        const int deg = end - beg;
-        const float d = p.mean ? static_cast<float>(deg > 1 ? deg : 1) : 1.f;
         if (p.acc_f32) {
-            // partial products of a phased (sharded) product: kept in fp32 so that the bf16 rounding happens ONCE,
-            // when the caller stores the finished row, not once per phase
             const float* zf = reinterpret_cast<const float*>(p.z);
             float* yf = reinterpret_cast<float*>(p.y) + static_cast<int64_t>(row) * p.ldy + fl;
             float r[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = (p.mean ? acc[j] / d : acc[j]) * p.alpha;
+            for (int j = 0; j < 8; ++j) r[j] = (p.mean ? accs[j] / d : accs[j]) * p.alpha;
             if (zf) {
                 const float4 z0 = *reinterpret_cast<const float4*>(zf + static_cast<int64_t>(row) * p.ldz + fl);
                 const float4 z1 = *reinterpret_cast<const float4*>(zf + static_cast<int64_t>(row) * p.ldz + fl + 4);
@@ -626,7 +781,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_bf16_kernel(Spmm
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float r = p.mean ? acc[j] / d : acc[j];
+            const float r = p.mean ? accs[j] / d : accs[j];
             o[j] = fmaf(p.beta, zz[j], r * p.alpha);
         }
         uint4 q = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),

@@ -303,26 +303,35 @@ __global__ __launch_bounds__(256) void column_sums_kernel(ColumnSumArgs p)
     }
 }
 
-// out[c] = sum_b partial[b][c]: 64 columns per block, 4 groups of partial rows per column combined through LDS
+// out[c] = sum_b partial[b][c]: 16 columns per block, 16 groups of partial rows per column combined through LDS in group
+// order (one 64-column block with 4 groups walked 256 dependent loads per thread: 60 us for 1024 x 64 partials, three times
+// the pass that produced them -- profiles/r4b_kernel_stats_C3a.csv)
 __global__ __launch_bounds__(256) void column_sums_finish_kernel(const float* __restrict__ partial, int n_partials, int f,
                                                                  float* __restrict__ out)
 {
     __shared__ float sm[256];
     const int tid = threadIdx.x;
-    const int c = static_cast<int>(blockIdx.x) * 64 + (tid & 63), grp = tid >> 6;
+    const int c = static_cast<int>(blockIdx.x) * 16 + (tid & 15), grp = tid >> 4;
     float acc = 0.f;
-    if (c < f)
-        for (int b = grp; b < n_partials; b += 4) acc += partial[static_cast<int64_t>(b) * f + c];
+    if (c < f) {
+#pragma unroll 4
+        for (int b = grp; b < n_partials; b += 16) acc += partial[static_cast<int64_t>(b) * f + c];
+    }
     sm[tid] = acc;
     __syncthreads();
-    if (grp == 0 && c < f) out[c] = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
+    if (grp == 0 && c < f) {
+        float total = sm[tid];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) total += sm[tid + 16 * g];
+        out[c] = total;
+    }
 }
 
 unsigned column_sum_blocks(int64_t n_rows, int f, int v)
 {
     const int rpp = 256 / (f / v);
     int64_t b = (n_rows + rpp - 1) / rpp;
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;                       // 2 blocks per CU stream the matrix at full rate; fewer partials to add up
     return static_cast<unsigned>(b < 1 ? 1 : b);
 }
 }  // namespace
@@ -446,7 +455,7 @@ extern "C" int pygsd_column_sums(const void* x, int64_t ldx, int64_t n_rows, int
     else
         hipLaunchKernelGGL(column_sums_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
     if (int rc = check_launch("column_sums_kernel")) return rc;
-    hipLaunchKernelGGL(column_sums_finish_kernel, dim3((static_cast<unsigned>(f) + 63u) / 64u), dim3(256), 0, s,
+    hipLaunchKernelGGL(column_sums_finish_kernel, dim3((static_cast<unsigned>(f) + 15u) / 16u), dim3(256), 0, s,
                        static_cast<const float*>(workspace), static_cast<int>(blocks), f, out);
     return check_launch("column_sums_finish_kernel");
 }

@@ -146,7 +146,7 @@ def signed_c3(n=500000, entries=10000000, h=64):
         simpa.zero_grad(set_to_none=True); xp.grad = xn.grad = None
         simpa(pos, wp, neg, wn, xp, xn).sum().backward()
     ms, prof = timed(step2)
-    out["C3_simpa_hop2"] = {"nodes": n, "hidden": h, "ms_per_step": ms, "entries_per_s": ei.size(1) / ms * 1e3,
+    out["C3_simpa_hop2"] = {"nodes": n, "hidden": h, "pos_entries": int(pos.size(1)), "neg_entries": int(neg.size(1)), "ms_per_step": ms, "entries_per_s": ei.size(1) / ms * 1e3,
                             "kernels": prof, "note": "6 SpMM fwd + 6 bwd (4 on A_p, 2 on A_n) per step; the reference's unused last-hop product is skipped"}
     print("C3_simpa_hop2", json.dumps(out["C3_simpa_hop2"]), flush=True)
     torch.cuda.empty_cache()

@@ -29,7 +29,7 @@ def main():
     n_cols, nnz = 1000000, 20000000
     out = {}
     g = torch.Generator(device="cuda").manual_seed(0)
-    for deg in (4, 6, 8, 12, 16, 24, 32, 48):
+    for deg in (4, 6, 8, 12, 16, 24, 32, 48, 64):
         n_rows = nnz // deg
         ei = torch.stack([torch.randint(0, n_cols, (nnz,), device=dev, generator=g),
                           torch.randint(0, n_rows, (nnz,), device=dev, generator=g)])
@@ -42,14 +42,17 @@ def main():
             for name, fn in (("single", lambda: _spmm_raw(csr, va, xa, None, 1.0, 0.0, False)),
                              ("dual", lambda: _spmm2_raw(csr, va, vb, xa, xb, None, None, 1.0, 0.0))):
                 rec = {}
-                for mode in ("0", "1"):
+                for mode, v1, key in (("0", "0", "row_per_wave_ms"), ("1", "0", "packed_ms"), ("1", "1", "packed_v1_ms")):
                     os.environ["PYGSD_SPMM_PACKED"] = mode
-                    rec["row_per_wave_ms" if mode == "0" else "packed_ms"] = timed(fn)
+                    os.environ["PYGSD_SPMM_PACKED_V1"] = v1           # round 3's kernel (per-group col / val loads)
+                    rec[key] = timed(fn)
                 os.environ.pop("PYGSD_SPMM_PACKED")
+                os.environ.pop("PYGSD_SPMM_PACKED_V1")
                 rec["packed_speedup"] = rec["row_per_wave_ms"] / rec["packed_ms"]
+                rec["packed_vs_v1"] = rec["packed_v1_ms"] / rec["packed_ms"]
                 out[f"deg{deg}_F{f}_{name}"] = rec
                 print(f"deg {deg:3d} F {f:3d} {name:6s}: row/wave {rec['row_per_wave_ms']:.3f} ms  packed {rec['packed_ms']:.3f} ms  "
-                      f"x{rec['packed_speedup']:.2f}", flush=True)
+                      f"(round 3's: {rec['packed_v1_ms']:.3f})  x{rec['packed_speedup']:.2f}", flush=True)
             del xa, xb
         del csr, ei, va, vb
         torch.cuda.empty_cache()
