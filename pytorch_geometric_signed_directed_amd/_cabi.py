@@ -87,6 +87,8 @@ PROTOTYPES = {
                                      c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_magop_stage2": (c_int32, [c_int64, c_int32, c_int32, c_float, c_int32, c_float, c_float, c_void_p, c_size_t,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pygsd_magop_unit": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_float, c_void_p, c_size_t,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_self_loops_workspace": (c_int32, [c_int64, ctypes.POINTER(c_size_t)]),
     "pygsd_self_loops_scan": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_size_t, c_void_p,
                                         c_void_p, c_void_p]),

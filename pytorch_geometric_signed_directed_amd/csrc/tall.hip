@@ -164,6 +164,11 @@ __global__ __launch_bounds__(256) void tall_linear_f32_kernel(TallArgs p)
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The W fragments are re-read from LDS for every tile.  Left alone, the compiler hoists all KB x 4 x NT of them into
+        // registers (loop-invariant): 252-348 VGPRs, ONE or two wavefronts per SIMD and 0.42-0.52 of the HBM peak
+        // (profiles/r4d_configs.json).  One tile's fragments cost KB x NT KiB of LDS reads against KB x 4 x NT x 32 cycles
+        // of MFMA issue on each of the CU's four SIMDs: a quarter of the LDS bandwidth.
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const float xs[4] = {cur[kb].x, cur[kb].y, cur[kb].z, cur[kb].w};
@@ -331,7 +336,7 @@ unsigned column_sum_blocks(int64_t n_rows, int f, int v)
 {
     const int rpp = 256 / (f / v);
     int64_t b = (n_rows + rpp - 1) / rpp;
-    if (b > 512) b = 512;                       // 2 blocks per CU stream the matrix at full rate; fewer partials to add up
+    if (b > 1024) b = 1024;                     // (512 blocks streamed at 0.52 of the peak, 1024 at 0.80: profiles/r4d vs r4b)
     return static_cast<unsigned>(b < 1 ? 1 : b);
 }
 }  // namespace

@@ -11,6 +11,7 @@ One host round-trip is inherent: the number of distinct symmetrised entries size
 """
 import ctypes
 import math
+import os
 import threading
 from typing import Optional
 
@@ -175,6 +176,60 @@ def _pinned_info(dev):
     return hit
 
 
+_UNIT_BUILD = os.environ.get("PYGSD_TWO_STAGE_BUILD", "0") != "1"
+
+
+def set_unit_build(on: bool) -> bool:
+    """Unweighted graphs: the one-pass build behind the sort (pygsd_magop_unit, default) or the two-stage pipeline
+    (pygsd_magop_stage1 / _stage2; PYGSD_TWO_STAGE_BUILD=1) -- measurement / A-B.  Returns the previous setting."""
+    global _UNIT_BUILD
+    prev, _UNIT_BUILD = _UNIT_BUILD, bool(on)
+    return prev
+
+
+def _unit_operator_csr(row: Tensor, col: Tensor, e: int, n: int, sym: int, q: float, lambda_max: float, diag_shift: float):
+    """pygsd_magop_unit: edge list without weights -> final CSR + values in ONE call (the row pointer is a prefix chained
+    through the kernel that merges the rows, so nothing waits for a scan or a second stage).  ONE host read: E_s, the
+    bad-id witness and the over-long-row count.  None: a row longer than the kernel takes (caller: two-stage pipeline)."""
+    from ..sparse import CSR
+    dev = row.device
+    lib = _cabi.lib()
+    with torch.cuda.device(dev):
+        need = ctypes.c_size_t(0)
+        check(lib.pygsd_magop_workspace(e, n, 0, ctypes.byref(need)), "pygsd_magop_workspace")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        info = torch.empty(4, dtype=torch.int64, device=dev)
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        deg = torch.empty(n, dtype=torch.float32, device=dev)
+        cap = 2 * e + n                                   # upper bound: every listed edge distinct, no self loops
+        ccol = torch.empty(max(cap, 4), dtype=torch.int32, device=dev)
+        pad = max((cap + 3) // 4 * 4, 4)
+        vals = torch.empty((4, pad), dtype=torch.float32, device=dev)
+        check(lib.pygsd_magop_unit(ptr(row), ptr(col), e, n, sym, float(q), float(lambda_max), float(diag_shift), ptr(ws),
+                                   need.value, ptr(rowptr), ptr(deg), ptr(ccol), ptr(vals[0]), ptr(vals[1]), ptr(vals[2]),
+                                   ptr(vals[3]), ptr(info), stream_ptr()), "pygsd_magop_unit")
+        host_info, ready = _pinned_info(dev)
+        host_info.copy_(info, non_blocking=True)
+        ready.record()
+        ready.synchronize()                               # the one host round-trip
+        es, too_long, bad, bad_id = host_info.tolist()
+    if bad:
+        raise IndexError(f"edge_index holds node id {bad_id}, outside [0, {n}); the HIP path gathers and "
+                         "scatters rows by these ids")
+    if too_long:
+        return None
+    nnz = es + n
+    if nnz < 0.9 * cap:
+        ccol = ccol[:nnz].clone()
+        tight = torch.empty((4, max((nnz + 3) // 4 * 4, 4)), dtype=torch.float32, device=dev)
+        tight[:, :nnz] = vals[:, :nnz]
+        vals = tight
+    else:
+        ccol = ccol[:nnz]
+    csr = CSR(n, n, nnz, rowptr, ccol, None)
+    return csr, (vals[2, :nnz], vals[3, :nnz]), (vals[0, :nnz], vals[1, :nnz]), deg
+
+
 def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, signed: bool,
                        absolute_degree: bool, q: float, normalization: Optional[str], lambda_max: float,
                        diag_shift: float = -1.0):
@@ -204,6 +259,11 @@ def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int
             w = None                    # an empty tensor has no address: both stages must agree on the layout
     sym = 1 if normalization is not None else 0
     lib = _cabi.lib()
+    if w is None and _UNIT_BUILD:
+        built = _unit_operator_csr(row, col, e, n, sym, q, lambda_max, diag_shift)
+        if built is not None:
+            return built
+        # a node with more than 512 symmetrised entries: the two-stage pipeline below has a path for rows up to 4096
     with torch.cuda.device(dev):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_magop_workspace(e, n, 0 if w is None else 1, ctypes.byref(need)), "pygsd_magop_workspace")

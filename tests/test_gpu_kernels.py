@@ -831,16 +831,24 @@ def _generic_operator(ei, w, n, signed, absdeg, q, norm, lam):
 
 
 def _assert_fused_equals_generic(ei, w, n, signed, absdeg, q, norm, lam):
-    from pytorch_geometric_signed_directed_amd.utils._laplacian import fused_operator_csr
-    got = fused_operator_csr(ei, w, n, signed, absdeg, q, norm, lam)
-    assert got is not None
-    csr, vf, vb, deg = got
+    """The fused build(s) against the generic pipeline, bit for bit.  Without weights there are two fused pipelines -- the
+    one-pass build behind the sort (pygsd_magop_unit, the default) and the two-stage one -- and both are held to it."""
+    from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
     wcsr, wvf, wvb, wdeg = _generic_operator(ei, w, n, signed, absdeg, q, norm, lam)
-    assert csr.nnz == wcsr.nnz
-    assert torch.equal(csr.rowptr, wcsr.rowptr) and torch.equal(csr.col, wcsr.col)
-    assert torch.equal(deg, wdeg)
-    for a, b in zip(vf + vb, wvf + wvb):                 # same formulas in the same order: bit-identical
-        assert torch.equal(a, b)
+    csr = None
+    for unit in ((True, False) if w is None else (True,)):
+        prev = L.set_unit_build(unit)
+        try:
+            got = L.fused_operator_csr(ei, w, n, signed, absdeg, q, norm, lam)
+        finally:
+            L.set_unit_build(prev)
+        assert got is not None
+        csr, vf, vb, deg = got
+        assert csr.nnz == wcsr.nnz
+        assert torch.equal(csr.rowptr, wcsr.rowptr) and torch.equal(csr.col, wcsr.col)
+        assert torch.equal(deg, wdeg)
+        for a, b in zip(vf + vb, wvf + wvb):                 # same formulas in the same order: bit-identical
+            assert torch.equal(a, b)
     return csr
 
 
@@ -899,6 +907,45 @@ def test_fused_operator_build_long_rows_and_fallback(weighted):
     x = torch.randn(n, 4, device=d)
     conv(x, x, ei2, w2)
     assert conv._operator.csr.nnz == _generic_operator(ei2, w2, n, True, True, 0.25, "sym", 2.0)[0].nnz
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm,lam", [("sym", 2.0), (None, 3.0)])
+def test_unit_operator_build_long_rows_chained_prefix_and_determinism(norm, lam):
+    """pygsd_magop_unit (unweighted graphs: rows merged and written in one pass, row pointer chained through the kernel by a
+    decoupled look-back): rows of 64 / 65 / 103 / 303 / 512 stream entries (from 65: the rank sort through LDS, direct stores),
+    duplicates, reciprocal pairs, self loops, isolated nodes, a node count that is not a multiple of the 16 rows of a
+    block -- bit-identical to the generic pipeline and from run to run; 513 entries make it step aside."""
+    from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
+    n = 50007
+    g = torch.Generator().manual_seed(13)
+    ei, _ = _messy_graph(n, 600000, seed=3, signed=False)
+    ei = ei[:, (ei[0] < n - 40) & (ei[1] < n - 40)]                  # the last 40 nodes are isolated
+    extra = []
+    for hub, k, dup in ((7, 64, 0), (8, 65, 0), (9, 100, 3), (4000, 300, 3), (n - 50, 509, 3)):   # stream entries: k + dup
+        drop = (ei[0] == hub) | (ei[1] == hub)
+        ei = ei[:, ~drop]
+        other = torch.randperm(n - 5000, generator=g)[:k] + 4500      # distinct neighbours, none of them a hub
+        half = k // 2
+        extra.append(torch.stack([torch.full((half,), hub), other[:half]]))               # out-edges
+        extra.append(torch.stack([other[half:], torch.full((k - half,), hub)]))           # in-edges
+        extra.append(torch.stack([torch.full((dup,), hub), other[:dup]]))                  # duplicates of some of them
+    ei = torch.cat([ei] + extra, dim=1)
+    ei = ei[:, torch.randperm(ei.size(1), generator=g)].to(dev())
+    row, col = ei[0].contiguous(), ei[1].contiguous()
+    sym = 1 if norm is not None else 0
+    first = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, lam, -1.0)
+    assert first is not None
+    lens = (first[0].rowptr[1:] - first[0].rowptr[:-1]).cpu()
+    assert [int(lens[k]) for k in (7, 8, 9, 4000, n - 50, n - 1)] == [65, 66, 101, 301, 510, 1]     # distinct entries + diagonal
+    again = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, lam, -1.0)
+    assert torch.equal(first[0].rowptr, again[0].rowptr) and torch.equal(first[0].col, again[0].col)
+    for a, b in zip(first[1] + first[2], again[1] + again[2]):
+        assert torch.equal(a, b)
+    _assert_fused_equals_generic(ei, None, n, False, True, 0.25, norm, lam)
+    over = torch.cat([ei, torch.stack([torch.full((1,), n - 50, device=dev()), torch.full((1,), 3, device=dev())])], dim=1)
+    assert L._unit_operator_csr(over[0].contiguous(), over[1].contiguous(), over.size(1), n, sym, 0.25, lam, -1.0) is None
+    assert L.fused_operator_csr(over, None, n, False, True, 0.25, norm, lam) is not None      # two-stage pipeline took it
 
 
 @pytest.mark.gpu

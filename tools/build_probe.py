@@ -15,14 +15,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_geometric_signed_directed_amd import graphs  # noqa: E402
 from pytorch_geometric_signed_directed_amd.utils._laplacian import (assemble_operator_csr, fused_operator_csr,  # noqa: E402
-                                                                     laplacian_parts, laplacian_values)
+                                                                     laplacian_parts, laplacian_values, set_unit_build)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--nodes", type=int, default=1000000)
 ap.add_argument("--edges", type=int, default=20000000)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--norm", default="sym", help="sym | none")
-ap.add_argument("--only", default="", help="comma list of legs: fused,generic,fused_signed,generic_signed")
+ap.add_argument("--only", default="", help="comma list of legs: fused (= round 4's one-pass unweighted build), two_stage (round 3's), "
+                                           "generic, fused_signed, generic_signed")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 NORM = None if args.norm == "none" else "sym"
@@ -58,7 +59,15 @@ ei_np, _, _ = graphs.dsbm_for_edges(n, e, seed=0)
 ei = torch.from_numpy(ei_np).to(dev)
 ei_s_np, sign_np, _, _ = graphs.sdsbm_for_edges(n, e, seed=1)
 ei_s, w_s = torch.from_numpy(ei_s_np).to(dev), torch.from_numpy(sign_np).to(dev)
-legs = {"fused": lambda: fused(ei, None, n, False), "generic": lambda: generic(ei, None, n, False),
+def two_stage():
+    prev = set_unit_build(False)
+    try:
+        return fused(ei, None, n, False)
+    finally:
+        set_unit_build(prev)
+
+
+legs = {"fused": lambda: fused(ei, None, n, False), "two_stage": two_stage, "generic": lambda: generic(ei, None, n, False),
         "fused_signed": lambda: fused(ei_s, w_s, n, True), "generic_signed": lambda: generic(ei_s, w_s, n, True)}
 only = [s for s in args.only.split(",") if s] or list(legs)
 out = {"nodes": n, "edges": int(ei.size(1)), "iters": args.iters}

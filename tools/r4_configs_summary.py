@@ -34,14 +34,18 @@ def spmm_bytes(nnz, n, f, s=4, val=True, z=False):
     return nnz * (4 + (4 if val else 0) + f * s) + n * f * s * (2 if z else 1) + 4 * (n + 1)
 
 
-def model(step, cfg):
+def model(step, cfg, present=()):
     """{kernel short name: (algorithmic bytes per launch averaged over the step's launches of that kernel, flops or None, what)}"""
     if step == "C3a":
         n, pos, neg = cfg["nodes"], cfg["pos_entries"], cfg["neg_entries"]
         fwd_p, fwd_n = spmm_bytes(pos, n, 32, val=False, z=True), spmm_bytes(neg, n, 32, val=False, z=True)
         bwd_p, bwd_n = spmm_bytes(pos, n, 32), spmm_bytes(neg, n, 32)
-        return {"spmm_packed_kernel<8,false>": ((fwd_p + bwd_p) / 2, None, "positive part (5.4 entries per row), width 32: value-less mean forward (+ own block as Z), weighted backward"),
-                "spmm_vec_kernel<8,false,false>": ((fwd_n + bwd_n) / 2, None, "negative part (14.6 entries per row), width 32, forward + backward"),
+        both = "spmm_vec_kernel<8,false,false>" not in present       # round 4's crossover packs the 14.6-entry rows too
+        spmm = ({"spmm_packed_kernel<8,false>": ((fwd_p + bwd_p + fwd_n + bwd_n) / 4, None, "positive (5.4 entries per row) and negative "
+                 "(14.6) part, width 32: value-less mean forward (+ own block as Z), weighted backward")} if both else
+                {"spmm_packed_kernel<8,false>": ((fwd_p + bwd_p) / 2, None, "positive part (5.4 entries per row), width 32: value-less mean forward (+ own block as Z), weighted backward"),
+                 "spmm_vec_kernel<8,false,false>": ((fwd_n + bwd_n) / 2, None, "negative part (14.6 entries per row), width 32, forward + backward")})
+        return {**spmm,
                 "tall_linear_f32_kernel<4,8>": (n * (64 + 128) * 4, 2 * n * 64 * 128, "x [own_b | own_u | agg_b | agg_u]"),
                 "tall_linear_f32_kernel<8,4>": (n * (128 + 64) * 4, 2 * n * 128 * 64, "dx = [g | g_a] W^T"),
                 "tall_gram_f32_kernel": (n * (64 + 128) * 4, 2 * n * 64 * 128, "dW = x^T [g | g_a]"),
@@ -109,7 +113,8 @@ def main():
         for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum", "SQ_INSTS_VALU_SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES_SQ_WAVES"):
             for k, v in counters(f"{TAG}_pmc_{step}_{c}").items():
                 pmc.setdefault(k, {}).update(v)
-        alg = model(step, cfg)
+        names = {short(r["Name"]) for r in csv.DictReader(open(stats[0]))}
+        alg = model(step, cfg, names)
         kernels, library = {}, {}
         for row in csv.DictReader(open(stats[0])):
             k = short(row["Name"])
