@@ -300,15 +300,15 @@ int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, in
                        float diag_shift, void* workspace, size_t workspace_bytes, const int32_t* rowptr,
                        const float* deg, int32_t* col, float* vb_real, float* vb_imag, float* vf_real,
                        float* vf_imag, void* stream);
-/* The UNWEIGHTED build in one call (round 4): edge list -> final CSR + the four value arrays, no second stage.  With unit
- * weights a node's degree is half its number of symmetrised entries (known from the row bounds of the sorted stream) and the
- * row pointer is a prefix sum chained through the kernel that merges the rows (decoupled look-back over its blocks), so the
- * wavefront that orders a row in registers also writes its values and diagonal into the final slots -- no 16-byte records, no
- * separate scan, no values pass (get_magnetic_Laplacian.py:47-85 with edge_weight = None, as MagNetConv.py:157-181 calls it
- * on every uncached forward).  Outputs as pygsd_magop_stage1 + _stage2 (rowptr [n + 1], deg [n], col / v* allocated for
- * 2 n_edges + n slots, 16-byte aligned); d_info[0] = E_s, d_info[1] != 0: a node has more than 512 symmetrised entries (or the
- * prefix chain gave up) and the outputs are invalid -- the caller then takes the two-stage pipeline; d_info[2], [3] as
- * stage 1.  workspace from pygsd_magop_workspace(n_edges, n, 0). */
+/* The UNWEIGHTED build in one call (round 4): edge list -> final CSR + the four value arrays.  With unit weights a node's
+ * degree is half its number of symmetrised entries (known from the row bounds of the sorted stream), multiplicities and phase
+ * arguments are small integers: the wavefront that orders a row parks ONE 8-byte record per distinct neighbour, and after the
+ * scan of the distinct counts the same mapping writes values and diagonals into the final slots -- half the intermediate
+ * traffic of pygsd_magop_stage1 + _stage2, bit-identical results (get_magnetic_Laplacian.py:47-85 with edge_weight = None,
+ * as MagNetConv.py:157-181 calls it on every uncached forward).  Outputs as the two stages (rowptr [n + 1], deg [n], col / v*
+ * allocated for 2 n_edges + n slots, 16-byte aligned); d_info[0] = E_s, d_info[1] != 0: a node has more than 512 symmetrised
+ * entries and the outputs are invalid -- the caller then takes the two-stage pipeline; d_info[2], [3] as stage 1.  workspace
+ * from pygsd_magop_workspace(n_edges, n, 0). */
 int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, float q, float lambda_max,
                      float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr, float* deg, int32_t* ccol,
                      float* vb_real, float* vb_imag, float* vf_real, float* vf_imag, int64_t* d_info, void* stream);

@@ -627,26 +627,29 @@ __global__ void diagonal_of_empty_rows(const int32_t* __restrict__ rowptr, const
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Round 4: the UNWEIGHTED build in one pass behind the sort (the graphs of the BASELINE magnetic configurations: DSBM edge lists
-// without weights).  With unit weights everything the second stage waited for is known before the rows are merged:
-//   * a node's degree is half the number of its stream entries (every listed non-loop edge adds 1/2 to A_s at both ends, duplicates
-//     and reciprocal pairs included) -- read off the row bounds, so deg^-1/2 of EVERY node exists before any value is formed;
-//   * the only thing still global is the row pointer (distinct entries per row + the diagonal), and a prefix sum can be chained
-//     through the kernel that counts: a decoupled look-back over the blocks (each block publishes the total of its 16 rows, then
-//     the running prefix; a block spins only on blocks that STARTED before it -- block ids are tickets).
-// So the wavefront that ordered a row in registers also writes it: columns, the four value arrays and the diagonal go straight
-// into their final CSR slots.  Gone: the 16-byte record per stream position (640 MB written by row_merge_wave, read back by
-// values_entries), the separate scan, row_tables, values_entries' second trip through shift[] / deg[] and a kernel boundary.
-// Same formulas in the same order as values_entries (bit-compatible: tests hold the three pipelines to equality).
+// Round 4: the UNWEIGHTED build (the graphs of the BASELINE magnetic configurations: DSBM edge lists without weights).
+// With unit weights a node's degree is half the number of its stream entries (every listed non-loop edge adds 1/2 to A_s at both
+// ends, duplicates and reciprocal pairs included): it is read off the row bounds, so deg^-1/2 of EVERY node exists before a row is
+// merged, and multiplicity and phase argument of an entry are small integers.  The two stages then shrink to
+//   A  unit_merge_rows   a wavefront orders a row in registers and parks the MERGED row: ONE 8-byte record per DISTINCT
+//                        neighbour (col | multiplicity | Theta_arg) instead of a 16-byte record per stream position
+//   -  scan of (distinct + 1) -> row pointer
+//   B  unit_write_rows   the same rows-per-wavefront mapping reads the merged rows back (coalesced 8-byte loads), forms the values
+//                        (same formulas, same order as values_entries: bit-compatible) and writes a wavefront's contiguous slot
+//                        range through LDS with aligned 16-byte stores
+// i.e. 330 + 330 MB of intermediate traffic instead of 640 + 640 at the north star, no shift[] table, no per-record row lookups.
+// (Tried first and measured: A and B in ONE kernel with the row pointer chained through it by a decoupled look-back -- no
+// intermediate at all.  Bit-identical, but the chain's waiting dominated: 5.4 ms with 16-row blocks, 1.8 ms with 256-row blocks
+// against 0.88 ms for the two kernels it replaced; commit "Unweighted operator build in one kernel behind the sort".)
 // Rows of 65 .. kUnitRowMax entries are rank-sorted through a small LDS scratch by their wavefront; longer rows are counted and the
 // host takes the two-stage pipeline above.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kUnitRowMax = 512;
-constexpr uint64_t kStatusMask = (1ull << 62) - 1ull;
 
 __global__ void unit_row_tables(const int32_t* __restrict__ rs, int32_t n, int32_t sym, float* __restrict__ deg,
-                                float* __restrict__ dinv)
+                                float* __restrict__ dinv, int32_t* __restrict__ row_u)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) row_u[n] = 0;        // the scan's (n + 1)-th input
     GRID_STRIDE(r, n)
     {
         // the butterfly of merge_one_row adds multiples of 1/2 (exact in any order): the same value as (entries) / 2
@@ -668,8 +671,8 @@ struct UnitArgs {
     float* vb_im;
     float* vf_re;
     float* vf_im;
-    unsigned long long* status;    // [blocks] look-back words: flag << 62 | value
-    int32_t* ticket;
+    int32_t* row_u;                // [n + 1] distinct entries per row (kernel A -> scan -> rowptr)
+    int32_t* row_left;             // [n] distinct entries left of the diagonal
     int64_t* info;
     int64_t m;
     int32_t n, sym;
@@ -737,295 +740,217 @@ __device__ __forceinline__ void unit_diagonal(const UnitArgs& p, float* st, int6
     unit_store<STAGED>(p, st, wslot0, slot, row, dg, 0.f, dg, 0.f);
 }
 
-// Rows per block: 4 wavefronts x kUnitGroups groups x kRowsPerWave rows.  The look-back costs a block a few device-scope round
-// trips (microseconds); with 16 rows per block (62 500 blocks at the north star, ~1300 in flight, every one of them waiting for a
-// chain through its predecessors) the first version of this kernel took 5.4 ms.  256 rows per block amortise the wait over ~80 KB
-// of stream and leave three generations of blocks; between its two phases a block keeps its merged rows as 8-byte records in the
-// sort's dead input buffer (written and re-read by the same CU: L2 traffic).
-constexpr int kUnitGroups = 16;
-constexpr int kUnitRows = 4 * kUnitGroups * kRowsPerWave;
-
+// Kernel A: one wavefront per kRowsPerWave rows (as row_merge_wave): order each row in registers, park the MERGED row -- one 8-byte
+// record per distinct neighbour: col | multiplicity << 32 | (Theta_arg + 64) << 40 -- at the head of the row's range of the sort's
+// dead input buffer, count the distinct entries and those left of the diagonal.
 template <typename KT>
-__global__ __launch_bounds__(256) void row_finish_unit(UnitArgs p)
+__global__ __launch_bounds__(256) void unit_merge_rows(UnitArgs p)
 {
     __shared__ uint32_t lk[4][kUnitRowMax];       // rank-sort staging of a 65+ entry row, one per wavefront
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * 4 + wv) * kRowsPerWave;
+    if (r0 >= p.n) return;
+    const int rows = p.n - r0 < kRowsPerWave ? static_cast<int>(p.n - r0) : kRowsPerWave;
+    int32_t beg[kRowsPerWave], cnt[kRowsPerWave];
+    uint32_t c2[kRowsPerWave];
+    const int32_t bound = p.rs[r0 + (lane <= rows ? lane : rows)];
+#pragma unroll
+    for (int j = 0; j < kRowsPerWave; ++j) {
+        beg[j] = __builtin_amdgcn_readlane(bound, j < rows ? j : rows);
+        cnt[j] = j < rows ? __builtin_amdgcn_readlane(bound, j + 1 < rows ? j + 1 : rows) - beg[j] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < kRowsPerWave; ++j) {                      // unconditional loads from clamped addresses (row_merge_wave)
+        int64_t pos = static_cast<int64_t>(beg[j]) + lane;
+        pos = pos < p.m ? pos : p.m - 1;
+        c2[j] = static_cast<uint32_t>(__builtin_nontemporal_load(p.keys + pos));
+    }
+#pragma unroll
+    for (int j = 0; j < kRowsPerWave; ++j) {
+        if (j >= rows) continue;
+        const int32_t r = static_cast<int32_t>(r0) + j;
+        int u = 0, left = 0;
+        if (cnt[j] <= 64) {
+            const bool have = lane < cnt[j];
+            KT k = have ? static_cast<KT>((static_cast<KT>(c2[j]) << 6) | static_cast<KT>(lane)) : static_cast<KT>(~static_cast<KT>(0));
+            k = wave_bitonic<KT>(k, lane);
+            const uint32_t c2s = static_cast<uint32_t>(k >> 6);
+            const uint32_t cv = c2s >> 1;
+            const bool rev = (c2s & 1u) != 0;
+            const uint32_t prev = __shfl_up(cv, 1);
+            const bool hd = have && (lane == 0 || prev != cv);
+            const uint64_t H = __ballot(hd);
+            const uint64_t above = lane == 63 ? 0ull : ((H >> (lane + 1)) << (lane + 1));
+            const int end = above ? (__ffsll(static_cast<long long>(above)) - 1) : cnt[j];
+            const int ln = end - lane;
+            const uint64_t D = __ballot(have && rev);
+            const uint64_t run = (ln >= 64 ? ~0ull : ((1ull << (ln > 0 ? ln : 0)) - 1ull)) << lane;
+            const int n1 = __popcll(D & run);
+            u = __popcll(H);
+            left = __popcll(__ballot(hd && static_cast<int32_t>(cv) < r));
+            if (hd) {
+                const int rank = __popcll(H & ((1ull << lane) - 1ull));
+                p.scratch[beg[j] + rank] = static_cast<uint64_t>(cv) | (static_cast<uint64_t>(ln) << 32) |
+                                           (static_cast<uint64_t>(ln - 2 * n1 + 64) << 40);
+            }
+        } else if (cnt[j] <= kUnitRowMax) {
+            // rank sort through LDS: rank = number of keys that sort before this one ((col, dir) order; identical keys are
+            // indistinguishable, so ties may fall either way); SORTED KEYS (not merged records) -> scratch[beg + rank]
+            for (int i = lane; i < cnt[j]; i += 64) lk[wv][i] = static_cast<uint32_t>(p.keys[beg[j] + i]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int i = lane; i < cnt[j]; i += 64) {
+                const uint32_t mine = lk[wv][i];
+                int rk = 0;
+                for (int t = 0; t < cnt[j]; ++t) {
+                    const uint32_t o = lk[wv][t];
+                    rk += (o < mine || (o == mine && t < i)) ? 1 : 0;
+                }
+                p.scratch[beg[j] + rk] = mine;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the wavefront re-reads what its lanes wrote
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (int i0 = 0; i0 < cnt[j]; i0 += 64) {
+                const int i = i0 + lane;
+                bool hd = false, lt = false;
+                if (i < cnt[j]) {
+                    const uint32_t cur = static_cast<uint32_t>(p.scratch[beg[j] + i]) >> 1;
+                    hd = i == 0 || (static_cast<uint32_t>(p.scratch[beg[j] + i - 1]) >> 1) != cur;
+                    lt = hd && static_cast<int32_t>(cur) < r;
+                }
+                u += __popcll(__ballot(hd));
+                left += __popcll(__ballot(lt));
+            }
+        } else {
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 1), 1ull);    // host: two-stage pipeline
+        }
+        if (lane == 0) {
+            p.row_u[r] = u;
+            p.row_left[r] = left;
+        }
+    }
+}
+
+// Kernel B (after the scan of distinct + 1 -> row pointer): the same wavefront-per-rows mapping reads the merged rows back (one
+// coalesced 8-byte load per distinct entry) and writes columns, the four value arrays and the diagonal into their final slots.
+__global__ __launch_bounds__(256) void unit_write_rows(UnitArgs p)
+{
     __shared__ __attribute__((aligned(16))) float stage[4][5 * kStageW];
-    __shared__ int16_t row_u[kUnitRows], row_left[kUnitRows];
-    __shared__ int32_t wave_total[4];
-    __shared__ int32_t s_bid;
-    __shared__ int64_t s_prefix;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_bid = atomicAdd(p.ticket, 1);                 // blocks take their rows in the order they START
-    __syncthreads();
-    const int bid = s_bid;
-    const int64_t wave_r0 = static_cast<int64_t>(bid) * kUnitRows + static_cast<int64_t>(wv) * (kUnitGroups * kRowsPerWave);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * 4 + wv) * kRowsPerWave;
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.info[0] = static_cast<int64_t>(p.rowptr[p.n]) - p.n;     // E_s for the host
+    if (r0 >= p.n) return;
+    const int rows = p.n - r0 < kRowsPerWave ? static_cast<int>(p.n - r0) : kRowsPerWave;
     float sn1, cs1;
     sincosf(p.two_pi_q, &sn1, &cs1);
-
-    // ---- phase 1: order every row, count its distinct entries, park the merged row in the scratch stream --------------
-    int32_t total = 0;
-    for (int grp = 0; grp < kUnitGroups; ++grp) {
-        const int64_t r0 = wave_r0 + grp * kRowsPerWave;
-        const int rows = r0 >= p.n ? 0 : (p.n - r0 < kRowsPerWave ? static_cast<int>(p.n - r0) : kRowsPerWave);
-        if (rows == 0) break;                                      // wave-uniform
-        int32_t beg[kRowsPerWave], cnt[kRowsPerWave];
-        uint32_t c2[kRowsPerWave];
-        const int32_t bound = p.rs[r0 + (lane <= rows ? lane : rows)];
+    float* st = &stage[wv][0];
+    int32_t beg[kRowsPerWave], cnt[kRowsPerWave], u[kRowsPerWave], left[kRowsPerWave];
+    const int idx = lane <= rows ? lane : rows;
+    const int32_t bound = p.rs[r0 + idx];
+    const int32_t rp = p.rowptr[r0 + idx];                         // lanes 0 .. rows: the rows' first slots (rowptr[n] exists)
+    const int32_t lf = lane < rows ? p.row_left[r0 + lane] : 0;
+    bool short_rows = true;
 #pragma unroll
-        for (int j = 0; j < kRowsPerWave; ++j) {
-            beg[j] = __builtin_amdgcn_readlane(bound, j < rows ? j : rows);
-            cnt[j] = j < rows ? __builtin_amdgcn_readlane(bound, j + 1 < rows ? j + 1 : rows) - beg[j] : 0;
-        }
+    for (int j = 0; j < kRowsPerWave; ++j) {
+        beg[j] = __builtin_amdgcn_readlane(bound, j < rows ? j : rows);
+        cnt[j] = j < rows ? __builtin_amdgcn_readlane(bound, j + 1 < rows ? j + 1 : rows) - beg[j] : 0;
+        const int32_t s0 = __builtin_amdgcn_readlane(rp, j < rows ? j : rows), s1 = __builtin_amdgcn_readlane(rp, j + 1 < rows ? j + 1 : rows);
+        u[j] = j < rows ? s1 - s0 - 1 : 0;
+        left[j] = __builtin_amdgcn_readlane(lf, j < rows ? j : 0);
+        short_rows = short_rows && cnt[j] <= 64;
+    }
+    int64_t slot0 = __builtin_amdgcn_readlane(rp, 0);
+    const int64_t wslot0 = slot0;
+    if (p.info[1] != 0) return;                                    // a row this pipeline does not take: outputs are discarded
+    if (short_rows) {
+        uint64_t rec[kRowsPerWave];
 #pragma unroll
-        for (int j = 0; j < kRowsPerWave; ++j) {                  // unconditional loads from clamped addresses (row_merge_wave)
-            int64_t pos = static_cast<int64_t>(beg[j]) + lane;
-            pos = pos < p.m ? pos : p.m - 1;
-            c2[j] = static_cast<uint32_t>(__builtin_nontemporal_load(p.keys + pos));
-        }
+        for (int j = 0; j < kRowsPerWave; ++j) rec[j] = lane < u[j] ? p.scratch[beg[j] + lane] : 0ull;
 #pragma unroll
         for (int j = 0; j < kRowsPerWave; ++j) {
             if (j >= rows) continue;
             const int32_t r = static_cast<int32_t>(r0) + j;
-            const int li = wv * (kUnitGroups * kRowsPerWave) + grp * kRowsPerWave + j;     // row index inside the block
-            int u = 0, left = 0;
-            if (cnt[j] <= 64) {
-                const bool have = lane < cnt[j];
-                KT k = have ? static_cast<KT>((static_cast<KT>(c2[j]) << 6) | static_cast<KT>(lane)) : static_cast<KT>(~static_cast<KT>(0));
-                k = wave_bitonic<KT>(k, lane);
-                const uint32_t c2s = static_cast<uint32_t>(k >> 6);
-                const uint32_t cv = c2s >> 1;
-                const bool rev = (c2s & 1u) != 0;
-                const uint32_t prev = __shfl_up(cv, 1);
-                const bool hd = have && (lane == 0 || prev != cv);
-                const uint64_t H = __ballot(hd);
-                const uint64_t above = lane == 63 ? 0ull : ((H >> (lane + 1)) << (lane + 1));
-                const int end = above ? (__ffsll(static_cast<long long>(above)) - 1) : cnt[j];
-                const int ln = end - lane;
-                const uint64_t D = __ballot(have && rev);
-                const uint64_t run = (ln >= 64 ? ~0ull : ((1ull << (ln > 0 ? ln : 0)) - 1ull)) << lane;
-                const int n1 = __popcll(D & run);
-                u = __popcll(H);
-                left = __popcll(__ballot(hd && static_cast<int32_t>(cv) < r));
-                if (hd) {
-                    // merged record: col | multiplicity << 32 | (Theta_arg + 64) << 40  (multiplicities <= 64)
-                    const int rank = __popcll(H & ((1ull << lane) - 1ull));
-                    p.scratch[beg[j] + rank] = static_cast<uint64_t>(cv) | (static_cast<uint64_t>(ln) << 32) |
-                                               (static_cast<uint64_t>(ln - 2 * n1 + 64) << 40);
-                }
-            } else if (cnt[j] <= kUnitRowMax) {
-                // rank sort through LDS: rank = number of keys that sort before this one ((col, dir) order; identical keys are
-                // indistinguishable, so ties may fall either way); SORTED KEYS (not merged records) -> scratch[beg + rank]
-                for (int i = lane; i < cnt[j]; i += 64) lk[wv][i] = static_cast<uint32_t>(p.keys[beg[j] + i]);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int i = lane; i < cnt[j]; i += 64) {
-                    const uint32_t mine = lk[wv][i];
-                    int rk = 0;
-                    for (int t = 0; t < cnt[j]; ++t) {
-                        const uint32_t o = lk[wv][t];
-                        rk += (o < mine || (o == mine && t < i)) ? 1 : 0;
-                    }
-                    p.scratch[beg[j] + rk] = mine;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the wavefront re-reads what its lanes wrote
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                for (int i0 = 0; i0 < cnt[j]; i0 += 64) {
-                    const int i = i0 + lane;
-                    bool hd = false, lt = false;
-                    if (i < cnt[j]) {
-                        const uint32_t cur = static_cast<uint32_t>(p.scratch[beg[j] + i]) >> 1;
-                        hd = i == 0 || (static_cast<uint32_t>(p.scratch[beg[j] + i - 1]) >> 1) != cur;
-                        lt = hd && static_cast<int32_t>(cur) < r;
-                    }
-                    u += __popcll(__ballot(hd));
-                    left += __popcll(__ballot(lt));
-                }
-            } else {
-                if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 1), 1ull);    // host: two-stage pipeline
+            if (lane == 0) unit_diagonal<true>(p, st, wslot0, r, slot0 + left[j]);
+            if (lane < u[j]) {
+                const int32_t c = static_cast<int32_t>(rec[j] & 0xFFFFFFFFull);
+                const int ln = static_cast<int>((rec[j] >> 32) & 0xFFull), th = static_cast<int>((rec[j] >> 40) & 0xFFull) - 64;
+                unit_values<true>(p, st, wslot0, r, c, ln, th, cs1, sn1, slot0 + lane + (c > r ? 1 : 0));
             }
-            if (lane == 0) {
-                row_u[li] = static_cast<int16_t>(u);
-                row_left[li] = static_cast<int16_t>(left);
-            }
-            total += u + 1;
+            slot0 += u[j] + 1;
         }
-    }
-
-    // ---- chained prefix over the blocks (decoupled look-back) ------------------------------------------------
-    if (lane == 0) wave_total[wv] = total;
-    __syncthreads();
-    if (wv == 0) {
-        // wavefront 0 looks back 64 predecessors at a time
-        const unsigned long long mine = static_cast<unsigned long long>(wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3]);
-        unsigned long long excl = 0;
-        if (bid > 0) {
-            if (lane == 0) __hip_atomic_store(p.status + bid, (1ull << 62) | mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            int top = bid - 1;                                     // nearest predecessor not yet accounted for
-            long spins = 0;
-            while (true) {
-                const int i = top - lane;                          // lane 0 = nearest
-                unsigned long long sv = 2ull << 62;                // in front of block 0: an inclusive prefix of 0
-                if (i >= 0) sv = __hip_atomic_load(p.status + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long flag = sv >> 62;
-                const uint64_t done = __ballot(flag == 2), none = __ballot(flag == 0);
-                // the usable run: lanes 0 .. stop-1 hold aggregates, lane `stop` (if any) an inclusive prefix; an unpublished
-                // predecessor nearer than that cuts the run short
-                const int first_done = done ? __ffsll(static_cast<long long>(done)) - 1 : 64;
-                const int first_none = none ? __ffsll(static_cast<long long>(none)) - 1 : 64;
-                const int take = first_none < first_done ? first_none : (first_done < 64 ? first_done + 1 : 64);
-                unsigned long long part = lane < take ? (sv & kStatusMask) : 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // drain [wslot0, slot0): the 16-byte aligned middle as dwordx4, the ragged ends (<= 6 slots) as dwords
+        const int64_t lo = wslot0, hi = slot0, a0 = (lo + 3) & ~int64_t(3), a1 = hi & ~int64_t(3);
+        float* const outs[5] = {reinterpret_cast<float*>(p.ccol), p.vb_re, p.vb_im, p.vf_re, p.vf_im};
+        if (a0 < a1) {
+            const int quads = static_cast<int>((a1 - a0) >> 2);
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
-                excl += part;
-                top -= take;
-                if (first_done < first_none) break;                // reached an inclusive prefix (or the front)
-                if (take == 0) {
-                    if (++spins > (1l << 20)) {                    // a predecessor that never publishes: give up loudly
-                        if (lane == 0) p.info[1] = 1;              // (the host then rebuilds with the two-stage pipeline)
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
+            for (int arr = 0; arr < 5; ++arr) {
+                for (int g = lane; g < quads; g += 64) {
+                    const int o = static_cast<int>(a0 - lo) + 4 * g;
+                    const float* src = st + arr * kStageW + o;
+                    const f32x4 v = {src[0], src[1], src[2], src[3]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(outs[arr] + a0) + g);
                 }
             }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(p.status + bid, (2ull << 62) | (excl + mine), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            s_prefix = static_cast<int64_t>(excl);
-        }
-    }
-    __syncthreads();
-    int64_t slot0 = s_prefix;
-    for (int w = 0; w < wv; ++w) slot0 += wave_total[w];
-
-    // ---- phase 2: the rows' entries and diagonals into their final slots ------------------------------------
-    float* st = &stage[wv][0];
-    for (int grp = 0; grp < kUnitGroups; ++grp) {
-        const int64_t r0 = wave_r0 + grp * kRowsPerWave;
-        const int rows = r0 >= p.n ? 0 : (p.n - r0 < kRowsPerWave ? static_cast<int>(p.n - r0) : kRowsPerWave);
-        if (rows == 0) break;
-        const int li0 = wv * (kUnitGroups * kRowsPerWave) + grp * kRowsPerWave;
-        int32_t beg[kRowsPerWave], cnt[kRowsPerWave];
-        const int32_t bound = p.rs[r0 + (lane <= rows ? lane : rows)];
-        bool short_rows = true;
-#pragma unroll
-        for (int j = 0; j < kRowsPerWave; ++j) {
-            beg[j] = __builtin_amdgcn_readlane(bound, j < rows ? j : rows);
-            cnt[j] = j < rows ? __builtin_amdgcn_readlane(bound, j + 1 < rows ? j + 1 : rows) - beg[j] : 0;
-            short_rows = short_rows && cnt[j] <= 64;
-        }
-        const int64_t wslot0 = slot0;
-        if (short_rows) {
-            uint64_t rec[kRowsPerWave];
-#pragma unroll
-            for (int j = 0; j < kRowsPerWave; ++j) {               // the merged rows parked in phase 1 (this CU's L2)
-                const int u = j < rows ? row_u[li0 + j] : 0;
-                rec[j] = lane < u ? p.scratch[beg[j] + lane] : 0ull;
+            const int head_n = static_cast<int>(a0 - lo), ends = head_n + static_cast<int>(hi - a1);
+            if (lane < 5 * 8) {
+                const int arr = lane >> 3, e = lane & 7;
+                if (e < ends) {
+                    const int64_t sl = e < head_n ? lo + e : a1 + (e - head_n);
+                    outs[arr][sl] = st[arr * kStageW + static_cast<int>(sl - lo)];
+                }
             }
-#pragma unroll
-            for (int j = 0; j < kRowsPerWave; ++j) {
-                if (j >= rows) continue;
-                const int32_t r = static_cast<int32_t>(r0) + j;
-                const int u = row_u[li0 + j], left = row_left[li0 + j];
-                if (lane == 0) {
-                    p.rowptr[r] = static_cast<int32_t>(slot0);
-                    unit_diagonal<true>(p, st, wslot0, r, slot0 + left);
-                }
-                if (lane < u) {
-                    const int32_t c = static_cast<int32_t>(rec[j] & 0xFFFFFFFFull);
-                    const int ln = static_cast<int>((rec[j] >> 32) & 0xFFull), th = static_cast<int>((rec[j] >> 40) & 0xFFull) - 64;
-                    unit_values<true>(p, st, wslot0, r, c, ln, th, cs1, sn1, slot0 + lane + (c > r ? 1 : 0));
-                }
-                slot0 += u + 1;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // drain [wslot0, slot0): the 16-byte aligned middle as dwordx4, the ragged ends (<= 6 slots) as dwords
-            const int64_t lo = wslot0, hi = slot0, a0 = (lo + 3) & ~int64_t(3), a1 = hi & ~int64_t(3);
-            float* const outs[5] = {reinterpret_cast<float*>(p.ccol), p.vb_re, p.vb_im, p.vf_re, p.vf_im};
-            if (a0 < a1) {
-                const int quads = static_cast<int>((a1 - a0) >> 2);
-#pragma unroll
-                for (int arr = 0; arr < 5; ++arr) {
-                    for (int g = lane; g < quads; g += 64) {
-                        const int o = static_cast<int>(a0 - lo) + 4 * g;
-                        const float* src = st + arr * kStageW + o;
-                        const f32x4 v = {src[0], src[1], src[2], src[3]};
-                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(outs[arr] + a0) + g);
-                    }
-                }
-                const int head_n = static_cast<int>(a0 - lo), ends = head_n + static_cast<int>(hi - a1);
-                if (lane < 5 * 8) {
-                    const int arr = lane >> 3, e = lane & 7;
-                    if (e < ends) {
-                        const int64_t sl = e < head_n ? lo + e : a1 + (e - head_n);
-                        outs[arr][sl] = st[arr * kStageW + static_cast<int>(sl - lo)];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int arr = 0; arr < 5; ++arr)
-                    for (int64_t sl = lo + lane; sl < hi; sl += 64) outs[arr][sl] = st[arr * kStageW + static_cast<int>(sl - lo)];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the next group re-uses the staging region
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
 #pragma unroll
-            for (int j = 0; j < kRowsPerWave; ++j) {
-                if (j >= rows) continue;
-                const int32_t r = static_cast<int32_t>(r0) + j;
-                const int u = row_u[li0 + j], left = row_left[li0 + j];
-                if (lane == 0) {
-                    p.rowptr[r] = static_cast<int32_t>(slot0);
-                    unit_diagonal<false>(p, st, wslot0, r, slot0 + left);
+            for (int arr = 0; arr < 5; ++arr)
+                for (int64_t sl = lo + lane; sl < hi; sl += 64) outs[arr][sl] = st[arr * kStageW + static_cast<int>(sl - lo)];
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < kRowsPerWave; ++j) {
+        if (j >= rows) continue;
+        const int32_t r = static_cast<int32_t>(r0) + j;
+        if (lane == 0) unit_diagonal<false>(p, st, wslot0, r, slot0 + left[j]);
+        if (cnt[j] <= 64) {
+            if (lane < u[j]) {
+                const uint64_t rc = p.scratch[beg[j] + lane];
+                const int32_t c = static_cast<int32_t>(rc & 0xFFFFFFFFull);
+                const int ln = static_cast<int>((rc >> 32) & 0xFFull), th = static_cast<int>((rc >> 40) & 0xFFull) - 64;
+                unit_values<false>(p, st, wslot0, r, c, ln, th, cs1, sn1, slot0 + lane + (c > r ? 1 : 0));
+            }
+        } else if (cnt[j] <= kUnitRowMax) {
+            int base_rank = 0;
+            for (int i0 = 0; i0 < cnt[j]; i0 += 64) {
+                const int i = i0 + lane;
+                bool hd = false;
+                uint32_t cur = 0;
+                if (i < cnt[j]) {
+                    cur = static_cast<uint32_t>(p.scratch[beg[j] + i]) >> 1;
+                    hd = i == 0 || (static_cast<uint32_t>(p.scratch[beg[j] + i - 1]) >> 1) != cur;
                 }
-                if (cnt[j] <= 64) {
-                    if (lane < u) {
-                        const uint64_t rc = p.scratch[beg[j] + lane];
-                        const int32_t c = static_cast<int32_t>(rc & 0xFFFFFFFFull);
-                        const int ln = static_cast<int>((rc >> 32) & 0xFFull), th = static_cast<int>((rc >> 40) & 0xFFull) - 64;
-                        unit_values<false>(p, st, wslot0, r, c, ln, th, cs1, sn1, slot0 + lane + (c > r ? 1 : 0));
+                const uint64_t H = __ballot(hd);
+                if (hd) {
+                    int ln = 0, n1 = 0;
+                    for (int t = i; t < cnt[j]; ++t) {             // the run: short (multiplicity of one neighbour)
+                        const uint32_t k2 = static_cast<uint32_t>(p.scratch[beg[j] + t]);
+                        if ((k2 >> 1) != cur) break;
+                        ++ln;
+                        n1 += static_cast<int>(k2 & 1u);
                     }
-                } else if (cnt[j] <= kUnitRowMax) {
-                    int base_rank = 0;
-                    for (int i0 = 0; i0 < cnt[j]; i0 += 64) {
-                        const int i = i0 + lane;
-                        bool hd = false;
-                        uint32_t cur = 0;
-                        if (i < cnt[j]) {
-                            cur = static_cast<uint32_t>(p.scratch[beg[j] + i]) >> 1;
-                            hd = i == 0 || (static_cast<uint32_t>(p.scratch[beg[j] + i - 1]) >> 1) != cur;
-                        }
-                        const uint64_t H = __ballot(hd);
-                        if (hd) {
-                            int ln = 0, n1 = 0;
-                            for (int t = i; t < cnt[j]; ++t) {     // the run: short (multiplicity of one neighbour)
-                                const uint32_t k2 = static_cast<uint32_t>(p.scratch[beg[j] + t]);
-                                if ((k2 >> 1) != cur) break;
-                                ++ln;
-                                n1 += static_cast<int>(k2 & 1u);
-                            }
-                            const int rk = base_rank + __popcll(H & ((1ull << lane) - 1ull));
-                            const int32_t c = static_cast<int32_t>(cur);
-                            unit_values<false>(p, st, wslot0, r, c, ln, ln - 2 * n1, cs1, sn1, slot0 + rk + (c > r ? 1 : 0));
-                        }
-                        base_rank += __popcll(H);
-                    }
+                    const int rk = base_rank + __popcll(H & ((1ull << lane) - 1ull));
+                    const int32_t c = static_cast<int32_t>(cur);
+                    unit_values<false>(p, st, wslot0, r, c, ln, ln - 2 * n1, cs1, sn1, slot0 + rk + (c > r ? 1 : 0));
                 }
-                slot0 += u + 1;
+                base_rank += __popcll(H);
             }
         }
-    }
-    // the wavefront that owns the last row closes the row pointer
-    {
-        const int64_t my_last = wave_r0 + kUnitGroups * kRowsPerWave;      // one past this wavefront's rows
-        if (wave_r0 < p.n && my_last >= p.n && lane == 0) {
-            p.rowptr[p.n] = static_cast<int32_t>(slot0);
-            p.info[0] = slot0 - p.n;
-        }
+        slot0 += u[j] + 1;
     }
 }
 
@@ -1038,7 +963,7 @@ using RowSortConfig = rocprim::radix_sort_config<
 
 struct MagopWs {
     size_t keys_a, keys_b, w_a, w_b, rs, ucnt, dinv, shift, ent, long_rows, n_long, sort_tmp, scan_tmp, sort_tmp_bytes,
-        scan_tmp_bytes, status, ticket, total;
+        scan_tmp_bytes, total;
 };
 
 int magop_layout(int64_t e, int32_t n, int weighted, MagopWs* w)
@@ -1073,8 +998,6 @@ int magop_layout(int64_t e, int32_t n, int weighted, MagopWs* w)
     w->scan_tmp = take(scan_tmp);
     w->sort_tmp_bytes = sort_tmp;
     w->scan_tmp_bytes = scan_tmp;
-    w->status = take((nn / kUnitRows + 2) * 8);                // look-back words of row_finish_unit, one per block of its rows
-    w->ticket = take(256);
     w->total = off + 256;
     return 0;
 }
@@ -1241,20 +1164,24 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
     } else {
         PYGSD_HIP_TRY(hipMemsetAsync(rs, 0, sizeof(int32_t) * (static_cast<size_t>(n) + 2), s));
     }
-    hipLaunchKernelGGL(unit_row_tables, dim3(grid_for(n)), dim3(kBlock), 0, s, rs, n, sym, deg, dinv);
+    int32_t* ucnt = reinterpret_cast<int32_t*>(base + l.ucnt);
+    int32_t* left = reinterpret_cast<int32_t*>(base + l.shift);
+    hipLaunchKernelGGL(unit_row_tables, dim3(grid_for(n)), dim3(kBlock), 0, s, rs, n, sym, deg, dinv, ucnt);
     if (int rc = check_launch("unit_row_tables")) return rc;
-    const unsigned blocks = static_cast<unsigned>((static_cast<int64_t>(n) + kUnitRows - 1) / kUnitRows);
-    unsigned long long* status = reinterpret_cast<unsigned long long*>(base + l.status);
-    int32_t* ticket = reinterpret_cast<int32_t*>(base + l.ticket);
-    PYGSD_HIP_TRY(hipMemsetAsync(status, 0, static_cast<size_t>(blocks + 1) * 8, s));
-    PYGSD_HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(int32_t), s));
     // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64
     const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * static_cast<double>(q));
-    UnitArgs a{keys_b, keys_a, rs, deg, dinv, rowptr, ccol, vb_real, vb_imag, vf_real, vf_imag, status, ticket, d_info,
+    UnitArgs a{keys_b, keys_a, rs, deg, dinv, rowptr, ccol, vb_real, vb_imag, vf_real, vf_imag, ucnt, left, d_info,
                m > 0 ? m : 1, n, sym, two_pi_q, lambda_max, diag_shift};
+    const int64_t per_block = 4 * kRowsPerWave;
+    const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n) + per_block - 1) / per_block);
     if (n <= (1 << 25))
-        hipLaunchKernelGGL(row_finish_unit<uint32_t>, dim3(blocks), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(unit_merge_rows<uint32_t>, dim3(grid), dim3(kBlock), 0, s, a);
     else
-        hipLaunchKernelGGL(row_finish_unit<uint64_t>, dim3(blocks), dim3(kBlock), 0, s, a);
-    return check_launch("row_finish_unit");
+        hipLaunchKernelGGL(unit_merge_rows<uint64_t>, dim3(grid), dim3(kBlock), 0, s, a);
+    if (int rc = check_launch("unit_merge_rows")) return rc;
+    size_t tb = l.scan_tmp_bytes;
+    PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb, rocprim::make_transform_iterator(ucnt, PlusOne()), rowptr, 0,
+                                          static_cast<size_t>(n) + 1, rocprim::plus<int32_t>(), s));
+    hipLaunchKernelGGL(unit_write_rows, dim3(grid), dim3(kBlock), 0, s, a);
+    return check_launch("unit_write_rows");
 }

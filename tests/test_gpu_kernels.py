@@ -911,9 +911,8 @@ def test_fused_operator_build_long_rows_and_fallback(weighted):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("norm,lam", [("sym", 2.0), (None, 3.0)])
-def test_unit_operator_build_long_rows_chained_prefix_and_determinism(norm, lam):
-    """pygsd_magop_unit (unweighted graphs: rows merged and written in one pass, row pointer chained through the kernel by a
-    decoupled look-back): rows of 64 / 65 / 103 / 303 / 512 stream entries (from 65: the rank sort through LDS, direct stores),
+def test_unit_operator_build_long_rows_and_determinism(norm, lam):
+    """pygsd_magop_unit (unweighted graphs: merged rows parked as 8-byte records, written after the scan): rows of 64 / 65 / 103 / 303 / 512 stream entries (from 65: the rank sort through LDS, direct stores),
     duplicates, reciprocal pairs, self loops, isolated nodes, a node count that is not a multiple of the 16 rows of a
     block -- bit-identical to the generic pipeline and from run to run; 513 entries make it step aside."""
     from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
