@@ -80,6 +80,15 @@ typedef struct pygsd_long_rows {
     int64_t workspace_bytes;
 } pygsd_long_rows;
 
+/* K = 1 magnetic layer forward with 64 input and 64 output features (the north-star shape of MagNetConv.py:189-247), the dense
+ * stage in the dual SpMM's epilogue:  Ta = S_a X_a, Tb = S_b X_b (both written: the backward's operands), and
+ *   out_r = (Xa - Xb) W[0] + (Ta - Tb) W[1] + bias ,  out_i = (Xa + Xb) W[0] + (Ta + Tb) W[1] + bias
+ * with W [2][64][64] row-major and bias [64] or NULL -- what pygsd_spmm2_csr_f32 followed by pygsd_magnetic_dense_fwd_f32
+ * compute, without re-reading T from HBM.  Rows longer than PYGSD_LONG_ROW are not split here: callers with hub rows keep the
+ * two-call form.  Optional path (dense.set_fused_k1 / PYGSD_FUSE_K1), see DESIGN.md for the measurement. */
+int pygsd_spmm2_k1_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val_a, const float* val_b, const float* Xa,
+                             const float* Xb, int64_t ldx, float* Ta, float* Tb, int64_t ldt, const float* W, const float* bias,
+                             float* out_r, float* out_i, int64_t ldo, int32_t n_rows, int64_t nnz_hint, void* stream);
 int pygsd_spmm_long_rows_workspace(int32_t n_long, int32_t max_entries, int32_t n_feat, int32_t dual,
                                    int64_t* bytes);
 

@@ -46,6 +46,8 @@ PROTOTYPES = {
     "pygsd_spmm2_csr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                       c_int32, c_float, c_float, c_int64, c_void_p, c_void_p]),
+    "pygsd_spmm2_k1_dense_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                           c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p]),
     "pygsd_sddmm_coo_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                       c_int32, c_void_p, c_void_p]),
     # the attention / segment entry points take (..., long_rows descriptor or NULL, stream) last

@@ -187,6 +187,113 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_kernel(SpmmArgs 
 }
 
 // ------------------------------------------------------------------------------------------
+// K = 1 magnetic layer, forward, F_in = F_out = 64 (the north-star shape): the dense stage in the dual SpMM's epilogue.
+//   T1_r = S_r^T x_r, T1_i = S_i^T x_i (written: the backward needs them)
+//   out_real = (x_r - x_i) W_0 + (T1_r - T1_i) W_1 + b ,  out_imag = (x_r + x_i) W_0 + (T1_r + T1_i) W_1 + b
+// (MagNetConv.py:189-247 for K = 1).  After the butterfly every lane group holds the row's two products; the 64 lanes
+// then compute one output column each: 128 features are broadcast with v_readlane (an SGPR operand of the FMA), W sits in LDS
+// ([128][64], lane j reads column j: conflict-free), 256 FMAs per lane on a kernel whose VALU is idle two thirds of the time
+// (it is bound by the gathers).  Saves the separate dense pass' re-read of T1 and a launch; costs LDS (32 KB per block) and
+// ~600 VALU instructions per row.  Behind PYGSD_FUSE_K1 / dense.set_fused_k1 -- measured both ways, see DESIGN.md.
+// ------------------------------------------------------------------------------------------
+struct SpmmK1Args {
+    SpmmArgs s;
+    const float* w;         // [2][64][64]
+    const float* bias;      // [64] or null
+    float* out_r;
+    float* out_i;
+    int64_t ldo;
+};
+
+template <bool DEEP>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void spmm2_k1_dense_kernel(SpmmK1Args q)
+{
+    constexpr int LPR = 16, NPW = 4;
+    constexpr int UB = DEEP ? 8 : 2;
+    __shared__ float wl[128 * 64];
+    const SpmmArgs& p = q.s;
+    for (int i = threadIdx.x; i < 128 * 64; i += kWavesPerBlock * 64) wl[i] = q.w[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(
+        static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6));
+    if (row >= p.n_rows) return;
+    const int sub = lane / LPR;
+    const int fl = (lane % LPR) * 4;
+    const int beg = p.rowptr[row];
+    const int end = p.rowptr[row + 1];
+    float4 acc_a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xa = p.xa + fl;
+    const float* xb = p.xb + fl;
+    for (int base = beg; base < end; base += 64) {
+        const int cnt = (end - base) < 64 ? (end - base) : 64;
+        int c = 0;
+        float wa = 0.f, wb = 0.f;
+        if (lane < cnt) {
+            c = __builtin_nontemporal_load(p.col + base + lane);
+            wa = __builtin_nontemporal_load(p.va + base + lane);
+            wb = __builtin_nontemporal_load(p.vb + base + lane);
+        }
+        int u = 0;
+        for (; cnt - u >= NPW * UB; u += NPW * UB)
+            gather_step<LPR, true, UB>(u, cnt, sub, true, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
+        if (UB >= 8 && cnt - u >= NPW * (UB / 2)) {
+            gather_step<LPR, true, (UB >= 8 ? UB / 2 : 1)>(u, cnt, sub, true, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
+            u += NPW * (UB / 2);
+        }
+        for (; u < cnt; u += NPW * 2)
+            gather_step<LPR, true, 2>(u, cnt, sub, true, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
+    }
+    // the row's own features (T_0): loaded behind the gather loop, so that the loop keeps the plain kernel's register count
+    // (and with it 4 wavefronts per SIMD); their latency overlaps the butterfly and the T_1 stores
+    const float4 x0a = ld4(xa + static_cast<int64_t>(row) * p.ldx);
+    const float4 x0b = ld4(xb + static_cast<int64_t>(row) * p.ldx);
+    reduce_groups<LPR>(acc_a);
+    reduce_groups<LPR>(acc_b);
+    if (sub == 0) {
+        const int64_t yo = static_cast<int64_t>(row) * p.ldy + fl;
+        st4(p.ya + yo, acc_a);
+        st4(p.yb + yo, acc_b);
+    }
+    // lane group 0 (lanes 0..15) holds feature quads 0..15 of all four 64-vectors
+    const float d0[4] = {x0a.x - x0b.x, x0a.y - x0b.y, x0a.z - x0b.z, x0a.w - x0b.w};
+    const float s0[4] = {x0a.x + x0b.x, x0a.y + x0b.y, x0a.z + x0b.z, x0a.w + x0b.w};
+    const float d1[4] = {acc_a.x - acc_b.x, acc_a.y - acc_b.y, acc_a.z - acc_b.z, acc_a.w - acc_b.w};
+    const float s1[4] = {acc_a.x + acc_b.x, acc_a.y + acc_b.y, acc_a.z + acc_b.z, acc_a.w + acc_b.w};
+    float o_r = 0.f, o_i = 0.f;
+    const float* wcol = wl + lane;                                  // column j = lane of W_0 (rows 0..63) and W_1 (64..127)
+    // (partially unrolled: fully unrolled, the 128 LDS reads are hoisted in front of the FMAs and the kernel needs 150 VGPRs --
+    // one wavefront per SIMD fewer than the plain dual kernel, whose occupancy is what the gathers live on)
+#pragma unroll 2
+    for (int qd = 0; qd < 16; ++qd) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const float w0 = wcol[(4 * qd + cc) * 64];
+            const float dv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d0[cc]), qd));
+            const float sv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s0[cc]), qd));
+            o_r = fmaf(dv, w0, o_r);
+            o_i = fmaf(sv, w0, o_i);
+        }
+    }
+#pragma unroll 2
+    for (int qd = 0; qd < 16; ++qd) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const float w1 = wcol[(64 + 4 * qd + cc) * 64];
+            const float dv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d1[cc]), qd));
+            const float sv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1[cc]), qd));
+            o_r = fmaf(dv, w1, o_r);
+            o_i = fmaf(sv, w1, o_i);
+        }
+    }
+    const float bj = q.bias ? q.bias[lane] : 0.f;
+    const int64_t oo = static_cast<int64_t>(row) * q.ldo + lane;
+    q.out_r[oo] = o_r + bj;
+    q.out_i[oo] = o_i + bj;
+}
+
+// ------------------------------------------------------------------------------------------
 // Hub rows (power-law tails).  One wavefront per row makes a row with 10^5..10^6 entries the critical path
 // (27 us per 1000 entries: 27 ms for a 1M-entry hub against 0.14 ms for the rest of a 4M-entry operator).
 // Rows longer than PYGSD_LONG_ROW entries are therefore skipped by the main kernel and handled here:
@@ -951,4 +1058,30 @@ extern "C" int pygsd_sddmm_coo_f32(const int32_t* ia, const int32_t* ib, int64_t
         hipLaunchKernelGGL(sddmm_kernel<false>, dim3(grid), dim3(256), 0, s, ia, ib, nnz, A, lda, B, ldb,
                            n_feat, out);
     return check_launch("sddmm_kernel");
+}
+
+extern "C" int pygsd_spmm2_k1_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val_a, const float* val_b,
+                                        const float* Xa, const float* Xb, int64_t ldx, float* Ta, float* Tb, int64_t ldt,
+                                        const float* W, const float* bias, float* out_r, float* out_i, int64_t ldo,
+                                        int32_t n_rows, int64_t nnz_hint, void* stream)
+{
+    PYGSD_REQUIRE(n_rows >= 0, "pygsd_spmm2_k1_dense_f32: negative size");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(rowptr && col && val_a && val_b && Xa && Xb && Ta && Tb && W && out_r && out_i,
+                  "pygsd_spmm2_k1_dense_f32: null pointer");
+    PYGSD_REQUIRE(ldx >= 64 && ldt >= 64 && ldo >= 64 && ldx % 4 == 0 && ldt % 4 == 0,
+                  "pygsd_spmm2_k1_dense_f32: 64 features, row strides >= 64 and multiples of 4");
+    PYGSD_REQUIRE(aligned16(Xa) && aligned16(Xb) && aligned16(Ta) && aligned16(Tb), "pygsd_spmm2_k1_dense_f32: feature matrices "
+                  "must be 16-byte aligned");
+    SpmmK1Args a{SpmmArgs{rowptr, col, val_a, val_b, Xa, Xb, Ta, Tb, nullptr, nullptr, ldx, ldt, 0, n_rows, 64, 1.f, 0.f, 0, 0},
+                 W, bias, out_r, out_i, ldo};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_SPMM2, s);
+    const dim3 block(kWavesPerBlock * 64);
+    const unsigned gx = (static_cast<unsigned>(n_rows) + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (nnz_hint >= static_cast<int64_t>(28) * n_rows)
+        hipLaunchKernelGGL(spmm2_k1_dense_kernel<true>, dim3(gx), block, 0, s, a);
+    else
+        hipLaunchKernelGGL(spmm2_k1_dense_kernel<false>, dim3(gx), block, 0, s, a);
+    return check_launch("spmm2_k1_dense_kernel");
 }

@@ -109,6 +109,33 @@ class FixedSpmm2(torch.autograd.Function):
         return gxa, gxb, gza, gzb, None, None, None
 
 
+_FUSED_K1 = os.environ.get("PYGSD_FUSE_K1", "0") == "1"
+
+
+def set_fused_k1(on: bool) -> bool:
+    """K = 1 layers with 64 -> 64 features: run the forward dense stage in the dual SpMM's epilogue
+    (pygsd_spmm2_k1_dense_f32) instead of as its own MFMA pass.  Off by default (PYGSD_FUSE_K1=1 turns it on): measured
+    both ways, DESIGN.md section 5.  Returns the previous setting."""
+    global _FUSED_K1
+    prev, _FUSED_K1 = _FUSED_K1, bool(on)
+    return prev
+
+
+def spmm2_k1_dense_raw(csr, va: Tensor, vb: Tensor, x_real: Tensor, x_imag: Tensor, weight: Tensor, bias: Optional[Tensor]):
+    """-> (T1_real, T1_imag, out_real, out_imag) of a K = 1, 64 -> 64 magnetic layer in ONE launch."""
+    n = csr.n_rows
+    xa, xb = x_real.contiguous(), x_imag.contiguous()
+    w = weight.detach().contiguous()
+    bd = None if bias is None else bias.detach().contiguous()
+    ta, tb = torch.empty_like(xa), torch.empty_like(xb)
+    out_r, out_i = torch.empty((n, 64), dtype=torch.float32, device=xa.device), torch.empty((n, 64), dtype=torch.float32, device=xa.device)
+    with torch.cuda.device(xa.device):
+        check(_cabi.lib().pygsd_spmm2_k1_dense_f32(ptr(csr.rowptr), ptr(csr.col), ptr(va), ptr(vb), ptr(xa), ptr(xb), 64, ptr(ta),
+                                                   ptr(tb), 64, ptr(w), ptr(bd), ptr(out_r), ptr(out_i), 64, n, csr.nnz,
+                                                   stream_ptr()), "pygsd_spmm2_k1_dense_f32")
+    return ta, tb, out_r, out_i
+
+
 class MagneticConvFunction(torch.autograd.Function):
     """One autograd node for a whole MagNetConv / MSConv layer with fixed operator values:
     K fused dual-value SpMMs (Chebyshev recurrence in the kernel epilogue) + one fused MFMA dense
@@ -120,6 +147,13 @@ class MagneticConvFunction(torch.autograd.Function):
     def forward(ctx, x_real, x_imag, weight, bias, op):
         k1 = weight.size(0)
         csr, (vr, vi) = op.csr, op.values_fwd
+        if (_FUSED_K1 and k1 == 2 and weight.size(1) == 64 and weight.size(2) == 64 and x_real.dtype == torch.float32
+                and csr.n_rows == csr.n_cols == x_real.size(0) and csr.nnz > 0 and csr.hubs() is None):
+            xr, xi = x_real.contiguous(), x_imag.contiguous()
+            t1r, t1i, out_r, out_i = spmm2_k1_dense_raw(csr, vr, vi, xr, xi, weight, bias)
+            ctx.op, ctx.k1, ctx.has_bias = op, k1, bias is not None
+            ctx.save_for_backward(weight, xr, t1r, xi, t1i)
+            return out_r, out_i
         ta, tb = [x_real.contiguous()], [x_imag.contiguous()]
         for k in range(1, k1):
             if k == 1:

@@ -1225,3 +1225,35 @@ def test_hip_matmul_is_differentiable():
     pt = a0.to(dev()).t().requires_grad_()                          # a transposed view as the left operand: P^T (A P)
     (matmul(pt, go.to(dev())) * b0.to(dev())).sum().backward()
     close(pt.grad, (go.double() @ b0.double().t()).t(), what="d (transposed view)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,e,bias", [(3000, 120000, True), (777, 9000, False), (5, 7, True)])
+def test_fused_k1_forward_matches_the_two_kernel_form(n, e, bias):
+    """pygsd_spmm2_k1_dense_f32 (K = 1, 64 -> 64: the dense stage in the dual SpMM's epilogue) against the default route (dual
+    SpMM, then the MFMA dense pass) through the layer: outputs and every gradient; T_1 is bit-identical (same gather order)."""
+    from pytorch_geometric_signed_directed_amd import dense
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    g = torch.Generator().manual_seed(n)
+    ei = torch.randint(0, n, (2, e), generator=g).to(dev())
+    xr0, xi0 = torch.randn(n, 64, generator=g).to(dev()), torch.randn(n, 64, generator=g).to(dev())
+    gr, gi = torch.randn(n, 64, generator=g).to(dev()), torch.randn(n, 64, generator=g).to(dev())
+    torch.manual_seed(n)
+    layer = MagNetConv(64, 64, 1, 0.25, False, bias=bias, cached=True).to(dev())
+    if bias:
+        with torch.no_grad():
+            layer.bias.uniform_(-0.5, 0.5)
+    res = []
+    for fused in (False, True):
+        prev = dense.set_fused_k1(fused)
+        try:
+            layer.zero_grad(set_to_none=True)
+            a, b = xr0.clone().requires_grad_(), xi0.clone().requires_grad_()
+            o_r, o_i = layer(a, b, ei)
+            ((o_r * gr).sum() + (o_i * gi).sum()).backward()
+            res.append([o_r.detach(), o_i.detach(), a.grad, b.grad, layer.weight.grad.clone()] + ([layer.bias.grad.clone()] if bias else []))
+        finally:
+            dense.set_fused_k1(prev)
+    names = ["out_real", "out_imag", "dx_real", "dx_imag", "dW", "db"]
+    for k, (want, got) in enumerate(zip(*res)):
+        close(got, want, norm=k >= 4, what=f"fused K=1 forward: {names[k]}")
