@@ -202,6 +202,23 @@ def self_launch(args_list, gpus):
     return subprocess.call(cmd, env=env)
 
 
+def dram_bound_reference():
+    """The same kernel where the gathered set is 8x the Infinity Cache (DSBM 4M nodes / 80M edges: 2 GiB gathered) -- a
+    DRAM-bound fraction beside the fabric-side `frac` of this run.  REPLAYED from a separate, tracked capture
+    (tools/northstar_x4.py -> profiles/r4_northstar_x4.json); null if the file is missing."""
+    path = os.path.join(ROOT, "profiles", "r4_northstar_x4.json")
+    try:
+        rec = json.load(open(path))
+        k = rec["dual_spmm"]
+        return {"source": "profiles/r4_northstar_x4.json (tools/northstar_x4.py, a separate run -- replayed, not measured here)",
+                "workload": rec["workload"], "gathered_set_GiB": rec["gathered_set_GiB"],
+                "achieved": k["algorithmic_GBps"], "frac": k["fraction_of_8TBps"],
+                "streaming_copy_GBps_same_run": k["streaming_copy_GBps_same_run"],
+                "frac_of_streaming_copy": k["fraction_of_streaming_copy"], "ms_per_launch": k["ms_per_launch"]}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -566,7 +583,8 @@ def main():
                                     "requests routed to the memory side, cache hits included)",
                          "traffic": traffic, "traffic_source": traffic_source,
                          "launches": int(launches), "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": alg_total / max(launches, 1)},
+                         "algorithmic_bytes_per_launch": alg_total / max(launches, 1),
+                         "dram_bound_reference": dram_bound_reference()},
             "kernel_ms_per_step": {"spmm2": kernel_ms / args.steps,
                                    **{k: v[1] / args.steps for k, v in other.items()}},
         }

@@ -42,6 +42,25 @@ def timed(step, iters=10, warm=3):
     return ms, {k: {"launches_per_step": n / iters, "ms_per_launch": (t / n if n else 0.0)} for k, (n, t) in prof.items()}
 
 
+def replayed(step, iters=20):
+    """The same step captured into a hipGraph (hipgraph.capture_step) and replayed: the step without its host launch path
+    (a few dozen launches of tens of microseconds each).  None when the capture fails."""
+    from pytorch_geometric_signed_directed_amd.hipgraph import capture_step
+    try:
+        g = capture_step(step)
+        for _ in range(3):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            g()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+    except Exception as exc:  # noqa: BLE001
+        print("hipGraph capture failed:", repr(exc)[:200], flush=True)
+        return None
+
+
 def spmm_bytes(nnz, n, f, s=4, val=True):
     return nnz * (4 + (4 if val else 0) + f * s) + n * f * s + 4 * (n + 1)
 
@@ -129,7 +148,8 @@ def signed_c3(n=500000, entries=10000000, h=64):
         b = spmm_bytes(pos.size(1), n, h // 2, val=False) + spmm_bytes(neg.size(1), n, h // 2, val=False)
         k = prof["spmm"]
         out["C3_sgcnconv_first"] = {"nodes": n, "pos_entries": int(pos.size(1)), "neg_entries": int(neg.size(1)),
-                                    "hidden": h, "ms_per_step": ms, "entries_per_s": ei.size(1) / ms * 1e3, "kernels": prof,
+                                    "hidden": h, "ms_per_step": ms, "ms_per_step_hipgraph_replay": replayed(step),
+                                    "entries_per_s": ei.size(1) / ms * 1e3, "kernels": prof,
                                     "spmm_alg_GBps_fwd_pair": b / (2 * k["ms_per_launch"]) / 1e6 if k["ms_per_launch"] else None}
         out["C3_sgcnconv_first"].update(residency(n * (h // 2) * 4, out["C3_sgcnconv_first"]["spmm_alg_GBps_fwd_pair"]))
         print("C3_sgcnconv_first", json.dumps(out["C3_sgcnconv_first"]), flush=True)
@@ -146,7 +166,8 @@ def signed_c3(n=500000, entries=10000000, h=64):
         simpa.zero_grad(set_to_none=True); xp.grad = xn.grad = None
         simpa(pos, wp, neg, wn, xp, xn).sum().backward()
     ms, prof = timed(step2)
-    out["C3_simpa_hop2"] = {"nodes": n, "hidden": h, "pos_entries": int(pos.size(1)), "neg_entries": int(neg.size(1)), "ms_per_step": ms, "entries_per_s": ei.size(1) / ms * 1e3,
+    out["C3_simpa_hop2"] = {"nodes": n, "hidden": h, "pos_entries": int(pos.size(1)), "neg_entries": int(neg.size(1)), "ms_per_step": ms,
+                            "ms_per_step_hipgraph_replay": replayed(step2), "entries_per_s": ei.size(1) / ms * 1e3,
                             "kernels": prof, "note": "6 SpMM fwd + 6 bwd (4 on A_p, 2 on A_n) per step; the reference's unused last-hop product is skipped"}
     print("C3_simpa_hop2", json.dumps(out["C3_simpa_hop2"]), flush=True)
     torch.cuda.empty_cache()
@@ -196,6 +217,7 @@ def digcn_c5(n=2000000, e=25000000, h=64):
         b = spmm_bytes(nnz, n, h, s=s_el)
         k = prof["spmm"]
         res[str(dtype).split(".")[-1]] = {"ms_per_block_step": ms, "ms_per_block_step_incl_sum_loss": ms_loss,
+                                          "ms_per_block_step_hipgraph_replay": replayed(step),
                                           "nnz_per_operator": nnz, "kernels": prof,
                                           "spmm_alg_GBps": b / k["ms_per_launch"] / 1e6 if k["ms_per_launch"] else None,
                                           "nnz_per_s": 2 * nnz / ms * 1e3}

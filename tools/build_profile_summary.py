@@ -1,6 +1,6 @@
-"""Condense the operator-build captures of tools/capture_r3.sh (gpurun_out/r3_prof_build: rocprofv3 --kernel-trace --stats;
-gpurun_out/r3_pmc_build_fetch / _write: separate --pmc FETCH_SIZE / WRITE_SIZE passes of the same command) into
-profiles/r3_build_kernel_stats.csv: per kernel of ONE fused north-star build (unweighted leg), average duration, launches
+"""Condense the operator-build captures (ROUND=r3: tools/capture_r3.sh -> gpurun_out/r3_prof_build, r3_pmc_build_fetch / _write;
+ROUND=r4: tools/capture_r4_final.sh -> gpurun_out/r4_prof_build, r4_pmc_build_FETCH_SIZE / _WRITE_SIZE: rocprofv3 --kernel-trace
+--stats and separate --pmc FETCH_SIZE / WRITE_SIZE passes of the same command) into profiles/<round>_build_kernel_stats.csv: per kernel of ONE fused north-star build (unweighted leg), average duration, launches
 per build, FETCH_SIZE / WRITE_SIZE per launch and the bytes the kernel has to move by its algorithm.
 HBM bytes per MI355X_MICROARCH.md: the counters are in KiB; FETCH_SIZE tallies the 128-byte requests of wide (8 / 16 bytes
 per lane) reads as 64 bytes on gfx950, so fetched bytes = FETCH_SIZE x 1024 x 2 (marked `x2`; narrower accesses are
@@ -14,8 +14,10 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
+ROUND = os.environ.get("ROUND", "r3")
 NAMES = ["edge_keys", "onesweep_histograms", "onesweep_iteration", "key_row_starts", "row_merge_wave", "row_merge_block",
-         "lookback_scan", "init_lookback", "row_tables", "values_entries", "diagonal_of_empty_rows"]
+         "lookback_scan", "init_lookback", "unit_row_tables", "unit_merge_rows", "unit_write_rows", "row_tables", "values_entries",
+         "diagonal_of_empty_rows"]
 
 
 def short(name):
@@ -44,7 +46,7 @@ def counters(directory, counter):
 
 
 def main():
-    probe = json.load(open(os.path.join(OUT, "r3_build_probe.json")))
+    probe = json.load(open(os.path.join(OUT, ROUND + "_build_probe.json")))
     n, e, nnz = probe["nodes"], probe["edges"], probe["operator_nnz"]
     m = 2 * e
     # what each kernel must move (unweighted leg): bytes in + out by the algorithm
@@ -56,18 +58,23 @@ def main():
         "row_merge_wave": 8 * m + 16 * m + 12 * n,         # keys in, 16-byte records out, per-row count / degree
         "row_tables": 16 * n,
         "values_entries": 16 * m + 20 * nnz + 12 * n,      # records in, col + 4 value arrays out (+ row tables, gathers extra)
+        # round 4, unweighted: merged rows as 8-byte records (one per distinct neighbour), read back after the scan
+        "unit_row_tables": 12 * n,
+        "unit_merge_rows": 8 * m + 8 * (nnz - n) + 12 * n,
+        "unit_write_rows": 8 * (nnz - n) + 20 * nnz + 16 * n,
     }
     stats = {}
-    for path in glob.glob(os.path.join(OUT, "r3_prof_build", "**", "*kernel_stats.csv"), recursive=True):
+    for path in glob.glob(os.path.join(OUT, ROUND + "_prof_build", "**", "*kernel_stats.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
             k = short(row["Name"])
             if k:
                 rec = stats.setdefault(k, {"calls": 0, "total_ns": 0.0})
                 rec["calls"] += int(row["Calls"])
                 rec["total_ns"] += float(row["TotalDurationNs"])
-    fetch, write = counters("r3_pmc_build_fetch", "FETCH_SIZE"), counters("r3_pmc_build_write", "WRITE_SIZE")
+    names = ("r3_pmc_build_fetch", "r3_pmc_build_write") if ROUND == "r3" else (ROUND + "_pmc_build_FETCH_SIZE", ROUND + "_pmc_build_WRITE_SIZE")
+    fetch, write = counters(names[0], "FETCH_SIZE"), counters(names[1], "WRITE_SIZE")
     os.makedirs(PROF, exist_ok=True)
-    with open(os.path.join(PROF, "r3_build_kernel_stats.csv"), "w", newline="") as fh:
+    with open(os.path.join(PROF, ROUND + "_build_kernel_stats.csv"), "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel", "calls_in_trace", "avg_us", "FETCH_SIZE_KiB_per_launch", "fetched_MB_x2", "WRITE_SIZE_KiB_per_launch",
                     "written_MB", "algorithmic_MB", "algorithmic_GBps_at_avg"])
@@ -78,8 +85,8 @@ def main():
                         None if f is None else round(f * 1024 * 2 / 1e6, 1), None if wr is None else round(wr, 1),
                         None if wr is None else round(wr * 1024 / 1e6, 1), None if alg is None else round(alg / 1e6, 1),
                         None if alg is None else round(alg / avg, 1)])
-    json.dump(probe, open(os.path.join(PROF, "r3_build_probe.json"), "w"), indent=1)
-    print(open(os.path.join(PROF, "r3_build_kernel_stats.csv")).read())
+    json.dump(probe, open(os.path.join(PROF, ROUND + "_build_probe.json"), "w"), indent=1)
+    print(open(os.path.join(PROF, ROUND + "_build_kernel_stats.csv")).read())
 
 
 if __name__ == "__main__":
