@@ -188,8 +188,8 @@ def set_unit_build(on: bool) -> bool:
 
 
 def _unit_operator_csr(row: Tensor, col: Tensor, e: int, n: int, sym: int, q: float, lambda_max: float, diag_shift: float):
-    """pygsd_magop_unit: edge list without weights -> final CSR + values in ONE call (the row pointer is a prefix chained
-    through the kernel that merges the rows, so nothing waits for a scan or a second stage).  ONE host read: E_s, the
+    """pygsd_magop_unit: edge list without weights -> final CSR + values in ONE call (unit weights: degrees from the row
+    bounds, merged rows parked as 8-byte records between the merge and the write kernel).  ONE host read: E_s, the
     bad-id witness and the over-long-row count.  None: a row longer than the kernel takes (caller: two-stage pipeline)."""
     from ..sparse import CSR
     dev = row.device
