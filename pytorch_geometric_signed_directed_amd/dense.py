@@ -340,7 +340,8 @@ def _gemm_fallback(segments, w, transposed, bias, k_total, f_out):
             y = gemm(t, blk, bias=bias if y is None else None, out=y, accumulate=y is not None)
             at += t.size(1)
         return y
-    _cabi.note_library_route("tall_product", f"{tuple(x0.shape)} {x0.dtype} x K={k_total} -> {f_out}")
+    if x0.is_cuda:                    # (CPU tensors only reach this through the gloo restatements of the sharded tests)
+        _cabi.note_library_route("tall_product", f"{tuple(x0.shape)} {x0.dtype} x K={k_total} -> {f_out}")
     y, at = None, 0
     for t in segments:
         blk = w[:, at:at + t.size(1)].t() if transposed else w[at:at + t.size(1)]
@@ -445,7 +446,8 @@ def tall_gram(xs, gs) -> Tensor:
     g = gs[0] if len(gs) == 1 else torch.cat(gs, dim=1)
     if _TALL_KERNELS and x.is_cuda and dtype == torch.float32 and g.dtype == torch.float32:
         return gemm(x.t(), g)                       # generic HIP GEMM, reduction over the rows split over the blocks
-    _cabi.note_library_route("tall_gram", f"{tuple(x.shape)}^T {tuple(g.shape)} {dtype}")
+    if x.is_cuda:
+        _cabi.note_library_route("tall_gram", f"{tuple(x.shape)}^T {tuple(g.shape)} {dtype}")
     slab = _TallLinear.SLAB
     s = n // slab
     if s < 8:

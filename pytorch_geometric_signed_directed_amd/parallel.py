@@ -1160,6 +1160,140 @@ class ShardedDiGCNInceptionBlock(_GradSync, torch.nn.Module):
         return tuple(_zero_pad_rows(self.plan, t) for t in (x0, x1, x2))
 
 
+class ShardedSGCNConv(_GradSync, torch.nn.Module):
+    """SGCNConv (reference nn/signed/SGCNConv.py:94-126: mean over positive / negative incoming edges, concatenated with
+    the node's own features, Linear) over a node-range-sharded graph, for in_dim >= out_dim (the narrowing layers of SGCN).
+    As the un-sharded layer it multiplies first: one local product x [own_b | own_u | agg_1 | ...] (the Linear's blocks as
+    column blocks), then every aggregated block -- out_dim wide -- goes through ONE shared all-gather and its own
+    mean-reducing operator rows; the exchange moves m * out_dim columns per node (m = 2 first / 4 deep aggregation) instead
+    of the m input blocks.  Parameters (`lin_b`, `lin_u`: the reference's state_dict keys) are replicated, their gradients
+    all-reduced at the end of every backward pass."""
+
+    def __init__(self, in_dim: int, out_dim: int, first_aggr: bool, num_nodes: int, pos_edge_index: Tensor,
+                 neg_edge_index: Tensor, bias: bool = True, device=None, group=None, exchange=None, balance: bool = True,
+                 kernels=None):
+        super().__init__()
+        if in_dim < out_dim:
+            raise NotImplementedError("ShardedSGCNConv multiplies before it aggregates: in_dim >= out_dim")
+        self.in_dim, self.out_dim, self.first_aggr = in_dim, out_dim, first_aggr
+        k = 2 if first_aggr else 3
+        self.lin_b = torch.nn.Linear(k * in_dim, out_dim, bias)
+        self.lin_u = torch.nn.Linear(k * in_dim, out_dim, bias)
+        device = device or pos_edge_index.device
+        self.to(device)
+        self.exchange = exchange if exchange is not None else DistExchange(group)
+        pos, neg = pos_edge_index.to(device), neg_edge_index.to(device)
+        self.plan = make_plan(num_nodes, self.exchange, torch.cat([pos, neg], dim=1), 1, 1, 1, balance)
+        self.engine = PropagateEngine(self.plan, self.exchange, 1, 1, 1, kernels)      # mean: one phase
+        self.op_pos = ShardedOperator(pos, None, self.plan, self.engine, reduce="mean")
+        self.op_neg = ShardedOperator(neg, None, self.plan, self.engine, reduce="mean")
+        self._install_grad_sync()
+
+    def shard_rows(self, x: Tensor) -> Tensor:
+        return self.plan.shard_rows(x)
+
+    def forward(self, x_local: Tensor) -> Tensor:
+        from .dense import tall_linear
+        f, o = self.in_dim, self.out_dim
+        wb, wu = self.lin_b.weight, self.lin_u.weight
+        if self.first_aggr:             # columns: own_b | own_u | agg_b(pos) | agg_u(neg)
+            w_big = torch.cat([wb[:, f:].t(), wu[:, f:].t(), wb[:, :f].t(), wu[:, :f].t()], dim=1)
+            spec = ((self.op_pos, 0), (self.op_neg, 1))
+        else:                           # x = [lo | hi]; columns: own_b | own_u | pos_b | neg_b | pos_u | neg_u
+            zeros = wb.new_zeros(f, o)
+            top = torch.cat([wb[:, 2 * f:].t(), zeros, wb[:, :f].t(), zeros, zeros, wu[:, f:2 * f].t()], dim=1)
+            bot = torch.cat([zeros, wu[:, 2 * f:].t(), zeros, wb[:, f:2 * f].t(), wu[:, :f].t(), zeros], dim=1)
+            w_big = torch.cat([top, bot], dim=0)
+            spec = ((self.op_pos, 0), (self.op_neg, 0), (self.op_pos, 1), (self.op_neg, 1))
+        bias = None
+        if self.lin_b.bias is not None:
+            bias = torch.cat([self.lin_b.bias, self.lin_u.bias, self.lin_b.bias.new_zeros(len(spec) * o)])
+        y = tall_linear(x_local, w_big, bias)
+        parts = [y[:, (2 + j) * o:(3 + j) * o] for j in range(len(spec))]
+        agg = _ShardedProduct.apply(self.engine, [op.op_fwd for op, _ in spec], [op.op_bwd for op, _ in spec], *parts)
+        halves = [y[:, :o], y[:, o:2 * o]]
+        for (_, half), a in zip(spec, agg):
+            halves[half] = halves[half] + a
+        return _zero_pad_rows(self.plan, torch.cat(halves, dim=1))
+
+
+class ShardedSIMPA(_GradSync, torch.nn.Module):
+    """SIMPA (reference nn/signed/SIMPA.py:52-144, the aggregation of SSSNET) over a node-range-sharded graph: the hop
+    schedule of the un-sharded layer, every product of the random-walk operators A_p = D^-1 (A+ + fill I), A_n = D^-1 A-
+    (nn/general/conv_base.py:12-31, aggregation at edge_index[0]) an all-gather + this rank's operator rows.  The two
+    operators are normalised on every rank from the whole edge list (`normalise`, default utils._norm.conv_norm_rw: a
+    row's degree needs only the row's own entries, so sharding that build is possible, not done).  Hop weights
+    (`_w_p`, `_w_n` / `_w_sp` ... `_w_tn`: the reference's state_dict keys) are replicated, their gradients all-reduced."""
+
+    def __init__(self, hop: int, fill_value: float, num_nodes: int, edge_index_p: Tensor, edge_weight_p: Optional[Tensor],
+                 edge_index_n: Tensor, edge_weight_n: Optional[Tensor], directed: bool = False, device=None, group=None,
+                 exchange=None, balance: bool = True, kernels=None, normalise=None):
+        super().__init__()
+        from .nn.general.conv_base import flipped_edge_index
+        if normalise is None:
+            from .utils._norm import conv_norm_rw as normalise
+        self._hop_p, self._hop_n = hop + 1, int((1 + hop) * hop / 2)
+        self._undirected = not directed
+        names = ("_w_p", "_w_n") if self._undirected else ("_w_sp", "_w_sn", "_w_tp", "_w_tn")
+        for name in names:
+            rows = self._hop_n if name.endswith("n") else self._hop_p
+            self.register_parameter(name, torch.nn.Parameter(torch.ones(rows, 1)))
+        device = device or edge_index_p.device
+        self.to(device)
+        self.exchange = exchange if exchange is not None else DistExchange(group)
+        ei_p, ei_n = edge_index_p.to(device), edge_index_n.to(device)
+        w_p = None if edge_weight_p is None else edge_weight_p.to(device)
+        w_n = None if edge_weight_n is None else edge_weight_n.to(device)
+        self.plan = make_plan(num_nodes, self.exchange, torch.cat([ei_p, ei_n], dim=1), 1, 1, 1, balance)
+        self.engine = PropagateEngine(self.plan, self.exchange, 1, 1, 1, kernels)
+
+        def operator(ei, w, fill):
+            nei, nw = normalise(ei, fill, w, num_nodes)
+            return ShardedOperator(nei, nw, self.plan, self.engine, flow="target_to_source")
+
+        self.ops = {"p": operator(ei_p, w_p, fill_value), "n": operator(ei_n, w_n, 0.0)}
+        if directed:
+            self.ops["tp"] = operator(flipped_edge_index(ei_p), w_p, fill_value)
+            self.ops["tn"] = operator(flipped_edge_index(ei_n), w_n, 0.0)
+        self._install_grad_sync()
+
+    def shard_rows(self, x: Tensor) -> Tensor:
+        return self.plan.shard_rows(x)
+
+    def _product(self, key: str, x: Tensor) -> Tensor:
+        op = self.ops[key]
+        (y,) = _ShardedProduct.apply(self.engine, [op.op_fwd], [op.op_bwd], x)
+        return y
+
+    def _stream(self, kp: str, kn: str, x_pos: Tensor, x_neg: Tensor, wp: Tensor, wn: Tensor) -> Tensor:
+        """[feat_p | feat_n] of one (positive, negative) pair in the reference's accumulation order (SIMPA.py:77-93)."""
+        feat_p, feat_n = wp[0] * x_pos, None
+        cur_p, aux_n, j, last = x_pos, x_neg, 0, self._hop_p - 1
+        for h in range(self._hop_p):
+            if h > 0:
+                cur_p = self._product(kp, cur_p)
+                if h != last:          # the reference also advances aux_n at the last hop, but never reads it again
+                    aux_n = self._product(kp, aux_n)
+                feat_p = feat_p + wp[h] * cur_p
+            if h != last:
+                cur_n = self._product(kn, aux_n)
+                feat_n = wn[j] * cur_n if feat_n is None else feat_n + wn[j] * cur_n
+                j += 1
+                for _ in range(self._hop_p - 2 - h):
+                    cur_n = self._product(kp, cur_n)
+                    feat_n = feat_n + wn[j] * cur_n
+                    j += 1
+        return torch.cat([feat_p, torch.zeros_like(feat_p) if feat_n is None else feat_n], dim=1)
+
+    def forward(self, x_p: Tensor, x_n: Tensor, x_pt: Optional[Tensor] = None, x_nt: Optional[Tensor] = None) -> Tensor:
+        """Local rows in (x_p, x_n[, x_pt, x_nt]: [n_pad, F]), local rows of [feat_p | feat_n (| target streams)] out."""
+        if self._undirected:
+            return _zero_pad_rows(self.plan, self._stream("p", "n", x_p, x_n, self._w_p, self._w_n))
+        source = self._stream("p", "n", x_p, x_n, self._w_sp, self._w_sn)
+        target = self._stream("tp", "tn", x_pt, x_nt, self._w_tp, self._w_tn)
+        return _zero_pad_rows(self.plan, torch.cat([source, target], dim=1))
+
+
 # ------------------------------------------------------------------------------------------------
 # helpers kept for callers / tests
 # ------------------------------------------------------------------------------------------------

@@ -113,6 +113,9 @@ def _suite(rank, world, port, ret):
             out["magnetic " + str(cfg)] = _magnetic_case(rank, world, cfg)
         for cfg in DIGCN[world]:
             out["digcn " + str(cfg)] = _digcn_case(rank, world, *cfg)
+        if world in (2, 4):
+            for kind in ("sgcn_first", "sgcn_deep", "simpa_undirected", "simpa_directed"):
+                out["signed " + kind] = _signed_case(rank, world, kind)
         if world == 4:
             out["build"] = _build_case()
         ret[rank] = out
@@ -137,8 +140,54 @@ def test_sharded_layers_match_oracle(world):
                 assert v[2] == v[3], (rank, name, v)
             elif name.startswith("digcn"):
                 assert v <= 1.0, (rank, name, v)
+            elif name.startswith("signed"):
+                assert v[0] <= 1e-5 and v[1] <= 1e-5, (rank, name, v)      # elements (mixed bar) / row reductions (max norm)
             else:
                 assert v is True, (rank, name)
+
+
+def _signed_case(rank, world, kind):
+    """ShardedSGCNConv / ShardedSIMPA (BASELINE config 3's layers in sharded form; round 4) with the HIP kernels, against the
+    un-sharded oracle layer: (worst element error |d| / (1 + |want|) over output and input gradients, worst max-norm error
+    over the all-reduced parameter gradients)."""
+    from oracle import ref_layers as R
+    from pytorch_geometric_signed_directed_amd.parallel import ShardedSGCNConv, ShardedSIMPA, all_gather_rows
+    dev = torch.device("cuda:0")
+    n, f = 900, 64
+    g = torch.Generator().manual_seed(31)
+    pos, neg = torch.randint(0, n, (2, 6 * n), generator=g), torch.randint(0, n - 7, (2, 14 * n), generator=g)
+    w_p, w_n = torch.rand(pos.size(1), generator=g) + 0.5, torch.rand(neg.size(1), generator=g) + 0.5
+    torch.manual_seed(19)
+    if kind.startswith("sgcn"):
+        first = kind == "sgcn_first"
+        layer = ShardedSGCNConv(f if first else f // 2, f // 2, first, n, pos.to(dev), neg.to(dev), device=dev)
+        xs = [torch.randn(n, f, generator=g)]
+    else:
+        directed = kind == "simpa_directed"
+        layer = ShardedSIMPA(2, 0.5, n, pos.to(dev), w_p.to(dev), neg.to(dev), w_n.to(dev), directed, device=dev)
+        xs = [torch.randn(n, f, generator=g) for _ in range(4 if directed else 2)]
+    with torch.no_grad():
+        for prm in layer.parameters():
+            prm.uniform_(0.5, 1.5)
+            dist.broadcast(prm.data, 0)
+    plan = layer.plan
+    local = [layer.shard_rows(x.to(dev)).requires_grad_() for x in xs]
+    out = layer(*local)
+    go = torch.randn(n, out.size(1), generator=g)
+    (out * layer.shard_rows(go.to(dev))).sum().backward()
+    got = [plan.unshard_rows(all_gather_rows(t.detach())).cpu() for t in [out] + [a.grad for a in local]]
+    ref_in = [x.clone().requires_grad_() for x in xs]
+    sd = {k: v.detach().cpu().clone().requires_grad_() for k, v in layer.named_parameters()}
+    if kind.startswith("sgcn"):
+        want = R.sgcn_conv(ref_in[0], pos, neg, (sd["lin_b.weight"], sd["lin_b.bias"]), (sd["lin_u.weight"], sd["lin_u.bias"]),
+                           kind == "sgcn_first", layer.in_dim)
+    else:
+        want = R.simpa(pos, w_p, neg, w_n, ref_in[0], ref_in[1], sd, 2, 0.5, kind == "simpa_directed", *ref_in[2:])
+    (want * go).sum().backward()
+    elem = max(float(((a - b).abs() / (1 + b.abs())).max()) for a, b in zip(got, [want.detach()] + [x.grad for x in ref_in]))
+    red = max(float((prm.grad.cpu() - sd[k].grad).abs().max()) / max(1.0, float(sd[k].grad.abs().max()))
+              for k, prm in layer.named_parameters())
+    return elem, red
 
 
 def _digcn_case(rank, world, n, f, dtype_name, block, phases):

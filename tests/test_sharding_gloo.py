@@ -424,3 +424,60 @@ def test_sharded_digcn_and_inception_block_equal_unsharded_oracle(world, n, f, p
     ret = mgr.dict()
     mp.spawn(_digcn_worker, args=(world, _free_port(), n, f, phases, block, ret), nprocs=world, join=True)
     assert len(ret) == world and max(ret.values()) <= 2e-6, dict(ret)
+
+
+def _signed_worker(rank, world, port, kind, ret):
+    """ShardedSGCNConv (first / deep aggregation) and ShardedSIMPA (undirected / directed, hop 2) against the un-sharded
+    oracle layer: outputs, input gradients and the all-reduced parameter gradients (SGCNConv.py:94-126, SIMPA.py:52-144)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytorch_geometric_signed_directed_amd.parallel import ShardedSGCNConv, ShardedSIMPA, all_gather_rows
+        C.patch_device_builders()
+        n, f = 57, 8
+        g, pos, w_p = _graph(n, 21, True)
+        _, neg, w_n = _graph(n, 22, False)
+        neg = neg[:, :200]
+        w_n = w_n[:200]
+        torch.manual_seed(17)
+        if kind.startswith("sgcn"):
+            first = kind == "sgcn_first"
+            layer = ShardedSGCNConv(f, f // 2, first, n, pos, neg, kernels=C.KERNELS)
+            xs = [torch.randn(n, f if first else 2 * f, generator=g)]
+        else:
+            directed = kind == "simpa_directed"
+            layer = ShardedSIMPA(2, 0.5, n, pos, w_p, neg, w_n, directed, kernels=C.KERNELS,
+                                 normalise=lambda ei, fill, w, nn_: R.conv_norm_rw(ei, w, nn_, fill))
+            xs = [torch.randn(n, f, generator=g) for _ in range(4 if directed else 2)]
+        with torch.no_grad():
+            for prm in layer.parameters():
+                prm.uniform_(0.5, 1.5)
+                dist.broadcast(prm.data, 0)
+        plan = layer.plan
+        local = [layer.shard_rows(x).requires_grad_() for x in xs]
+        out = layer(*local)
+        go = torch.randn(n, out.size(1), generator=g)
+        (out * layer.shard_rows(go)).sum().backward()
+        got = [plan.unshard_rows(all_gather_rows(t.detach())) for t in [out] + [a.grad for a in local]]
+        ref_in = [x.clone().requires_grad_() for x in xs]
+        sd = {k: v.detach().clone().requires_grad_() for k, v in layer.named_parameters()}
+        if kind.startswith("sgcn"):
+            want = R.sgcn_conv(ref_in[0], pos, neg, (sd["lin_b.weight"], sd["lin_b.bias"]), (sd["lin_u.weight"], sd["lin_u.bias"]),
+                               kind == "sgcn_first", f)
+        else:
+            want = R.simpa(pos, w_p, neg, w_n, ref_in[0], ref_in[1], sd, 2, 0.5, kind == "simpa_directed", *ref_in[2:])
+        (want * go).sum().backward()
+        pairs = list(zip(got, [want.detach()] + [x.grad for x in ref_in]))
+        pairs += [(prm.grad, sd[k].grad) for k, prm in layer.named_parameters()]
+        ret[rank] = max(float((a - b).abs().max()) / max(1.0, float(b.abs().max())) for a, b in pairs)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "sgcn_first"), (3, "sgcn_deep"), (2, "simpa_undirected"), (3, "simpa_directed")])
+def test_sharded_signed_layers_equal_the_unsharded_oracle(world, kind):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_signed_worker, args=(world, _free_port(), kind, ret), nprocs=world, join=True)
+    assert len(ret) == world and max(ret.values()) <= 4e-6, dict(ret)
