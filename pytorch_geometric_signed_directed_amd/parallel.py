@@ -958,16 +958,14 @@ class ShardedMagNetConv(torch.nn.Module):
 
 
 class ShardedOperator:
-    """A COO operator out[scatter] += w * x[gather] sharded by node range in the row layout: this rank keeps the
-    by-target rows of its nodes (forward) and the by-source rows of its nodes (backward), columns = padded ids
-    into the all-gathered features.  fp32 or bf16 features (bf16 halves the exchanged bytes as well as the
+    """A COO operator out[scatter] += w * x[gather] sharded by node range: this rank keeps the by-target rows (forward) and
+    the by-source rows (backward) it multiplies -- its own nodes' in the row layout, its row block's in the grid -- with
+    columns = padded ids into the exchanged features.  fp32 or bf16 features (bf16 halves the exchanged bytes as well as the
     gathered ones; with more than one phase its partial products accumulate in fp32 and are rounded once)."""
 
     def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], plan: ShardPlan, engine: PropagateEngine,
                  flow: str = "source_to_target", reduce: str = "add"):
         from .sparse import csr_from_coo, gather_values
-        if engine.grid:
-            raise ValueError("ShardedOperator multiplies its own rows: row layout only")
         self.plan, self.engine = plan, engine
         g, s = (0, 1) if flow == "source_to_target" else (1, 0)
         pid = plan.to_padded(edge_index)
@@ -975,11 +973,22 @@ class ShardedOperator:
         mean = reduce == "mean"
         if mean and engine.phases > 1:
             raise ValueError("reduce='mean' needs an un-phased engine")
-        lo, hi = plan.pad_lo, plan.pad_lo + plan.n_pad
-        keep_t = ((scatter >= lo) & (scatter < hi)).nonzero(as_tuple=True)[0]
-        fwd = csr_from_coo(scatter[keep_t] - lo, gather[keep_t], plan.n_pad, plan.n_total)
-        keep_s = ((gather >= lo) & (gather < hi)).nonzero(as_tuple=True)[0]
-        bwd = csr_from_coo(gather[keep_s] - lo, scatter[keep_s], plan.n_pad, plan.n_total)
+        if engine.grid:
+            # grid layout (round 4): this rank multiplies ROW BLOCK i -- the i-th 1/p_r of every rank's range, in the
+            # engine's product order -- with its column slice of the features; a row keeps all its entries
+            rows = engine.block_row_ids(pid.device)
+            where = torch.full((plan.n_total,), -1, dtype=torch.long, device=pid.device)
+            where[rows] = torch.arange(rows.numel(), device=pid.device)
+            at_t, at_s = where[scatter], where[gather]
+            keep_t, keep_s = (at_t >= 0).nonzero(as_tuple=True)[0], (at_s >= 0).nonzero(as_tuple=True)[0]
+            fwd = csr_from_coo(at_t[keep_t], gather[keep_t], engine.block_rows, plan.n_total)
+            bwd = csr_from_coo(at_s[keep_s], scatter[keep_s], engine.block_rows, plan.n_total)
+        else:
+            lo, hi = plan.pad_lo, plan.pad_lo + plan.n_pad
+            keep_t = ((scatter >= lo) & (scatter < hi)).nonzero(as_tuple=True)[0]
+            fwd = csr_from_coo(scatter[keep_t] - lo, gather[keep_t], plan.n_pad, plan.n_total)
+            keep_s = ((gather >= lo) & (gather < hi)).nonzero(as_tuple=True)[0]
+            bwd = csr_from_coo(gather[keep_s] - lo, scatter[keep_s], plan.n_pad, plan.n_total)
         w = edge_weight
         if mean:                                                       # backward of mean: 1 / in-degree per entry
             ones = torch.ones(pid.size(1), dtype=torch.float32, device=pid.device)
@@ -1069,7 +1078,8 @@ class ShardedDiGCNConv(_GradSync, torch.nn.Module):
 
     def __init__(self, in_channels: int, out_channels: int, num_nodes: int, edge_index: Tensor,
                  edge_weight: Tensor, bias: bool = True, device=None, group=None, exchange=None,
-                 phases: Optional[int] = None, balance: bool = True, plan: Optional[ShardPlan] = None, kernels=None):
+                 phases: Optional[int] = None, balance: bool = True, plan: Optional[ShardPlan] = None, kernels=None,
+                 grid_cols: int = 1, return_chunks: int = 1):
         super().__init__()
         from .nn import DiGCNConv
         proto = DiGCNConv(in_channels, out_channels, bias=bias)
@@ -1082,8 +1092,9 @@ class ShardedDiGCNConv(_GradSync, torch.nn.Module):
         self.exchange = exchange if exchange is not None else DistExchange(group)
         edge_index = edge_index.to(device)
         phases = 1 if phases is None else int(phases)       # measured: a second phase does not pay for one-operand rows
-        self.plan = plan or make_plan(num_nodes, self.exchange, edge_index, 1, phases, 1, balance)
-        self.engine = PropagateEngine(self.plan, self.exchange, 1, phases, 1, kernels)
+        # grid_cols > 1 (round 4): p_r x p_c process grid -- column-slice all-to-all in, products home over all links
+        self.plan = plan or make_plan(num_nodes, self.exchange, edge_index, grid_cols, phases, return_chunks, balance)
+        self.engine = PropagateEngine(self.plan, self.exchange, grid_cols, phases, return_chunks, kernels)
         self.op = ShardedOperator(edge_index, edge_weight.to(device), self.plan, self.engine)
         self._install_grad_sync()
 
@@ -1129,7 +1140,8 @@ class ShardedDiGCNInceptionBlock(_GradSync, torch.nn.Module):
 
     def __init__(self, in_dim: int, out_dim: int, num_nodes: int, edge_index: Tensor, edge_weight: Tensor,
                  edge_index2: Tensor, edge_weight2: Tensor, device=None, group=None, exchange=None,
-                 phases: Optional[int] = None, balance: bool = True, kernels=None):
+                 phases: Optional[int] = None, balance: bool = True, kernels=None, grid_cols: int = 1,
+                 return_chunks: int = 1):
         super().__init__()
         from .nn import DiGCNConv
         self.ln = torch.nn.Linear(in_dim, out_dim)
@@ -1140,8 +1152,8 @@ class ShardedDiGCNInceptionBlock(_GradSync, torch.nn.Module):
         edge_index, edge_index2 = edge_index.to(device), edge_index2.to(device)
         both = torch.cat([edge_index, edge_index2], dim=1)
         phases = 1 if phases is None else int(phases)       # see ShardedDiGCNConv
-        self.plan = make_plan(num_nodes, self.exchange, both, 1, phases, 1, balance)
-        self.engine = PropagateEngine(self.plan, self.exchange, 1, phases, 1, kernels)
+        self.plan = make_plan(num_nodes, self.exchange, both, grid_cols, phases, return_chunks, balance)
+        self.engine = PropagateEngine(self.plan, self.exchange, grid_cols, phases, return_chunks, kernels)
         self.op1 = ShardedOperator(edge_index, edge_weight.to(device), self.plan, self.engine)
         self.op2 = ShardedOperator(edge_index2, edge_weight2.to(device), self.plan, self.engine)
         self._install_grad_sync()

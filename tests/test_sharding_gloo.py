@@ -301,7 +301,7 @@ def test_ranks_as_threads_equal_the_unsharded_oracle(world, layout, k, phases, c
         C.run_ranks_as_threads(3, lambda rank, ex: (1 // (rank - 1), ex.all_reduce(torch.ones(1)))[1])
 
 
-def _digcn_worker(rank, world, port, n, f, phases, block, ret):
+def _digcn_worker(rank, world, port, n, f, phases, block, ret, grid_cols=1, chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))   # the oracle runs in every rank: no oversubscription
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -316,9 +316,10 @@ def _digcn_worker(rank, world, port, n, f, phases, block, ret):
         x, go = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
         torch.manual_seed(13)
         if block:
-            layer = ShardedDiGCNInceptionBlock(f, f, n, ei, w, ei2, w2, phases=phases, kernels=C.KERNELS)
+            layer = ShardedDiGCNInceptionBlock(f, f, n, ei, w, ei2, w2, phases=phases, kernels=C.KERNELS, grid_cols=grid_cols,
+                                               return_chunks=chunks)
         else:
-            layer = ShardedDiGCNConv(f, f, n, ei, w, phases=phases, kernels=C.KERNELS)
+            layer = ShardedDiGCNConv(f, f, n, ei, w, phases=phases, kernels=C.KERNELS, grid_cols=grid_cols, return_chunks=chunks)
         with torch.no_grad():
             for prm in layer.parameters():
                 prm.uniform_(-0.5, 0.5)
@@ -481,3 +482,12 @@ def test_sharded_signed_layers_equal_the_unsharded_oracle(world, kind):
     ret = mgr.dict()
     mp.spawn(_signed_worker, args=(world, _free_port(), kind, ret), nprocs=world, join=True)
     assert len(ret) == world and max(ret.values()) <= 4e-6, dict(ret)
+
+
+@pytest.mark.parametrize("world,n,f,grid_cols,chunks,block", [(4, 90, 8, 2, 1, False), (4, 90, 16, 4, 2, True), (8, 130, 8, 2, 2, True)])
+def test_sharded_digcn_in_the_grid_layout(world, n, f, grid_cols, chunks, block):
+    """One-operand operators in the p_r x p_c process grid (round 4): column-slice all-to-all in, row-chunked all-to-all back."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_digcn_worker, args=(world, _free_port(), n, f, 1, block, ret, grid_cols, chunks), nprocs=world, join=True)
+    assert len(ret) == world and max(ret.values()) <= 2e-6, dict(ret)

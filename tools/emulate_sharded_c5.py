@@ -21,6 +21,11 @@ def main():
     ap.add_argument("--edges", type=int, default=25000000)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--grid-cols", type=int, default=1, help="p_c of the p_r x p_c process grid (1 = row layout)")
+    ap.add_argument("--return-chunks", type=int, default=1)
+    ap.add_argument("--phases", type=int, default=1)
+    ap.add_argument("--single-gpu-ms", default="9.80,5.30", help="fp32,bf16 block step on one GPU (profiles/r4j_configs.json)")
+    ap.add_argument("--tag", default="")
     args = ap.parse_args()
     from pytorch_geometric_signed_directed_amd import graphs
     from pytorch_geometric_signed_directed_amd.parallel import EmulatedExchange, ShardedDiGCNInceptionBlock
@@ -38,11 +43,13 @@ def main():
         deg = torch.zeros(n, device=dev).index_add_(0, ei[0], w)
         ops.append((ei, deg[ei[0]].rsqrt() * w * deg[ei[1]].rsqrt()))
     out = {"world": args.world, "nodes": n, "entries_per_operator": int(ops[0][0].size(1)), "hidden": h,
-           "link_gbps": args.link_gbps, "single_gpu_ms": {"float32": 12.25, "bfloat16": 7.25}, "runs": {}}
+           "link_gbps": args.link_gbps, "grid_cols": args.grid_cols, "return_chunks": args.return_chunks, "phases": args.phases,
+           "single_gpu_ms": dict(zip(("float32", "bfloat16"), (float(v) for v in args.single_gpu_ms.split(",")))), "runs": {}}
     for dtype in (torch.float32, torch.bfloat16):
         ex = EmulatedExchange(args.world, 0, args.link_gbps)
         torch.manual_seed(0)
-        block = ShardedDiGCNInceptionBlock(h, h, n, ops[0][0], ops[0][1], ops[1][0], ops[1][1], device=dev, exchange=ex)
+        block = ShardedDiGCNInceptionBlock(h, h, n, ops[0][0], ops[0][1], ops[1][0], ops[1][1], device=dev, exchange=ex,
+                                           grid_cols=args.grid_cols, return_chunks=args.return_chunks, phases=args.phases)
         block.to(dtype)
         x = block.shard_rows(torch.randn(n, h, device=dev)).to(dtype).requires_grad_()
 
@@ -71,7 +78,7 @@ def main():
         print(name, json.dumps(rec), flush=True)
         del block, x
         torch.cuda.empty_cache()
-    with open(os.path.join(ROOT, "gpurun_out", "emulated_sharded_c5.json"), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", f"emulated_sharded_c5{args.tag}.json"), "w") as fh:
         json.dump(out, fh, indent=1)
 
 
