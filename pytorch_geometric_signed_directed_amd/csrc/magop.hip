@@ -27,6 +27,7 @@
 // Bit-compatible with the generic pipeline: same formulas in the same order (tests/test_gpu_kernels.py holds the two to
 // equality).
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -180,6 +181,69 @@ __device__ __forceinline__ KT wave_bitonic(KT v, int lane)
     v = compare_exchange<X4>(v, lane, b2);
     v = compare_exchange<X2>(v, lane, b1);
     v = compare_exchange<X1>(v, lane, b0);
+    return v;
+}
+
+// 32-bit keys, `used` (wavefront-uniform) of them real, the rest ~0 in the upper lanes.  The lower lane of a pair keeps the minimum,
+// the upper one the maximum = the median of {mine, partner's, 0 or ~0}: ONE v_med3_u32 behind the lane exchange instead of
+// min + max + select (the row kernels are VALU-bound: 153 vector instructions per row before, 72 of them this network).  A merge
+// whose upper half holds padding only moves nothing: skipped.
+struct BitonicSel {
+    uint32_t s0, s1, s2, s3, s4, s5;          // 0 on the lower lane of a pair at distance 1, 2, 4, 8, 16, 32; ~0 on the upper
+};
+
+__device__ __forceinline__ BitonicSel bitonic_sel(int lane)
+{
+    BitonicSel s;
+    s.s0 = (lane & 1) ? ~0u : 0u;
+    s.s1 = (lane & 2) ? ~0u : 0u;
+    s.s2 = (lane & 4) ? ~0u : 0u;
+    s.s3 = (lane & 8) ? ~0u : 0u;
+    s.s4 = (lane & 16) ? ~0u : 0u;
+    s.s5 = (lane & 32) ? ~0u : 0u;
+    return s;
+}
+
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
+    const uint32_t t = mn < c ? c : mn;                           // max(min(a, b), c)
+    return mx < t ? mx : t;                                       // min(max(a, b), .)
+}
+
+template <Exchange E>
+__device__ __forceinline__ uint32_t cx(uint32_t v, int lane, uint32_t sel)
+{
+    return umed3(v, exchange32<E>(v, lane), sel);
+}
+
+__device__ __forceinline__ uint32_t wave_bitonic32(uint32_t v, int lane, int used, const BitonicSel& s)
+{
+    v = cx<X1>(v, lane, s.s0);                                    // k = 2
+    v = cx<X3>(v, lane, s.s1);                                    // k = 4
+    v = cx<X1>(v, lane, s.s0);
+    v = cx<X7>(v, lane, s.s2);                                    // k = 8
+    v = cx<X2>(v, lane, s.s1);
+    v = cx<X1>(v, lane, s.s0);
+    v = cx<X15>(v, lane, s.s3);                                   // k = 16
+    v = cx<X4>(v, lane, s.s2);
+    v = cx<X2>(v, lane, s.s1);
+    v = cx<X1>(v, lane, s.s0);
+    if (used > 16) {
+        v = cx<X31>(v, lane, s.s4);                               // k = 32
+        v = cx<X8>(v, lane, s.s3);
+        v = cx<X4>(v, lane, s.s2);
+        v = cx<X2>(v, lane, s.s1);
+        v = cx<X1>(v, lane, s.s0);
+    }
+    if (used > 32) {
+        v = cx<X63>(v, lane, s.s5);                               // k = 64
+        v = cx<X16>(v, lane, s.s4);
+        v = cx<X8>(v, lane, s.s3);
+        v = cx<X4>(v, lane, s.s2);
+        v = cx<X2>(v, lane, s.s1);
+        v = cx<X1>(v, lane, s.s0);
+    }
     return v;
 }
 
@@ -740,9 +804,78 @@ __device__ __forceinline__ void unit_diagonal(const UnitArgs& p, float* st, int6
     unit_store<STAGED>(p, st, wslot0, slot, row, dg, 0.f, dg, 0.f);
 }
 
-// Kernel A: one wavefront per kRowsPerWave rows (as row_merge_wave): order each row in registers, park the MERGED row -- one 8-byte
-// record per distinct neighbour: col | multiplicity << 32 | (Theta_arg + 64) << 40 -- at the head of the row's range of the sort's
-// dead input buffer, count the distinct entries and those left of the diagonal.
+// One row of <= 64 stream entries, one (col << 1 | dir) key per lane: ordered in registers, duplicates / reciprocal pairs merged;
+// ONE 8-byte record per distinct neighbour -- col | multiplicity << 32 | (Theta_arg + 64) << 40 -- parked at scratch[gbeg + rank].
+// (`cnt`, `r`, `gbeg` wavefront-uniform)
+template <typename KT>
+__device__ __forceinline__ void unit_merge_short(const UnitArgs& p, uint32_t c2, int cnt, int32_t r, int64_t gbeg, int lane,
+                                                 const BitonicSel& sel, int& u, int& left)
+{
+    const bool have = lane < cnt;
+    uint32_t c2s;
+    if constexpr (sizeof(KT) == 4) {
+        const uint32_t k = have ? ((c2 << 6) | static_cast<uint32_t>(lane)) : ~0u;
+        c2s = wave_bitonic32(k, lane, cnt, sel) >> 6;
+    } else {
+        KT k = have ? static_cast<KT>((static_cast<KT>(c2) << 6) | static_cast<KT>(lane)) : static_cast<KT>(~static_cast<KT>(0));
+        c2s = static_cast<uint32_t>(wave_bitonic<KT>(k, lane) >> 6);
+    }
+    const uint32_t cv = c2s >> 1;
+    const uint32_t prev = dpp_mov<0x138>(cv);                     // wave_shr:1 (lane 0 reads 0: it is a head anyway)
+    const bool hd = have && (lane == 0 || prev != cv);
+    const uint64_t H = __ballot(hd);
+    const uint64_t D = __ballot(have && (c2s & 1u) != 0);         // entries of the reversed orientation
+    u = __popcll(H);
+    left = __popcll(__ballot(hd && static_cast<int32_t>(cv) < r));
+    // the run of this head ends at the next head (or at cnt); reversed entries inside it = prefix count there - prefix count here
+    const uint64_t above = (H >> lane) >> 1;
+    const int end = above ? lane + 1 + (__ffsll(static_cast<long long>(above)) - 1) : cnt;
+    const int rl_here = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(D >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(D), 0u)));
+    const int rl_end = __builtin_amdgcn_ds_bpermute((end & 63) << 2, rl_here);
+    const int n1 = (end < cnt ? rl_end : __popcll(D)) - rl_here;
+    if (hd) {
+        const int ln = end - lane;
+        const int rank = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(H >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(H), 0u)));
+        p.scratch[gbeg + rank] = static_cast<uint64_t>(cv) | (static_cast<uint64_t>(ln) << 32) |
+                                 (static_cast<uint64_t>(ln - 2 * n1 + 64) << 40);
+    }
+}
+
+// One row of 65 .. kUnitRowMax entries whose keys sit in LDS (`src`): rank sort -- rank = number of keys that sort before this one
+// ((col, dir) order; identical keys are indistinguishable, so ties may fall either way); SORTED KEYS (not merged records) ->
+// scratch[gbeg + rank], then the distinct / left-of-diagonal counts from the sorted run.
+__device__ __forceinline__ void unit_merge_long(const UnitArgs& p, const uint32_t* src, int cnt, int32_t r, int64_t gbeg, int lane,
+                                                int& u, int& left)
+{
+    for (int i = lane; i < cnt; i += 64) {
+        const uint32_t mine = src[i];
+        int rk = 0;
+        for (int t = 0; t < cnt; ++t) {
+            const uint32_t o = src[t];
+            rk += (o < mine || (o == mine && t < i)) ? 1 : 0;
+        }
+        p.scratch[gbeg + rk] = mine;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the wavefront re-reads what its lanes wrote
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    u = 0;
+    left = 0;
+    for (int i0 = 0; i0 < cnt; i0 += 64) {
+        const int i = i0 + lane;
+        bool hd = false, lt = false;
+        if (i < cnt) {
+            const uint32_t cur = static_cast<uint32_t>(p.scratch[gbeg + i]) >> 1;
+            hd = i == 0 || (static_cast<uint32_t>(p.scratch[gbeg + i - 1]) >> 1) != cur;
+            lt = hd && static_cast<int32_t>(cur) < r;
+        }
+        u += __popcll(__ballot(hd));
+        left += __popcll(__ballot(lt));
+    }
+}
+
+// Kernel A: one wavefront per kRowsPerWave rows (as row_merge_wave): order each row in registers, park the MERGED row at the head
+// of the row's range of the sort's dead input buffer, count the distinct entries and those left of the diagonal.
 template <typename KT>
 __global__ __launch_bounds__(256) void unit_merge_rows(UnitArgs p)
 {
@@ -753,6 +886,7 @@ __global__ __launch_bounds__(256) void unit_merge_rows(UnitArgs p)
     const int rows = p.n - r0 < kRowsPerWave ? static_cast<int>(p.n - r0) : kRowsPerWave;
     int32_t beg[kRowsPerWave], cnt[kRowsPerWave];
     uint32_t c2[kRowsPerWave];
+    const BitonicSel sel = bitonic_sel(lane);
     const int32_t bound = p.rs[r0 + (lane <= rows ? lane : rows)];
 #pragma unroll
     for (int j = 0; j < kRowsPerWave; ++j) {
@@ -771,58 +905,13 @@ __global__ __launch_bounds__(256) void unit_merge_rows(UnitArgs p)
         const int32_t r = static_cast<int32_t>(r0) + j;
         int u = 0, left = 0;
         if (cnt[j] <= 64) {
-            const bool have = lane < cnt[j];
-            KT k = have ? static_cast<KT>((static_cast<KT>(c2[j]) << 6) | static_cast<KT>(lane)) : static_cast<KT>(~static_cast<KT>(0));
-            k = wave_bitonic<KT>(k, lane);
-            const uint32_t c2s = static_cast<uint32_t>(k >> 6);
-            const uint32_t cv = c2s >> 1;
-            const bool rev = (c2s & 1u) != 0;
-            const uint32_t prev = __shfl_up(cv, 1);
-            const bool hd = have && (lane == 0 || prev != cv);
-            const uint64_t H = __ballot(hd);
-            const uint64_t above = lane == 63 ? 0ull : ((H >> (lane + 1)) << (lane + 1));
-            const int end = above ? (__ffsll(static_cast<long long>(above)) - 1) : cnt[j];
-            const int ln = end - lane;
-            const uint64_t D = __ballot(have && rev);
-            const uint64_t run = (ln >= 64 ? ~0ull : ((1ull << (ln > 0 ? ln : 0)) - 1ull)) << lane;
-            const int n1 = __popcll(D & run);
-            u = __popcll(H);
-            left = __popcll(__ballot(hd && static_cast<int32_t>(cv) < r));
-            if (hd) {
-                const int rank = __popcll(H & ((1ull << lane) - 1ull));
-                p.scratch[beg[j] + rank] = static_cast<uint64_t>(cv) | (static_cast<uint64_t>(ln) << 32) |
-                                           (static_cast<uint64_t>(ln - 2 * n1 + 64) << 40);
-            }
+            unit_merge_short<KT>(p, c2[j], cnt[j], r, beg[j], lane, sel, u, left);
         } else if (cnt[j] <= kUnitRowMax) {
-            // rank sort through LDS: rank = number of keys that sort before this one ((col, dir) order; identical keys are
-            // indistinguishable, so ties may fall either way); SORTED KEYS (not merged records) -> scratch[beg + rank]
             for (int i = lane; i < cnt[j]; i += 64) lk[wv][i] = static_cast<uint32_t>(p.keys[beg[j] + i]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int i = lane; i < cnt[j]; i += 64) {
-                const uint32_t mine = lk[wv][i];
-                int rk = 0;
-                for (int t = 0; t < cnt[j]; ++t) {
-                    const uint32_t o = lk[wv][t];
-                    rk += (o < mine || (o == mine && t < i)) ? 1 : 0;
-                }
-                p.scratch[beg[j] + rk] = mine;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the wavefront re-reads what its lanes wrote
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (int i0 = 0; i0 < cnt[j]; i0 += 64) {
-                const int i = i0 + lane;
-                bool hd = false, lt = false;
-                if (i < cnt[j]) {
-                    const uint32_t cur = static_cast<uint32_t>(p.scratch[beg[j] + i]) >> 1;
-                    hd = i == 0 || (static_cast<uint32_t>(p.scratch[beg[j] + i - 1]) >> 1) != cur;
-                    lt = hd && static_cast<int32_t>(cur) < r;
-                }
-                u += __popcll(__ballot(hd));
-                left += __popcll(__ballot(lt));
-            }
+            unit_merge_long(p, lk[wv], cnt[j], r, beg[j], lane, u, left);
         } else {
             if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 1), 1ull);    // host: two-stage pipeline
         }
@@ -954,6 +1043,308 @@ __global__ __launch_bounds__(256) void unit_write_rows(UnitArgs p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4, second form of the unweighted build: NO global sort.  The radix sort above moves 8-byte keys twice and a histogram
+// pass on top (0.70 ms of rocPRIM kernels at the north star) only to bucket the stream by row; the row-bucketed stream is then
+// read back twice more (row bounds, merge).  Here the stream is split ONCE, into buckets of 2^rl consecutive rows that fit a
+// workgroup's LDS, and everything finer happens inside LDS:
+//   1  bucket_pass<false>  per tile of the edge list (one workgroup): entries per bucket, counted in LDS -> hist[bucket][tile]
+//   -  exclusive scan of hist (bucket-major): every (bucket, tile) pair owns a private range of the stream -- no global atomics,
+//      no look-back; the order inside a bucket is whatever the LDS atomics gave, which is immaterial: unit weights make a row's
+//      merge order-free, and the rows are ordered by column below
+//   2  bucket_pass<true>   the same tiles again: 4-byte entries  row_low << (cbits + 1) | col << 1 | dir  to their ranges
+//   3  bucket_merge_rows   one workgroup per bucket: the bucket is counted by row in LDS (-> row bounds, degrees, deg^-1/2),
+//      placed by row in LDS, and each row is ordered and merged by a wavefront exactly as unit_merge_rows does (same records, same
+//      place: scratch[row start + rank]); unit_write_rows follows unchanged.
+// Traffic at the north star: 2 x 320 MB of edge list in, 160 MB out and in, against 320 + 320 (keys) + 320 (histogram) +
+// 2 x 640 (two sort passes) + 320 (row bounds) + 320 (merge).  A bucket that does not fit (kBucketCap entries) or a row above
+// kUnitRowMax is counted in info[1]: the host takes the two-stage pipeline, as before.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kMaxBuckets = 2048;         // LDS of bucket_scatter: 32 k staged entries + the head map + two tables of this many words
+constexpr int kPassThreads = 512;
+constexpr int kPassBatch = 4;
+constexpr int kTileEdges = 16384;         // edges per tile (= per workgroup of the two passes): 32 k entries staged in LDS
+constexpr int kScatterThreads = 1024;
+
+struct BucketPlan {
+    int rl;            // log2(rows per bucket)
+    int nb;            // buckets
+    int g;             // tiles of the edge list (= workgroups of the two passes)
+    int cbits;         // bits of a column id
+    int cap;           // entries a bucket may hold (LDS of bucket_merge_rows)
+    int threads;       // workgroup size of bucket_merge_rows
+};
+
+inline int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// false: this graph is not taken by the bucket form (ids too wide for a 4-byte entry, too many buckets, rows too dense)
+inline bool bucket_plan(int64_t e, int32_t n, BucketPlan* pl)
+{
+    if (n <= 0 || e <= 0) return false;
+    const int64_t m = 2 * e;
+    const int big = env_int("PYGSD_BUCKET_WIDE", 1);            // 1: 1024-thread workgroups holding 32 k entries; 0: 512 / 16 k
+    pl->threads = big ? 1024 : 512;
+    pl->cap = pl->threads * 32;
+    pl->cbits = bits_for(static_cast<uint64_t>(n > 1 ? n - 1 : 1));
+    int rl = big ? 10 : 9;
+    while (rl > 3 && (static_cast<int64_t>(n) >> rl) < 1024) --rl;                        // enough buckets to fill the chip
+    while (rl > 3 && (m << rl) / n > static_cast<int64_t>(pl->cap) * 5 / 8) --rl;          // average bucket <= 5/8 of the LDS
+    if ((m << rl) / n > static_cast<int64_t>(pl->cap) * 5 / 8) return false;
+    const int64_t nb = (static_cast<int64_t>(n) + (int64_t(1) << rl) - 1) >> rl;
+    // (25: the in-register sort key, col << 7 | dir << 6 | lane)
+    if (nb > kMaxBuckets || rl + pl->cbits + 1 > 32 || pl->cbits > 25) return false;
+    const int64_t g = (e + kTileEdges - 1) / kTileEdges;
+    if (g * nb + 1 > (int64_t(1) << 23)) return false;          // hist / off: <= 32 MB each
+    pl->rl = rl;
+    pl->nb = static_cast<int>(nb);
+    pl->g = static_cast<int>(g);
+    return true;
+}
+
+// Pass 1: a tile's entries per bucket, counted in LDS -> hist[bucket][tile]; node-id range check (info[2], info[3]) folded in.
+__global__ __launch_bounds__(kPassThreads) void bucket_count(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t e,
+                                                             int32_t n, BucketPlan pl, int32_t* __restrict__ hist,
+                                                             int64_t* __restrict__ info)
+{
+    __shared__ uint32_t cnt[kMaxBuckets];
+    const int wg = blockIdx.x, t = threadIdx.x;
+    for (int b = t; b < pl.nb; b += kPassThreads) cnt[b] = 0u;
+    __syncthreads();
+    const int64_t lo = static_cast<int64_t>(wg) * kTileEdges, hi = lo + kTileEdges < e ? lo + kTileEdges : e;
+    const uint64_t nn = static_cast<uint64_t>(n);
+    for (int64_t k0 = lo; k0 < hi; k0 += kPassThreads * kPassBatch) {
+        int64_t r[kPassBatch], c[kPassBatch];
+#pragma unroll
+        for (int u = 0; u < kPassBatch; ++u) {
+            const int64_t k = k0 + u * kPassThreads + t;
+            const bool ok = k < hi;
+            r[u] = ok ? row[k] : 0;                               // (0, 0): a self loop, dropped below
+            c[u] = ok ? col[k] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kPassBatch; ++u) {
+            const bool bad_r = static_cast<uint64_t>(r[u]) >= nn, bad_c = static_cast<uint64_t>(c[u]) >= nn;
+            if (bad_r || bad_c) {
+                info[2] = 1;                                       // racing writers all store valid witnesses
+                info[3] = bad_r ? r[u] : c[u];
+            } else if (r[u] != c[u]) {
+                atomicAdd(&cnt[static_cast<uint32_t>(r[u]) >> pl.rl], 1u);
+                atomicAdd(&cnt[static_cast<uint32_t>(c[u]) >> pl.rl], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = t; b < pl.nb; b += kPassThreads) hist[static_cast<int64_t>(b) * pl.g + wg] = static_cast<int32_t>(cnt[b]);
+    if (wg == 0 && t == 0) hist[static_cast<int64_t>(pl.nb) * pl.g] = 0;            // the scan's last input: off[nb * g] = entries
+}
+
+// Pass 2: the tile again.  Its (bucket, tile) counts are re-read from the scanned table (adjacent words), scanned locally, and the
+// entries are placed BY BUCKET in LDS first; the tile then leaves as runs of consecutive words per bucket (lanes write neighbouring
+// addresses) -- 4-byte stores straight to the buckets ran at 75 G requests/s (0.59 ms for this pass), whatever the tiling.
+// Which bucket a staged slot belongs to is read off a bit map of the buckets' first slots: {32 head bits, heads before this word}
+// per 32 slots -> index among the tile's non-empty buckets -> that bucket's (global - staged) offset.  (A binary search over the
+// buckets' first slots instead cost 11 dependent LDS reads and ~75 VALU instructions per 64 entries: 0.20 ms for the pass.)
+// LDS: stage[2 * kTileEdges], cur[nb] (placement cursors), gdc[nb] (offsets of the non-empty buckets, compacted), hp[1024].
+__global__ __launch_bounds__(kScatterThreads) void bucket_scatter(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t e,
+                                                                  int32_t n, BucketPlan pl, const int32_t* __restrict__ off,
+                                                                  uint32_t* __restrict__ stream)
+{
+    static_assert(2 * kTileEdges == 32 * kScatterThreads, "one 32-slot word of the head map per thread");
+    extern __shared__ __attribute__((aligned(8))) uint32_t scatter_lds[];
+    uint32_t* stage = scatter_lds;
+    uint2* hp = reinterpret_cast<uint2*>(stage + 2 * kTileEdges);
+    uint32_t* cur = reinterpret_cast<uint32_t*>(hp + kScatterThreads);
+    uint32_t* gdc = cur + pl.nb;
+    __shared__ uint32_t wsum[kScatterThreads / 64], wsum2[kScatterThreads / 64], total_s;
+    const int st = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    constexpr int PER = (kMaxBuckets + kScatterThreads - 1) / kScatterThreads;
+    uint32_t cnts[PER], goff[PER], mine = 0;
+    hp[t] = make_uint2(0u, 0u);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = t * PER + j;
+        cnts[j] = 0;
+        goff[j] = 0;
+        if (b < pl.nb) {
+            const int32_t* o = off + static_cast<int64_t>(b) * pl.g + st;
+            goff[j] = static_cast<uint32_t>(o[0]);
+            cnts[j] = static_cast<uint32_t>(o[1]) - goff[j];
+        }
+        mine += cnts[j] | (cnts[j] ? 0x10000u : 0u);             // entries (<= 2^15) | non-empty buckets << 16
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (int w = 0; w < wv; ++w) run += wsum[w];
+    uint32_t slot = run & 0xFFFFu, nz = run >> 16;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = t * PER + j;
+        if (b < pl.nb) {
+            cur[b] = slot;
+            if (cnts[j]) {
+                atomicOr(&hp[slot >> 5].x, 1u << (slot & 31u));
+                gdc[nz++] = goff[j] - slot;
+            }
+        }
+        slot += cnts[j];
+    }
+    if (t == kScatterThreads - 1) total_s = slot;                 // the tile's entries
+    __syncthreads();
+    {
+        const uint32_t pc = __popc(hp[t].x);
+        uint32_t pinc = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(pinc, d);
+            if (lane >= d) pinc += o;
+        }
+        if (lane == 63) wsum2[wv] = pinc;
+        __syncthreads();
+        uint32_t before = pinc - pc;
+        for (int w = 0; w < wv; ++w) before += wsum2[w];
+        hp[t].y = before;
+    }
+    const int64_t lo = static_cast<int64_t>(st) * kTileEdges, hi = lo + kTileEdges < e ? lo + kTileEdges : e;
+    const uint64_t nn = static_cast<uint64_t>(n);
+    const uint32_t rmask = (1u << pl.rl) - 1u;
+    const int sh = pl.cbits + 1;
+    int64_t r[kPassBatch], c[kPassBatch], rn[kPassBatch], cn[kPassBatch];
+#pragma unroll
+    for (int u = 0; u < kPassBatch; ++u) {
+        const int64_t k = lo + u * kScatterThreads + t;
+        const bool ok = k < hi;
+        rn[u] = ok ? row[k] : 0;
+        cn[u] = ok ? col[k] : 0;
+    }
+    for (int64_t k0 = lo; k0 < hi; k0 += kScatterThreads * kPassBatch) {
+#pragma unroll
+        for (int u = 0; u < kPassBatch; ++u) {
+            r[u] = rn[u];
+            c[u] = cn[u];
+            const int64_t k = k0 + (kPassBatch + u) * kScatterThreads + t;      // the next batch is in flight during this one's placement
+            const bool ok = k < hi;
+            rn[u] = ok ? row[k] : 0;
+            cn[u] = ok ? col[k] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kPassBatch; ++u) {
+            if (static_cast<uint64_t>(r[u]) >= nn || static_cast<uint64_t>(c[u]) >= nn || r[u] == c[u]) continue;
+            const uint32_t rr = static_cast<uint32_t>(r[u]), cc = static_cast<uint32_t>(c[u]);
+            stage[atomicAdd(&cur[rr >> pl.rl], 1u)] = ((rr & rmask) << sh) | (cc << 1);
+            stage[atomicAdd(&cur[cc >> pl.rl], 1u)] = ((cc & rmask) << sh) | (rr << 1) | 1u;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = total_s;
+    for (uint32_t q = t; q < total; q += kScatterThreads) {
+        const uint2 w = hp[q >> 5];
+        const uint32_t idx = __popc(w.x & ((2u << (q & 31u)) - 1u)) + w.y - 1u;
+        stream[gdc[idx] + q] = stage[q];
+    }
+}
+
+// One workgroup per bucket of 2^rl rows.  LDS: placed[cap] (the bucket's keys, row by row), rcnt[2^rl + 1] (row counts, then
+// placement cursors), roff[2^rl + 1] (row offsets inside the bucket).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void bucket_merge_rows(UnitArgs p, BucketPlan pl, const uint32_t* __restrict__ stream,
+                                                             const int32_t* __restrict__ off)
+{
+    constexpr int EPT = 32, WAVES = THREADS / 64;
+    extern __shared__ uint32_t bucket_lds[];
+    uint32_t* placed = bucket_lds;
+    uint32_t* rcnt = bucket_lds + pl.cap;
+    uint32_t* roff = rcnt + (1 << pl.rl) + 8;
+    __shared__ uint32_t wsum[WAVES];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nrow = 1 << pl.rl;
+    const int32_t row0 = b << pl.rl;
+    const int32_t b0 = off[static_cast<int64_t>(b) * pl.g], b1 = off[static_cast<int64_t>(b + 1) * pl.g];
+    const int cnt_b = b1 - b0;
+    if (b == pl.nb - 1 && t == 0) {
+        const_cast<int32_t*>(p.rs)[p.n] = b1;
+        p.row_u[p.n] = 0;                                         // the scan's (n + 1)-th input
+    }
+    if (cnt_b > pl.cap) {                                          // host: two-stage pipeline
+        if (t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 1), 1ull);
+        return;
+    }
+    for (int i = t; i <= nrow; i += THREADS) rcnt[i] = 0;
+    uint32_t ent[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int i = t + k * THREADS;
+        ent[k] = i < cnt_b ? __builtin_nontemporal_load(stream + b0 + i) : 0u;
+    }
+    __syncthreads();
+    const int sh = pl.cbits + 1;
+    const uint32_t kmask = (1u << sh) - 1u;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+        if (t + k * THREADS < cnt_b) atomicAdd(&rcnt[ent[k] >> sh], 1u);
+    __syncthreads();
+    // exclusive scan of the row counts (nrow <= 512 <= THREADS): wavefront scans + the wavefronts' sums
+    uint32_t mine = t < nrow ? rcnt[t] : 0u, inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    const uint32_t excl = base + inc - mine;
+    if (t < nrow) {
+        roff[t] = excl;
+        rcnt[t] = excl;                                            // placement cursor
+        const int32_t r = row0 + t;
+        if (r < p.n) {
+            const_cast<int32_t*>(p.rs)[r] = b0 + static_cast<int32_t>(excl);
+            const float d = static_cast<float>(mine) / 2.f;        // (unit_row_tables)
+            const_cast<float*>(p.deg)[r] = d;
+            if (p.sym) const_cast<float*>(p.dinv)[r] = d == 0.f ? 0.f : powf(d, -0.5f);
+        }
+    }
+    if (t == 0) roff[nrow] = static_cast<uint32_t>(cnt_b);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+        if (t + k * THREADS < cnt_b) placed[atomicAdd(&rcnt[ent[k] >> sh], 1u)] = ent[k] & kmask;
+    __syncthreads();
+    const BitonicSel sel = bitonic_sel(lane);
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);          // (the compiler does not know t >> 6 is wavefront-uniform)
+    for (int rr = wvu; rr < nrow; rr += WAVES) {
+        const int32_t r = row0 + rr;
+        if (r >= p.n) break;
+        const int beg = __builtin_amdgcn_readfirstlane(static_cast<int>(roff[rr]));
+        const int cnt = __builtin_amdgcn_readfirstlane(static_cast<int>(roff[rr + 1])) - beg;
+        int u = 0, left = 0;
+        if (cnt <= 64) {
+            const uint32_t c2 = placed[beg + (lane < cnt ? lane : 0)];
+            unit_merge_short<uint32_t>(p, c2, cnt, r, static_cast<int64_t>(b0) + beg, lane, sel, u, left);
+        } else if (cnt <= kUnitRowMax) {
+            unit_merge_long(p, placed + beg, cnt, r, static_cast<int64_t>(b0) + beg, lane, u, left);
+        } else {
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 1), 1ull);
+        }
+        if (lane == 0) {
+            p.row_u[r] = u;
+            p.row_left[r] = left;
+        }
+    }
+}
+
 // rocPRIM's gfx950 default for 64-bit keys sorts 8 bits per pass (3 passes for 20 row bits); 10 bits per pass with
 // 1024-thread blocks needs 2 -- tools/probes/sort_probe.hip, 40 M keys: 0.82 -> 0.64 ms (keys), 1.08 -> 0.85 ms (pairs)
 using RowSortConfig = rocprim::radix_sort_config<
@@ -962,7 +1353,7 @@ using RowSortConfig = rocprim::radix_sort_config<
                                         rocprim::block_radix_rank_algorithm::match>>;
 
 struct MagopWs {
-    size_t keys_a, keys_b, w_a, w_b, rs, ucnt, dinv, shift, ent, long_rows, n_long, sort_tmp, scan_tmp, sort_tmp_bytes,
+    size_t keys_a, keys_b, w_a, w_b, rs, ucnt, dinv, shift, ent, long_rows, n_long, sort_tmp, scan_tmp, hist, off, sort_tmp_bytes,
         scan_tmp_bytes, total;
 };
 
@@ -981,6 +1372,14 @@ int magop_layout(int64_t e, int32_t n, int weighted, MagopWs* w)
         PYGSD_HIP_TRY(rocprim::radix_sort_keys<RowSortConfig>(nullptr, sort_tmp, k, k, m, b0, b1, hipStream_t(nullptr)));
     PYGSD_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tmp, rocprim::make_transform_iterator(i32, PlusOne()), i32, 0,
                                           nn + 1, rocprim::plus<int32_t>(), hipStream_t(nullptr)));
+    BucketPlan pl;
+    size_t table = 0;
+    if (!weighted && bucket_plan(e, n, &pl)) {
+        table = static_cast<size_t>(pl.nb) * pl.g + 1;
+        size_t scan2 = 0;
+        PYGSD_HIP_TRY(rocprim::exclusive_scan(nullptr, scan2, i32, i32, 0, table, rocprim::plus<int32_t>(), hipStream_t(nullptr)));
+        if (scan2 > scan_tmp) scan_tmp = scan2;
+    }
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += round_up(bytes, 256); return o; };
     w->keys_a = take(m * 8);        // edge_keys output; dead after the sort: the records (16 B) reuse keys_a + ent
@@ -996,6 +1395,8 @@ int magop_layout(int64_t e, int32_t n, int weighted, MagopWs* w)
     w->n_long = take(256);
     w->sort_tmp = take(sort_tmp);
     w->scan_tmp = take(scan_tmp);
+    w->hist = take(table * 4);
+    w->off = take(table * 4);
     w->sort_tmp_bytes = sort_tmp;
     w->scan_tmp_bytes = scan_tmp;
     w->total = off + 256;
@@ -1152,33 +1553,66 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
         PYGSD_HIP_TRY(hipMemsetAsync(rowptr, 0, sizeof(int32_t), s));
         return 0;
     }
-    if (n_edges > 0) {
-        hipLaunchKernelGGL(edge_keys, dim3(grid_for(n_edges)), dim3(kBlock), 0, s, row, col, static_cast<const float*>(nullptr),
-                           n_edges, n, keys_a, static_cast<float*>(nullptr), d_info);
-        if (int rc = check_launch("edge_keys")) return rc;
-        size_t tb = l.sort_tmp_bytes;
-        const unsigned b0 = 32u, b1 = 32u + static_cast<unsigned>(bits_for(static_cast<uint64_t>(n)));
-        PYGSD_HIP_TRY(rocprim::radix_sort_keys<RowSortConfig>(base + l.sort_tmp, tb, keys_a, keys_b, static_cast<size_t>(m), b0, b1, s));
-        hipLaunchKernelGGL(key_row_starts, dim3(grid_for(m + 1)), dim3(kBlock), 0, s, keys_b, m, n, rs);
-        if (int rc = check_launch("key_row_starts")) return rc;
-    } else {
-        PYGSD_HIP_TRY(hipMemsetAsync(rs, 0, sizeof(int32_t) * (static_cast<size_t>(n) + 2), s));
-    }
     int32_t* ucnt = reinterpret_cast<int32_t*>(base + l.ucnt);
     int32_t* left = reinterpret_cast<int32_t*>(base + l.shift);
-    hipLaunchKernelGGL(unit_row_tables, dim3(grid_for(n)), dim3(kBlock), 0, s, rs, n, sym, deg, dinv, ucnt);
-    if (int rc = check_launch("unit_row_tables")) return rc;
     // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64
     const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * static_cast<double>(q));
     UnitArgs a{keys_b, keys_a, rs, deg, dinv, rowptr, ccol, vb_real, vb_imag, vf_real, vf_imag, ucnt, left, d_info,
                m > 0 ? m : 1, n, sym, two_pi_q, lambda_max, diag_shift};
     const int64_t per_block = 4 * kRowsPerWave;
     const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n) + per_block - 1) / per_block);
-    if (n <= (1 << 25))
-        hipLaunchKernelGGL(unit_merge_rows<uint32_t>, dim3(grid), dim3(kBlock), 0, s, a);
-    else
-        hipLaunchKernelGGL(unit_merge_rows<uint64_t>, dim3(grid), dim3(kBlock), 0, s, a);
-    if (int rc = check_launch("unit_merge_rows")) return rc;
+    BucketPlan pl;
+    const char* form = getenv("PYGSD_UNIT_BUILD_FORM");          // "sort": the radix-sort form (measurement / tests)
+    const bool buckets = !(form && strcmp(form, "sort") == 0) && bucket_plan(n_edges, n, &pl);
+    if (buckets) {
+        int32_t* hist = reinterpret_cast<int32_t*>(base + l.hist);
+        int32_t* off = reinterpret_cast<int32_t*>(base + l.off);
+        uint32_t* stream = reinterpret_cast<uint32_t*>(keys_b);
+        hipLaunchKernelGGL(bucket_count, dim3(pl.g), dim3(kPassThreads), 0, s, row, col, n_edges, n, pl, hist, d_info);
+        if (int rc = check_launch("bucket_count")) return rc;
+        size_t tb = l.scan_tmp_bytes;
+        PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb, hist, off, 0, static_cast<size_t>(pl.nb) * pl.g + 1,
+                                              rocprim::plus<int32_t>(), s));
+        const size_t lds2 = (static_cast<size_t>(2 * kTileEdges) + 2 * kScatterThreads + 2 * static_cast<size_t>(pl.nb)) * sizeof(uint32_t);
+        static const hipError_t once2 = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_scatter),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        PYGSD_HIP_TRY(once2);
+        hipLaunchKernelGGL(bucket_scatter, dim3(pl.g), dim3(kScatterThreads), lds2, s, row, col, n_edges, n, pl, off, stream);
+        if (int rc = check_launch("bucket_scatter")) return rc;
+        const size_t lds = (static_cast<size_t>(pl.cap) + 2 * ((size_t(1) << pl.rl) + 8)) * sizeof(uint32_t);
+        if (pl.threads == 1024) {
+            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows<1024>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            PYGSD_HIP_TRY(once);
+            hipLaunchKernelGGL(bucket_merge_rows<1024>, dim3(pl.nb), dim3(1024), lds, s, a, pl, stream, off);
+        } else {
+            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows<512>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            PYGSD_HIP_TRY(once);
+            hipLaunchKernelGGL(bucket_merge_rows<512>, dim3(pl.nb), dim3(512), lds, s, a, pl, stream, off);
+        }
+        if (int rc = check_launch("bucket_merge_rows")) return rc;
+    } else {
+        if (n_edges > 0) {
+            hipLaunchKernelGGL(edge_keys, dim3(grid_for(n_edges)), dim3(kBlock), 0, s, row, col, static_cast<const float*>(nullptr),
+                               n_edges, n, keys_a, static_cast<float*>(nullptr), d_info);
+            if (int rc = check_launch("edge_keys")) return rc;
+            size_t tb = l.sort_tmp_bytes;
+            const unsigned b0 = 32u, b1 = 32u + static_cast<unsigned>(bits_for(static_cast<uint64_t>(n)));
+            PYGSD_HIP_TRY(rocprim::radix_sort_keys<RowSortConfig>(base + l.sort_tmp, tb, keys_a, keys_b, static_cast<size_t>(m), b0, b1, s));
+            hipLaunchKernelGGL(key_row_starts, dim3(grid_for(m + 1)), dim3(kBlock), 0, s, keys_b, m, n, rs);
+            if (int rc = check_launch("key_row_starts")) return rc;
+        } else {
+            PYGSD_HIP_TRY(hipMemsetAsync(rs, 0, sizeof(int32_t) * (static_cast<size_t>(n) + 2), s));
+        }
+        hipLaunchKernelGGL(unit_row_tables, dim3(grid_for(n)), dim3(kBlock), 0, s, rs, n, sym, deg, dinv, ucnt);
+        if (int rc = check_launch("unit_row_tables")) return rc;
+        if (n <= (1 << 25))
+            hipLaunchKernelGGL(unit_merge_rows<uint32_t>, dim3(grid), dim3(kBlock), 0, s, a);
+        else
+            hipLaunchKernelGGL(unit_merge_rows<uint64_t>, dim3(grid), dim3(kBlock), 0, s, a);
+        if (int rc = check_launch("unit_merge_rows")) return rc;
+    }
     size_t tb = l.scan_tmp_bytes;
     PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb, rocprim::make_transform_iterator(ucnt, PlusOne()), rowptr, 0,
                                           static_cast<size_t>(n) + 1, rocprim::plus<int32_t>(), s));

@@ -1,0 +1,27 @@
+#!/bin/bash
+# GPU box: SQ / LDS counters of the unweighted operator build's kernels (separate --pmc passes, no trace domains)
+TAG=${TAG:-r4}
+cd /root/repo; export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_BUSY_CYCLES" "FETCH_SIZE WRITE_SIZE"; do
+  i=$((i+1))
+  rm -rf gpurun_out/pmc_build_${TAG}_$i
+  timeout 200 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_build_${TAG}_$i -o b -- python tools/build_probe.py --only fused --iters 2 > gpurun_out/pmc_build_${TAG}_$i.log 2>&1
+done
+python - <<P
+import csv, glob, collections, json
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc_build_${TAG}_*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "pygsd" not in k: continue
+        import re
+        m = re.search(r"namespace\)::(\w+)", k)
+        short = m.group(1) if m else k[:40]
+        acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {c: sum(v)/len(v) for c, v in d.items()} for k, d in acc.items()}
+json.dump(out, open("gpurun_out/${TAG}_build_pmc.json", "w"), indent=1)
+for k, d in out.items():
+    print(k)
+    for c, v in sorted(d.items()): print(f"   {c:26s} {v:16.0f}")
+P
