@@ -698,7 +698,7 @@ __global__ void diagonal_of_empty_rows(const int32_t* __restrict__ rowptr, const
 //   A  unit_merge_rows   a wavefront orders a row in registers and parks the MERGED row: ONE 8-byte record per DISTINCT
 //                        neighbour (col | multiplicity | Theta_arg) instead of a 16-byte record per stream position
 //   -  scan of (distinct + 1) -> row pointer
-//   B  unit_write_rows   the same rows-per-wavefront mapping reads the merged rows back (coalesced 8-byte loads), forms the values
+//   B  unit_write_chunks a workgroup per 16 rows walks the merged rows (coalesced 8-byte loads, every lane busy), forms the values
 //                        (same formulas, same order as values_entries: bit-compatible) and writes a wavefront's contiguous slot
 //                        range through LDS with aligned 16-byte stores
 // i.e. 330 + 330 MB of intermediate traffic instead of 640 + 640 at the north star, no shift[] table, no per-record row lookups.
@@ -711,9 +711,12 @@ __global__ void diagonal_of_empty_rows(const int32_t* __restrict__ rowptr, const
 constexpr int kUnitRowMax = 512;
 
 __global__ void unit_row_tables(const int32_t* __restrict__ rs, int32_t n, int32_t sym, float* __restrict__ deg,
-                                float* __restrict__ dinv, int32_t* __restrict__ row_u)
+                                float* __restrict__ dinv, int32_t* __restrict__ row_u, float two_pi_q, float* __restrict__ trig)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) row_u[n] = 0;        // the scan's (n + 1)-th input
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        row_u[n] = 0;                                             // the scan's (n + 1)-th input
+        sincosf(two_pi_q, trig + 1, trig);
+    }
     GRID_STRIDE(r, n)
     {
         // the butterfly of merge_one_row adds multiples of 1/2 (exact in any order): the same value as (entries) / 2
@@ -741,24 +744,28 @@ struct UnitArgs {
     int64_t m;
     int32_t n, sym;
     float two_pi_q, lam, diag_shift;
+    float* trig;                   // {cos, sin}(2 pi q), formed once by the first kernel of the build
 };
 
-// A wavefront's rows occupy ONE contiguous slot range of the final CSR ([first slot of its first row, + sum of (distinct + 1))):
-// with rows of <= 64 entries (<= 4 x 65 slots) the five arrays are staged in LDS and drained with aligned 16-byte stores -- 4-byte
-// stores over five streams ran at 2.4 TB/s in the first version of values_entries, whatever else changed.
-constexpr int kStageW = kRowsPerWave * 65 + 4;
+// A chunk of kChunkRows consecutive rows occupies ONE contiguous slot range of the final CSR ([first slot of its first row,
+// + sum of (distinct + 1))): with rows of <= 64 entries (<= kChunkRows x 65 slots) the five arrays are staged in LDS and drained with
+// aligned 16-byte stores -- 4-byte stores over five streams ran at 2.4 TB/s in the first version of values_entries, whatever else
+// changed.  STRIDE: words between the staged arrays; 0 = straight to global memory (rows the staging does not take).
+constexpr int kChunkRows = 16;
+constexpr int kChunkSlots = kChunkRows * 65 + 4;
+constexpr uint64_t kNoRecord = ~0ull;
 
-template <bool STAGED>
+template <int STRIDE>
 __device__ __forceinline__ void unit_store(const UnitArgs& p, float* st, int64_t wslot0, int64_t slot, int32_t c, float v0, float v1,
                                            float v2, float v3)
 {
-    if constexpr (STAGED) {
+    if constexpr (STRIDE != 0) {
         const int o = static_cast<int>(slot - wslot0);
         st[o] = __int_as_float(c);
-        st[kStageW + o] = v0;
-        st[2 * kStageW + o] = v1;
-        st[3 * kStageW + o] = v2;
-        st[4 * kStageW + o] = v3;
+        st[STRIDE + o] = v0;
+        st[2 * STRIDE + o] = v1;
+        st[3 * STRIDE + o] = v2;
+        st[4 * STRIDE + o] = v3;
     } else {
         p.ccol[slot] = c;
         p.vb_re[slot] = v0;
@@ -768,9 +775,10 @@ __device__ __forceinline__ void unit_store(const UnitArgs& p, float* st, int64_t
     }
 }
 
-template <bool STAGED>
-__device__ __forceinline__ void unit_values(const UnitArgs& p, float* st, int64_t wslot0, int32_t row, int32_t c, int len, int theta,
-                                            float cs1, float sn1, int64_t slot)
+// `ir`, `ic`: deg^-1/2 of the row and of the column (read by the caller; unused without the normalisation)
+template <int STRIDE>
+__device__ __forceinline__ void unit_values(const UnitArgs& p, float* st, int64_t wslot0, float ir, float ic, int32_t c, int len,
+                                            int theta, float cs1, float sn1, int64_t slot)
 {
     // (values_entries, specialised: A_s = len / 2, Theta_arg = theta, both small integers as floats)
     const float th = static_cast<float>(theta);
@@ -783,7 +791,6 @@ __device__ __forceinline__ void unit_values(const UnitArgs& p, float* st, int64_
     }
     float mag = static_cast<float>(len) / 2.f, mmag = mag;
     if (p.sym) {
-        const float ir = p.dinv[row], ic = p.dinv[c];
         mag = ir * mag * ic;
         mmag = ic * mmag * ir;
     }
@@ -794,18 +801,20 @@ __device__ __forceinline__ void unit_values(const UnitArgs& p, float* st, int64_
         v2 = scale_lam(v2, p.lam);
         v3 = scale_lam(v3, p.lam);
     }
-    unit_store<STAGED>(p, st, wslot0, slot, c, v0, v1, v2, v3);
+    unit_store<STRIDE>(p, st, wslot0, slot, c, v0, v1, v2, v3);
 }
 
-template <bool STAGED>
+template <int STRIDE>
 __device__ __forceinline__ void unit_diagonal(const UnitArgs& p, float* st, int64_t wslot0, int32_t row, int64_t slot)
 {
     const float dg = scale_lam(p.sym ? 1.f : p.deg[row], p.lam) + p.diag_shift;
-    unit_store<STAGED>(p, st, wslot0, slot, row, dg, 0.f, dg, 0.f);
+    unit_store<STRIDE>(p, st, wslot0, slot, row, dg, 0.f, dg, 0.f);
 }
 
 // One row of <= 64 stream entries, one (col << 1 | dir) key per lane: ordered in registers, duplicates / reciprocal pairs merged;
-// ONE 8-byte record per distinct neighbour -- col | multiplicity << 32 | (Theta_arg + 64) << 40 -- parked at scratch[gbeg + rank].
+// ONE 8-byte record per distinct neighbour -- col | multiplicity << 32 | (Theta_arg + 64) << 40 | rank << 48 | (row mod kChunkRows) << 54
+// -- parked at scratch[gbeg + rank]; the positions behind a row's distinct entries (duplicates merged away) are marked kNoRecord, so
+// the write kernel can walk a chunk's positions without looking at its rows.
 // (`cnt`, `r`, `gbeg` wavefront-uniform)
 template <typename KT>
 __device__ __forceinline__ void unit_merge_short(const UnitArgs& p, uint32_t c2, int cnt, int32_t r, int64_t gbeg, int lane,
@@ -833,11 +842,14 @@ __device__ __forceinline__ void unit_merge_short(const UnitArgs& p, uint32_t c2,
     const int rl_here = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(D >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(D), 0u)));
     const int rl_end = __builtin_amdgcn_ds_bpermute((end & 63) << 2, rl_here);
     const int n1 = (end < cnt ? rl_end : __popcll(D)) - rl_here;
+    const int rank = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(H >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(H), 0u)));
     if (hd) {
         const int ln = end - lane;
-        const int rank = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(H >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(H), 0u)));
         p.scratch[gbeg + rank] = static_cast<uint64_t>(cv) | (static_cast<uint64_t>(ln) << 32) |
-                                 (static_cast<uint64_t>(ln - 2 * n1 + 64) << 40);
+                                 (static_cast<uint64_t>(ln - 2 * n1 + 64) << 40) | (static_cast<uint64_t>(rank) << 48) |
+                                 (static_cast<uint64_t>(r & (kChunkRows - 1)) << 54);
+    } else if (have) {
+        p.scratch[gbeg + u + (lane - rank)] = kNoRecord;          // (lane - rank: entries before this one that are no heads)
     }
 }
 
@@ -922,124 +934,136 @@ __global__ __launch_bounds__(256) void unit_merge_rows(UnitArgs p)
     }
 }
 
-// Kernel B (after the scan of distinct + 1 -> row pointer): the same wavefront-per-rows mapping reads the merged rows back (one
-// coalesced 8-byte load per distinct entry) and writes columns, the four value arrays and the diagonal into their final slots.
-__global__ __launch_bounds__(256) void unit_write_rows(UnitArgs p)
+// A row written straight to global memory by one wavefront (chunks holding a row of more than 64 entries): merged records for rows
+// of <= 64 entries, the SORTED KEYS unit_merge_long left for longer ones.
+__device__ __forceinline__ void unit_write_row_direct(const UnitArgs& p, int32_t r, int32_t beg, int cnt, int u, int left, int64_t slot0,
+                                                      int lane, float cs1, float sn1)
 {
-    __shared__ __attribute__((aligned(16))) float stage[4][5 * kStageW];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * 4 + wv) * kRowsPerWave;
-    if (blockIdx.x == 0 && threadIdx.x == 0) p.info[0] = static_cast<int64_t>(p.rowptr[p.n]) - p.n;     // E_s for the host
-    if (r0 >= p.n) return;
-    const int rows = p.n - r0 < kRowsPerWave ? static_cast<int>(p.n - r0) : kRowsPerWave;
-    float sn1, cs1;
-    sincosf(p.two_pi_q, &sn1, &cs1);
-    float* st = &stage[wv][0];
-    int32_t beg[kRowsPerWave], cnt[kRowsPerWave], u[kRowsPerWave], left[kRowsPerWave];
-    const int idx = lane <= rows ? lane : rows;
-    const int32_t bound = p.rs[r0 + idx];
-    const int32_t rp = p.rowptr[r0 + idx];                         // lanes 0 .. rows: the rows' first slots (rowptr[n] exists)
-    const int32_t lf = lane < rows ? p.row_left[r0 + lane] : 0;
-    bool short_rows = true;
-#pragma unroll
-    for (int j = 0; j < kRowsPerWave; ++j) {
-        beg[j] = __builtin_amdgcn_readlane(bound, j < rows ? j : rows);
-        cnt[j] = j < rows ? __builtin_amdgcn_readlane(bound, j + 1 < rows ? j + 1 : rows) - beg[j] : 0;
-        const int32_t s0 = __builtin_amdgcn_readlane(rp, j < rows ? j : rows), s1 = __builtin_amdgcn_readlane(rp, j + 1 < rows ? j + 1 : rows);
-        u[j] = j < rows ? s1 - s0 - 1 : 0;
-        left[j] = __builtin_amdgcn_readlane(lf, j < rows ? j : 0);
-        short_rows = short_rows && cnt[j] <= 64;
+    if (lane == 0) unit_diagonal<0>(p, nullptr, 0, r, slot0 + left);
+    const float ir = p.sym ? p.dinv[r] : 0.f;
+    if (cnt <= 64) {
+        if (lane < u) {
+            const uint64_t rc = p.scratch[beg + lane];
+            const int32_t c = static_cast<int32_t>(rc & 0xFFFFFFFFull);
+            const int ln = static_cast<int>((rc >> 32) & 0xFFull), th = static_cast<int>((rc >> 40) & 0xFFull) - 64;
+            unit_values<0>(p, nullptr, 0, ir, p.sym ? p.dinv[c] : 0.f, c, ln, th, cs1, sn1, slot0 + lane + (c > r ? 1 : 0));
+        }
+    } else if (cnt <= kUnitRowMax) {
+        int base_rank = 0;
+        for (int i0 = 0; i0 < cnt; i0 += 64) {
+            const int i = i0 + lane;
+            bool hd = false;
+            uint32_t cur = 0;
+            if (i < cnt) {
+                cur = static_cast<uint32_t>(p.scratch[beg + i]) >> 1;
+                hd = i == 0 || (static_cast<uint32_t>(p.scratch[beg + i - 1]) >> 1) != cur;
+            }
+            const uint64_t H = __ballot(hd);
+            if (hd) {
+                int ln = 0, n1 = 0;
+                for (int t = i; t < cnt; ++t) {                    // the run: short (multiplicity of one neighbour)
+                    const uint32_t k2 = static_cast<uint32_t>(p.scratch[beg + t]);
+                    if ((k2 >> 1) != cur) break;
+                    ++ln;
+                    n1 += static_cast<int>(k2 & 1u);
+                }
+                const int rk = base_rank + __popcll(H & ((1ull << lane) - 1ull));
+                const int32_t c = static_cast<int32_t>(cur);
+                unit_values<0>(p, nullptr, 0, ir, p.sym ? p.dinv[c] : 0.f, c, ln, ln - 2 * n1, cs1, sn1, slot0 + rk + (c > r ? 1 : 0));
+            }
+            base_rank += __popcll(H);
+        }
     }
-    int64_t slot0 = __builtin_amdgcn_readlane(rp, 0);
-    const int64_t wslot0 = slot0;
+}
+
+// Kernel B (after the scan of distinct + 1 -> row pointer): one workgroup per chunk of kChunkRows rows walks the chunk's positions of
+// the record buffer -- one coalesced 8-byte load per position, every lane busy whatever the rows' lengths (a record names its row and
+// its rank in it) -- forms the values and stages columns, the four value arrays and the diagonals at their final slots in LDS; the
+// chunk's contiguous slot range leaves with aligned 16-byte stores.  (Before: a wavefront per four rows, a row per pass: 131 vector
+// instructions per row with 41 of 64 lanes busy -- VALU-bound at half its time; now 58.)
+// Measured and dropped: persistent workgroups running  row bounds -> records -> deg^-1/2 gathers -> stores  as a pipeline over
+// chunks c, c + G, c + 2 G (0.37 ms either way: on gfx9 a wait for the loads of the next round also waits for the drain's stores,
+// which share their counter -- the same reason a grid-stride copy runs at 4.5 TB/s here and a block-per-piece copy at 6.2).
+__global__ __launch_bounds__(256) void unit_write_chunks(UnitArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float stage[5 * kChunkSlots];
+    __shared__ int32_t s_rs[kChunkRows + 1], s_rp[kChunkRows + 1], s_left[kChunkRows];
+    __shared__ float s_dinv[kChunkRows];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kChunkRows;
+    if (blockIdx.x == 0 && t == 0) p.info[0] = static_cast<int64_t>(p.rowptr[p.n]) - p.n;     // E_s for the host
+    const int rows = p.n - r0 < kChunkRows ? static_cast<int>(p.n - r0) : kChunkRows;
+    // the chunk's positions of the record buffer: two wavefront-uniform (scalar) loads, so the records can leave before the
+    // per-row bounds below are back
+    const int32_t beg = p.rs[r0], end = p.rs[r0 + rows];
+    bool is_long = false;
+    if (t <= rows) {
+        s_rs[t] = p.rs[r0 + t];
+        s_rp[t] = p.rowptr[r0 + t];                                // (rowptr[n] exists)
+    }
+    if (t < rows) {
+        s_left[t] = p.row_left[r0 + t];
+        s_dinv[t] = p.sym ? p.dinv[r0 + t] : 0.f;
+        is_long = p.rs[r0 + t + 1] - p.rs[r0 + t] > 64;
+    }
     if (p.info[1] != 0) return;                                    // a row this pipeline does not take: outputs are discarded
-    if (short_rows) {
-        uint64_t rec[kRowsPerWave];
+    constexpr int PER = kChunkRows * 64 / 256;                     // rows of <= 64 entries: <= PER positions per thread
+    uint64_t rc[PER];
+    float ic[PER];
 #pragma unroll
-        for (int j = 0; j < kRowsPerWave; ++j) rec[j] = lane < u[j] ? p.scratch[beg[j] + lane] : 0ull;
-#pragma unroll
-        for (int j = 0; j < kRowsPerWave; ++j) {
-            if (j >= rows) continue;
-            const int32_t r = static_cast<int32_t>(r0) + j;
-            if (lane == 0) unit_diagonal<true>(p, st, wslot0, r, slot0 + left[j]);
-            if (lane < u[j]) {
-                const int32_t c = static_cast<int32_t>(rec[j] & 0xFFFFFFFFull);
-                const int ln = static_cast<int>((rec[j] >> 32) & 0xFFull), th = static_cast<int>((rec[j] >> 40) & 0xFFull) - 64;
-                unit_values<true>(p, st, wslot0, r, c, ln, th, cs1, sn1, slot0 + lane + (c > r ? 1 : 0));
-            }
-            slot0 += u[j] + 1;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // drain [wslot0, slot0): the 16-byte aligned middle as dwordx4, the ragged ends (<= 6 slots) as dwords
-        const int64_t lo = wslot0, hi = slot0, a0 = (lo + 3) & ~int64_t(3), a1 = hi & ~int64_t(3);
-        float* const outs[5] = {reinterpret_cast<float*>(p.ccol), p.vb_re, p.vb_im, p.vf_re, p.vf_im};
-        if (a0 < a1) {
-            const int quads = static_cast<int>((a1 - a0) >> 2);
-#pragma unroll
-            for (int arr = 0; arr < 5; ++arr) {
-                for (int g = lane; g < quads; g += 64) {
-                    const int o = static_cast<int>(a0 - lo) + 4 * g;
-                    const float* src = st + arr * kStageW + o;
-                    const f32x4 v = {src[0], src[1], src[2], src[3]};
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(outs[arr] + a0) + g);
-                }
-            }
-            const int head_n = static_cast<int>(a0 - lo), ends = head_n + static_cast<int>(hi - a1);
-            if (lane < 5 * 8) {
-                const int arr = lane >> 3, e = lane & 7;
-                if (e < ends) {
-                    const int64_t sl = e < head_n ? lo + e : a1 + (e - head_n);
-                    outs[arr][sl] = st[arr * kStageW + static_cast<int>(sl - lo)];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int arr = 0; arr < 5; ++arr)
-                for (int64_t sl = lo + lane; sl < hi; sl += 64) outs[arr][sl] = st[arr * kStageW + static_cast<int>(sl - lo)];
-        }
+    for (int k = 0; k < PER; ++k) {                               // every load of the chunk in flight before the first is used
+        const int32_t i = beg + t + k * 256;
+        rc[k] = i < end ? __builtin_nontemporal_load(p.scratch + i) : kNoRecord;
+    }
+    const bool any_long = __syncthreads_or(is_long) != 0;
+    const float cs1 = p.trig[0], sn1 = p.trig[1];
+    if (any_long) {
+        for (int j = __builtin_amdgcn_readfirstlane(wv); j < rows; j += 4)
+            unit_write_row_direct(p, static_cast<int32_t>(r0) + j, s_rs[j], s_rs[j + 1] - s_rs[j], s_rp[j + 1] - s_rp[j] - 1, s_left[j],
+                                  s_rp[j], lane, cs1, sn1);
         return;
     }
 #pragma unroll
-    for (int j = 0; j < kRowsPerWave; ++j) {
-        if (j >= rows) continue;
+    for (int k = 0; k < PER; ++k) ic[k] = (p.sym && rc[k] != kNoRecord) ? p.dinv[rc[k] & 0xFFFFFFFFull] : 0.f;
+    const int64_t wslot0 = s_rp[0];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (rc[k] == kNoRecord) continue;
+        const int32_t c = static_cast<int32_t>(rc[k] & 0xFFFFFFFFull);
+        const int ln = static_cast<int>((rc[k] >> 32) & 0xFFull), th = static_cast<int>((rc[k] >> 40) & 0xFFull) - 64;
+        const int rank = static_cast<int>((rc[k] >> 48) & 0x3Full), j = static_cast<int>((rc[k] >> 54) & (kChunkRows - 1));
         const int32_t r = static_cast<int32_t>(r0) + j;
-        if (lane == 0) unit_diagonal<false>(p, st, wslot0, r, slot0 + left[j]);
-        if (cnt[j] <= 64) {
-            if (lane < u[j]) {
-                const uint64_t rc = p.scratch[beg[j] + lane];
-                const int32_t c = static_cast<int32_t>(rc & 0xFFFFFFFFull);
-                const int ln = static_cast<int>((rc >> 32) & 0xFFull), th = static_cast<int>((rc >> 40) & 0xFFull) - 64;
-                unit_values<false>(p, st, wslot0, r, c, ln, th, cs1, sn1, slot0 + lane + (c > r ? 1 : 0));
-            }
-        } else if (cnt[j] <= kUnitRowMax) {
-            int base_rank = 0;
-            for (int i0 = 0; i0 < cnt[j]; i0 += 64) {
-                const int i = i0 + lane;
-                bool hd = false;
-                uint32_t cur = 0;
-                if (i < cnt[j]) {
-                    cur = static_cast<uint32_t>(p.scratch[beg[j] + i]) >> 1;
-                    hd = i == 0 || (static_cast<uint32_t>(p.scratch[beg[j] + i - 1]) >> 1) != cur;
-                }
-                const uint64_t H = __ballot(hd);
-                if (hd) {
-                    int ln = 0, n1 = 0;
-                    for (int t = i; t < cnt[j]; ++t) {             // the run: short (multiplicity of one neighbour)
-                        const uint32_t k2 = static_cast<uint32_t>(p.scratch[beg[j] + t]);
-                        if ((k2 >> 1) != cur) break;
-                        ++ln;
-                        n1 += static_cast<int>(k2 & 1u);
-                    }
-                    const int rk = base_rank + __popcll(H & ((1ull << lane) - 1ull));
-                    const int32_t c = static_cast<int32_t>(cur);
-                    unit_values<false>(p, st, wslot0, r, c, ln, ln - 2 * n1, cs1, sn1, slot0 + rk + (c > r ? 1 : 0));
-                }
-                base_rank += __popcll(H);
+        unit_values<kChunkSlots>(p, stage, wslot0, s_dinv[j], ic[k], c, ln, th, cs1, sn1,
+                                 static_cast<int64_t>(s_rp[j]) + rank + (c > r ? 1 : 0));
+    }
+    if (t < rows) unit_diagonal<kChunkSlots>(p, stage, wslot0, static_cast<int32_t>(r0) + t, static_cast<int64_t>(s_rp[t]) + s_left[t]);
+    __syncthreads();
+    // drain [wslot0, hi): the 16-byte aligned middle as dwordx4, the ragged ends (<= 6 slots) as dwords
+    const int64_t lo = wslot0, hi = s_rp[rows], a0 = (lo + 3) & ~int64_t(3), a1 = hi & ~int64_t(3);
+    float* const outs[5] = {reinterpret_cast<float*>(p.ccol), p.vb_re, p.vb_im, p.vf_re, p.vf_im};
+    if (a0 < a1) {
+        const int quads = static_cast<int>((a1 - a0) >> 2);
+#pragma unroll
+        for (int arr = 0; arr < 5; ++arr) {
+            for (int g = t; g < quads; g += 256) {
+                const int o = static_cast<int>(a0 - lo) + 4 * g;
+                const float* src = stage + arr * kChunkSlots + o;
+                const f32x4 v = {src[0], src[1], src[2], src[3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(outs[arr] + a0) + g);
             }
         }
-        slot0 += u[j] + 1;
+        const int head_n = static_cast<int>(a0 - lo), ends = head_n + static_cast<int>(hi - a1);
+        if (t < 5 * 8) {
+            const int arr = t >> 3, e = t & 7;
+            if (e < ends) {
+                const int64_t sl = e < head_n ? lo + e : a1 + (e - head_n);
+                outs[arr][sl] = stage[arr * kChunkSlots + static_cast<int>(sl - lo)];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int arr = 0; arr < 5; ++arr)
+            for (int64_t sl = lo + t; sl < hi; sl += 256) outs[arr][sl] = stage[arr * kChunkSlots + static_cast<int>(sl - lo)];
     }
 }
 
@@ -1055,7 +1079,7 @@ __global__ __launch_bounds__(256) void unit_write_rows(UnitArgs p)
 //   2  bucket_pass<true>   the same tiles again: 4-byte entries  row_low << (cbits + 1) | col << 1 | dir  to their ranges
 //   3  bucket_merge_rows   one workgroup per bucket: the bucket is counted by row in LDS (-> row bounds, degrees, deg^-1/2),
 //      placed by row in LDS, and each row is ordered and merged by a wavefront exactly as unit_merge_rows does (same records, same
-//      place: scratch[row start + rank]); unit_write_rows follows unchanged.
+//      place: scratch[row start + rank]); unit_write_chunks follows unchanged.
 // Traffic at the north star: 2 x 320 MB of edge list in, 160 MB out and in, against 320 + 320 (keys) + 320 (histogram) +
 // 2 x 640 (two sort passes) + 320 (row bounds) + 320 (merge).  A bucket that does not fit (kBucketCap entries) or a row above
 // kUnitRowMax is counted in info[1]: the host takes the two-stage pipeline, as before.
@@ -1108,10 +1132,11 @@ inline bool bucket_plan(int64_t e, int32_t n, BucketPlan* pl)
 // Pass 1: a tile's entries per bucket, counted in LDS -> hist[bucket][tile]; node-id range check (info[2], info[3]) folded in.
 __global__ __launch_bounds__(kPassThreads) void bucket_count(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t e,
                                                              int32_t n, BucketPlan pl, int32_t* __restrict__ hist,
-                                                             int64_t* __restrict__ info)
+                                                             int64_t* __restrict__ info, float two_pi_q, float* __restrict__ trig)
 {
     __shared__ uint32_t cnt[kMaxBuckets];
     const int wg = blockIdx.x, t = threadIdx.x;
+    if (wg == 0 && t == 0) sincosf(two_pi_q, trig + 1, trig);
     for (int b = t; b < pl.nb; b += kPassThreads) cnt[b] = 0u;
     __syncthreads();
     const int64_t lo = static_cast<int64_t>(wg) * kTileEdges, hi = lo + kTileEdges < e ? lo + kTileEdges : e;
@@ -1558,7 +1583,7 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
     // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64
     const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * static_cast<double>(q));
     UnitArgs a{keys_b, keys_a, rs, deg, dinv, rowptr, ccol, vb_real, vb_imag, vf_real, vf_imag, ucnt, left, d_info,
-               m > 0 ? m : 1, n, sym, two_pi_q, lambda_max, diag_shift};
+               m > 0 ? m : 1, n, sym, two_pi_q, lambda_max, diag_shift, reinterpret_cast<float*>(base + l.n_long)};
     const int64_t per_block = 4 * kRowsPerWave;
     const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n) + per_block - 1) / per_block);
     BucketPlan pl;
@@ -1568,7 +1593,7 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
         int32_t* hist = reinterpret_cast<int32_t*>(base + l.hist);
         int32_t* off = reinterpret_cast<int32_t*>(base + l.off);
         uint32_t* stream = reinterpret_cast<uint32_t*>(keys_b);
-        hipLaunchKernelGGL(bucket_count, dim3(pl.g), dim3(kPassThreads), 0, s, row, col, n_edges, n, pl, hist, d_info);
+        hipLaunchKernelGGL(bucket_count, dim3(pl.g), dim3(kPassThreads), 0, s, row, col, n_edges, n, pl, hist, d_info, two_pi_q, a.trig);
         if (int rc = check_launch("bucket_count")) return rc;
         size_t tb = l.scan_tmp_bytes;
         PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb, hist, off, 0, static_cast<size_t>(pl.nb) * pl.g + 1,
@@ -1605,7 +1630,7 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
         } else {
             PYGSD_HIP_TRY(hipMemsetAsync(rs, 0, sizeof(int32_t) * (static_cast<size_t>(n) + 2), s));
         }
-        hipLaunchKernelGGL(unit_row_tables, dim3(grid_for(n)), dim3(kBlock), 0, s, rs, n, sym, deg, dinv, ucnt);
+        hipLaunchKernelGGL(unit_row_tables, dim3(grid_for(n)), dim3(kBlock), 0, s, rs, n, sym, deg, dinv, ucnt, two_pi_q, a.trig);
         if (int rc = check_launch("unit_row_tables")) return rc;
         if (n <= (1 << 25))
             hipLaunchKernelGGL(unit_merge_rows<uint32_t>, dim3(grid), dim3(kBlock), 0, s, a);
@@ -1616,6 +1641,7 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
     size_t tb = l.scan_tmp_bytes;
     PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb, rocprim::make_transform_iterator(ucnt, PlusOne()), rowptr, 0,
                                           static_cast<size_t>(n) + 1, rocprim::plus<int32_t>(), s));
-    hipLaunchKernelGGL(unit_write_rows, dim3(grid), dim3(kBlock), 0, s, a);
-    return check_launch("unit_write_rows");
+    hipLaunchKernelGGL(unit_write_chunks, dim3(static_cast<unsigned>((static_cast<int64_t>(n) + kChunkRows - 1) / kChunkRows)), dim3(kBlock), 0,
+                       s, a);
+    return check_launch("unit_write_chunks");
 }

@@ -227,6 +227,9 @@ def _unit_operator_csr(row: Tensor, col: Tensor, e: int, n: int, sym: int, q: fl
     else:
         ccol = ccol[:nnz]
     csr = CSR(n, n, nnz, rowptr, ccol, None)
+    # every row this build takes has <= 512 stream entries (pygsd_magop_unit's bound), i.e. <= 513 slots < PYGSD_LONG_ROW: no hub
+    # rows, known without the device->host read CSR.hubs() would make on its first use (one per uncached forward)
+    csr._hubs = ()
     return csr, (vals[2, :nnz], vals[3, :nnz]), (vals[0, :nnz], vals[1, :nnz]), deg
 
 
