@@ -316,8 +316,12 @@ int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, in
  * traffic of pygsd_magop_stage1 + _stage2, bit-identical results (get_magnetic_Laplacian.py:47-85 with edge_weight = None,
  * as MagNetConv.py:157-181 calls it on every uncached forward).  Outputs as the two stages (rowptr [n + 1], deg [n], col / v*
  * allocated for 2 n_edges + n slots, 16-byte aligned); d_info[0] = E_s, d_info[1] != 0: a node has more than 512 symmetrised
- * entries and the outputs are invalid -- the caller then takes the two-stage pipeline; d_info[2], [3] as stage 1.  workspace
- * from pygsd_magop_workspace(n_edges, n, 0). */
+ * entries (or, in the bucket form below, 512 consecutive rows hold more than 32 768) and the outputs are invalid -- the caller
+ * then takes the two-stage pipeline; d_info[2], [3] as stage 1.  workspace from pygsd_magop_workspace(n_edges, n, 0).
+ * Two forms with bit-identical outputs: by default the stream is never sorted globally -- it is split once into buckets of up to
+ * 1024 consecutive rows that fit a workgroup's LDS and ordered there (graphs of <= 2^25 nodes, <= 3000 buckets, an average
+ * bucket of <= 24 576 entries); other graphs, or PYGSD_UNIT_BUILD_FORM=sort in the environment, take a radix sort on the row
+ * bits first. */
 int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, float q, float lambda_max,
                      float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr, float* deg, int32_t* ccol,
                      float* vb_real, float* vb_imag, float* vf_real, float* vf_imag, int64_t* d_info, void* stream);

@@ -984,9 +984,10 @@ __device__ __forceinline__ void unit_write_row_direct(const UnitArgs& p, int32_t
 // Measured and dropped: persistent workgroups running  row bounds -> records -> deg^-1/2 gathers -> stores  as a pipeline over
 // chunks c, c + G, c + 2 G (0.37 ms either way: on gfx9 a wait for the loads of the next round also waits for the drain's stores,
 // which share their counter -- the same reason a grid-stride copy runs at 4.5 TB/s here and a block-per-piece copy at 6.2).
-__global__ __launch_bounds__(256) void unit_write_chunks(UnitArgs p)
+template <int THREADS, int SLOTS>
+__global__ __launch_bounds__(THREADS) void unit_write_chunks(UnitArgs p)
 {
-    __shared__ __attribute__((aligned(16))) float stage[5 * kChunkSlots];
+    __shared__ __attribute__((aligned(16))) float stage[5 * SLOTS];
     __shared__ int32_t s_rs[kChunkRows + 1], s_rp[kChunkRows + 1], s_left[kChunkRows];
     __shared__ float s_dinv[kChunkRows];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1005,20 +1006,21 @@ __global__ __launch_bounds__(256) void unit_write_chunks(UnitArgs p)
         s_left[t] = p.row_left[r0 + t];
         s_dinv[t] = p.sym ? p.dinv[r0 + t] : 0.f;
         is_long = p.rs[r0 + t + 1] - p.rs[r0 + t] > 64;
+        if (t == 0) is_long = is_long || p.rowptr[r0 + rows] - p.rowptr[r0] > SLOTS - 4;      // more slots than the staging holds
     }
     if (p.info[1] != 0) return;                                    // a row this pipeline does not take: outputs are discarded
-    constexpr int PER = kChunkRows * 64 / 256;                     // rows of <= 64 entries: <= PER positions per thread
+    constexpr int PER = kChunkRows * 64 / THREADS;                     // rows of <= 64 entries: <= PER positions per thread
     uint64_t rc[PER];
     float ic[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {                               // every load of the chunk in flight before the first is used
-        const int32_t i = beg + t + k * 256;
+        const int32_t i = beg + t + k * THREADS;
         rc[k] = i < end ? __builtin_nontemporal_load(p.scratch + i) : kNoRecord;
     }
     const bool any_long = __syncthreads_or(is_long) != 0;
     const float cs1 = p.trig[0], sn1 = p.trig[1];
     if (any_long) {
-        for (int j = __builtin_amdgcn_readfirstlane(wv); j < rows; j += 4)
+        for (int j = __builtin_amdgcn_readfirstlane(wv); j < rows; j += THREADS / 64)
             unit_write_row_direct(p, static_cast<int32_t>(r0) + j, s_rs[j], s_rs[j + 1] - s_rs[j], s_rp[j + 1] - s_rp[j] - 1, s_left[j],
                                   s_rp[j], lane, cs1, sn1);
         return;
@@ -1033,10 +1035,10 @@ __global__ __launch_bounds__(256) void unit_write_chunks(UnitArgs p)
         const int ln = static_cast<int>((rc[k] >> 32) & 0xFFull), th = static_cast<int>((rc[k] >> 40) & 0xFFull) - 64;
         const int rank = static_cast<int>((rc[k] >> 48) & 0x3Full), j = static_cast<int>((rc[k] >> 54) & (kChunkRows - 1));
         const int32_t r = static_cast<int32_t>(r0) + j;
-        unit_values<kChunkSlots>(p, stage, wslot0, s_dinv[j], ic[k], c, ln, th, cs1, sn1,
+        unit_values<SLOTS>(p, stage, wslot0, s_dinv[j], ic[k], c, ln, th, cs1, sn1,
                                  static_cast<int64_t>(s_rp[j]) + rank + (c > r ? 1 : 0));
     }
-    if (t < rows) unit_diagonal<kChunkSlots>(p, stage, wslot0, static_cast<int32_t>(r0) + t, static_cast<int64_t>(s_rp[t]) + s_left[t]);
+    if (t < rows) unit_diagonal<SLOTS>(p, stage, wslot0, static_cast<int32_t>(r0) + t, static_cast<int64_t>(s_rp[t]) + s_left[t]);
     __syncthreads();
     // drain [wslot0, hi): the 16-byte aligned middle as dwordx4, the ragged ends (<= 6 slots) as dwords
     const int64_t lo = wslot0, hi = s_rp[rows], a0 = (lo + 3) & ~int64_t(3), a1 = hi & ~int64_t(3);
@@ -1045,9 +1047,9 @@ __global__ __launch_bounds__(256) void unit_write_chunks(UnitArgs p)
         const int quads = static_cast<int>((a1 - a0) >> 2);
 #pragma unroll
         for (int arr = 0; arr < 5; ++arr) {
-            for (int g = t; g < quads; g += 256) {
+            for (int g = t; g < quads; g += THREADS) {
                 const int o = static_cast<int>(a0 - lo) + 4 * g;
-                const float* src = stage + arr * kChunkSlots + o;
+                const float* src = stage + arr * SLOTS + o;
                 const f32x4 v = {src[0], src[1], src[2], src[3]};
                 __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(outs[arr] + a0) + g);
             }
@@ -1057,13 +1059,13 @@ __global__ __launch_bounds__(256) void unit_write_chunks(UnitArgs p)
             const int arr = t >> 3, e = t & 7;
             if (e < ends) {
                 const int64_t sl = e < head_n ? lo + e : a1 + (e - head_n);
-                outs[arr][sl] = stage[arr * kChunkSlots + static_cast<int>(sl - lo)];
+                outs[arr][sl] = stage[arr * SLOTS + static_cast<int>(sl - lo)];
             }
         }
     } else {
 #pragma unroll
         for (int arr = 0; arr < 5; ++arr)
-            for (int64_t sl = lo + t; sl < hi; sl += 256) outs[arr][sl] = stage[arr * kChunkSlots + static_cast<int>(sl - lo)];
+            for (int64_t sl = lo + t; sl < hi; sl += THREADS) outs[arr][sl] = stage[arr * SLOTS + static_cast<int>(sl - lo)];
     }
 }
 
@@ -1072,19 +1074,22 @@ __global__ __launch_bounds__(256) void unit_write_chunks(UnitArgs p)
 // pass on top (0.70 ms of rocPRIM kernels at the north star) only to bucket the stream by row; the row-bucketed stream is then
 // read back twice more (row bounds, merge).  Here the stream is split ONCE, into buckets of 2^rl consecutive rows that fit a
 // workgroup's LDS, and everything finer happens inside LDS:
-//   1  bucket_pass<false>  per tile of the edge list (one workgroup): entries per bucket, counted in LDS -> hist[bucket][tile]
+//   1  bucket_count        per tile of the edge list (one workgroup, 16 k edges): entries per bucket, counted in LDS ->
+//      hist[bucket][tile]
 //   -  exclusive scan of hist (bucket-major): every (bucket, tile) pair owns a private range of the stream -- no global atomics,
 //      no look-back; the order inside a bucket is whatever the LDS atomics gave, which is immaterial: unit weights make a row's
 //      merge order-free, and the rows are ordered by column below
-//   2  bucket_pass<true>   the same tiles again: 4-byte entries  row_low << (cbits + 1) | col << 1 | dir  to their ranges
+//   2  bucket_scatter      the same tiles again: 4-byte entries  row_low << (cbits + 1) | col << 1 | dir  to their ranges,
+//      staged by bucket in LDS so that a tile leaves as runs of neighbouring words
 //   3  bucket_merge_rows   one workgroup per bucket: the bucket is counted by row in LDS (-> row bounds, degrees, deg^-1/2),
 //      placed by row in LDS, and each row is ordered and merged by a wavefront exactly as unit_merge_rows does (same records, same
 //      place: scratch[row start + rank]); unit_write_chunks follows unchanged.
 // Traffic at the north star: 2 x 320 MB of edge list in, 160 MB out and in, against 320 + 320 (keys) + 320 (histogram) +
-// 2 x 640 (two sort passes) + 320 (row bounds) + 320 (merge).  A bucket that does not fit (kBucketCap entries) or a row above
+// 2 x 640 (two sort passes) + 320 (row bounds) + 320 (merge): 0.55 ms for the three kernels against 1.19 ms (profiles/
+// r4w_build_kernel_stats.csv).  A bucket that does not fit (32 k entries) or a row above
 // kUnitRowMax is counted in info[1]: the host takes the two-stage pipeline, as before.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int kMaxBuckets = 2048;         // LDS of bucket_scatter: 32 k staged entries + the head map + two tables of this many words
+constexpr int kMaxBuckets = 3000;         // LDS of bucket_scatter: 32 k staged entries + the head map + two tables of this many words
 constexpr int kPassThreads = 512;
 constexpr int kPassBatch = 4;
 constexpr int kTileEdges = 16384;         // edges per tile (= per workgroup of the two passes): 32 k entries staged in LDS
@@ -1099,25 +1104,19 @@ struct BucketPlan {
     int threads;       // workgroup size of bucket_merge_rows
 };
 
-inline int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 // false: this graph is not taken by the bucket form (ids too wide for a 4-byte entry, too many buckets, rows too dense)
 inline bool bucket_plan(int64_t e, int32_t n, BucketPlan* pl)
 {
     if (n <= 0 || e <= 0) return false;
     const int64_t m = 2 * e;
-    const int big = env_int("PYGSD_BUCKET_WIDE", 1);            // 1: 1024-thread workgroups holding 32 k entries; 0: 512 / 16 k
-    pl->threads = big ? 1024 : 512;
-    pl->cap = pl->threads * 32;
+    pl->threads = 1024;
+    pl->cap = pl->threads * 32;                                  // 128 KB of LDS: one workgroup per CU
     pl->cbits = bits_for(static_cast<uint64_t>(n > 1 ? n - 1 : 1));
-    int rl = big ? 10 : 9;
+    int rl = 10;
     while (rl > 3 && (static_cast<int64_t>(n) >> rl) < 1024) --rl;                        // enough buckets to fill the chip
-    while (rl > 3 && (m << rl) / n > static_cast<int64_t>(pl->cap) * 5 / 8) --rl;          // average bucket <= 5/8 of the LDS
-    if ((m << rl) / n > static_cast<int64_t>(pl->cap) * 5 / 8) return false;
+    // average bucket <= 3/4 of the LDS (24 k entries; the buckets of a graph without hubs scatter by a few hundred around it)
+    while (rl > 3 && (m << rl) / n > static_cast<int64_t>(pl->cap) * 3 / 4) --rl;
+    if ((m << rl) / n > static_cast<int64_t>(pl->cap) * 3 / 4) return false;
     const int64_t nb = (static_cast<int64_t>(n) + (int64_t(1) << rl) - 1) >> rl;
     // (25: the in-register sort key, col << 7 | dir << 6 | lane)
     if (nb > kMaxBuckets || rl + pl->cbits + 1 > 32 || pl->cbits > 25) return false;
@@ -1605,17 +1604,10 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
         hipLaunchKernelGGL(bucket_scatter, dim3(pl.g), dim3(kScatterThreads), lds2, s, row, col, n_edges, n, pl, off, stream);
         if (int rc = check_launch("bucket_scatter")) return rc;
         const size_t lds = (static_cast<size_t>(pl.cap) + 2 * ((size_t(1) << pl.rl) + 8)) * sizeof(uint32_t);
-        if (pl.threads == 1024) {
-            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows<1024>),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            PYGSD_HIP_TRY(once);
-            hipLaunchKernelGGL(bucket_merge_rows<1024>, dim3(pl.nb), dim3(1024), lds, s, a, pl, stream, off);
-        } else {
-            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows<512>),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            PYGSD_HIP_TRY(once);
-            hipLaunchKernelGGL(bucket_merge_rows<512>, dim3(pl.nb), dim3(512), lds, s, a, pl, stream, off);
-        }
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows<1024>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        PYGSD_HIP_TRY(once);
+        hipLaunchKernelGGL(bucket_merge_rows<1024>, dim3(pl.nb), dim3(1024), lds, s, a, pl, stream, off);
         if (int rc = check_launch("bucket_merge_rows")) return rc;
     } else {
         if (n_edges > 0) {
@@ -1641,7 +1633,7 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
     size_t tb = l.scan_tmp_bytes;
     PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb, rocprim::make_transform_iterator(ucnt, PlusOne()), rowptr, 0,
                                           static_cast<size_t>(n) + 1, rocprim::plus<int32_t>(), s));
-    hipLaunchKernelGGL(unit_write_chunks, dim3(static_cast<unsigned>((static_cast<int64_t>(n) + kChunkRows - 1) / kChunkRows)), dim3(kBlock), 0,
-                       s, a);
+    const unsigned chunks = static_cast<unsigned>((static_cast<int64_t>(n) + kChunkRows - 1) / kChunkRows);
+    hipLaunchKernelGGL((unit_write_chunks<256, kChunkSlots>), dim3(chunks), dim3(256), 0, s, a);
     return check_launch("unit_write_chunks");
 }

@@ -910,12 +910,17 @@ def test_fused_operator_build_long_rows_and_fallback(weighted):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["bucket", "sort"])
 @pytest.mark.parametrize("norm,lam", [("sym", 2.0), (None, 3.0)])
-def test_unit_operator_build_long_rows_and_determinism(norm, lam):
-    """pygsd_magop_unit (unweighted graphs: merged rows parked as 8-byte records, written after the scan): rows of 64 / 65 / 103 / 303 / 512 stream entries (from 65: the rank sort through LDS, direct stores),
-    duplicates, reciprocal pairs, self loops, isolated nodes, a node count that is not a multiple of the 16 rows of a
-    block -- bit-identical to the generic pipeline and from run to run; 513 entries make it step aside."""
+def test_unit_operator_build_long_rows_and_determinism(norm, lam, form, monkeypatch):
+    """pygsd_magop_unit (unweighted graphs: merged rows parked as 8-byte records, written after the scan) in both its forms -- the
+    stream split into LDS-sized row buckets (default) and the radix sort on the row bits: rows of 64 / 65 / 103 / 303 / 512 stream
+    entries (from 65: the rank sort through LDS, direct stores), duplicates, reciprocal pairs, self loops, isolated nodes, a node
+    count that is not a multiple of the 16 rows of a chunk -- bit-identical to the generic pipeline and from run to run (the bucket
+    form places entries with LDS atomics: the order they arrive in must not show); 513 entries make it step aside."""
     from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
+    if form == "sort":
+        monkeypatch.setenv("PYGSD_UNIT_BUILD_FORM", "sort")
     n = 50007
     g = torch.Generator().manual_seed(13)
     ei, _ = _messy_graph(n, 600000, seed=3, signed=False)
@@ -945,6 +950,51 @@ def test_unit_operator_build_long_rows_and_determinism(norm, lam):
     over = torch.cat([ei, torch.stack([torch.full((1,), n - 50, device=dev()), torch.full((1,), 3, device=dev())])], dim=1)
     assert L._unit_operator_csr(over[0].contiguous(), over[1].contiguous(), over.size(1), n, sym, 0.25, lam, -1.0) is None
     assert L.fused_operator_csr(over, None, n, False, True, 0.25, norm, lam) is not None      # two-stage pipeline took it
+
+
+@pytest.mark.gpu
+def test_unit_operator_build_bucket_that_does_not_fit_lds(monkeypatch):
+    """128 neighbouring rows of 300 entries each: 38 400 entries in one bucket of the bucket form (32 768 fit a workgroup's LDS) --
+    it reports the graph as not taken and the two-stage pipeline builds the same operator; the sort form takes it (no row above
+    512 entries)."""
+    from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
+    n = 200000
+    g = torch.Generator().manual_seed(5)
+    ei, _ = _messy_graph(n, 1500000, seed=11, signed=False)
+    ei = ei[:, (ei[0] >= 2048) & (ei[1] >= 2048)]
+    hubs = torch.arange(1024, 1152).repeat_interleave(300)
+    others = torch.randint(4096, n, (hubs.numel(),), generator=g)
+    ei = torch.cat([ei, torch.stack([hubs, others])], dim=1)
+    ei = ei[:, torch.randperm(ei.size(1), generator=g)].to(dev())
+    row, col = ei[0].contiguous(), ei[1].contiguous()
+    assert L._unit_operator_csr(row, col, ei.size(1), n, 1, 0.25, 2.0, -1.0) is None
+    _assert_fused_equals_generic(ei, None, n, False, True, 0.25, "sym", 2.0)
+    monkeypatch.setenv("PYGSD_UNIT_BUILD_FORM", "sort")
+    assert L._unit_operator_csr(row, col, ei.size(1), n, 1, 0.25, 2.0, -1.0) is not None
+    _assert_fused_equals_generic(ei, None, n, False, True, 0.25, "sym", 2.0)
+
+
+@pytest.mark.gpu
+def test_unit_operator_build_forms_agree_at_512_rows_per_bucket():
+    """600 k nodes: buckets of 512 rows, 20 k entries each (the geometry of the north star) -- the two forms of the unweighted build
+    give the same arrays bit for bit, with and without the normalisation."""
+    import os
+    from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
+    n = 600000
+    ei, _ = _messy_graph(n, 10000000, seed=21, signed=False)
+    ei = ei.to(dev())
+    row, col = ei[0].contiguous(), ei[1].contiguous()
+    for sym in (1, 0):
+        a = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, 2.0, -1.0)
+        os.environ["PYGSD_UNIT_BUILD_FORM"] = "sort"
+        try:
+            b = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, 2.0, -1.0)
+        finally:
+            del os.environ["PYGSD_UNIT_BUILD_FORM"]
+        assert a is not None and b is not None and a[0].nnz == b[0].nnz
+        assert torch.equal(a[0].rowptr, b[0].rowptr) and torch.equal(a[0].col, b[0].col) and torch.equal(a[3], b[3])
+        for x, y in zip(a[1] + a[2], b[1] + b[2]):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
 
 
 @pytest.mark.gpu

@@ -3,7 +3,7 @@
 TAG=${TAG:-r4}
 cd /root/repo; export TMPDIR=/tmp
 rm -rf gpurun_out/prof_build_$TAG
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_build_$TAG -o build -- python tools/build_probe.py --only fused --iters 6 > gpurun_out/${TAG}_build_probe.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_build_$TAG -o build -- python tools/build_probe.py --only fused --iters 6 ${PROBE_ARGS:-} > gpurun_out/${TAG}_build_probe.log 2>&1
 f=$(find gpurun_out/prof_build_$TAG -name '*kernel_stats.csv' | head -1)
 cp "$f" gpurun_out/${TAG}_build_kernel_stats.csv
 python - <<P

@@ -3,7 +3,7 @@
 TAG=${TAG:-r4}
 cd /root/repo; export TMPDIR=/tmp
 i=0
-for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES"; do
+for set in ${PMC_SETS:-"FETCH_SIZE" "WRITE_SIZE"}; do
   i=$((i+1))
   rm -rf gpurun_out/pmc_build_${TAG}_$i
   timeout 200 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_build_${TAG}_$i -o b -- python tools/build_probe.py --only fused --iters 2 > gpurun_out/pmc_build_${TAG}_$i.log 2>&1
