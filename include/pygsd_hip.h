@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 10
+#define PYGSD_ABI_VERSION 11
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -321,10 +321,13 @@ int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, in
  * Two forms with bit-identical outputs: by default the stream is never sorted globally -- it is split once into buckets of up to
  * 1024 consecutive rows that fit a workgroup's LDS and ordered there (graphs of <= 2^25 nodes, <= 3000 buckets, an average
  * bucket of <= 24 576 entries); other graphs, or PYGSD_UNIT_BUILD_FORM=sort in the environment, take a radix sort on the row
- * bits first. */
+ * bits first.
+ * phase: 0 = the whole build; 1 = everything up to the row pointer -- d_info is final when this part has run, so the caller can
+ * queue its device -> host read of d_info here and then call again with phase = 2 (same arguments, untouched workspace) for the
+ * kernel that writes the slots: the host then learns the sizes while 40 % of the build is still running, instead of after it. */
 int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, float q, float lambda_max,
                      float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr, float* deg, int32_t* ccol,
-                     float* vb_real, float* vb_imag, float* vf_real, float* vf_imag, int64_t* d_info, void* stream);
+                     float* vb_real, float* vb_imag, float* vf_real, float* vf_imag, int64_t* d_info, int32_t phase, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * add_remaining_self_loops + degree normalisation: torch_geometric's gcn_norm as called at

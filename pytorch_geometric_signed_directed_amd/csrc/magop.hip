@@ -710,19 +710,37 @@ __global__ void diagonal_of_empty_rows(const int32_t* __restrict__ rowptr, const
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kUnitRowMax = 512;
 
-__global__ void unit_row_tables(const int32_t* __restrict__ rs, int32_t n, int32_t sym, float* __restrict__ deg,
-                                float* __restrict__ dinv, int32_t* __restrict__ row_u, float two_pi_q, float* __restrict__ trig)
+__global__ void unit_finish_info(const int32_t* __restrict__ rowptr, int32_t n, int64_t* __restrict__ info)
+{
+    info[0] = static_cast<int64_t>(rowptr[n]) - n;                // E_s for the host
+}
+
+// deg^-1/2 of a node with k stream entries (degree k / 2), k = 0 .. kUnitRowMax.  The write kernel gathers the 2-byte entry count
+// of an entry's column and looks the factor up in an LDS copy of this table: the gathered table is 2 n bytes instead of 4 n -- it
+// stays in the 4 MB L2 of an XCD next to the streams, where the fp32 table missed often enough to add 0.53 GB of fabric reads to the
+// kernel's 1.3 GB (profiles/r4w_build_pmc.json).  Same expression as before, so the same bits.
+__device__ __forceinline__ void unit_lut(int k, float* __restrict__ lut)
+{
+    const float d = static_cast<float>(k) / 2.f;                  // (the butterfly of merge_one_row adds multiples of 1/2: exact)
+    lut[k] = d == 0.f ? 0.f : powf(d, -0.5f);
+}
+
+__device__ __forceinline__ uint16_t clamp16(int32_t c) { return static_cast<uint16_t>(c < 65535 ? c : 65535); }
+
+__global__ void unit_row_tables(const int32_t* __restrict__ rs, int32_t n, float* __restrict__ deg, uint16_t* __restrict__ cnt16,
+                                int32_t* __restrict__ row_u, float two_pi_q, float* __restrict__ trig, float* __restrict__ lut)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         row_u[n] = 0;                                             // the scan's (n + 1)-th input
         sincosf(two_pi_q, trig + 1, trig);
     }
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k <= kUnitRowMax; k += blockDim.x) unit_lut(k, lut);
     GRID_STRIDE(r, n)
     {
-        // the butterfly of merge_one_row adds multiples of 1/2 (exact in any order): the same value as (entries) / 2
-        const float d = static_cast<float>(rs[r + 1] - rs[r]) / 2.f;
-        deg[r] = d;
-        if (sym) dinv[r] = d == 0.f ? 0.f : powf(d, -0.5f);
+        const int32_t c = rs[r + 1] - rs[r];
+        deg[r] = static_cast<float>(c) / 2.f;                     // = the sum of the row's A_s entries, multiples of 1/2
+        cnt16[r] = clamp16(c);
     }
 }
 
@@ -731,7 +749,8 @@ struct UnitArgs {
     uint64_t* scratch;             // the sort's input buffer (dead): sorted keys of the 65+ entry rows
     const int32_t* rs;             // [n + 2] row bounds of the stream
     const float* deg;
-    const float* dinv;
+    const uint16_t* cnt16;         // [n] stream entries per row (<= kUnitRowMax where the build is valid): what deg^-1/2 is read off
+    const float* lut;              // [kUnitRowMax + 1] deg^-1/2 of a row with k entries -- see unit_lut
     int32_t* rowptr;
     int32_t* ccol;
     float* vb_re;
@@ -940,13 +959,13 @@ __device__ __forceinline__ void unit_write_row_direct(const UnitArgs& p, int32_t
                                                       int lane, float cs1, float sn1)
 {
     if (lane == 0) unit_diagonal<0>(p, nullptr, 0, r, slot0 + left);
-    const float ir = p.sym ? p.dinv[r] : 0.f;
+    const float ir = p.sym ? p.lut[p.cnt16[r]] : 0.f;
     if (cnt <= 64) {
         if (lane < u) {
             const uint64_t rc = p.scratch[beg + lane];
             const int32_t c = static_cast<int32_t>(rc & 0xFFFFFFFFull);
             const int ln = static_cast<int>((rc >> 32) & 0xFFull), th = static_cast<int>((rc >> 40) & 0xFFull) - 64;
-            unit_values<0>(p, nullptr, 0, ir, p.sym ? p.dinv[c] : 0.f, c, ln, th, cs1, sn1, slot0 + lane + (c > r ? 1 : 0));
+            unit_values<0>(p, nullptr, 0, ir, p.sym ? p.lut[p.cnt16[c]] : 0.f, c, ln, th, cs1, sn1, slot0 + lane + (c > r ? 1 : 0));
         }
     } else if (cnt <= kUnitRowMax) {
         int base_rank = 0;
@@ -969,7 +988,7 @@ __device__ __forceinline__ void unit_write_row_direct(const UnitArgs& p, int32_t
                 }
                 const int rk = base_rank + __popcll(H & ((1ull << lane) - 1ull));
                 const int32_t c = static_cast<int32_t>(cur);
-                unit_values<0>(p, nullptr, 0, ir, p.sym ? p.dinv[c] : 0.f, c, ln, ln - 2 * n1, cs1, sn1, slot0 + rk + (c > r ? 1 : 0));
+                unit_values<0>(p, nullptr, 0, ir, p.sym ? p.lut[p.cnt16[c]] : 0.f, c, ln, ln - 2 * n1, cs1, sn1, slot0 + rk + (c > r ? 1 : 0));
             }
             base_rank += __popcll(H);
         }
@@ -989,10 +1008,10 @@ __global__ __launch_bounds__(THREADS) void unit_write_chunks(UnitArgs p)
 {
     __shared__ __attribute__((aligned(16))) float stage[5 * SLOTS];
     __shared__ int32_t s_rs[kChunkRows + 1], s_rp[kChunkRows + 1], s_left[kChunkRows];
-    __shared__ float s_dinv[kChunkRows];
+    __shared__ float s_lut[kUnitRowMax + 1];
+    __shared__ int32_t s_cnt[kChunkRows];                          // the rows' entry counts: their own deg^-1/2 is s_lut[s_cnt[j]]
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kChunkRows;
-    if (blockIdx.x == 0 && t == 0) p.info[0] = static_cast<int64_t>(p.rowptr[p.n]) - p.n;     // E_s for the host
     const int rows = p.n - r0 < kChunkRows ? static_cast<int>(p.n - r0) : kChunkRows;
     // the chunk's positions of the record buffer: two wavefront-uniform (scalar) loads, so the records can leave before the
     // per-row bounds below are back
@@ -1004,11 +1023,14 @@ __global__ __launch_bounds__(THREADS) void unit_write_chunks(UnitArgs p)
     }
     if (t < rows) {
         s_left[t] = p.row_left[r0 + t];
-        s_dinv[t] = p.sym ? p.dinv[r0 + t] : 0.f;
+        const int32_t cn = p.sym ? p.cnt16[r0 + t] : 0;
+        s_cnt[t] = cn < kUnitRowMax ? cn : kUnitRowMax;
         is_long = p.rs[r0 + t + 1] - p.rs[r0 + t] > 64;
         if (t == 0) is_long = is_long || p.rowptr[r0 + rows] - p.rowptr[r0] > SLOTS - 4;      // more slots than the staging holds
     }
     if (p.info[1] != 0) return;                                    // a row this pipeline does not take: outputs are discarded
+    if (p.sym)
+        for (int k = t; k <= kUnitRowMax; k += THREADS) s_lut[k] = p.lut[k];
     constexpr int PER = kChunkRows * 64 / THREADS;                     // rows of <= 64 entries: <= PER positions per thread
     uint64_t rc[PER];
     float ic[PER];
@@ -1026,7 +1048,12 @@ __global__ __launch_bounds__(THREADS) void unit_write_chunks(UnitArgs p)
         return;
     }
 #pragma unroll
-    for (int k = 0; k < PER; ++k) ic[k] = (p.sym && rc[k] != kNoRecord) ? p.dinv[rc[k] & 0xFFFFFFFFull] : 0.f;
+    for (int k = 0; k < PER; ++k) {                               // the 2-byte gathers leave together; the LDS look-ups follow
+        const uint16_t cn = (p.sym && rc[k] != kNoRecord) ? p.cnt16[rc[k] & 0xFFFFFFFFull] : uint16_t(0);
+        ic[k] = __uint_as_float(cn);
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) ic[k] = p.sym ? s_lut[__float_as_uint(ic[k]) < kUnitRowMax ? __float_as_uint(ic[k]) : kUnitRowMax] : 0.f;
     const int64_t wslot0 = s_rp[0];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -1035,7 +1062,7 @@ __global__ __launch_bounds__(THREADS) void unit_write_chunks(UnitArgs p)
         const int ln = static_cast<int>((rc[k] >> 32) & 0xFFull), th = static_cast<int>((rc[k] >> 40) & 0xFFull) - 64;
         const int rank = static_cast<int>((rc[k] >> 48) & 0x3Full), j = static_cast<int>((rc[k] >> 54) & (kChunkRows - 1));
         const int32_t r = static_cast<int32_t>(r0) + j;
-        unit_values<SLOTS>(p, stage, wslot0, s_dinv[j], ic[k], c, ln, th, cs1, sn1,
+        unit_values<SLOTS>(p, stage, wslot0, p.sym ? s_lut[s_cnt[j]] : 0.f, ic[k], c, ln, th, cs1, sn1,
                                  static_cast<int64_t>(s_rp[j]) + rank + (c > r ? 1 : 0));
     }
     if (t < rows) unit_diagonal<SLOTS>(p, stage, wslot0, static_cast<int32_t>(r0) + t, static_cast<int64_t>(s_rp[t]) + s_left[t]);
@@ -1131,11 +1158,15 @@ inline bool bucket_plan(int64_t e, int32_t n, BucketPlan* pl)
 // Pass 1: a tile's entries per bucket, counted in LDS -> hist[bucket][tile]; node-id range check (info[2], info[3]) folded in.
 __global__ __launch_bounds__(kPassThreads) void bucket_count(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t e,
                                                              int32_t n, BucketPlan pl, int32_t* __restrict__ hist,
-                                                             int64_t* __restrict__ info, float two_pi_q, float* __restrict__ trig)
+                                                             int64_t* __restrict__ info, float two_pi_q, float* __restrict__ trig,
+                                                             float* __restrict__ lut)
 {
     __shared__ uint32_t cnt[kMaxBuckets];
     const int wg = blockIdx.x, t = threadIdx.x;
-    if (wg == 0 && t == 0) sincosf(two_pi_q, trig + 1, trig);
+    if (wg == 0) {
+        if (t == 0) sincosf(two_pi_q, trig + 1, trig);
+        for (int k = t; k <= kUnitRowMax; k += kPassThreads) unit_lut(k, lut);
+    }
     for (int b = t; b < pl.nb; b += kPassThreads) cnt[b] = 0u;
     __syncthreads();
     const int64_t lo = static_cast<int64_t>(wg) * kTileEdges, hi = lo + kTileEdges < e ? lo + kTileEdges : e;
@@ -1335,9 +1366,8 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows(UnitArgs p, BucketP
         const int32_t r = row0 + t;
         if (r < p.n) {
             const_cast<int32_t*>(p.rs)[r] = b0 + static_cast<int32_t>(excl);
-            const float d = static_cast<float>(mine) / 2.f;        // (unit_row_tables)
-            const_cast<float*>(p.deg)[r] = d;
-            if (p.sym) const_cast<float*>(p.dinv)[r] = d == 0.f ? 0.f : powf(d, -0.5f);
+            const_cast<float*>(p.deg)[r] = static_cast<float>(mine) / 2.f;         // (unit_row_tables)
+            const_cast<uint16_t*>(p.cnt16)[r] = clamp16(static_cast<int32_t>(mine));
         }
     }
     if (t == 0) roff[nrow] = static_cast<uint32_t>(cnt_b);
@@ -1413,7 +1443,7 @@ int magop_layout(int64_t e, int32_t n, int weighted, MagopWs* w)
     w->w_b = take(weighted ? m * 4 : 0);
     w->rs = take((nn + 2) * 4);
     w->ucnt = take((nn + 1) * 4);
-    w->dinv = take((nn + 1) * 4);
+    w->dinv = take((nn + 1) * 4 + (kUnitRowMax + 1) * 4 + 256);     // (pygsd_magop_unit: 2-byte entry counts [n] + its deg^-1/2 table)
     w->shift = take((nn + 1) * 4);
     w->long_rows = take((nn + 1) * 4);
     w->n_long = take(256);
@@ -1553,9 +1583,10 @@ extern "C" int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, 
 extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, float q,
                                 float lambda_max, float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr,
                                 float* deg, int32_t* ccol, float* vb_real, float* vb_imag, float* vf_real, float* vf_imag,
-                                int64_t* d_info, void* stream)
+                                int64_t* d_info, int32_t phase, void* stream)
 {
     PYGSD_REQUIRE(n >= 0 && n_edges >= 0 && 2 * n_edges < (int64_t(1) << 31), "pygsd_magop_unit: size out of int32 range");
+    PYGSD_REQUIRE(phase >= 0 && phase <= 2, "pygsd_magop_unit: phase must be 0 (all), 1 (up to the row pointer) or 2 (the write kernel)");
     PYGSD_REQUIRE(workspace && rowptr && d_info && (n == 0 || (deg && ccol && vb_real && vb_imag && vf_real && vf_imag)),
                   "pygsd_magop_unit: null pointer");
     PYGSD_REQUIRE(n_edges == 0 || (row && col), "pygsd_magop_unit: null edge list");
@@ -1570,21 +1601,27 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
     uint64_t* keys_a = reinterpret_cast<uint64_t*>(base + l.keys_a);
     uint64_t* keys_b = reinterpret_cast<uint64_t*>(base + l.keys_b);
     int32_t* rs = reinterpret_cast<int32_t*>(base + l.rs);
-    float* dinv = reinterpret_cast<float*>(base + l.dinv);
+    const uint16_t* cnt16 = reinterpret_cast<const uint16_t*>(base + l.dinv);
+    const float* lut = reinterpret_cast<const float*>(base + l.dinv + round_up(static_cast<size_t>(n) * 2 + 2, 256));
     const int64_t m = 2 * n_edges;
-    PYGSD_HIP_TRY(hipMemsetAsync(d_info, 0, 4 * sizeof(int64_t), s));
+    if (phase != 2) PYGSD_HIP_TRY(hipMemsetAsync(d_info, 0, 4 * sizeof(int64_t), s));
     if (n == 0) {
-        PYGSD_HIP_TRY(hipMemsetAsync(rowptr, 0, sizeof(int32_t), s));
+        if (phase != 2) PYGSD_HIP_TRY(hipMemsetAsync(rowptr, 0, sizeof(int32_t), s));
         return 0;
     }
     int32_t* ucnt = reinterpret_cast<int32_t*>(base + l.ucnt);
     int32_t* left = reinterpret_cast<int32_t*>(base + l.shift);
     // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64
     const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * static_cast<double>(q));
-    UnitArgs a{keys_b, keys_a, rs, deg, dinv, rowptr, ccol, vb_real, vb_imag, vf_real, vf_imag, ucnt, left, d_info,
+    UnitArgs a{keys_b, keys_a, rs, deg, cnt16, lut, rowptr, ccol, vb_real, vb_imag, vf_real, vf_imag, ucnt, left, d_info,
                m > 0 ? m : 1, n, sym, two_pi_q, lambda_max, diag_shift, reinterpret_cast<float*>(base + l.n_long)};
     const int64_t per_block = 4 * kRowsPerWave;
     const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n) + per_block - 1) / per_block);
+    const unsigned chunks = static_cast<unsigned>((static_cast<int64_t>(n) + kChunkRows - 1) / kChunkRows);
+    if (phase == 2) {
+        hipLaunchKernelGGL((unit_write_chunks<256, kChunkSlots>), dim3(chunks), dim3(256), 0, s, a);
+        return check_launch("unit_write_chunks");
+    }
     BucketPlan pl;
     const char* form = getenv("PYGSD_UNIT_BUILD_FORM");          // "sort": the radix-sort form (measurement / tests)
     const bool buckets = !(form && strcmp(form, "sort") == 0) && bucket_plan(n_edges, n, &pl);
@@ -1592,7 +1629,8 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
         int32_t* hist = reinterpret_cast<int32_t*>(base + l.hist);
         int32_t* off = reinterpret_cast<int32_t*>(base + l.off);
         uint32_t* stream = reinterpret_cast<uint32_t*>(keys_b);
-        hipLaunchKernelGGL(bucket_count, dim3(pl.g), dim3(kPassThreads), 0, s, row, col, n_edges, n, pl, hist, d_info, two_pi_q, a.trig);
+        hipLaunchKernelGGL(bucket_count, dim3(pl.g), dim3(kPassThreads), 0, s, row, col, n_edges, n, pl, hist, d_info, two_pi_q, a.trig,
+                           const_cast<float*>(a.lut));
         if (int rc = check_launch("bucket_count")) return rc;
         size_t tb = l.scan_tmp_bytes;
         PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb, hist, off, 0, static_cast<size_t>(pl.nb) * pl.g + 1,
@@ -1622,7 +1660,8 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
         } else {
             PYGSD_HIP_TRY(hipMemsetAsync(rs, 0, sizeof(int32_t) * (static_cast<size_t>(n) + 2), s));
         }
-        hipLaunchKernelGGL(unit_row_tables, dim3(grid_for(n)), dim3(kBlock), 0, s, rs, n, sym, deg, dinv, ucnt, two_pi_q, a.trig);
+        hipLaunchKernelGGL(unit_row_tables, dim3(grid_for(n)), dim3(kBlock), 0, s, rs, n, deg, const_cast<uint16_t*>(a.cnt16), ucnt, two_pi_q,
+                           a.trig, const_cast<float*>(a.lut));
         if (int rc = check_launch("unit_row_tables")) return rc;
         if (n <= (1 << 25))
             hipLaunchKernelGGL(unit_merge_rows<uint32_t>, dim3(grid), dim3(kBlock), 0, s, a);
@@ -1633,7 +1672,9 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
     size_t tb = l.scan_tmp_bytes;
     PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb, rocprim::make_transform_iterator(ucnt, PlusOne()), rowptr, 0,
                                           static_cast<size_t>(n) + 1, rocprim::plus<int32_t>(), s));
-    const unsigned chunks = static_cast<unsigned>((static_cast<int64_t>(n) + kChunkRows - 1) / kChunkRows);
+    hipLaunchKernelGGL(unit_finish_info, dim3(1), dim3(1), 0, s, rowptr, n, d_info);          // E_s: d_info is final from here on
+    if (int rc = check_launch("unit_finish_info")) return rc;
+    if (phase == 1) return 0;
     hipLaunchKernelGGL((unit_write_chunks<256, kChunkSlots>), dim3(chunks), dim3(256), 0, s, a);
     return check_launch("unit_write_chunks");
 }

@@ -165,15 +165,29 @@ _PINNED = threading.local()
 
 
 def _pinned_info(dev):
-    """(pinned int64[4], event) for the device -> host read of the fused build; one per (thread, device) -- thread-local,
-    so the buffers of a pool's worker threads die with their threads."""
+    """(pinned int64[4], event `ready`, side stream, event `mid`) for the device -> host read of the fused build; one per
+    (thread, device) -- thread-local, so the buffers of a pool's worker threads die with their threads."""
     table = getattr(_PINNED, "table", None)
     if table is None:
         table = _PINNED.table = {}
     hit = table.get(dev.index)
     if hit is None:
-        hit = table[dev.index] = (torch.empty(4, dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+        hit = table[dev.index] = (torch.empty(4, dtype=torch.int64, pin_memory=True), torch.cuda.Event(),
+                                  torch.cuda.Stream(device=dev), torch.cuda.Event())
     return hit
+
+
+def _queue_info_read(info: Tensor, dev):
+    """Queue the device -> host copy of a build's `info` words BEHIND what the current stream holds now, on a side stream -- the
+    kernels the caller launches next (the rest of the build) do not wait for the copy, and the host does not wait for them:
+    `ready.synchronize()` returns as soon as the words have landed.  -> (pinned int64[4], ready)."""
+    host_info, ready, side, mid = _pinned_info(dev)
+    mid.record()
+    side.wait_event(mid)
+    with torch.cuda.stream(side):
+        host_info.copy_(info, non_blocking=True)
+        ready.record()
+    return host_info, ready
 
 
 _UNIT_BUILD = os.environ.get("PYGSD_TWO_STAGE_BUILD", "0") != "1"
@@ -188,9 +202,11 @@ def set_unit_build(on: bool) -> bool:
 
 
 def _unit_operator_csr(row: Tensor, col: Tensor, e: int, n: int, sym: int, q: float, lambda_max: float, diag_shift: float):
-    """pygsd_magop_unit: edge list without weights -> final CSR + values in ONE call (unit weights: degrees from the row
-    bounds, merged rows parked as 8-byte records between the merge and the write kernel).  ONE host read: E_s, the
-    bad-id witness and the over-long-row count.  None: a row longer than the kernel takes (caller: two-stage pipeline)."""
+    """pygsd_magop_unit: edge list without weights -> final CSR + values (unit weights: degrees from the row bounds, merged
+    rows parked as 8-byte records between the merge and the write kernel).  ONE host read -- E_s, the bad-id witness and the
+    over-long-row count -- queued between the library's two parts, so the host is back before the write kernel has finished
+    and the layer's next launches queue behind it without a gap.  None: a row longer than the kernel takes (caller: two-stage
+    pipeline)."""
     from ..sparse import CSR
     dev = row.device
     lib = _cabi.lib()
@@ -205,13 +221,12 @@ def _unit_operator_csr(row: Tensor, col: Tensor, e: int, n: int, sym: int, q: fl
         ccol = torch.empty(max(cap, 4), dtype=torch.int32, device=dev)
         pad = max((cap + 3) // 4 * 4, 4)
         vals = torch.empty((4, pad), dtype=torch.float32, device=dev)
-        check(lib.pygsd_magop_unit(ptr(row), ptr(col), e, n, sym, float(q), float(lambda_max), float(diag_shift), ptr(ws),
-                                   need.value, ptr(rowptr), ptr(deg), ptr(ccol), ptr(vals[0]), ptr(vals[1]), ptr(vals[2]),
-                                   ptr(vals[3]), ptr(info), stream_ptr()), "pygsd_magop_unit")
-        host_info, ready = _pinned_info(dev)
-        host_info.copy_(info, non_blocking=True)
-        ready.record()
-        ready.synchronize()                               # the one host round-trip
+        args = (ptr(row), ptr(col), e, n, sym, float(q), float(lambda_max), float(diag_shift), ptr(ws), need.value, ptr(rowptr),
+                ptr(deg), ptr(ccol), ptr(vals[0]), ptr(vals[1]), ptr(vals[2]), ptr(vals[3]), ptr(info))
+        check(lib.pygsd_magop_unit(*args, 1, stream_ptr()), "pygsd_magop_unit")          # everything up to the row pointer
+        host_info, ready = _queue_info_read(info, dev)   # behind the first part; the host waits for THIS, not for the write
+        check(lib.pygsd_magop_unit(*args, 2, stream_ptr()), "pygsd_magop_unit")          # the kernel that writes the slots
+        ready.synchronize()                           # the one host round-trip: over while 40 % of the build is still running
         es, too_long, bad, bad_id = host_info.tolist()
     if bad:
         raise IndexError(f"edge_index holds node id {bad_id}, outside [0, {n}); the HIP path gathers and "
@@ -277,9 +292,7 @@ def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int
         check(lib.pygsd_magop_stage1(ptr(row), ptr(col), ptr(w), e, n, 1 if signed else 0, 1 if absolute_degree else 0,
                                      sym, ptr(ws), need.value, ptr(rowptr), ptr(deg), ptr(info), stream_ptr()),
               "pygsd_magop_stage1")
-        host_info, ready = _pinned_info(dev)
-        host_info.copy_(info, non_blocking=True)      # queued behind stage 1; the host waits for THIS, not for stage 2
-        ready.record()
+        host_info, ready = _queue_info_read(info, dev)   # queued behind stage 1; the host waits for THIS, not for stage 2
         # E_s is not known on the host yet -- and is not needed to LAUNCH the second stage: the outputs are allocated
         # at their upper bound (every listed edge distinct, no self loops: 2 E + n; the bound is tight on the graphs this
         # is built for) and narrowed after the one host read below, which then overlaps the second stage instead of
