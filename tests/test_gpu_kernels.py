@@ -953,6 +953,28 @@ def test_unit_operator_build_long_rows_and_determinism(norm, lam, form, monkeypa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["bucket", "sort"])
+def test_unit_operator_build_degenerate_graphs(form, monkeypatch):
+    """One node, two nodes, only self loops, one edge listed many times (multiplicity 40 in one record), a star whose centre is the
+    last node, fewer nodes than the 16 rows of a write chunk or the 8 rows of the smallest bucket: both forms against the generic
+    pipeline."""
+    if form == "sort":
+        monkeypatch.setenv("PYGSD_UNIT_BUILD_FORM", "sort")
+    d = dev()
+    cases = [
+        (1, [[0], [0]]),
+        (2, [[0, 1, 1], [1, 0, 1]]),
+        (5, [[2, 3, 3], [2, 3, 3]]),                                       # self loops only: the identity-shaped operator
+        (3, [[0] * 40 + [1] * 3, [2] * 40 + [0] * 3]),
+        (9, [list(range(8)) + [8] * 8, [8] * 8 + list(range(8))]),
+        (17, [[16, 0, 5], [0, 16, 5]]),
+    ]
+    for n, ei in cases:
+        _assert_fused_equals_generic(torch.tensor(ei, device=d), None, n, False, True, 0.25, "sym", 2.0)
+        _assert_fused_equals_generic(torch.tensor(ei, device=d), None, n, False, True, 0.1, None, 3.0)
+
+
+@pytest.mark.gpu
 def test_unit_operator_build_bucket_that_does_not_fit_lds(monkeypatch):
     """128 neighbouring rows of 300 entries each: 38 400 entries in one bucket of the bucket form (32 768 fit a workgroup's LDS) --
     it reports the graph as not taken and the two-stage pipeline builds the same operator; the sort form takes it (no row above
