@@ -70,8 +70,96 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
 
     const int lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int n_tiles = (p.n_rows + 15) >> 4;
-    for (int tile = static_cast<int>(blockIdx.x) * WAVES + (tid >> 6); tile < n_tiles;
-         tile += static_cast<int>(gridDim.x) * WAVES) {
+    const int stride = static_cast<int>(gridDim.x) * WAVES;
+    // (wavefront-uniform, which the compiler cannot see through tid >> 6: without it the term's base pointers p.a[k] are fetched by
+    // VECTOR loads, and the wait for them drains every row load in flight)
+    int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * WAVES + (tid >> 6));
+    if constexpr (FIN > 0) {
+        // The (tile, Chebyshev term) steps of a wavefront form ONE stream, run as a two-stage pipeline: the 16-byte row loads of
+        // step s + 1 are issued before the MFMAs of step s, and a tile's stores go out behind the loads of the next tile's first
+        // term -- so the wait in front of the next MFMAs covers loads only (vmcnt counts in order: a wait for a load issued AFTER
+        // the stores would wait for them too, which is what holds a grid-stride copy at 4.5 TB/s on this part), and a row's HBM
+        // latency is hidden by this wavefront's own MFMAs, not only by the other wavefronts of its SIMD.
+        constexpr int NL = FIN / 16;
+        float4 ra[2][NL], rb[2][NL];
+        f32x4 acc_r[NT], acc_i[NT];
+        float4 bv[NT];                                             // the bias of this lane's columns, read once: a load in the
+#pragma unroll                                                     // store epilogue would put a full wait in front of the stores
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = p.bias ? ldg4(p.bias + n0 + nt * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        auto issue = [&](int tl, int k, float4 (&qa)[NL], float4 (&qb)[NL]) {
+            const int r0 = tl << 4;
+            const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;      // clamped: stores are masked
+            const float* ap = p.a[k] + static_cast<int64_t>(lrow) * FIN + 4 * g;
+            const float* bp = p.b[k] + static_cast<int64_t>(lrow) * FIN + 4 * g;
+#pragma unroll
+            for (int t = 0; t < NL; ++t) {
+                qa[t] = ldg4(ap + 16 * t);
+                qb[t] = ldg4(bp + 16 * t);
+            }
+        };
+        auto step = [&](int tl, int k, const float4 (&qa)[NL], const float4 (&qb)[NL]) {
+            if (k == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc_r[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc_i[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            const float* wk = lds + (k * FIN + 4 * g) * ws + i;
+#pragma unroll
+            for (int t = 0; t < NL; ++t) {
+                const float4 a = qa[t], b = qb[t];
+                const float d[4] = {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w};
+                const float sm[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+                const float* wt = wk + 16 * t * ws;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float w = wt[m * ws + nt * 16];
+                        acc_r[nt] = mfma(w, d[m], acc_r[nt]);   // (W^T)(D^T): rows = out features
+                        acc_i[nt] = mfma(w, sm[m], acc_i[nt]);
+                    }
+                }
+            }
+            if (k == p.k1 - 1) {
+                const int r0 = tl << 4;
+                // transposed C/D: lane (i, g), reg r  ->  out[node r0 + i][feature n0 + 16 nt + 4 g + r]
+                if (r0 + i < p.n_rows) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int col = n0 + nt * 16 + 4 * g;
+                        const int64_t o = static_cast<int64_t>(r0 + i) * p.f_out + col;
+                        *reinterpret_cast<float4*>(p.out_r + o) = make_float4(acc_r[nt][0] + bv[nt].x, acc_r[nt][1] + bv[nt].y,
+                                                                              acc_r[nt][2] + bv[nt].z, acc_r[nt][3] + bv[nt].w);
+                        *reinterpret_cast<float4*>(p.out_i + o) = make_float4(acc_i[nt][0] + bv[nt].x, acc_i[nt][1] + bv[nt].y,
+                                                                              acc_i[nt][2] + bv[nt].z, acc_i[nt][3] + bv[nt].w);
+                    }
+                }
+            }
+        };
+        int k = 0;
+        if (tile >= n_tiles) return;
+        issue(tile, 0, ra[0], rb[0]);
+        for (;;) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {                 // (unrolled: the two register sets are named, not indexed)
+                // `return`, not `break`: an edge from here back to the loop header -- never taken, but the compiler cannot know --
+                // makes the header wait for loads that are pending on that path only (a vmcnt(2) that also covered the stores)
+                if (tile >= n_tiles) return;
+                const int nk = k + 1 < p.k1 ? k + 1 : 0;
+                const int ntile = nk ? tile : tile + stride;
+                // no branch around the prefetch (past the last step it re-reads this step's rows, L2 hits): with one, the wait below
+                // is placed for the path that skipped it and then covers the prefetched loads as well
+                issue(ntile < n_tiles ? ntile : tile, ntile < n_tiles ? nk : k, ra[half ^ 1], rb[half ^ 1]);
+                step(tile, k, ra[half], rb[half]);
+                tile = ntile;
+                k = nk;
+            }
+        }
+        return;
+    }
+    for (; tile < n_tiles; tile += stride) {
         const int r0 = tile << 4;
         const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;  // clamped: stores are masked
         f32x4 acc_r[NT], acc_i[NT];
@@ -84,7 +172,6 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
             const float* ap = p.a[k] + static_cast<int64_t>(lrow) * f_in + 4 * g;
             const float* bp = p.b[k] + static_cast<int64_t>(lrow) * f_in + 4 * g;
             const float* wk = lds + (k * f_in + 4 * g) * ws + i;
-#pragma unroll
             for (int t = 0; t < f_in; t += 16) {
                 const float4 a = ldg4(ap + t);
                 const float4 b = ldg4(bp + t);
