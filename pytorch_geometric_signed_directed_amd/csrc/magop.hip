@@ -271,7 +271,10 @@ __device__ __forceinline__ void merge_one_row(int32_t r, int32_t beg, int32_t cn
 {
     const bool have = lane < cnt;
     KT lk = have ? static_cast<KT>((static_cast<KT>(c2) << 6) | static_cast<KT>(lane)) : static_cast<KT>(~static_cast<KT>(0));
-    lk = wave_bitonic<KT>(lk, lane);
+    if constexpr (sizeof(KT) == 4)
+        lk = wave_bitonic32(lk, lane, cnt, bitonic_sel(lane));    // (one v_med3_u32 per exchange; merges over padding skipped)
+    else
+        lk = wave_bitonic<KT>(lk, lane);
     // invalid keys sorted last: lanes < cnt hold the row in (col, dir, list position) order
     const int src = static_cast<int>(lk & 63);
     const uint32_t c2s = static_cast<uint32_t>(lk >> 6);
