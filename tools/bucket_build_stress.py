@@ -1,0 +1,66 @@
+"""Stress (GPU box): random graphs of random shapes -- sizes, densities, duplicate / reciprocal / self-loop shares, hub rows --
+through both forms of the unweighted operator build (bucket split vs radix sort, csrc/magop.hip); every output array must agree
+bit for bit, and the bucket form (LDS atomics place the entries in arrival order) must reproduce itself run to run."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytorch_geometric_signed_directed_amd.utils import _laplacian as L  # noqa: E402
+
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(int(os.environ.get("SEED", "0")))
+
+
+def build(row, col, e, n, sym, form):
+    if form == "sort":
+        os.environ["PYGSD_UNIT_BUILD_FORM"] = "sort"
+    try:
+        return L._unit_operator_csr(row, col, e, n, sym, 0.25, 2.0, -1.0)
+    finally:
+        os.environ.pop("PYGSD_UNIT_BUILD_FORM", None)
+
+
+def same(a, b):
+    if (a is None) != (b is None):
+        return False
+    if a is None:
+        return True
+    ok = a[0].nnz == b[0].nnz and torch.equal(a[0].rowptr, b[0].rowptr) and torch.equal(a[0].col, b[0].col) and torch.equal(a[3], b[3])
+    for x, y in zip(a[1] + a[2], b[1] + b[2]):
+        ok = ok and torch.equal(x.view(torch.int32), y.view(torch.int32))
+    return bool(ok)
+
+
+bad = 0
+cases = int(os.environ.get("CASES", "40"))
+for it in range(cases):
+    n = int(10 ** rng.uniform(0.5, 6.2))
+    deg = rng.choice([0.5, 2, 8, 20, 45, 90])
+    e = max(1, min(int(n * deg), 24_000_000))
+    r = rng.integers(0, n, e)
+    c = rng.integers(0, n, e)
+    parts = [np.stack([r, c])]
+    k = int(e * rng.uniform(0, 0.3))
+    if k:
+        parts.append(np.stack([c[:k], r[:k]]))                    # reciprocal pairs
+        parts.append(np.stack([r[:k // 2], c[:k // 2]]))          # duplicates
+    if n > 600 and rng.random() < 0.5:                            # a few hub rows of 70 .. 500 entries
+        for _ in range(3):
+            h = int(rng.integers(0, n))
+            m = int(rng.integers(70, 500))
+            parts.append(np.stack([np.full(m, h), rng.integers(0, n, m)]))
+    ei = np.concatenate(parts, axis=1)
+    ei = torch.from_numpy(ei[:, rng.permutation(ei.shape[1])]).to(dev)
+    row, col = ei[0].contiguous(), ei[1].contiguous()
+    sym = int(rng.integers(0, 2))
+    a = build(row, col, ei.size(1), n, sym, "bucket")
+    b = build(row, col, ei.size(1), n, sym, "sort")
+    a2 = build(row, col, ei.size(1), n, sym, "bucket")
+    ok = same(a, b) and same(a, a2)
+    bad += 0 if ok else 1
+    print(f"case {it}: n={n} e={ei.size(1)} sym={sym} taken={a is not None} {'ok' if ok else 'MISMATCH'}", flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
