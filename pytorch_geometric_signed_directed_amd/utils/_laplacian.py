@@ -194,8 +194,9 @@ _UNIT_BUILD = os.environ.get("PYGSD_TWO_STAGE_BUILD", "0") != "1"
 
 
 def set_unit_build(on: bool) -> bool:
-    """Unweighted graphs: the one-pass build behind the sort (pygsd_magop_unit, default) or the two-stage pipeline
-    (pygsd_magop_stage1 / _stage2; PYGSD_TWO_STAGE_BUILD=1) -- measurement / A-B.  Returns the previous setting."""
+    """Unweighted graphs: pygsd_magop_unit (default; inside the library the bucket split, or the radix-sort form with
+    PYGSD_UNIT_BUILD_FORM=sort) or the two-stage pipeline (pygsd_magop_stage1 / _stage2; PYGSD_TWO_STAGE_BUILD=1) --
+    measurement / A-B.  Returns the previous setting."""
     global _UNIT_BUILD
     prev, _UNIT_BUILD = _UNIT_BUILD, bool(on)
     return prev
