@@ -1002,7 +1002,7 @@ __device__ __forceinline__ void unit_write_row_direct(const UnitArgs& p, int32_t
 // the record buffer -- one coalesced 8-byte load per position, every lane busy whatever the rows' lengths (a record names its row and
 // its rank in it) -- forms the values and stages columns, the four value arrays and the diagonals at their final slots in LDS; the
 // chunk's contiguous slot range leaves with aligned 16-byte stores.  (Before: a wavefront per four rows, a row per pass: 131 vector
-// instructions per row with 41 of 64 lanes busy -- VALU-bound at half its time; now 58.)
+// instructions per row with 41 of 64 lanes busy -- VALU-bound at half its time; now 65.)
 // Measured and dropped: persistent workgroups running  row bounds -> records -> deg^-1/2 gathers -> stores  as a pipeline over
 // chunks c, c + G, c + 2 G (0.37 ms either way: on gfx9 a wait for the loads of the next round also waits for the drain's stores,
 // which share their counter -- the same reason a grid-stride copy runs at 4.5 TB/s here and a block-per-piece copy at 6.2).
