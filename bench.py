@@ -151,7 +151,7 @@ def measure_traffic(args, kernel_substring="spmm_vec_kernel"):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    child = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-pmc", "--steps", "3", "--warmup", "1",
+    child = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-pmc", "--no-x4", "--steps", "3", "--warmup", "1",
              "--nodes", str(args.nodes), "--edges", str(args.edges), "--hidden", str(args.hidden)]
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -202,21 +202,84 @@ def self_launch(args_list, gpus):
     return subprocess.call(cmd, env=env)
 
 
-def dram_bound_reference():
-    """The same kernel where the gathered set is 8x the Infinity Cache (DSBM 4M nodes / 80M edges: 2 GiB gathered) -- a
-    DRAM-bound fraction beside the fabric-side `frac` of this run.  REPLAYED from a separate, tracked capture
-    (tools/northstar_x4.py -> profiles/r4_northstar_x4.json); null if the file is missing."""
+def dram_bound_replay():
+    """Fallback only: the x4 figure REPLAYED from a separate, tracked capture (tools/northstar_x4.py ->
+    profiles/r4_northstar_x4.json); null if the file is missing."""
     path = os.path.join(ROOT, "profiles", "r4_northstar_x4.json")
     try:
         rec = json.load(open(path))
         k = rec["dual_spmm"]
         return {"source": "profiles/r4_northstar_x4.json (tools/northstar_x4.py, a separate run -- replayed, not measured here)",
+                "measured_in_this_run": False,
                 "workload": rec["workload"], "gathered_set_GiB": rec["gathered_set_GiB"],
                 "achieved": k["algorithmic_GBps"], "frac": k["fraction_of_8TBps"],
                 "streaming_copy_GBps_same_run": k["streaming_copy_GBps_same_run"],
                 "frac_of_streaming_copy": k["fraction_of_streaming_copy"], "ms_per_launch": k["ms_per_launch"]}
     except (OSError, KeyError, ValueError):
         return None
+
+
+def dram_bound_reference(device, hidden, copy_rate, scale=4, steps=6):
+    """The same layer and kernel where the gathered set is 8x the Infinity Cache (DSBM `scale` x 1M nodes / `scale` x 20M edges:
+    2 x 4M x 64 x 4 B = 1.9 GiB gathered) -- a DRAM-bound fraction beside the fabric-side `frac` of the headline, MEASURED IN
+    THIS RUN (round 5; rounds 3-4 replayed a separate capture): graph sampled on the host (~10 s), operator built once, 2 warm-up
+    + `steps` fwd+bwd steps with the per-launch recorder on.  Any failure falls back to the tracked replay, labelled so."""
+    from pytorch_geometric_signed_directed_amd import _cabi, graphs
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    try:
+        n, e_target = 1000000 * scale, 20000000 * scale
+        t0 = time.perf_counter()
+        ei_np, _, p = graphs.dsbm_for_edges(n, e_target, seed=1)
+        ei = torch.from_numpy(ei_np).to(device)
+        del ei_np
+        gen_s = time.perf_counter() - t0
+        g = torch.Generator().manual_seed(0)
+        xr = torch.randn(n, hidden, generator=g).to(device).requires_grad_()
+        xi = torch.randn(n, hidden, generator=g).to(device).requires_grad_()
+        torch.manual_seed(0)
+        layer = MagNetConv(hidden, hidden, K=1, q=0.25, trainable_q=False, cached=True).to(device)
+
+        def step():
+            layer.zero_grad(set_to_none=True)
+            xr.grad = xi.grad = None
+            o_r, o_i = layer(xr, xi, ei)
+            (o_r.sum() + o_i.sum()).backward()
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(device)
+        _cabi.prof_reset()
+        _cabi.prof_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(device)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        _cabi.prof_enable(False)
+        launches, total_ms = _cabi.prof_collect("spmm2")
+        _cabi.prof_reset()
+        nnz = layer._operator.nnz
+        alg = spmm_bytes(nnz, n, hidden) + spmm_bytes(nnz - n, n, hidden)
+        per_launch = total_ms / max(launches, 1)
+        gbps = alg / per_launch / 1e6
+        e = int(ei.size(1))
+        del layer, xr, xi, ei
+        torch.cuda.empty_cache()
+        return {"source": "MEASURED IN THIS RUN (bench.py::dram_bound_reference): same layer, same kernel, graph x" + str(scale),
+                "measured_in_this_run": True,
+                "workload": f"MagNetConv K=1 q=0.25 sym cached, DSBM {n} nodes / {e} edges (p={p:.3e}), h={hidden}, fp32, fwd+bwd",
+                "gathered_set_GiB": 2 * n * hidden * 4 / 2 ** 30, "infinity_cache_MiB": 256,
+                "operator_nnz": int(nnz), "steps": steps, "ms_per_step": ms, "edges_per_s": e / ms * 1e3,
+                "launches": int(launches), "ms_per_launch": per_launch, "algorithmic_bytes_per_launch": alg,
+                "achieved": gbps, "frac": gbps / HBM_PEAK_GBS,
+                "streaming_copy_GBps_same_run": copy_rate,
+                "frac_of_streaming_copy": gbps / copy_rate if copy_rate else None,
+                "graph_generation_s": gen_s}
+    except Exception as exc:  # noqa: BLE001 -- a side measurement must not cost the result line
+        rec = dram_bound_replay()
+        if rec is not None:
+            rec["source"] = f"live x{scale} run failed ({type(exc).__name__}: {exc}); " + rec["source"]
+        return rec
 
 
 def main():
@@ -241,6 +304,9 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the node-sharded layer even with one rank (exercises the RCCL path on 1 GPU)")
     ap.add_argument("--no-parity", action="store_true", help="skip the un-timed parity guard of the sharded mode")
+    ap.add_argument("--no-x4", action="store_true",
+                    help="do not run the DRAM-bound x4 graph (4M nodes / 80M edges, ~25 s) that feeds "
+                         "`roofline.dram_bound_reference`; the tracked capture is replayed instead, labelled so")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure `roofline.traffic` live (two rocprofv3 --pmc passes of a short child run of this "
                          "script); the value is then replayed from profiles/pmc_traffic.json and labelled so")
@@ -296,16 +362,38 @@ def main():
     e = edge_index.size(1)
     torch.manual_seed(0)
     layer_s = None
+    dense_g = {}
+
+    def backward(o_r, o_i, loss):
+        """"sum": the headline's loss: out_real.sum() + out_imag.sum() -- autograd hands the layer ONE gradient
+        row broadcast over the nodes, which the dense backward reads with row stride 0.  "dense": a dense [N, F] upstream
+        gradient per output, as a real training loss delivers (examples/magnet_node.py:22-27: NLL over log-softmax), handed to
+        the layer as is (g ~ N(0, 1), resident before the timed region): the layer's own cost with nothing broadcast.
+        "dense_loss": the same gradient through a loss inside the step, (o_r * g_r).sum() + (o_i * g_i).sum() -- its two
+        products, two reductions and two gradient products are timed with the layer."""
+        if loss == "sum":
+            (o_r.sum() + o_i.sum()).backward()
+            return
+        key = tuple(o_r.shape)
+        if key not in dense_g:
+            gen = torch.Generator(device=o_r.device).manual_seed(777)
+            dense_g[key] = (torch.randn(o_r.shape, generator=gen, device=o_r.device),
+                            torch.randn(o_i.shape, generator=gen, device=o_i.device))
+        g_r, g_i = dense_g[key]
+        if loss == "dense":
+            torch.autograd.backward((o_r, o_i), (g_r, g_i))
+        else:
+            ((o_r * g_r).sum() + (o_i * g_i).sum()).backward()
     if not sharded:
         layer = MagNetConv(hidden, hidden, K=1, q=0.25, trainable_q=False, cached=True).to(device)
         x_real.requires_grad_()
         x_imag.requires_grad_()
 
-        def step():
+        def step(loss="sum"):
             layer.zero_grad(set_to_none=True)
             x_real.grad = x_imag.grad = None
             o_r, o_i = layer(x_real, x_imag, edge_index)
-            (o_r.sum() + o_i.sum()).backward()
+            backward(o_r, o_i, loss)
 
         def op_nnz():
             return layer._operator.nnz
@@ -321,11 +409,11 @@ def main():
             b = ls.shard_rows(x_imag).requires_grad_()
             return ls, a, b
 
-        def sharded_step(ls, a, b):
+        def sharded_step(ls, a, b, loss="sum"):
             ls.zero_grad(set_to_none=True)
             a.grad = b.grad = None
             o_r, o_i = ls(a, b)
-            (o_r.sum() + o_i.sum()).backward()
+            backward(o_r, o_i, loss)
 
         def agree(failed: bool) -> bool:
             """True if ANY rank failed (decided over a gloo side group: it must work when RCCL does not)."""
@@ -352,8 +440,8 @@ def main():
             sys.stderr.write("bench.py: " + fallback_note + "\n")
             layer_s, xr_loc, xi_loc = make_sharded("rows", 1, 1, True)
 
-        def step():
-            sharded_step(layer_s, xr_loc, xi_loc)
+        def step(loss="sum"):
+            sharded_step(layer_s, xr_loc, xi_loc, loss)
 
         def op_nnz():
             return layer_s.global_nnz
@@ -389,6 +477,24 @@ def main():
     dt = reduce_max(time.perf_counter() - t0)
     per_step = [a.elapsed_time(b) for a, b in marks]
     med = reduce_max(statistics.median(per_step))
+
+    # ---- pass 1b / 1c (labelled, beside the headline): the same K steps with a DENSE upstream gradient, so that the
+    # headline does not lean on its loss: `out.sum()` lets the dense backward read one broadcast row (ldg = 0) where a real
+    # loss delivers [N, F] per output (+2 N F 4 B of reads per step).
+    def timed_pass(loss):
+        for _ in range(2):
+            step(loss)
+        sync()
+        t_begin = time.perf_counter()
+        for _ in range(args.steps):
+            step(loss)
+        sync()
+        return reduce_max(time.perf_counter() - t_begin) / args.steps * 1e3
+
+    ms_dense = timed_pass("dense")
+    ms_dense_loss = timed_pass("dense_loss")
+    dense_g.clear()
+    step()                                   # back on the headline's loss for the instrumented pass
 
     # ---- pass 2 (untimed): per-launch recorder and propagate instrumentation on.
     _cabi.prof_reset()
@@ -560,6 +666,14 @@ def main():
             "ms_per_step_min": min(per_step),
             "ms_per_step_max": max(per_step),
             "value_at_median": e / (med * 1e-3),
+            "ms_per_step_dense_grad": ms_dense,
+            "value_dense_grad": e / (ms_dense * 1e-3),
+            "ms_per_step_dense_grad_with_loss": ms_dense_loss,
+            "dense_grad_note": "same K steps, operator cached, with a dense [N, F] upstream gradient per output (g ~ N(0,1), "
+                               "resident) instead of the broadcast row that `out.sum()` hands the layer: `ms_per_step_dense_grad` "
+                               "= torch.autograd.backward((o_r, o_i), (g_r, g_i)) -- the layer alone, as under a real loss "
+                               "(examples/magnet_node.py:22-27); `..._with_loss` = ((o_r*g_r).sum() + (o_i*g_i).sum()).backward(), "
+                               "the loss's own element-wise passes timed with it",
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -584,10 +698,17 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "launches": int(launches), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_total / max(launches, 1),
-                         "dram_bound_reference": dram_bound_reference()},
+                         "dram_bound_reference": None},
             "kernel_ms_per_step": {"spmm2": kernel_ms / args.steps,
                                    **{k: v[1] / args.steps for k, v in other.items()}},
         }
+        if world == 1 and layer_s is None and not args.no_x4:
+            # the headline's tensors are no longer needed: free them before the 4M-node graph moves in
+            del layer, x_real, x_imag, edge_index
+            torch.cuda.empty_cache()
+            line["roofline"]["dram_bound_reference"] = dram_bound_reference(device, hidden, copy_rate)
+        else:
+            line["roofline"]["dram_bound_reference"] = dram_bound_replay()
         if exchange is not None:
             line["exchange"] = exchange
         if parity is not None:

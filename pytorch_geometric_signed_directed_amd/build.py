@@ -31,26 +31,49 @@ def _stale():
 
 
 def build_library(force=False, verbose=False):
-    """Compile the HIP sources in-tree.  Returns the path of the shared library."""
+    """Compile the HIP sources in-tree.  Returns the path of the shared library.
+
+    Safe under N ranks started from a source checkout (`_cabi.lib()` builds on first use): the whole build runs under an
+    exclusive file lock (`csrc/build/.lock`), staleness is re-checked once the lock is held (the rank that waited finds the
+    library its peer just linked), and every object and the library itself are written to `*.tmp.<pid>` and moved into
+    place with an atomic rename -- a reader can never `CDLL` or link a half-written file."""
     if not force and not _stale():
         return LIB
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     shared = _shared_deps()
+    pid = os.getpid()
+
+    def run_into(cmd, target):
+        tmp = f"{target}.tmp.{pid}"
+        if verbose:
+            print(" ".join(cmd + ["-o", target]), flush=True)
+        try:
+            subprocess.run(cmd + ["-o", tmp], cwd=CSRC, check=True)
+            os.replace(tmp, target)
+        finally:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
 
     def compile_one(src):
         obj = os.path.join(OBJ, src[:-4] + ".o")
         if force or _newer(obj, [os.path.join(CSRC, src)] + shared):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, cwd=CSRC, check=True)
+            run_into([hipcc] + FLAGS + ["-c", src], obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, cwd=CSRC, check=True)
+    run_into([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs, LIB)
     return LIB

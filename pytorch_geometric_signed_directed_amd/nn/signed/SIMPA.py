@@ -54,9 +54,15 @@ _HOST_WEIGHTS = TensorMemo(16)
 
 
 def _host_weights(w):
-    """The hop weights as Python floats (they become alpha / beta kernel arguments).  One device -> host read per
-    in-place VERSION of the parameter, not per call (memo.TensorMemo: weakly held, same opt-outs): an optimiser step
-    bumps the version, inference re-uses the copy -- no synchronisation in a forward whose weights did not change."""
+    """The hop weights as Python floats (they become alpha / beta kernel arguments).
+
+    While the weights are being TRAINED (grad mode on, `requires_grad`) the live tensor is read on every call, exactly as the
+    reference does (SIMPA.py:77-93 multiplies by the parameter itself): an optimiser step changes it between forwards anyway, and
+    the idioms that write a trainable parameter behind the version counter (`p.data.clamp_()`, `p.data.copy_()`) must not meet an
+    old copy.  Only inference (`torch.no_grad()` / frozen weights) re-uses one device -> host read per in-place VERSION of the
+    parameter (memo.TensorMemo: weakly held, same opt-outs): no synchronisation in a forward whose weights did not change."""
+    if torch.is_grad_enabled() and w.requires_grad:
+        return w.detach().reshape(-1).tolist()
     hit = _HOST_WEIGHTS.get((w,), "hop weights")
     if hit is None:
         hit = _HOST_WEIGHTS.put((w,), "hop weights", tuple(w.detach().reshape(-1).tolist()))
@@ -208,12 +214,18 @@ class SIMPA(torch.nn.Module):
             self._reset_parameters_directed()
 
     def _reset_parameters_undirected(self):
-        self._w_p.data.fill_(1.0)
-        self._w_n.data.fill_(1.0)
+        self._fill_weights(("_w_p", "_w_n"))
 
     def _reset_parameters_directed(self):
-        for name in ("_w_sp", "_w_sn", "_w_tp", "_w_tn"):
-            getattr(self, name).data.fill_(1.0)
+        self._fill_weights(("_w_sp", "_w_sn", "_w_tp", "_w_tn"))
+
+    def _fill_weights(self, names):
+        # an in-place write under no_grad bumps the version counter (`.data.fill_` would not), and the host copies of the hop
+        # weights are dropped outright: a reset can never meet the scalars of the old values
+        with torch.no_grad():
+            for name in names:
+                getattr(self, name).fill_(1.0)
+        _HOST_WEIGHTS.clear()
 
     def _fusable(self, w_p, w_n, x_pos, x_neg):
         return (x_pos.dim() == 2 and x_pos.is_cuda and x_pos.dtype == torch.float32 and x_neg.dtype == torch.float32

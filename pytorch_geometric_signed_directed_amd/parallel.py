@@ -1054,8 +1054,14 @@ class _GradSync:
                 mine = local.get(k)
                 if mine is None:                       # a parameter that got no gradient here still takes part
                     total = self.exchange.all_reduce(torch.zeros_like(prm))
+                    # other ranks' shares of a parameter this rank's graph skipped.  With `.grad` still None (the default
+                    # zero_grad(set_to_none=True)) the total BECOMES the gradient: every rank has to end the pass with the
+                    # same `.grad`, or the replicated parameters drift apart at the next optimiser step.  (No host read
+                    # decides this: where no rank had a share the gradient is an explicit zero on all of them alike.)
                     if prm.grad is not None:
-                        prm.grad.add_(total)           # other ranks' shares of a parameter this rank's graph skipped
+                        prm.grad.add_(total)
+                    elif prm.requires_grad:
+                        prm.grad = total
                     continue
                 total = self.exchange.all_reduce(mine.detach().clone().contiguous())
                 held, version = seen[k]
