@@ -224,13 +224,18 @@ C3 = dict(n=500000, entries=10000000, h=64, hop=2, fill=0.5)
 def _check_arbitrated(got, ref32, truth, what, norm=False):
     assert got.shape == truth.shape, (what, got.shape, truth.shape)
     err, ref = FS.errors(got.detach(), truth.detach()), FS.errors(ref32.detach(), truth.detach())
+    apart = FS.errors(got.detach(), ref32.detach())             # HIP <-> the reference's fp32 op sequence, directly (round 5)
     key = "max_norm_rel_err" if norm else "max_mixed_err"
     bar = max(TOL, 1.5 * ref[key])
+    bar_ref = max(TOL, 2.0 * ref[key])
     test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
     RECORDS.append(dict(err, test=test, what=what + " (float64 arbiter)", bar="norm" if norm else "abs", tol=bar,
-                        reference_sequence_err_vs_f64=ref[key]))
+                        reference_sequence_err_vs_f64=ref[key], hip_vs_reference_sequence=apart[key],
+                        hip_vs_reference_sequence_bar=bar_ref))
     assert err[key] <= bar, (f"{what} vs float64: {err[key]:.3e} > max({TOL}, 1.5 x {ref[key]:.3e} of the fp32 reference "
                              f"sequence) (abs {err['max_abs_err']:.3e}, |want| <= {err['max_abs_want']:.3g})")
+    assert apart[key] <= bar_ref, (f"{what} vs the fp32 reference sequence: {apart[key]:.3e} > max({TOL}, 2 x {ref[key]:.3e} = "
+                                   f"the reference's own distance from float64)")
 
 
 @pytest.fixture(scope="module")

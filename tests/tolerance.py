@@ -64,24 +64,43 @@ def close_arbitrated(got, reference_sequence, truth64, tol=TOL, what="", norm=Fa
     with err = max |d| / (1 + |want|) per element, or (norm=True: reductions over the N rows, see `close`) the max-norm
     relative error -- i.e. the HIP result must be inside the 1e-5 bar around the TRUE value, or -- where fp32 arithmetic
     itself cannot reach that (long sums of O(10) terms) -- no more than 1.5x as far from the truth as the reference's
-    own fp32 op sequence is.  Both errors are recorded."""
+    own fp32 op sequence is.
+
+    north_star's sentence is about the REFERENCE path ("within 1e-5 of the reference CPU/PyTorch path"), so the distance
+    HIP <-> fp32 reference sequence is measured directly as well (round 5), recorded as `hip_vs_reference_sequence`, and held to
+
+        err(got, reference sequence)  <=  max(tol, 2 * err(reference sequence, float64))
+
+    -- inside the literal bar, or, where the reference's own fp32 rounding is larger than the bar, no further from the
+    reference than twice the reference is from the truth.  All three errors are recorded."""
     abs_err, mixed, rel, top = errors(got, truth64)
     _, ref_mixed, ref_rel, _ = errors(reference_sequence, truth64)
-    mine, theirs = (rel, ref_rel) if norm else (mixed, ref_mixed)
+    _, vs_ref_mixed, vs_ref_rel, _ = errors(got, reference_sequence)
+    mine, theirs, apart = (rel, ref_rel, vs_ref_rel) if norm else (mixed, ref_mixed, vs_ref_mixed)
     bar = max(tol, 1.5 * theirs)
+    bar_ref = max(tol, 2.0 * theirs)
     test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
     RECORDS.append({"test": test, "what": what + " (float64 arbiter)", "max_abs_err": abs_err, "max_mixed_err": mixed,
                     "max_norm_rel_err": rel, "max_abs_want": top, "bar": "norm" if norm else "abs", "tol": bar,
-                    "reference_sequence_err_vs_f64": theirs})
+                    "reference_sequence_err_vs_f64": theirs, "hip_vs_reference_sequence": apart,
+                    "hip_vs_reference_sequence_bar": bar_ref})
     assert mine <= bar, (f"{what} vs float64: {mine:.3e} > max({tol}, 1.5 x {theirs:.3e} of the fp32 reference "
                          f"sequence) (max abs err {abs_err:.3e}, |want| <= {top:.3g})")
+    assert apart <= bar_ref, (f"{what} vs the fp32 reference sequence: {apart:.3e} > max({tol}, 2 x {theirs:.3e} = the reference's "
+                              f"own distance from float64) (HIP vs float64 {mine:.3e}, |want| <= {top:.3g})")
     return abs_err
 
 
 def dump(path=None):
+    """Per-test worst errors of this session -> gpurun_out/parity_errors_<pid>.json, and -- when PYGSD_PARITY_OUT names a path
+    (relative ones are taken from the repository root, e.g. profiles/r5_parity_errors.json) -- to that tracked path as well, so
+    that whoever runs the suite can leave the record where the review reads it."""
     if not RECORDS:
         return
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    extra = os.environ.get("PYGSD_PARITY_OUT")
+    if path is None and extra:
+        dump(extra if os.path.isabs(extra) else os.path.join(root, extra))
     path = path or os.path.join(root, "gpurun_out", f"parity_errors_{os.getpid()}.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -97,6 +116,9 @@ def dump(path=None):
                 k["arbitrated_checks"] = k.get("arbitrated_checks", 0) + 1
                 k["worst_reference_sequence_err_vs_f64"] = max(k.get("worst_reference_sequence_err_vs_f64", 0.0),
                                                                r["reference_sequence_err_vs_f64"])
+                k["hip_vs_reference_sequence"] = max(k.get("hip_vs_reference_sequence", 0.0), r["hip_vs_reference_sequence"])
+                k["hip_vs_reference_sequence_bar"] = max(k.get("hip_vs_reference_sequence_bar", 0.0),
+                                                         r["hip_vs_reference_sequence_bar"])
             k["loosest_bar"] = max(k.get("loosest_bar", 0.0), r["tol"])
         with open(path, "w") as fh:
             json.dump({"checks": len(RECORDS), "per_test_worst": sorted(worst.values(), key=lambda r: r["test"])},
