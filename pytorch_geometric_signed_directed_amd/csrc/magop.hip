@@ -802,7 +802,8 @@ template <int STRIDE>
 __device__ __forceinline__ void unit_values(const UnitArgs& p, float* st, int64_t wslot0, float ir, float ic, int32_t c, int len,
                                             int theta, float cs1, float sn1, int64_t slot)
 {
-    // (values_entries, specialised: A_s = len / 2, Theta_arg = theta, both small integers as floats)
+    // (values_entries, specialised: A_s = len / 2, Theta_arg = theta, both small integers as floats; with weights of +-1 the caller
+    // passes len = the sum of the run's weights = entries - 2 x negative ones)
     const float th = static_cast<float>(theta);
     float sn, cs;
     if (fabsf(th) == 1.0f) {
@@ -838,10 +839,15 @@ __device__ __forceinline__ void unit_diagonal(const UnitArgs& p, float* st, int6
 // -- parked at scratch[gbeg + rank]; the positions behind a row's distinct entries (duplicates merged away) are marked kNoRecord, so
 // the write kernel can walk a chunk's positions without looking at its rows.
 // (`cnt`, `r`, `gbeg` wavefront-uniform)
-template <typename KT>
+// SIGNED (weights of +-1; 32-bit keys only): the key is  col << 2 | dir << 1 | (w < 0) ; the record also carries the run's number
+// of negative entries in bits 25 .. 31 (a column id has <= 24 bits there), and Theta_arg = sum of (+w forward, -w reversed).  Sums
+// of +-1 are small integers: exact in every order, like the unit sums -- which is why an unordered LDS placement may feed this.
+template <typename KT, bool SIGNED = false>
 __device__ __forceinline__ void unit_merge_short(const UnitArgs& p, uint32_t c2, int cnt, int32_t r, int64_t gbeg, int lane,
                                                  const BitonicSel& sel, int& u, int& left)
 {
+    static_assert(!SIGNED || sizeof(KT) == 4, "the signed form is built for the bucket plan (32-bit keys)");
+    constexpr int S = SIGNED ? 1 : 0;
     const bool have = lane < cnt;
     uint32_t c2s;
     if constexpr (sizeof(KT) == 4) {
@@ -851,11 +857,11 @@ __device__ __forceinline__ void unit_merge_short(const UnitArgs& p, uint32_t c2,
         KT k = have ? static_cast<KT>((static_cast<KT>(c2) << 6) | static_cast<KT>(lane)) : static_cast<KT>(~static_cast<KT>(0));
         c2s = static_cast<uint32_t>(wave_bitonic<KT>(k, lane) >> 6);
     }
-    const uint32_t cv = c2s >> 1;
+    const uint32_t cv = c2s >> (1 + S);
     const uint32_t prev = dpp_mov<0x138>(cv);                     // wave_shr:1 (lane 0 reads 0: it is a head anyway)
     const bool hd = have && (lane == 0 || prev != cv);
     const uint64_t H = __ballot(hd);
-    const uint64_t D = __ballot(have && (c2s & 1u) != 0);         // entries of the reversed orientation
+    const uint64_t D = __ballot(have && ((c2s >> S) & 1u) != 0);  // entries of the reversed orientation
     u = __popcll(H);
     left = __popcll(__ballot(hd && static_cast<int32_t>(cv) < r));
     // the run of this head ends at the next head (or at cnt); reversed entries inside it = prefix count there - prefix count here
@@ -865,11 +871,20 @@ __device__ __forceinline__ void unit_merge_short(const UnitArgs& p, uint32_t c2,
     const int rl_end = __builtin_amdgcn_ds_bpermute((end & 63) << 2, rl_here);
     const int n1 = (end < cnt ? rl_end : __popcll(D)) - rl_here;
     const int rank = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(H >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(H), 0u)));
+    int nneg = 0, nrn = 0;                                        // negative entries of the run; negative AND reversed ones
+    if constexpr (SIGNED) {
+        const uint64_t N = __ballot(have && (c2s & 1u) != 0);
+        const int ln_ = end - lane;
+        const uint64_t run = (ln_ >= 64 ? ~0ull : ((1ull << (ln_ > 0 ? ln_ : 0)) - 1ull)) << lane;      // lanes [lane, end)
+        nneg = __popcll(N & run);
+        nrn = __popcll(N & D & run);
+    }
     if (hd) {
         const int ln = end - lane;
-        p.scratch[gbeg + rank] = static_cast<uint64_t>(cv) | (static_cast<uint64_t>(ln) << 32) |
-                                 (static_cast<uint64_t>(ln - 2 * n1 + 64) << 40) | (static_cast<uint64_t>(rank) << 48) |
-                                 (static_cast<uint64_t>(r & (kChunkRows - 1)) << 54);
+        // Theta_arg = (forward +) - (forward -) - (reversed +) + (reversed -) = ln - 2 n1 - 2 nneg + 4 nrn
+        p.scratch[gbeg + rank] = static_cast<uint64_t>(cv) | (static_cast<uint64_t>(nneg) << 25) | (static_cast<uint64_t>(ln) << 32) |
+                                 (static_cast<uint64_t>(ln - 2 * n1 - 2 * nneg + 4 * nrn + 64) << 40) |
+                                 (static_cast<uint64_t>(rank) << 48) | (static_cast<uint64_t>(r & (kChunkRows - 1)) << 54);
     } else if (have) {
         p.scratch[gbeg + u + (lane - rank)] = kNoRecord;          // (lane - rank: entries before this one that are no heads)
     }
@@ -878,9 +893,11 @@ __device__ __forceinline__ void unit_merge_short(const UnitArgs& p, uint32_t c2,
 // One row of 65 .. kUnitRowMax entries whose keys sit in LDS (`src`): rank sort -- rank = number of keys that sort before this one
 // ((col, dir) order; identical keys are indistinguishable, so ties may fall either way); SORTED KEYS (not merged records) ->
 // scratch[gbeg + rank], then the distinct / left-of-diagonal counts from the sorted run.
+template <bool SIGNED = false>
 __device__ __forceinline__ void unit_merge_long(const UnitArgs& p, const uint32_t* src, int cnt, int32_t r, int64_t gbeg, int lane,
                                                 int& u, int& left)
 {
+    constexpr int S = SIGNED ? 1 : 0;                             // (signed keys: col << 2 | dir << 1 | negative)
     for (int i = lane; i < cnt; i += 64) {
         const uint32_t mine = src[i];
         int rk = 0;
@@ -899,8 +916,8 @@ __device__ __forceinline__ void unit_merge_long(const UnitArgs& p, const uint32_
         const int i = i0 + lane;
         bool hd = false, lt = false;
         if (i < cnt) {
-            const uint32_t cur = static_cast<uint32_t>(p.scratch[gbeg + i]) >> 1;
-            hd = i == 0 || (static_cast<uint32_t>(p.scratch[gbeg + i - 1]) >> 1) != cur;
+            const uint32_t cur = static_cast<uint32_t>(p.scratch[gbeg + i]) >> (1 + S);
+            hd = i == 0 || (static_cast<uint32_t>(p.scratch[gbeg + i - 1]) >> (1 + S)) != cur;
             lt = hd && static_cast<int32_t>(cur) < r;
         }
         u += __popcll(__ballot(hd));
@@ -958,17 +975,21 @@ __global__ __launch_bounds__(256) void unit_merge_rows(UnitArgs p)
 
 // A row written straight to global memory by one wavefront (chunks holding a row of more than 64 entries): merged records for rows
 // of <= 64 entries, the SORTED KEYS unit_merge_long left for longer ones.
+template <bool SIGNED = false>
 __device__ __forceinline__ void unit_write_row_direct(const UnitArgs& p, int32_t r, int32_t beg, int cnt, int u, int left, int64_t slot0,
                                                       int lane, float cs1, float sn1)
 {
+    constexpr int S = SIGNED ? 1 : 0;
     if (lane == 0) unit_diagonal<0>(p, nullptr, 0, r, slot0 + left);
     const float ir = p.sym ? p.lut[p.cnt16[r]] : 0.f;
     if (cnt <= 64) {
         if (lane < u) {
             const uint64_t rc = p.scratch[beg + lane];
-            const int32_t c = static_cast<int32_t>(rc & 0xFFFFFFFFull);
+            const int32_t c = static_cast<int32_t>(rc & (SIGNED ? 0x1FFFFFFull : 0xFFFFFFFFull));
+            const int nneg = SIGNED ? static_cast<int>((rc >> 25) & 0x7Full) : 0;
             const int ln = static_cast<int>((rc >> 32) & 0xFFull), th = static_cast<int>((rc >> 40) & 0xFFull) - 64;
-            unit_values<0>(p, nullptr, 0, ir, p.sym ? p.lut[p.cnt16[c]] : 0.f, c, ln, th, cs1, sn1, slot0 + lane + (c > r ? 1 : 0));
+            unit_values<0>(p, nullptr, 0, ir, p.sym ? p.lut[p.cnt16[c]] : 0.f, c, ln - 2 * nneg, th, cs1, sn1,
+                           slot0 + lane + (c > r ? 1 : 0));
         }
     } else if (cnt <= kUnitRowMax) {
         int base_rank = 0;
@@ -977,21 +998,25 @@ __device__ __forceinline__ void unit_write_row_direct(const UnitArgs& p, int32_t
             bool hd = false;
             uint32_t cur = 0;
             if (i < cnt) {
-                cur = static_cast<uint32_t>(p.scratch[beg + i]) >> 1;
-                hd = i == 0 || (static_cast<uint32_t>(p.scratch[beg + i - 1]) >> 1) != cur;
+                cur = static_cast<uint32_t>(p.scratch[beg + i]) >> (1 + S);
+                hd = i == 0 || (static_cast<uint32_t>(p.scratch[beg + i - 1]) >> (1 + S)) != cur;
             }
             const uint64_t H = __ballot(hd);
             if (hd) {
-                int ln = 0, n1 = 0;
+                int ln = 0, n1 = 0, nneg = 0, nrn = 0;
                 for (int t = i; t < cnt; ++t) {                    // the run: short (multiplicity of one neighbour)
                     const uint32_t k2 = static_cast<uint32_t>(p.scratch[beg + t]);
-                    if ((k2 >> 1) != cur) break;
+                    if ((k2 >> (1 + S)) != cur) break;
                     ++ln;
-                    n1 += static_cast<int>(k2 & 1u);
+                    const int rv = static_cast<int>((k2 >> S) & 1u), ng = SIGNED ? static_cast<int>(k2 & 1u) : 0;
+                    n1 += rv;
+                    nneg += ng;
+                    nrn += rv & ng;
                 }
                 const int rk = base_rank + __popcll(H & ((1ull << lane) - 1ull));
                 const int32_t c = static_cast<int32_t>(cur);
-                unit_values<0>(p, nullptr, 0, ir, p.sym ? p.lut[p.cnt16[c]] : 0.f, c, ln, ln - 2 * n1, cs1, sn1, slot0 + rk + (c > r ? 1 : 0));
+                unit_values<0>(p, nullptr, 0, ir, p.sym ? p.lut[p.cnt16[c]] : 0.f, c, ln - 2 * nneg, ln - 2 * n1 - 2 * nneg + 4 * nrn, cs1, sn1,
+                               slot0 + rk + (c > r ? 1 : 0));
             }
             base_rank += __popcll(H);
         }
@@ -1006,7 +1031,7 @@ __device__ __forceinline__ void unit_write_row_direct(const UnitArgs& p, int32_t
 // Measured and dropped: persistent workgroups running  row bounds -> records -> deg^-1/2 gathers -> stores  as a pipeline over
 // chunks c, c + G, c + 2 G (0.37 ms either way: on gfx9 a wait for the loads of the next round also waits for the drain's stores,
 // which share their counter -- the same reason a grid-stride copy runs at 4.5 TB/s here and a block-per-piece copy at 6.2).
-template <int THREADS, int SLOTS>
+template <int THREADS, int SLOTS, bool SIGNED = false>
 __global__ __launch_bounds__(THREADS) void unit_write_chunks(UnitArgs p)
 {
     __shared__ __attribute__((aligned(16))) float stage[5 * SLOTS];
@@ -1046,13 +1071,13 @@ __global__ __launch_bounds__(THREADS) void unit_write_chunks(UnitArgs p)
     const float cs1 = p.trig[0], sn1 = p.trig[1];
     if (any_long) {
         for (int j = __builtin_amdgcn_readfirstlane(wv); j < rows; j += THREADS / 64)
-            unit_write_row_direct(p, static_cast<int32_t>(r0) + j, s_rs[j], s_rs[j + 1] - s_rs[j], s_rp[j + 1] - s_rp[j] - 1, s_left[j],
-                                  s_rp[j], lane, cs1, sn1);
+            unit_write_row_direct<SIGNED>(p, static_cast<int32_t>(r0) + j, s_rs[j], s_rs[j + 1] - s_rs[j], s_rp[j + 1] - s_rp[j] - 1, s_left[j],
+                                          s_rp[j], lane, cs1, sn1);
         return;
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {                               // the 2-byte gathers leave together; the LDS look-ups follow
-        const uint16_t cn = (p.sym && rc[k] != kNoRecord) ? p.cnt16[rc[k] & 0xFFFFFFFFull] : uint16_t(0);
+        const uint16_t cn = (p.sym && rc[k] != kNoRecord) ? p.cnt16[rc[k] & (SIGNED ? 0x1FFFFFFull : 0xFFFFFFFFull)] : uint16_t(0);
         ic[k] = __uint_as_float(cn);
     }
 #pragma unroll
@@ -1061,11 +1086,12 @@ __global__ __launch_bounds__(THREADS) void unit_write_chunks(UnitArgs p)
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         if (rc[k] == kNoRecord) continue;
-        const int32_t c = static_cast<int32_t>(rc[k] & 0xFFFFFFFFull);
+        const int32_t c = static_cast<int32_t>(rc[k] & (SIGNED ? 0x1FFFFFFull : 0xFFFFFFFFull));
+        const int nneg = SIGNED ? static_cast<int>((rc[k] >> 25) & 0x7Full) : 0;
         const int ln = static_cast<int>((rc[k] >> 32) & 0xFFull), th = static_cast<int>((rc[k] >> 40) & 0xFFull) - 64;
         const int rank = static_cast<int>((rc[k] >> 48) & 0x3Full), j = static_cast<int>((rc[k] >> 54) & (kChunkRows - 1));
         const int32_t r = static_cast<int32_t>(r0) + j;
-        unit_values<SLOTS>(p, stage, wslot0, p.sym ? s_lut[s_cnt[j]] : 0.f, ic[k], c, ln, th, cs1, sn1,
+        unit_values<SLOTS>(p, stage, wslot0, p.sym ? s_lut[s_cnt[j]] : 0.f, ic[k], c, ln - 2 * nneg, th, cs1, sn1,
                                  static_cast<int64_t>(s_rp[j]) + rank + (c > r ? 1 : 0));
     }
     if (t < rows) unit_diagonal<SLOTS>(p, stage, wslot0, static_cast<int32_t>(r0) + t, static_cast<int64_t>(s_rp[t]) + s_left[t]);
@@ -1132,12 +1158,14 @@ struct BucketPlan {
     int cbits;         // bits of a column id
     int cap;           // entries a bucket may hold (LDS of bucket_merge_rows)
     int threads;       // workgroup size of bucket_merge_rows
+    int sb;            // sign bits per entry: 0 (unit weights), 1 (weights of +-1: pygsd_magop_unit_signed)
 };
 
 // false: this graph is not taken by the bucket form (ids too wide for a 4-byte entry, too many buckets, rows too dense)
-inline bool bucket_plan(int64_t e, int32_t n, BucketPlan* pl)
+inline bool bucket_plan(int64_t e, int32_t n, int sb, BucketPlan* pl)
 {
     if (n <= 0 || e <= 0) return false;
+    pl->sb = sb;
     const int64_t m = 2 * e;
     pl->threads = 1024;
     pl->cap = pl->threads * 32;                                  // 128 KB of LDS: one workgroup per CU
@@ -1148,8 +1176,8 @@ inline bool bucket_plan(int64_t e, int32_t n, BucketPlan* pl)
     while (rl > 3 && (m << rl) / n > static_cast<int64_t>(pl->cap) * 3 / 4) --rl;
     if ((m << rl) / n > static_cast<int64_t>(pl->cap) * 3 / 4) return false;
     const int64_t nb = (static_cast<int64_t>(n) + (int64_t(1) << rl) - 1) >> rl;
-    // (25: the in-register sort key, col << 7 | dir << 6 | lane)
-    if (nb > kMaxBuckets || rl + pl->cbits + 1 > 32 || pl->cbits > 25) return false;
+    // (25: the in-register sort key, col << 7 | dir << 6 | lane; one bit less for the column with a sign bit below dir)
+    if (nb > kMaxBuckets || rl + pl->cbits + 1 + sb > 32 || pl->cbits + sb > 25) return false;
     const int64_t g = (e + kTileEdges - 1) / kTileEdges;
     if (g * nb + 1 > (int64_t(1) << 23)) return false;          // hist / off: <= 32 MB each
     pl->rl = rl;
@@ -1159,13 +1187,18 @@ inline bool bucket_plan(int64_t e, int32_t n, BucketPlan* pl)
 }
 
 // Pass 1: a tile's entries per bucket, counted in LDS -> hist[bucket][tile]; node-id range check (info[2], info[3]) folded in.
-__global__ __launch_bounds__(kPassThreads) void bucket_count(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t e,
+// w != NULL (pygsd_magop_unit_signed): the weights of the tile's non-loop edges are validated on the way -- every one must be
+// exactly +1 or -1 (-1 only with allow_neg: the degree convention that counts |w|); anything else counts in info[1], the later
+// kernels of the build return at once and the host takes the two-stage pipeline.
+__global__ __launch_bounds__(kPassThreads) void bucket_count(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                                             const float* __restrict__ w, int32_t allow_neg, int64_t e,
                                                              int32_t n, BucketPlan pl, int32_t* __restrict__ hist,
                                                              int64_t* __restrict__ info, float two_pi_q, float* __restrict__ trig,
                                                              float* __restrict__ lut)
 {
     __shared__ uint32_t cnt[kMaxBuckets];
     const int wg = blockIdx.x, t = threadIdx.x;
+    bool odd_weight = false;
     if (wg == 0) {
         if (t == 0) sincosf(two_pi_q, trig + 1, trig);
         for (int k = t; k <= kUnitRowMax; k += kPassThreads) unit_lut(k, lut);
@@ -1176,12 +1209,14 @@ __global__ __launch_bounds__(kPassThreads) void bucket_count(const int64_t* __re
     const uint64_t nn = static_cast<uint64_t>(n);
     for (int64_t k0 = lo; k0 < hi; k0 += kPassThreads * kPassBatch) {
         int64_t r[kPassBatch], c[kPassBatch];
+        float wv[kPassBatch];
 #pragma unroll
         for (int u = 0; u < kPassBatch; ++u) {
             const int64_t k = k0 + u * kPassThreads + t;
             const bool ok = k < hi;
             r[u] = ok ? row[k] : 0;                               // (0, 0): a self loop, dropped below
             c[u] = ok ? col[k] : 0;
+            wv[u] = (w && ok) ? w[k] : 1.f;
         }
 #pragma unroll
         for (int u = 0; u < kPassBatch; ++u) {
@@ -1192,8 +1227,13 @@ __global__ __launch_bounds__(kPassThreads) void bucket_count(const int64_t* __re
             } else if (r[u] != c[u]) {
                 atomicAdd(&cnt[static_cast<uint32_t>(r[u]) >> pl.rl], 1u);
                 atomicAdd(&cnt[static_cast<uint32_t>(c[u]) >> pl.rl], 1u);
+                // (a NaN fails the first test)
+                if (!(fabsf(wv[u]) == 1.0f) || (wv[u] < 0.f && !allow_neg)) odd_weight = true;
             }
         }
+    }
+    if (w) {                                                       // (uniform: every thread of the grid takes the same side)
+        if (__syncthreads_or(odd_weight) && t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
     }
     __syncthreads();
     for (int b = t; b < pl.nb; b += kPassThreads) hist[static_cast<int64_t>(b) * pl.g + wg] = static_cast<int32_t>(cnt[b]);
@@ -1207,11 +1247,17 @@ __global__ __launch_bounds__(kPassThreads) void bucket_count(const int64_t* __re
 // per 32 slots -> index among the tile's non-empty buckets -> that bucket's (global - staged) offset.  (A binary search over the
 // buckets' first slots instead cost 11 dependent LDS reads and ~75 VALU instructions per 64 entries: 0.20 ms for the pass.)
 // LDS: stage[2 * kTileEdges], cur[nb] (placement cursors), gdc[nb] (offsets of the non-empty buckets, compacted), hp[1024].
-__global__ __launch_bounds__(kScatterThreads) void bucket_scatter(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t e,
+// SIGNED (weights of +-1, validated by bucket_count): the entry carries the sign below its direction bit,
+//   row_low << (cbits + 2) | col << 2 | dir << 1 | (w < 0)  -- both orientations of an edge carry the edge's sign.
+template <bool SIGNED>
+__global__ __launch_bounds__(kScatterThreads) void bucket_scatter(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                                                  const float* __restrict__ w, int64_t e,
                                                                   int32_t n, BucketPlan pl, const int32_t* __restrict__ off,
-                                                                  uint32_t* __restrict__ stream)
+                                                                  uint32_t* __restrict__ stream, const int64_t* __restrict__ info)
 {
     static_assert(2 * kTileEdges == 32 * kScatterThreads, "one 32-slot word of the head map per thread");
+    constexpr int S = SIGNED ? 1 : 0;
+    if (SIGNED && info[1] != 0) return;                           // a weight that is not +-1: the host takes the two-stage pipeline
     extern __shared__ __attribute__((aligned(8))) uint32_t scatter_lds[];
     uint32_t* stage = scatter_lds;
     uint2* hp = reinterpret_cast<uint2*>(stage + 2 * kTileEdges);
@@ -1276,31 +1322,36 @@ __global__ __launch_bounds__(kScatterThreads) void bucket_scatter(const int64_t*
     const int64_t lo = static_cast<int64_t>(st) * kTileEdges, hi = lo + kTileEdges < e ? lo + kTileEdges : e;
     const uint64_t nn = static_cast<uint64_t>(n);
     const uint32_t rmask = (1u << pl.rl) - 1u;
-    const int sh = pl.cbits + 1;
+    const int sh = pl.cbits + 1 + S;
     int64_t r[kPassBatch], c[kPassBatch], rn[kPassBatch], cn[kPassBatch];
+    float ww[kPassBatch], wn[kPassBatch];
 #pragma unroll
     for (int u = 0; u < kPassBatch; ++u) {
         const int64_t k = lo + u * kScatterThreads + t;
         const bool ok = k < hi;
         rn[u] = ok ? row[k] : 0;
         cn[u] = ok ? col[k] : 0;
+        wn[u] = (SIGNED && ok) ? w[k] : 1.f;
     }
     for (int64_t k0 = lo; k0 < hi; k0 += kScatterThreads * kPassBatch) {
 #pragma unroll
         for (int u = 0; u < kPassBatch; ++u) {
             r[u] = rn[u];
             c[u] = cn[u];
+            ww[u] = wn[u];
             const int64_t k = k0 + (kPassBatch + u) * kScatterThreads + t;      // the next batch is in flight during this one's placement
             const bool ok = k < hi;
             rn[u] = ok ? row[k] : 0;
             cn[u] = ok ? col[k] : 0;
+            wn[u] = (SIGNED && ok) ? w[k] : 1.f;
         }
 #pragma unroll
         for (int u = 0; u < kPassBatch; ++u) {
             if (static_cast<uint64_t>(r[u]) >= nn || static_cast<uint64_t>(c[u]) >= nn || r[u] == c[u]) continue;
             const uint32_t rr = static_cast<uint32_t>(r[u]), cc = static_cast<uint32_t>(c[u]);
-            stage[atomicAdd(&cur[rr >> pl.rl], 1u)] = ((rr & rmask) << sh) | (cc << 1);
-            stage[atomicAdd(&cur[cc >> pl.rl], 1u)] = ((cc & rmask) << sh) | (rr << 1) | 1u;
+            const uint32_t neg = (SIGNED && ww[u] < 0.f) ? 1u : 0u;
+            stage[atomicAdd(&cur[rr >> pl.rl], 1u)] = ((rr & rmask) << sh) | (cc << (1 + S)) | neg;
+            stage[atomicAdd(&cur[cc >> pl.rl], 1u)] = ((cc & rmask) << sh) | (rr << (1 + S)) | (1u << S) | neg;
         }
     }
     __syncthreads();
@@ -1431,7 +1482,7 @@ int magop_layout(int64_t e, int32_t n, int weighted, MagopWs* w)
                                           nn + 1, rocprim::plus<int32_t>(), hipStream_t(nullptr)));
     BucketPlan pl;
     size_t table = 0;
-    if (!weighted && bucket_plan(e, n, &pl)) {
+    if (!weighted && bucket_plan(e, n, 0, &pl)) {
         table = static_cast<size_t>(pl.nb) * pl.g + 1;
         size_t scan2 = 0;
         PYGSD_HIP_TRY(rocprim::exclusive_scan(nullptr, scan2, i32, i32, 0, table, rocprim::plus<int32_t>(), hipStream_t(nullptr)));
@@ -1627,7 +1678,7 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
     }
     BucketPlan pl;
     const char* form = getenv("PYGSD_UNIT_BUILD_FORM");          // "sort": the radix-sort form (measurement / tests)
-    const bool buckets = !(form && strcmp(form, "sort") == 0) && bucket_plan(n_edges, n, &pl);
+    const bool buckets = !(form && strcmp(form, "sort") == 0) && bucket_plan(n_edges, n, is_pm1 ? 1 : 0, &pl);
     if (buckets) {
         int32_t* hist = reinterpret_cast<int32_t*>(base + l.hist);
         int32_t* off = reinterpret_cast<int32_t*>(base + l.off);
