@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 11
+#define PYGSD_ABI_VERSION 12
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -328,6 +328,21 @@ int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, in
 int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, float q, float lambda_max,
                      float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr, float* deg, int32_t* ccol,
                      float* vb_real, float* vb_imag, float* vf_real, float* vf_imag, int64_t* d_info, int32_t phase, void* stream);
+/* The same one-call build for weights that are all +1 or -1 (round 5) -- the signed graphs of MSConv / MSGNN
+ * (get_magnetic_signed_Laplacian.py:52-90 as MSConv.py:78-119 calls it on every uncached forward: SDSBM / SSBM signs, BASELINE
+ * config 4) and edge lists that carry explicit unit weights.  Sums of +-1 are small integers, exact in every order of summation,
+ * so the unordered LDS placement of the bucket form serves here as it does for unit weights, with ONE extra bit per stream entry
+ * (the sign, below the direction bit) and the merged record also carrying the run's number of negative entries:
+ * A_s = (entries - 2 negative) / 2, Theta_arg = sum of +w (forward) / -w (reversed), bit-identical to the two stages and to the
+ * pygsd_maglap_* pipeline.  -1 is admitted where the degree counts |w| (is_signed && absolute_degree: deg = entries / 2, as with
+ * unit weights); elsewhere only +1.  Not taken -- d_info[1] != 0, outputs invalid, the caller takes pygsd_magop_stage1 / _stage2
+ * -- when a weight is anything else (validated on the device by the first kernel: no host read of the weights), when -1 meets
+ * another degree convention, and for the graphs the bucket form does not take (see above; here <= 2^24 nodes).  Arguments,
+ * workspace (pygsd_magop_workspace(n_edges, n, 0)), outputs, d_info and `phase` as pygsd_magop_unit. */
+int pygsd_magop_unit_signed(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n, int32_t is_signed,
+                            int32_t absolute_degree, int32_t sym, float q, float lambda_max, float diag_shift, void* workspace,
+                            size_t workspace_bytes, int32_t* rowptr, float* deg, int32_t* ccol, float* vb_real, float* vb_imag,
+                            float* vf_real, float* vf_imag, int64_t* d_info, int32_t phase, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * add_remaining_self_loops + degree normalisation: torch_geometric's gcn_norm as called at

@@ -1365,11 +1365,12 @@ __global__ __launch_bounds__(kScatterThreads) void bucket_scatter(const int64_t*
 
 // One workgroup per bucket of 2^rl rows.  LDS: placed[cap] (the bucket's keys, row by row), rcnt[2^rl + 1] (row counts, then
 // placement cursors), roff[2^rl + 1] (row offsets inside the bucket).
-template <int THREADS>
+template <int THREADS, bool SIGNED = false>
 __global__ __launch_bounds__(THREADS) void bucket_merge_rows(UnitArgs p, BucketPlan pl, const uint32_t* __restrict__ stream,
                                                              const int32_t* __restrict__ off)
 {
-    constexpr int EPT = 32, WAVES = THREADS / 64;
+    constexpr int EPT = 32, WAVES = THREADS / 64, S = SIGNED ? 1 : 0;
+    if (SIGNED && p.info[1] != 0) return;                          // a weight that is not +-1 (bucket_count): nothing to build
     extern __shared__ uint32_t bucket_lds[];
     uint32_t* placed = bucket_lds;
     uint32_t* rcnt = bucket_lds + pl.cap;
@@ -1396,7 +1397,7 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows(UnitArgs p, BucketP
         ent[k] = i < cnt_b ? __builtin_nontemporal_load(stream + b0 + i) : 0u;
     }
     __syncthreads();
-    const int sh = pl.cbits + 1;
+    const int sh = pl.cbits + 1 + S;
     const uint32_t kmask = (1u << sh) - 1u;
 #pragma unroll
     for (int k = 0; k < EPT; ++k)
@@ -1440,9 +1441,9 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows(UnitArgs p, BucketP
         int u = 0, left = 0;
         if (cnt <= 64) {
             const uint32_t c2 = placed[beg + (lane < cnt ? lane : 0)];
-            unit_merge_short<uint32_t>(p, c2, cnt, r, static_cast<int64_t>(b0) + beg, lane, sel, u, left);
+            unit_merge_short<uint32_t, SIGNED>(p, c2, cnt, r, static_cast<int64_t>(b0) + beg, lane, sel, u, left);
         } else if (cnt <= kUnitRowMax) {
-            unit_merge_long(p, placed + beg, cnt, r, static_cast<int64_t>(b0) + beg, lane, u, left);
+            unit_merge_long<SIGNED>(p, placed + beg, cnt, r, static_cast<int64_t>(b0) + beg, lane, u, left);
         } else {
             if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 1), 1ull);
         }
@@ -1634,11 +1635,14 @@ extern "C" int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, 
     return check_launch("diagonal_of_empty_rows");
 }
 
-extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, float q,
-                                float lambda_max, float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr,
-                                float* deg, int32_t* ccol, float* vb_real, float* vb_imag, float* vf_real, float* vf_imag,
-                                int64_t* d_info, int32_t phase, void* stream)
+// w == NULL: unit weights (pygsd_magop_unit).  w != NULL: weights that must all be +1 or -1 (pygsd_magop_unit_signed; -1 only with
+// allow_neg) -- the bucket form only; a graph its plan does not take is reported like an over-long row (d_info[1] != 0).
+static int magop_unit_impl(const int64_t* row, const int64_t* col, const float* w, int32_t allow_neg, int64_t n_edges, int32_t n,
+                           int32_t sym, float q, float lambda_max, float diag_shift, void* workspace, size_t workspace_bytes,
+                           int32_t* rowptr, float* deg, int32_t* ccol, float* vb_real, float* vb_imag, float* vf_real,
+                           float* vf_imag, int64_t* d_info, int32_t phase, void* stream)
 {
+    const bool is_pm1 = w != nullptr;
     PYGSD_REQUIRE(n >= 0 && n_edges >= 0 && 2 * n_edges < (int64_t(1) << 31), "pygsd_magop_unit: size out of int32 range");
     PYGSD_REQUIRE(phase >= 0 && phase <= 2, "pygsd_magop_unit: phase must be 0 (all), 1 (up to the row pointer) or 2 (the write kernel)");
     PYGSD_REQUIRE(workspace && rowptr && d_info && (n == 0 || (deg && ccol && vb_real && vb_imag && vf_real && vf_imag)),
@@ -1673,33 +1677,56 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
     const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n) + per_block - 1) / per_block);
     const unsigned chunks = static_cast<unsigned>((static_cast<int64_t>(n) + kChunkRows - 1) / kChunkRows);
     if (phase == 2) {
-        hipLaunchKernelGGL((unit_write_chunks<256, kChunkSlots>), dim3(chunks), dim3(256), 0, s, a);
+        if (is_pm1)
+            hipLaunchKernelGGL((unit_write_chunks<256, kChunkSlots, true>), dim3(chunks), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((unit_write_chunks<256, kChunkSlots>), dim3(chunks), dim3(256), 0, s, a);
         return check_launch("unit_write_chunks");
     }
     BucketPlan pl;
     const char* form = getenv("PYGSD_UNIT_BUILD_FORM");          // "sort": the radix-sort form (measurement / tests)
     const bool buckets = !(form && strcmp(form, "sort") == 0) && bucket_plan(n_edges, n, is_pm1 ? 1 : 0, &pl);
+    if (is_pm1 && !buckets) {
+        // the signed form exists for the bucket plan only: report "not taken" (every byte 1: non-zero) -- the caller's two-stage
+        // pipeline builds this graph
+        PYGSD_HIP_TRY(hipMemsetAsync(d_info + 1, 1, sizeof(int64_t), s));
+        return 0;
+    }
     if (buckets) {
         int32_t* hist = reinterpret_cast<int32_t*>(base + l.hist);
         int32_t* off = reinterpret_cast<int32_t*>(base + l.off);
         uint32_t* stream = reinterpret_cast<uint32_t*>(keys_b);
-        hipLaunchKernelGGL(bucket_count, dim3(pl.g), dim3(kPassThreads), 0, s, row, col, n_edges, n, pl, hist, d_info, two_pi_q, a.trig,
-                           const_cast<float*>(a.lut));
+        hipLaunchKernelGGL(bucket_count, dim3(pl.g), dim3(kPassThreads), 0, s, row, col, w, allow_neg, n_edges, n, pl, hist, d_info,
+                           two_pi_q, a.trig, const_cast<float*>(a.lut));
         if (int rc = check_launch("bucket_count")) return rc;
         size_t tb = l.scan_tmp_bytes;
         PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb, hist, off, 0, static_cast<size_t>(pl.nb) * pl.g + 1,
                                               rocprim::plus<int32_t>(), s));
         const size_t lds2 = (static_cast<size_t>(2 * kTileEdges) + 2 * kScatterThreads + 2 * static_cast<size_t>(pl.nb)) * sizeof(uint32_t);
-        static const hipError_t once2 = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_scatter),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        PYGSD_HIP_TRY(once2);
-        hipLaunchKernelGGL(bucket_scatter, dim3(pl.g), dim3(kScatterThreads), lds2, s, row, col, n_edges, n, pl, off, stream);
-        if (int rc = check_launch("bucket_scatter")) return rc;
         const size_t lds = (static_cast<size_t>(pl.cap) + 2 * ((size_t(1) << pl.rl) + 8)) * sizeof(uint32_t);
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows<1024>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        PYGSD_HIP_TRY(once);
-        hipLaunchKernelGGL(bucket_merge_rows<1024>, dim3(pl.nb), dim3(1024), lds, s, a, pl, stream, off);
+        if (is_pm1) {
+            static const hipError_t once2 = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_scatter<true>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            PYGSD_HIP_TRY(once2);
+            hipLaunchKernelGGL(bucket_scatter<true>, dim3(pl.g), dim3(kScatterThreads), lds2, s, row, col, w, n_edges, n, pl, off, stream,
+                               static_cast<const int64_t*>(d_info));
+            if (int rc = check_launch("bucket_scatter")) return rc;
+            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows<1024, true>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            PYGSD_HIP_TRY(once);
+            hipLaunchKernelGGL((bucket_merge_rows<1024, true>), dim3(pl.nb), dim3(1024), lds, s, a, pl, stream, off);
+        } else {
+            static const hipError_t once2 = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_scatter<false>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            PYGSD_HIP_TRY(once2);
+            hipLaunchKernelGGL(bucket_scatter<false>, dim3(pl.g), dim3(kScatterThreads), lds2, s, row, col, w, n_edges, n, pl, off, stream,
+                               static_cast<const int64_t*>(d_info));
+            if (int rc = check_launch("bucket_scatter")) return rc;
+            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows<1024, false>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            PYGSD_HIP_TRY(once);
+            hipLaunchKernelGGL((bucket_merge_rows<1024, false>), dim3(pl.nb), dim3(1024), lds, s, a, pl, stream, off);
+        }
         if (int rc = check_launch("bucket_merge_rows")) return rc;
     } else {
         if (n_edges > 0) {
@@ -1729,6 +1756,38 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
     hipLaunchKernelGGL(unit_finish_info, dim3(1), dim3(1), 0, s, rowptr, n, d_info);          // E_s: d_info is final from here on
     if (int rc = check_launch("unit_finish_info")) return rc;
     if (phase == 1) return 0;
-    hipLaunchKernelGGL((unit_write_chunks<256, kChunkSlots>), dim3(chunks), dim3(256), 0, s, a);
+    if (is_pm1)
+        hipLaunchKernelGGL((unit_write_chunks<256, kChunkSlots, true>), dim3(chunks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((unit_write_chunks<256, kChunkSlots>), dim3(chunks), dim3(256), 0, s, a);
     return check_launch("unit_write_chunks");
+}
+
+extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, float q,
+                                float lambda_max, float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr,
+                                float* deg, int32_t* ccol, float* vb_real, float* vb_imag, float* vf_real, float* vf_imag,
+                                int64_t* d_info, int32_t phase, void* stream)
+{
+    return magop_unit_impl(row, col, nullptr, 0, n_edges, n, sym, q, lambda_max, diag_shift, workspace, workspace_bytes, rowptr, deg,
+                           ccol, vb_real, vb_imag, vf_real, vf_imag, d_info, phase, stream);
+}
+
+extern "C" int pygsd_magop_unit_signed(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
+                                       int32_t is_signed, int32_t absolute_degree, int32_t sym, float q, float lambda_max,
+                                       float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr, float* deg,
+                                       int32_t* ccol, float* vb_real, float* vb_imag, float* vf_real, float* vf_imag,
+                                       int64_t* d_info, int32_t phase, void* stream)
+{
+    PYGSD_REQUIRE(w || n_edges == 0, "pygsd_magop_unit_signed: null weights (pygsd_magop_unit builds unweighted graphs)");
+    if (!w) {
+        PYGSD_REQUIRE(d_info, "pygsd_magop_unit_signed: null pointer");
+        if (phase != 2) PYGSD_HIP_TRY(hipMemsetAsync(d_info, 0, 4 * sizeof(int64_t), static_cast<hipStream_t>(stream)));
+        if (phase != 2) PYGSD_HIP_TRY(hipMemsetAsync(d_info + 1, 1, sizeof(int64_t), static_cast<hipStream_t>(stream)));
+        return 0;
+    }
+    // -1 is admitted where the degree counts |w| (signed Laplacian, absolute_degree): deg = entries / 2 then, as with unit weights.
+    // Elsewhere (deg = sum of A_s or of |A_s|) only +1 keeps that identity, so a -1 sends the graph to the two-stage pipeline.
+    const int32_t allow_neg = (is_signed && absolute_degree) ? 1 : 0;
+    return magop_unit_impl(row, col, w, allow_neg, n_edges, n, sym, q, lambda_max, diag_shift, workspace, workspace_bytes, rowptr, deg,
+                           ccol, vb_real, vb_imag, vf_real, vf_imag, d_info, phase, stream);
 }

@@ -19,6 +19,7 @@ import torch
 
 from .. import _cabi
 from .._cabi import check, ptr, stream_ptr
+from ..memo import TensorMemo
 
 Tensor = torch.Tensor
 
@@ -164,6 +165,7 @@ def laplacian_values(parts: LaplacianParts, q, normalization: Optional[str], mir
 _PINNED = threading.local()
 
 
+
 def _pinned_info(dev):
     """(pinned int64[4], event `ready`, side stream, event `mid`) for the device -> host read of the fused build; one per
     (thread, device) -- thread-local, so the buffers of a pool's worker threads die with their threads."""
@@ -193,6 +195,18 @@ def _queue_info_read(info: Tensor, dev):
 _UNIT_BUILD = os.environ.get("PYGSD_TWO_STAGE_BUILD", "0") != "1"
 
 
+_SIGNED_UNIT_BUILD = os.environ.get("PYGSD_SIGNED_UNIT_BUILD", "1") != "0"
+_NOT_PM1 = TensorMemo(8)  # weight tensors the +-1 build has turned down (weakly held, per in-place version)
+
+
+def set_signed_unit_build(on: bool) -> bool:
+    """Weights of +-1: pygsd_magop_unit_signed (default) or the two-stage pipeline (PYGSD_SIGNED_UNIT_BUILD=0) -- measurement /
+    A-B.  Returns the previous setting."""
+    global _SIGNED_UNIT_BUILD
+    prev, _SIGNED_UNIT_BUILD = _SIGNED_UNIT_BUILD, bool(on)
+    return prev
+
+
 def set_unit_build(on: bool) -> bool:
     """Unweighted graphs: pygsd_magop_unit (default; inside the library the bucket split, or the radix-sort form with
     PYGSD_UNIT_BUILD_FORM=sort) or the two-stage pipeline (pygsd_magop_stage1 / _stage2; PYGSD_TWO_STAGE_BUILD=1) --
@@ -202,12 +216,15 @@ def set_unit_build(on: bool) -> bool:
     return prev
 
 
-def _unit_operator_csr(row: Tensor, col: Tensor, e: int, n: int, sym: int, q: float, lambda_max: float, diag_shift: float):
+def _unit_operator_csr(row: Tensor, col: Tensor, e: int, n: int, sym: int, q: float, lambda_max: float, diag_shift: float,
+                       w: Optional[Tensor] = None, signed: bool = False, absolute_degree: bool = True):
     """pygsd_magop_unit: edge list without weights -> final CSR + values (unit weights: degrees from the row bounds, merged
     rows parked as 8-byte records between the merge and the write kernel).  ONE host read -- E_s, the bad-id witness and the
     over-long-row count -- queued between the library's two parts, so the host is back before the write kernel has finished
     and the layer's next launches queue behind it without a gap.  None: a row longer than the kernel takes (caller: two-stage
-    pipeline)."""
+    pipeline).
+    w given (round 5): pygsd_magop_unit_signed -- the same build for weights that are all +-1 (validated on the device; None
+    when they are not, or when -1 meets a degree convention other than the signed Laplacian's absolute one)."""
     from ..sparse import CSR
     dev = row.device
     lib = _cabi.lib()
@@ -222,11 +239,16 @@ def _unit_operator_csr(row: Tensor, col: Tensor, e: int, n: int, sym: int, q: fl
         ccol = torch.empty(max(cap, 4), dtype=torch.int32, device=dev)
         pad = max((cap + 3) // 4 * 4, 4)
         vals = torch.empty((4, pad), dtype=torch.float32, device=dev)
-        args = (ptr(row), ptr(col), e, n, sym, float(q), float(lambda_max), float(diag_shift), ptr(ws), need.value, ptr(rowptr),
+        tail = (sym, float(q), float(lambda_max), float(diag_shift), ptr(ws), need.value, ptr(rowptr),
                 ptr(deg), ptr(ccol), ptr(vals[0]), ptr(vals[1]), ptr(vals[2]), ptr(vals[3]), ptr(info))
-        check(lib.pygsd_magop_unit(*args, 1, stream_ptr()), "pygsd_magop_unit")          # everything up to the row pointer
+        if w is None:
+            fn, name, args = lib.pygsd_magop_unit, "pygsd_magop_unit", (ptr(row), ptr(col), e, n) + tail
+        else:
+            fn, name = lib.pygsd_magop_unit_signed, "pygsd_magop_unit_signed"
+            args = (ptr(row), ptr(col), ptr(w), e, n, 1 if signed else 0, 1 if absolute_degree else 0) + tail
+        check(fn(*args, 1, stream_ptr()), name)          # everything up to the row pointer
         host_info, ready = _queue_info_read(info, dev)   # behind the first part; the host waits for THIS, not for the write
-        check(lib.pygsd_magop_unit(*args, 2, stream_ptr()), "pygsd_magop_unit")          # the kernel that writes the slots
+        check(fn(*args, 2, stream_ptr()), name)          # the kernel that writes the slots
         ready.synchronize()                           # the one host round-trip: over while 40 % of the build is still running
         es, too_long, bad, bad_id = host_info.tolist()
     if bad:
@@ -283,6 +305,14 @@ def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int
         if built is not None:
             return built
         # a node with more than 512 symmetrised entries: the two-stage pipeline below has a path for rows up to 4096
+    elif w is not None and _UNIT_BUILD and _SIGNED_UNIT_BUILD and _NOT_PM1.get((edge_weight,), (signed, absolute_degree)) is None:
+        # weights that are all +-1 (SDSBM / SSBM signs, explicit unit weights) take the one-call build as well; the DEVICE decides
+        # (its first kernel validates the weights -- no host read of them), and a weight tensor that was turned down once is not
+        # offered again while it is the same tensor at the same version (memo.TensorMemo)
+        built = _unit_operator_csr(row, col, e, n, sym, q, lambda_max, diag_shift, w, signed, absolute_degree)
+        if built is not None:
+            return built
+        _NOT_PM1.put((edge_weight,), (signed, absolute_degree), True)
     with torch.cuda.device(dev):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_magop_workspace(e, n, 0 if w is None else 1, ctypes.byref(need)), "pygsd_magop_workspace")

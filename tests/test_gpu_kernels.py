@@ -996,6 +996,129 @@ def test_unit_operator_build_bucket_that_does_not_fit_lds(monkeypatch):
     _assert_fused_equals_generic(ei, None, n, False, True, 0.25, "sym", 2.0)
 
 
+def _same_operator(got, want):
+    csr, vf, vb, deg = got
+    wcsr, wvf, wvb, wdeg = want
+    assert csr.nnz == wcsr.nnz
+    assert torch.equal(csr.rowptr, wcsr.rowptr) and torch.equal(csr.col, wcsr.col)
+    assert torch.equal(deg, wdeg)
+    for a, b in zip(vf + vb, wvf + wvb):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))          # bit for bit (a -0.0 is not a 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("signed,absdeg,all_positive", [(True, True, False), (True, True, True), (True, False, True),
+                                                        (False, True, True)])
+@pytest.mark.parametrize("norm,lam", [("sym", 2.0), (None, 3.0)])
+def test_signed_unit_operator_build_is_bitwise_the_generic_pipeline(signed, absdeg, all_positive, norm, lam):
+    """pygsd_magop_unit_signed (round 5: weights of +-1 -- the signs of MSConv's graphs, get_magnetic_signed_Laplacian.py:52-90 --
+    through the bucket build with one sign bit per entry): duplicates of mixed signs (runs of 3 .. 40 entries of one neighbour,
+    A_s = 0 runs included), reciprocal pairs of equal and of opposite sign, self loops, isolated nodes, rows of 64 / 65 / 103 / 303 /
+    512 stream entries (from 65: the rank sort through LDS) -- bit-identical to the generic pipeline and from run to run (LDS
+    atomics place the entries: the arrival order must not show, which it cannot for sums of +-1).  Explicit all-ones weights take
+    it under every degree convention."""
+    from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
+    n = 50007
+    g = torch.Generator().manual_seed(17)
+    ei, _ = _messy_graph(n, 600000, seed=3, signed=False)
+    ei = ei[:, (ei[0] < n - 40) & (ei[1] < n - 40)]
+    extra = [torch.tensor([[11] * 40 + [12] * 3 + [13] * 2, [2000] * 40 + [11] * 3 + [2001] * 2])]       # multiplicity 40 / 3 / 2
+    for hub, k, dup in ((7, 64, 0), (8, 65, 0), (9, 100, 3), (4000, 300, 3), (n - 50, 509, 3)):
+        drop = (ei[0] == hub) | (ei[1] == hub)
+        ei = ei[:, ~drop]
+        other = torch.randperm(n - 5000, generator=g)[:k] + 4500
+        half = k // 2
+        extra.append(torch.stack([torch.full((half,), hub), other[:half]]))
+        extra.append(torch.stack([other[half:], torch.full((k - half,), hub)]))
+        extra.append(torch.stack([torch.full((dup,), hub), other[:dup]]))
+    ei = torch.cat([ei] + extra, dim=1)
+    ei = ei[:, torch.randperm(ei.size(1), generator=g)]
+    w = torch.ones(ei.size(1))
+    if not all_positive:
+        w = (torch.randint(0, 2, (ei.size(1),), generator=g) * 2 - 1).float()
+    d = dev()
+    ei, w = ei.to(d), w.to(d)
+    row, col = ei[0].contiguous(), ei[1].contiguous()
+    sym = 1 if norm is not None else 0
+    first = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, lam, -1.0, w, signed, absdeg)
+    assert first is not None
+    lens = (first[0].rowptr[1:] - first[0].rowptr[:-1]).cpu()
+    assert [int(lens[k]) for k in (7, 8, 9, 4000, n - 50, n - 1)] == [65, 66, 101, 301, 510, 1]
+    again = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, lam, -1.0, w, signed, absdeg)
+    _same_operator(again, first)
+    _same_operator(first, _generic_operator(ei, w, n, signed, absdeg, 0.25, norm, lam))
+    # the layer-facing entry takes the same route and hands back the same operator
+    _same_operator(L.fused_operator_csr(ei, w, n, signed, absdeg, 0.25, norm, lam), first)
+    prev = L.set_signed_unit_build(False)                            # ... as does the two-stage pipeline behind the switch
+    try:
+        _same_operator(L.fused_operator_csr(ei, w, n, signed, absdeg, 0.25, norm, lam), first)
+    finally:
+        L.set_signed_unit_build(prev)
+
+
+@pytest.mark.gpu
+def test_signed_unit_operator_build_steps_aside():
+    """What pygsd_magop_unit_signed does not take is decided ON THE DEVICE (no host read of the weights) and reported like an
+    over-long row: one weight that is not +-1, a NaN, a -1 under a degree convention that does not count |w|, a 513-entry row.  The
+    layer-facing build then runs the two-stage pipeline (same operator as the generic one) and remembers the weight tensor, so the
+    next build with the same tensor does not try again."""
+    from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
+    n = 20000
+    d = dev()
+    ei, _ = _messy_graph(n, 200000, seed=23, signed=False)
+    g = torch.Generator().manual_seed(4)
+    sign = (torch.randint(0, 2, (ei.size(1),), generator=g) * 2 - 1).float()
+    loops = (ei[0] == ei[1]).nonzero().view(-1)
+    plain = (ei[0] != ei[1]).nonzero().view(-1)
+    ei = ei.to(d)
+    row, col = ei[0].contiguous(), ei[1].contiguous()
+    e = ei.size(1)
+    ok = sign.clone()
+    ok[loops] = 7.5                                                  # a self loop's weight is never read by the reference: dropped first
+    assert L._unit_operator_csr(row, col, e, n, 1, 0.25, 2.0, -1.0, ok.to(d), True, True) is not None
+    for bad_value in (0.5, 2.0, float("nan"), 0.0):
+        w = sign.clone()
+        w[plain[len(plain) // 2]] = bad_value
+        assert L._unit_operator_csr(row, col, e, n, 1, 0.25, 2.0, -1.0, w.to(d), True, True) is None
+    assert L._unit_operator_csr(row, col, e, n, 1, 0.25, 2.0, -1.0, sign.to(d), True, False) is None    # -1, degree of |A_s|
+    assert L._unit_operator_csr(row, col, e, n, 1, 0.25, 2.0, -1.0, sign.to(d), False, True) is None    # -1, unsigned degree
+    assert L._unit_operator_csr(row, col, e, n, 1, 0.25, 2.0, -1.0, sign.abs().to(d), False, True) is not None
+    w = sign.clone()
+    w[plain[3]] = 0.25
+    wd = w.to(d)
+    want = _generic_operator(ei, wd, n, True, True, 0.25, "sym", 2.0)
+    assert L._NOT_PM1.get((wd,), (True, True)) is None
+    _same_operator(L.fused_operator_csr(ei, wd, n, True, True, 0.25, "sym", 2.0), want)
+    assert L._NOT_PM1.get((wd,), (True, True)) is True               # turned down once: remembered for this tensor / version
+    _same_operator(L.fused_operator_csr(ei, wd, n, True, True, 0.25, "sym", 2.0), want)
+    wd[int(plain[3])] = 1.0                                          # an in-place edit bumps the version: offered again, taken
+    assert L._NOT_PM1.get((wd,), (True, True)) is None
+    _same_operator(L.fused_operator_csr(ei, wd, n, True, True, 0.25, "sym", 2.0), _generic_operator(ei, wd, n, True, True, 0.25, "sym", 2.0))
+    # a row of 513 stream entries
+    k = 513
+    star = torch.stack([torch.full((k,), 5), torch.arange(100, 100 + k)]).to(d)
+    big = torch.cat([ei, star], dim=1)
+    wb = torch.cat([sign.to(d), torch.ones(k, device=d)])
+    assert L._unit_operator_csr(big[0].contiguous(), big[1].contiguous(), big.size(1), n, 1, 0.25, 2.0, -1.0, wb, True, True) is None
+    _same_operator(L.fused_operator_csr(big, wb, n, True, True, 0.25, "sym", 2.0), _generic_operator(big, wb, n, True, True, 0.25, "sym", 2.0))
+
+
+@pytest.mark.gpu
+def test_signed_unit_operator_build_at_512_rows_per_bucket():
+    """600 k nodes / 12 M signed edges: buckets of 512 rows (the north star's geometry) with the sign bit in the stream entry."""
+    from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
+    n, e = 600000, 12000000
+    g = torch.Generator().manual_seed(31)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei = torch.cat([ei, ei[:, : e // 20].flip(0)], dim=1)            # reciprocal pairs, signs drawn independently
+    w = (torch.randint(0, 2, (ei.size(1),), generator=g) * 2 - 1).float()
+    d = dev()
+    ei, w = ei.to(d), w.to(d)
+    got = L._unit_operator_csr(ei[0].contiguous(), ei[1].contiguous(), ei.size(1), n, 1, 0.25, 2.0, -1.0, w, True, True)
+    assert got is not None
+    _same_operator(got, _generic_operator(ei, w, n, True, True, 0.25, "sym", 2.0))
+
+
 @pytest.mark.gpu
 def test_unit_operator_build_forms_agree_at_512_rows_per_bucket():
     """600 k nodes: buckets of 512 rows, 20 k entries each (the geometry of the north star) -- the two forms of the unweighted build

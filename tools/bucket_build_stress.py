@@ -23,6 +23,14 @@ def build(row, col, e, n, sym, form):
         os.environ.pop("PYGSD_UNIT_BUILD_FORM", None)
 
 
+def generic(ei, w, n, sym, signed, absdeg):
+    parts = L.laplacian_parts(ei, w, n, signed, absdeg)
+    norm = "sym" if sym else None
+    off_r, off_i, diag, mir_r, mir_i = L.laplacian_values(parts, 0.25, norm, mirror=True)
+    csr, vf, vb = L.assemble_operator_csr(parts, off_r, off_i, mir_r, mir_i, diag, 2.0, -1.0)
+    return csr, vf, vb, parts.deg
+
+
 def same(a, b):
     if (a is None) != (b is None):
         return False
@@ -60,7 +68,20 @@ for it in range(cases):
     b = build(row, col, ei.size(1), n, sym, "sort")
     a2 = build(row, col, ei.size(1), n, sym, "bucket")
     ok = same(a, b) and same(a, a2)
+    # round 5: the same graph with weights of +-1 through pygsd_magop_unit_signed (signed Laplacian, absolute degree) against the
+    # generic pipeline (PYGSD_GENERIC_OPERATOR_BUILD's route), and with explicit all-ones weights under the unsigned convention
+    sgn = torch.from_numpy(rng.integers(0, 2, ei.size(1)).astype(np.float32) * 2 - 1).to(dev)
+    s1 = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, 2.0, -1.0, sgn, True, True)
+    s2 = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, 2.0, -1.0, sgn, True, True)
+    ones = torch.ones_like(sgn)
+    s3 = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, 2.0, -1.0, ones, False, True)
+    ok_s = (s1 is None) == (a is None) and same(s1, s2) and (s3 is None) == (a is None)
+    if s1 is not None and ei.size(1) <= 6_000_000:                # (the generic pipeline is the slow one)
+        ok_s = ok_s and same(s1, generic(ei, sgn, n, sym, True, True)) and same(s3, generic(ei, ones, n, sym, False, True))
+    elif s3 is not None:
+        ok_s = ok_s and same(s3, a)                               # all-ones weights = no weights
+    ok = ok and ok_s
     bad += 0 if ok else 1
-    print(f"case {it}: n={n} e={ei.size(1)} sym={sym} taken={a is not None} {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"case {it}: n={n} e={ei.size(1)} sym={sym} taken={a is not None} signed_taken={s1 is not None} {'ok' if ok else 'MISMATCH'}", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -23,7 +23,8 @@ ap.add_argument("--edges", type=int, default=20000000)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--norm", default="sym", help="sym | none")
 ap.add_argument("--only", default="", help="comma list of legs: fused (= round 4's one-pass unweighted build), two_stage (round 3's), "
-                                           "generic, fused_signed, generic_signed")
+                                           "generic, fused_signed (+-1 weights: round 5's one-call build), two_stage_signed, "
+                                           "fused_real_weights, generic_signed")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 NORM = None if args.norm == "none" else "sym"
@@ -67,8 +68,20 @@ def two_stage():
         set_unit_build(prev)
 
 
+def two_stage_signed():
+    from pytorch_geometric_signed_directed_amd.utils._laplacian import set_signed_unit_build
+    prev = set_signed_unit_build(False)
+    try:
+        return fused(ei_s, w_s, n, True)
+    finally:
+        set_signed_unit_build(prev)
+
+
+g_w = torch.Generator(device=dev).manual_seed(3)
+w_real = w_s * (torch.rand(w_s.shape, generator=g_w, device=dev) + 0.5)     # real-valued signed weights: the two-stage pipeline
 legs = {"fused": lambda: fused(ei, None, n, False), "two_stage": two_stage, "generic": lambda: generic(ei, None, n, False),
-        "fused_signed": lambda: fused(ei_s, w_s, n, True), "generic_signed": lambda: generic(ei_s, w_s, n, True)}
+        "fused_signed": lambda: fused(ei_s, w_s, n, True), "two_stage_signed": two_stage_signed,
+        "fused_real_weights": lambda: fused(ei_s, w_real, n, True), "generic_signed": lambda: generic(ei_s, w_s, n, True)}
 only = [s for s in args.only.split(",") if s] or list(legs)
 out = {"nodes": n, "edges": int(ei.size(1)), "iters": args.iters}
 csr = fused(ei, None, n, False)[0]
