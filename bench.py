@@ -295,8 +295,12 @@ def main():
                     help="multi-GPU work layout (parallel.ShardedMagNetConv): rows = all-gather of whole feature "
                          "blocks, grid = p_r x p_c process grid with column-slice all-to-alls (auto picks grid "
                          "above two ranks)")
-    ap.add_argument("--phases", type=int, default=None, help="column phases of the pipelined propagate (default 2)")
-    ap.add_argument("--return-chunks", type=int, default=None, help="row chunks of the grid's return (default 2)")
+    ap.add_argument("--phases", default=None,
+                    help="column phases of the pipelined propagate: a count (equal pieces) or fractions, e.g. 0.4,0.6 "
+                         "(default: parallel.DEFAULT_PHASES)")
+    ap.add_argument("--return-chunks", default=None,
+                    help="row chunks of the grid's return: a count or fractions, e.g. 0.5,0.36,0.14 (default: "
+                         "parallel.DEFAULT_RETURN_CHUNKS)")
     ap.add_argument("--grid-cols", type=int, default=None,
                     help="column slices of the grid (default: chosen from the world size); 1 with --layout grid runs the "
                          "grid SCHEDULE (all-to-all in, row-chunked all-to-all back) on one slice -- with --force-sharded "
@@ -428,7 +432,14 @@ def main():
             control = dist.group.WORLD
         err = None
         try:
-            layer_s, xr_loc, xi_loc = make_sharded(args.layout, args.phases, args.return_chunks, False)
+            from pytorch_geometric_signed_directed_amd.parallel import split_spec
+
+            def spec(raw):
+                if raw is None:
+                    return None
+                count, fracs = split_spec(raw)
+                return fracs if fracs is not None else count
+            layer_s, xr_loc, xi_loc = make_sharded(args.layout, spec(args.phases), spec(args.return_chunks), False)
             sharded_step(layer_s, xr_loc, xi_loc)
             torch.cuda.synchronize(device)
         except Exception as exc:  # noqa: BLE001 -- an RCCL failure of the pipelined schedule must not cost the whole run
@@ -530,36 +541,36 @@ def main():
                 ts.append(a.elapsed_time(b))
             return reduce_max(statistics.median(ts))
 
-        inbound_ms, return_ms = [], []
-        send0 = eng._pack([xr_loc.detach(), xi_loc.detach()], 0)
-        buf0 = send0.new_empty((world, eng.n_sub, send0.size(-1)))
-        for c in range(eng.phases):
-            inbound_ms.append(timed_collective(lambda: eng.ex.all_to_all(buf0, send0) if eng.grid
-                                               else eng.ex.all_gather(buf0, send0)))
-        in_bytes_per_link = (send0[0].numel() if eng.grid else send0.numel()) * esz
-        back_bytes_per_link = 0
+        inbound_ms, return_ms, in_bytes_per_link, back_bytes_per_link = [], [], [], []
+        for c in range(eng.phases):                       # (the pieces may be uneven: round 5's default schedule)
+            send_c = eng._pack([xr_loc.detach(), xi_loc.detach()], c).clone()
+            buf_c = send_c.new_empty((world, eng.phase_rows[c], send_c.size(-1)))
+            inbound_ms.append(timed_collective(lambda: eng.ex.all_to_all(buf_c, send_c) if eng.grid
+                                               else eng.ex.all_gather(buf_c, send_c)))
+            in_bytes_per_link.append((send_c[0].numel() if eng.grid else send_c.numel()) * esz)
         if eng.grid:
             fw2 = 2 * (hidden // eng.p_c)
-            back = xr_loc.new_zeros((world, eng.n_rsub, fw2))
-            recv = torch.empty_like(back)
-            back_bytes_per_link = back[0].numel() * esz
             for r in range(eng.return_chunks):
+                back = xr_loc.new_zeros((world, eng.chunk_rows[r], fw2))
+                recv = torch.empty_like(back)
+                back_bytes_per_link.append(back[0].numel() * esz)
                 return_ms.append(timed_collective(lambda: eng.ex.all_to_all(recv, back)))
         alone_total = sum(inbound_ms) + sum(return_ms)
 
         def rate(nbytes, ms):
             return nbytes / (ms * 1e-3) / 1e9 if ms and world > 1 else None
         exchange = {"layout": layer_s.layout, "p_r": eng.p_r, "p_c": eng.p_c, "phases": eng.phases,
-                    "return_chunks": eng.return_chunks, "propagates_per_step": 2,
+                    "return_chunks": eng.return_chunks, "phase_rows": eng.phase_rows,
+                    "return_chunk_rows": eng.chunk_rows if eng.grid else None, "propagates_per_step": 2,
                     "propagate_ms": summary.get("total_ms"), "product_ms": summary.get("product_ms"),
                     "pack_ms": summary.get("pack_ms"), "merge_ms": summary.get("merge_ms"),
                     "exposed_exchange_ms": summary.get("exposed_exchange_ms"),
                     "exchange_alone_ms": alone_total,
                     "collectives_alone": {
                         "inbound_ms_per_phase": inbound_ms, "inbound_bytes_per_link": in_bytes_per_link,
-                        "inbound_GBps_per_link": [rate(in_bytes_per_link, t) for t in inbound_ms],
+                        "inbound_GBps_per_link": [rate(b, t) for b, t in zip(in_bytes_per_link, inbound_ms)],
                         "return_ms_per_chunk": return_ms, "return_bytes_per_link": back_bytes_per_link,
-                        "return_GBps_per_link": [rate(back_bytes_per_link, t) for t in return_ms],
+                        "return_GBps_per_link": [rate(b, t) for b, t in zip(back_bytes_per_link, return_ms)],
                         "assumed_by_the_rehearsal_GBps_per_link": 61.0},
                     "backend": dist.get_backend(), "blocking_collectives": bool(getattr(layer_s.exchange, "synchronous", False)),
                     "TORCH_NCCL_AVOID_RECORD_STREAMS": os.environ.get("TORCH_NCCL_AVOID_RECORD_STREAMS"),

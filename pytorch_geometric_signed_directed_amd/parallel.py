@@ -379,30 +379,74 @@ def take_rows(csr: CSR, values: Sequence[Tensor], row_ids: Tensor) -> Tuple[CSR,
     return out, tuple(v[src].contiguous() for v in values)
 
 
-def split_phases(csr: CSR, values: Sequence[Tensor], n_pad: int, phases: int, world_size: int
-                 ) -> List[Tuple[CSR, Tuple[Tensor, ...]]]:
+def cut_points(total: int, count: int, fracs: Optional[Sequence[float]] = None) -> List[int]:
+    """count + 1 ascending bounds of [0, total): equal pieces (total must divide) or -- `fracs`, positive, any sum -- pieces
+    in those proportions, every piece at least one row while total >= count (an exchange of zero rows is no exchange)."""
+    if fracs is None:
+        if total % count:
+            raise ValueError(f"{total} rows do not split into {count} equal pieces")
+        step = total // count
+        return [k * step for k in range(count)] + [total]
+    if len(fracs) != count or any(f <= 0 for f in fracs):
+        raise ValueError(f"{count} positive fractions expected, got {tuple(fracs)}")
+    scale, acc, out = float(sum(fracs)), 0.0, [0]
+    for k, f in enumerate(fracs[:-1]):
+        acc += f / scale
+        lo = out[-1] + (1 if total >= count else 0)
+        hi = total - (count - 1 - k if total >= count else 0)
+        out.append(min(max(int(round(acc * total)), lo), hi))
+    return out + [total]
+
+
+def split_spec(spec) -> Tuple[int, Optional[Tuple[float, ...]]]:
+    """A pipeline depth given as a count (equal pieces) or as a sequence of fractions (uneven pieces: a short FIRST inbound
+    phase puts the first product on the compute stream early, a short LAST return chunk leaves little behind the last
+    product) -> (count, fractions or None).  A string "2" / "0.4,0.6" (environment) is parsed the same way."""
+    if isinstance(spec, str):
+        parts = [t for t in spec.replace(":", ",").split(",") if t.strip()]
+        spec = int(parts[0]) if len(parts) == 1 and parts[0].strip().isdigit() else [float(t) for t in parts]
+    if isinstance(spec, (int,)) or (hasattr(spec, "__int__") and not hasattr(spec, "__len__")):
+        return max(int(spec), 1), None
+    fr = tuple(float(f) for f in spec)
+    if len(fr) == 1:
+        return 1, None
+    return len(fr), fr
+
+
+def split_phases(csr: CSR, values: Sequence[Tensor], n_pad: int, phases: int, world_size: int,
+                 bounds: Optional[Sequence[int]] = None) -> List[Tuple[CSR, Tuple[Tensor, ...]]]:
     """Column blocks of an operator whose columns are PADDED node ids: block c holds the entries whose column
-    falls in sub-range c (of `phases`) of ITS rank's range, with the column re-based into phase c's exchange
-    buffer [world, n_pad / phases, ...] viewed as rows: (col // n_pad) * n_sub + (col % n_pad) % n_sub.
+    falls in sub-range c = [bounds[c], bounds[c + 1]) of ITS rank's range (`phases` equal pieces without `bounds`), with
+    the column re-based into phase c's exchange buffer [world, n_sub_c, ...] viewed as rows:
+    (col // n_pad) * n_sub_c + (col % n_pad) - bounds[c].
     A row's entries keep their order inside a block.  The blocks' col / value arrays are VIEWS into one buffer sorted
     by (phase, row): they keep all phases' memory alive together and are 4-byte aligned only."""
     if phases == 1:
         return [(csr, tuple(values))]
-    if n_pad % phases:
-        raise ValueError(f"n_pad = {n_pad} is not a multiple of {phases} phases")
-    n_sub = n_pad // phases
+    if bounds is None:
+        if n_pad % phases:
+            raise ValueError(f"n_pad = {n_pad} is not a multiple of {phases} phases")
+        bounds = cut_points(n_pad, phases)
+    bounds = [int(b) for b in bounds]
+    if len(bounds) != phases + 1 or bounds[0] != 0 or bounds[-1] != n_pad or any(a > b for a, b in zip(bounds, bounds[1:])):
+        raise ValueError(f"phase bounds {bounds} do not partition {n_pad} rows into {phases} phases")
+    n_subs = [bounds[c + 1] - bounds[c] for c in range(phases)]
     n_rows, nnz = csr.n_rows, csr.nnz
     if n_rows == 0 or nnz == 0:                    # an empty shard: every phase is an empty block of the same shape
         empty_ptr = torch.zeros(n_rows + 1, dtype=torch.int32, device=csr.rowptr.device)
-        return [(CSR(n_rows, world_size * n_sub, 0, empty_ptr, csr.col[:0], None), tuple(v[:0] for v in values))
-                for _ in range(phases)]
+        return [(CSR(n_rows, world_size * n_subs[c], 0, empty_ptr, csr.col[:0], None), tuple(v[:0] for v in values))
+                for c in range(phases)]
     col = csr.col.long()
     local = col % n_pad
-    compact = ((col // n_pad) * n_sub + local % n_sub).to(torch.int32)
+    inner = torch.tensor(bounds[1:-1], dtype=torch.long, device=col.device)
+    phase = torch.searchsorted(inner, local, right=True)
+    lo_t = torch.tensor(bounds[:-1], dtype=torch.long, device=col.device)
+    sub_t = torch.tensor(n_subs, dtype=torch.long, device=col.device)
+    compact = ((col // n_pad) * sub_t[phase] + local - lo_t[phase]).to(torch.int32)
     # ONE stable sort by (phase, row) instead of a boolean mask per phase: a handful of launches and a single
     # device -> host read whatever the number of phases (mask indexing costs a host round trip per mask and array;
     # with several ranks sharing one GPU those round trips took minutes at the 20M-edge size)
-    key = (local // n_sub) * n_rows + _row_of_slot(csr.rowptr, nnz)
+    key = phase * n_rows + _row_of_slot(csr.rowptr, nnz)
     skey, order = torch.sort(key, stable=True)
     edges = torch.arange(phases * n_rows + 1, dtype=torch.long, device=col.device)
     ptr_all = torch.searchsorted(skey, edges)                      # first sorted entry of every (phase, row)
@@ -413,7 +457,7 @@ def split_phases(csr: CSR, values: Sequence[Tensor], n_pad: int, phases: int, wo
     for c in range(phases):
         lo, hi = int(starts[c]), int(starts[c + 1])
         new_ptr = (ptr_all[c * n_rows:(c + 1) * n_rows + 1] - lo).to(torch.int32)
-        sub = CSR(n_rows, world_size * n_sub, hi - lo, new_ptr, cols[lo:hi], None)
+        sub = CSR(n_rows, world_size * n_subs[c], hi - lo, new_ptr, cols[lo:hi], None)
         out.append((sub, tuple(v[lo:hi] for v in vals)))
     return out
 
@@ -448,7 +492,7 @@ class PropagateEngine:
     """Executes  Y_g = alpha * S_g X_g  (g = feature group) for the operator rows of one rank: exchanges in,
     pipelined partial products, exchange back (grid only).  See the module docstring for the schedule."""
 
-    def __init__(self, plan: ShardPlan, exchange, p_c: int = 1, phases: int = 1, return_chunks: int = 1,
+    def __init__(self, plan: ShardPlan, exchange, p_c: int = 1, phases=1, return_chunks=1,
                  kernels: Optional[Tuple[Callable, Callable]] = None, force_grid: bool = False):
         self.plan, self.ex = plan, exchange
         world = plan.world_size
@@ -459,15 +503,22 @@ class PropagateEngine:
         # the degenerate 1 x 1 / p_r x 1 grid, so that a single rank can run the whole schedule over RCCL
         self.grid = self.p_c > 1 or bool(force_grid)
         self.i, self.j = plan.rank // self.p_c, plan.rank % self.p_c
-        self.phases = int(phases)
-        self.return_chunks = int(return_chunks) if self.grid else 1
-        if plan.n_pad % self.phases or (self.grid and plan.n_pad % (self.p_r * self.return_chunks)):
-            raise ValueError(f"n_pad = {plan.n_pad} must be a multiple of the phases ({self.phases}) and of "
-                             f"p_r x return chunks ({self.p_r} x {self.return_chunks}); build the plan with "
+        # phases / return_chunks: a count (equal pieces) or a sequence of fractions (round 5: uneven pieces -- the compute
+        # stream idles for the FIRST inbound phase and for the LAST return chunk only, so those two are the ones to keep short)
+        self.phases, self.phase_fracs = split_spec(phases)
+        self.return_chunks, self.chunk_fracs = split_spec(return_chunks) if self.grid else (1, None)
+        if (self.phase_fracs is None and plan.n_pad % self.phases) or (self.grid and plan.n_pad % self.p_r) or \
+                (self.grid and self.chunk_fracs is None and plan.n_pad % (self.p_r * self.return_chunks)):
+            raise ValueError(f"n_pad = {plan.n_pad} must be a multiple of the (equal) phases ({self.phases}) and of "
+                             f"p_r x (equal) return chunks ({self.p_r} x {self.return_chunks}); build the plan with "
                              f"align = PropagateEngine.alignment(...)")
-        self.n_sub = plan.n_pad // self.phases
         self.n_blk = plan.n_pad // self.p_r if self.grid else plan.n_pad
-        self.n_rsub = self.n_blk // self.return_chunks
+        self.phase_bounds = cut_points(plan.n_pad, self.phases, self.phase_fracs)          # inside a rank's range
+        self.chunk_bounds = cut_points(self.n_blk, self.return_chunks, self.chunk_fracs)   # inside a row block
+        self.phase_rows = [b - a for a, b in zip(self.phase_bounds, self.phase_bounds[1:])]
+        self.chunk_rows = [b - a for a, b in zip(self.chunk_bounds, self.chunk_bounds[1:])]
+        self.n_sub = self.phase_rows[0] if self.phase_fracs is None else None     # (equal pieces only: the old scalar names)
+        self.n_rsub = self.chunk_rows[0] if self.chunk_fracs is None else None
         self.block_rows = world * self.n_blk if self.grid else plan.n_pad
         self.dual_kernel, self.single_kernel = kernels or (_hip_dual, _hip_single)
         self.timing = None                                   # dict of event lists when profiling
@@ -485,10 +536,12 @@ class PropagateEngine:
         return t
 
     @staticmethod
-    def alignment(world_size: int, p_c: int, phases: int, return_chunks: int, force_grid: bool = False) -> int:
+    def alignment(world_size: int, p_c: int, phases, return_chunks, force_grid: bool = False) -> int:
         p_r = world_size // p_c
-        a = phases
-        b = p_r * return_chunks if (p_c > 1 or force_grid) else 1
+        n_ph, ph_fr = split_spec(phases)
+        n_rc, rc_fr = split_spec(return_chunks)
+        a = n_ph if ph_fr is None else 1                      # uneven pieces need no divisibility
+        b = (p_r * (n_rc if rc_fr is None else 1)) if (p_c > 1 or force_grid) else 1
         return a * b // math.gcd(a, b)
 
     # ---- which operator rows this rank multiplies, in product order ---------------------------------
@@ -499,31 +552,34 @@ class PropagateEngine:
         plan = self.plan
         if not self.grid:
             return torch.arange(plan.pad_lo, plan.pad_lo + plan.n_pad, dtype=torch.long, device=device)
-        r = torch.arange(self.return_chunks, dtype=torch.long, device=device).view(-1, 1, 1)
-        g = torch.arange(plan.world_size, dtype=torch.long, device=device).view(1, -1, 1)
-        t = torch.arange(self.n_rsub, dtype=torch.long, device=device).view(1, 1, -1)
-        return (g * plan.n_pad + self.i * self.n_blk + r * self.n_rsub + t).reshape(-1)
+        g = torch.arange(plan.world_size, dtype=torch.long, device=device).view(-1, 1)
+        ids = []
+        for r in range(self.return_chunks):
+            t = torch.arange(self.chunk_bounds[r], self.chunk_bounds[r + 1], dtype=torch.long, device=device).view(1, -1)
+            ids.append((g * plan.n_pad + self.i * self.n_blk + t).reshape(-1))
+        return torch.cat(ids)
 
     def phased(self, csr: CSR, values: Sequence[Tensor], dual: bool, mean: bool = False) -> PhasedOperator:
         """Operator rows (already restricted / ordered by `block_row_ids`, padded column ids) -> PhasedOperator."""
-        return PhasedOperator(split_phases(csr, values, self.plan.n_pad, self.phases, self.plan.world_size), dual, mean)
+        return PhasedOperator(split_phases(csr, values, self.plan.n_pad, self.phases, self.plan.world_size,
+                                           self.phase_bounds), dual, mean)
 
     # ---- packing ------------------------------------------------------------------------------------
     def _pack(self, xs: Sequence[Tensor], c: int) -> Tensor:
         """Sub-range c of the local rows of every feature group, packed for the exchange.
         rows: [n_sub, G * F] (groups side by side).  grid: [world, n_sub, G * fw], chunk d = column slice d % p_c."""
-        rows = slice(c * self.n_sub, (c + 1) * self.n_sub)
+        rows, n_sub = slice(self.phase_bounds[c], self.phase_bounds[c + 1]), self.phase_rows[c]
         if not self.grid:
             f = xs[0].size(1)
-            out = self._buf(f"send{c}", (self.n_sub, len(xs) * f), xs[0])
+            out = self._buf(f"send{c}", (n_sub, len(xs) * f), xs[0])
             for g, x in enumerate(xs):
                 out[:, g * f:(g + 1) * f] = x[rows]
             return out
         fw, groups = xs[0].size(1) // self.p_c, len(xs)
-        out = self._buf(f"send{c}", (self.plan.world_size, self.n_sub, groups * fw), xs[0])
-        dst = out.view(self.p_r, self.p_c, self.n_sub, groups, fw)
+        out = self._buf(f"send{c}", (self.plan.world_size, n_sub, groups * fw), xs[0])
+        dst = out.view(self.p_r, self.p_c, n_sub, groups, fw)
         for g, x in enumerate(xs):          # one strided copy per group writes all p_r replicas of the p_c slices
-            dst[:, :, :, g, :] = x[rows].view(self.n_sub, self.p_c, fw).permute(1, 0, 2)
+            dst[:, :, :, g, :] = x[rows].reshape(n_sub, self.p_c, fw).permute(1, 0, 2)
         return out
 
     def _pack_phase(self, xs: Sequence[Tensor], c: int) -> Tensor:
@@ -539,22 +595,37 @@ class PropagateEngine:
         f, groups, esz = xs[0].size(1), len(xs), xs[0].element_size()
         p_r, p_c = (self.p_r, self.p_c) if self.grid else (1, 1)
         lead = (self.plan.world_size,) if self.grid else ()
-        out = self._buf(f"send{c}", lead + (self.n_sub, groups * (f // p_c)), xs[0])
-        first = c * self.n_sub * ld * esz
+        n_sub = self.phase_rows[c]
+        out = self._buf(f"send{c}", lead + (n_sub, groups * (f // p_c)), xs[0])
+        first = self.phase_bounds[c] * ld * esz
         ptrs = (_cabi.c_void_p * groups)(*[x.data_ptr() + first for x in xs])
         with torch.cuda.device(xs[0].device):
-            _cabi.check(_cabi.lib().pygsd_pack_slices(ptrs, groups, self.n_sub, f * esz, ld * esz, p_r, p_c, 1,
+            _cabi.check(_cabi.lib().pygsd_pack_slices(ptrs, groups, n_sub, f * esz, ld * esz, p_r, p_c, 1,
                                                       _cabi.ptr(out), _cabi.stream_ptr()), "pygsd_pack_slices")
         return out
 
+    def chunk_view(self, flat: Tensor, r: int) -> Tensor:
+        """Return chunk r of a flat [block_rows, W] product / receive buffer as the all-to-all operand [world, rows of chunk r, W]
+        (the chunks are consecutive row ranges of world x chunk_rows[r] rows)."""
+        world = self.plan.world_size
+        lo = world * self.chunk_bounds[r]
+        return flat[lo:lo + world * self.chunk_rows[r]].view(world, self.chunk_rows[r], flat.size(-1))
+
     def _merge(self, recv: Tensor, groups: int) -> List[Tensor]:
-        """recv [R, world, n_rsub, G * fw] (chunk s of return exchange r = rows (block i', chunk r) of MY range x
-        column slice j' from rank s = i' * p_c + j') -> per group the [n_pad, F] rows in local order
-        i' * n_blk + r * n_rsub + t."""
+        """recv: flat [block_rows, G * fw]; its chunk r (`chunk_view`) holds, from rank s = i' * p_c + j', the rows
+        (block i', chunk r) of MY range x column slice j' -> per group the [n_pad, F] rows in local order
+        i' * n_blk + chunk_bounds[r] + t."""
         fw = recv.size(-1) // groups
-        v = recv.view(self.return_chunks, self.p_r, self.p_c, self.n_rsub, groups, fw)
-        v = v.permute(4, 1, 0, 3, 2, 5).reshape(groups, self.plan.n_pad, self.p_c * fw)
-        return [v[g] for g in range(groups)]
+        if self.chunk_fracs is None:
+            v = recv.view(self.return_chunks, self.p_r, self.p_c, self.n_rsub, groups, fw)
+            v = v.permute(4, 1, 0, 3, 2, 5).reshape(groups, self.plan.n_pad, self.p_c * fw)
+            return [v[g] for g in range(groups)]
+        out = recv.new_empty((groups, self.p_r, self.n_blk, self.p_c, fw))
+        for r in range(self.return_chunks):
+            v = self.chunk_view(recv, r).view(self.p_r, self.p_c, self.chunk_rows[r], groups, fw)
+            out[:, :, self.chunk_bounds[r]:self.chunk_bounds[r + 1]] = v.permute(3, 0, 2, 1, 4)
+        out = out.view(groups, self.plan.n_pad, self.p_c * fw)
+        return [out[g] for g in range(groups)]
 
     # ---- the propagate ------------------------------------------------------------------------------
     def run(self, xs: Sequence[Tensor], op, alpha: float = 1.0) -> List[Tensor]:
@@ -583,20 +654,18 @@ class PropagateEngine:
                 xs = [x.contiguous() for x in xs]
         for c in range(self.phases):                         # every exchange is issued before any product
             send = self._pack_phase(xs, c)
-            buf = self._buf(f"recv{c}", (world, self.n_sub, groups * fw), send)
+            buf = self._buf(f"recv{c}", (world, self.phase_rows[c], groups * fw), send)
             works.append(self.ex.all_to_all(buf, send) if self.grid else self.ex.all_gather(buf, send))
             bufs.append(buf)
         self._mark(ev, "packed")
         # the row layout hands its products to the caller (fresh tensors).  The grid's products are written by the
         # SpMM STRAIGHT INTO the return exchange's send buffer: group g = columns [g fw, (g + 1) fw) of rows that are
         # already ordered (return chunk, owner, row) -- chunk r of `home` is the all-to-all input as it stands
-        chunk_rows = world * self.n_rsub
         returns, recv, home = [], None, None
         if self.grid:
-            home = self._buf("home", (self.return_chunks, world, self.n_rsub, groups * fw), xs[0])
-            flat = home.view(self.block_rows, groups * fw)
-            ys = [flat[:, g * fw:(g + 1) * fw] for g in range(groups)]
-            recv = self._buf("back", (self.return_chunks, world, self.n_rsub, groups * fw), xs[0])
+            home = self._buf("home", (self.block_rows, groups * fw), xs[0])
+            ys = [home[:, g * fw:(g + 1) * fw] for g in range(groups)]
+            recv = self._buf("back", (self.block_rows, groups * fw), xs[0])
         else:
             # bf16 storage with more than one phase: the partial products accumulate in fp32 and are rounded ONCE
             widen = xs[0].dtype == torch.bfloat16 and self.phases > 1
@@ -605,9 +674,9 @@ class PropagateEngine:
         for c in range(self.phases):
             works[c].wait()
             self._mark(ev, "arrived")
-            buf = bufs[c].view(world * self.n_sub, groups * fw)
+            buf = bufs[c].view(world * self.phase_rows[c], groups * fw)
             last = c == self.phases - 1
-            spans = [(r * chunk_rows, (r + 1) * chunk_rows) for r in range(self.return_chunks)] \
+            spans = [(world * self.chunk_bounds[r], world * self.chunk_bounds[r + 1]) for r in range(self.return_chunks)] \
                 if (last and self.grid) else [(0, self.block_rows)]
             for r, (lo, hi) in enumerate(spans):
                 if dual:
@@ -619,7 +688,7 @@ class PropagateEngine:
                         self.single_kernel(csr, val, buf[:, g * fw:(g + 1) * fw], ys[g], lo, hi, alpha, c > 0,
                                            op[g].mean)
                 if last and self.grid:                       # chunk r goes home while chunk r + 1 is multiplied
-                    returns.append(self.ex.all_to_all(recv[r], home[r]))
+                    returns.append(self.ex.all_to_all(self.chunk_view(recv, r), self.chunk_view(home, r)))
             self._mark(ev, "multiplied")
         if not self.grid:
             if ys[0].dtype != xs[0].dtype:
@@ -690,22 +759,36 @@ def choose_cols(world_size: int, n_feat: int) -> int:
     return 1
 
 
-def _env_int(name: str, default: int) -> int:
+def _env_spec(name: str, default):
+    """A pipeline depth from the environment: a count ("2") or fractions ("0.4,0.6")."""
+    raw = os.environ.get(name)
+    if not raw:
+        return default
     try:
-        return max(int(os.environ.get(name, default)), 1)
+        count, fracs = split_spec(raw)
     except ValueError:
         return default
+    return fracs if fracs is not None else count
 
 
-def default_pipeline(world_size: int, grid: bool) -> Tuple[int, int]:
-    """(phases, return chunks): 2 x 2 when there is an exchange to hide (PYGSD_SHARD_PHASES /
-    PYGSD_SHARD_RETURN_CHUNKS override)."""
+# Round 5: uneven pieces by default.  The compute stream idles while the FIRST inbound phase is on the wire and while the LAST
+# return chunk travels home; everything in between is covered by a product.  A first phase of ~40 % of the rows is the shortest one
+# whose product still covers the second phase's wire time (product ~ wire per entry on this workload); three return chunks ending
+# in a short one leave ~1/8 of the return behind the last product (tools/emulate_sharded.py sweeps the shapes).
+DEFAULT_PHASES = (0.4, 0.6)
+DEFAULT_RETURN_CHUNKS = (0.5, 0.36, 0.14)
+
+
+def default_pipeline(world_size: int, grid: bool):
+    """(phases, return chunks) when there is an exchange to hide: counts or fraction tuples (PYGSD_SHARD_PHASES /
+    PYGSD_SHARD_RETURN_CHUNKS override: "2" = two equal pieces, "0.4,0.6" = uneven ones)."""
     if world_size == 1:
         return 1, 1
-    return _env_int("PYGSD_SHARD_PHASES", 2), (_env_int("PYGSD_SHARD_RETURN_CHUNKS", 2) if grid else 1)
+    return _env_spec("PYGSD_SHARD_PHASES", DEFAULT_PHASES), (_env_spec("PYGSD_SHARD_RETURN_CHUNKS", DEFAULT_RETURN_CHUNKS)
+                                                             if grid else 1)
 
 
-def make_plan(num_nodes: int, exchange, edge_index: Optional[Tensor], p_c: int, phases: int, return_chunks: int,
+def make_plan(num_nodes: int, exchange, edge_index: Optional[Tensor], p_c: int, phases, return_chunks,
               balance: bool = True, force_grid: bool = False) -> ShardPlan:
     """Equal-work ranges from the edge list (identical on every rank: rank 0's bounds are broadcast)."""
     world, rank = exchange.world_size, exchange.rank
@@ -893,8 +976,8 @@ class ShardedMagNetConv(torch.nn.Module):
             raise ValueError(f"grid of {p_c} column slices does not divide world {world} / width {in_channels}")
         self.layout = layout
         d_ph, d_rc = default_pipeline(world, layout == "grid")
-        phases = d_ph if phases is None else int(phases)
-        return_chunks = d_rc if return_chunks is None else int(return_chunks)
+        phases = d_ph if phases is None else phases                 # a count or a tuple of fractions (split_spec)
+        return_chunks = d_rc if return_chunks is None else return_chunks
         device = device or edge_index.device
         edge_index = edge_index.to(device)
         edge_weight = None if edge_weight is None else edge_weight.to(device)
@@ -1000,10 +1083,10 @@ class ShardedOperator:
         vf = None if w is None else gather_values(w[keep_t], fwd.perm)
         vb = None if wb is None else gather_values(wb[keep_s], bwd.perm)
         self.local_nnz = int(keep_t.numel())
-        self.op_fwd = PhasedOperator(split_phases(fwd, _vals(vf, fwd), plan.n_pad, engine.phases, plan.world_size),
-                                     False, mean)
-        self.op_bwd = PhasedOperator(split_phases(bwd, _vals(vb, bwd), plan.n_pad, engine.phases, plan.world_size),
-                                     False)
+        self.op_fwd = PhasedOperator(split_phases(fwd, _vals(vf, fwd), plan.n_pad, engine.phases, plan.world_size,
+                                                  engine.phase_bounds), False, mean)
+        self.op_bwd = PhasedOperator(split_phases(bwd, _vals(vb, bwd), plan.n_pad, engine.phases, plan.world_size,
+                                                  engine.phase_bounds), False)
 
 
 def _vals(v: Optional[Tensor], csr: CSR) -> Tuple[Tensor]:

@@ -99,6 +99,41 @@ def test_take_rows_and_split_phases_preserve_the_product():
     assert torch.allclose(acc, want, atol=1e-5)
 
 
+def test_uneven_pipeline_pieces():
+    """Round 5: phases / return chunks as FRACTIONS (a short first inbound phase, a short last return chunk): the cut points,
+    the spec parser, and split_phases over uneven column sub-ranges reproducing the product."""
+    from pytorch_geometric_signed_directed_amd.parallel import cut_points, split_spec
+    assert cut_points(12, 3) == [0, 4, 8, 12]
+    assert cut_points(100, 2, (0.4, 0.6)) == [0, 40, 100]
+    assert cut_points(125066, 3, (0.5, 0.36, 0.14)) == [0, 62533, 107557, 125066]
+    assert cut_points(3, 3, (0.98, 0.01, 0.01)) == [0, 1, 2, 3]              # every piece keeps a row
+    assert cut_points(2, 3, (1, 1, 1))[-1] == 2                               # fewer rows than pieces: some are empty
+    with pytest.raises(ValueError):
+        cut_points(10, 3)
+    with pytest.raises(ValueError):
+        cut_points(10, 2, (0.5, -0.5))
+    assert split_spec(2) == (2, None) and split_spec("3") == (3, None)
+    assert split_spec((0.4, 0.6)) == (2, (0.4, 0.6)) and split_spec("0.5,0.3,0.2") == (3, (0.5, 0.3, 0.2))
+    assert split_spec((1.0,)) == (1, None)
+    assert PropagateEngine.alignment(8, 4, (0.4, 0.6), (0.5, 0.3, 0.2)) == 2 and PropagateEngine.alignment(8, 4, 2, 2) == 4
+    world, n_pad = 3, 11
+    n = world * n_pad
+    csr, val = _random_csr(n, n, 400, 3)
+    x = torch.randn(n, 5, generator=torch.Generator().manual_seed(4))
+    want = _apply(csr, val, x)
+    for bounds in ([0, 3, 11], [0, 1, 2, 11], [0, 0, 11], [0, 11, 11]):
+        blocks = split_phases(csr, (val,), n_pad, len(bounds) - 1, world, bounds)
+        assert sum(b[0].nnz for b in blocks) == csr.nnz
+        acc = torch.zeros_like(want)
+        for c, (blk, (vc,)) in enumerate(blocks):
+            buf = x.view(world, n_pad, 5)[:, bounds[c]:bounds[c + 1]].reshape(-1, 5)
+            assert blk.n_cols == world * (bounds[c + 1] - bounds[c])
+            acc += _apply(blk, vc, buf)
+        assert torch.allclose(acc, want, atol=1e-5)
+    with pytest.raises(ValueError):
+        split_phases(csr, (val,), n_pad, 2, world, [0, 5, 10])
+
+
 def test_split_phases_of_an_empty_shard():
     """A rank that multiplies no rows (or rows without entries) still takes part in every phase: empty blocks of the
     phase buffers' shape instead of a zero slice step."""
@@ -113,7 +148,8 @@ def test_split_phases_of_an_empty_shard():
             assert blk.rowptr.numel() == n_rows + 1 and int(blk.rowptr.abs().sum()) == 0 and v.numel() == 0
 
 
-@pytest.mark.parametrize("world,p_c,phases,chunks", [(8, 4, 2, 2), (4, 4, 1, 3), (8, 2, 3, 1), (4, 1, 2, 1), (6, 2, 2, 2)])
+@pytest.mark.parametrize("world,p_c,phases,chunks", [(8, 4, 2, 2), (4, 4, 1, 3), (8, 2, 3, 1), (4, 1, 2, 1), (6, 2, 2, 2),
+                                                     (8, 4, (0.4, 0.6), (0.5, 0.36, 0.14)), (4, 2, 2, (0.7, 0.3))])
 def test_row_blocks_cover_every_padded_row_exactly_once(world, p_c, phases, chunks):
     align = PropagateEngine.alignment(world, p_c, phases, chunks)
     seen = torch.zeros(0, dtype=torch.long)
@@ -164,7 +200,9 @@ def _magnetic_worker(rank, world, port, cfg, ret):
         layer = ShardedMagNetConv(f, f, k, 0.25, n, ei, w, signed=signed, layout=layout, phases=phases,
                                   return_chunks=chunks, grid_cols=2 if (layout == "grid" and world == 2) else None,
                                   kernels=C.KERNELS, operator_rows=C.oracle_operator_rows(ei, w, n, 0.25, signed=signed))
-        assert layer.layout == layout and layer.engine.phases == phases
+        from pytorch_geometric_signed_directed_amd.parallel import default_pipeline, split_spec
+        want_phases = default_pipeline(world, layout == "grid")[0] if phases is None else phases
+        assert layer.layout == layout and layer.engine.phases == split_spec(want_phases)[0]
         plan = layer.plan
         if skew:
             assert plan.sizes != [plan.sizes[0]] * world            # balanced ranges are uneven here
@@ -201,6 +239,10 @@ def _magnetic_worker(rank, world, port, cfg, ret):
     (8, (70, 16, 2, "grid", 2, 2, False, True)),        # 2 x 4: the 8-GPU configuration, interleaved row blocks
     (8, (64, 16, 1, "grid", 1, 1, True, False)),        # 2 x 4 un-pipelined
     (6, (50, 8, 2, "grid", 2, 2, False, False)),        # 3 x 2
+    (8, (70, 16, 2, "grid", (0.4, 0.6), (0.5, 0.36, 0.14), False, True)),   # 2 x 4, round 5's default: uneven phases / return chunks
+    (4, (45, 16, 1, "grid", (0.3, 0.3, 0.4), (0.8, 0.2), True, True)),      # 1 x 4, three uneven phases
+    (3, (50, 4, 2, "rows", (0.25, 0.75), 1, False, True)),                  # rows layout, uneven phases
+    (8, (70, 16, 1, "grid", None, None, False, False)),                     # whatever the defaults are
 ])
 def test_sharded_magnetic_layer_equals_unsharded_oracle(world, cfg):
     mgr = mp.Manager()

@@ -65,6 +65,8 @@ def run_shape(args, edge_index, x_real, x_imag, layout, phases, chunks, link_gbp
            "link_gbps": link_gbps, "step_ms_median": statistics.median(times), "step_ms_min": min(times),
            "per_propagate": summary, "wire_ms_per_propagate": wire_ms,
            "overlap_fraction": (1.0 - summary["exposed_exchange_ms"] / wire_ms) if wire_ms > 0 else None,
+           "phase_rows": eng.phase_rows, "return_chunk_rows": eng.chunk_rows, "merge_on_read": bool(getattr(layer, "merge_on_read", False)),
+           "packed_backward": bool(getattr(layer, "packed_backward", False)),
            "local_operator_entries": layer.local_nnz, "rows_multiplied": eng.block_rows, "n_pad": layer.plan.n_pad}
     del layer
     torch.cuda.empty_cache()
@@ -85,7 +87,8 @@ def main():
     ap.add_argument("--K", type=int, default=1, help="Chebyshev order (2 K propagates per step)")
     ap.add_argument("--signed", action="store_true", help="MSConv on an SDSBM graph (BASELINE config C4 with --hidden 128 --K 2)")
     ap.add_argument("--shapes", nargs="+", default=None, metavar="LAYOUT:C:R",
-                    help="pipeline shapes to run, e.g. grid:2:2 rows:1:1 (default: the built-in sweep)")
+                    help="pipeline shapes to run, e.g. grid:2:2 rows:1:1 -- C / R a count (equal pieces) or fractions, "
+                         "grid:0.4,0.6:0.5,0.36,0.14 (default: the built-in sweep)")
     ap.add_argument("--single-gpu-ms", type=float, default=None, help="measured 1-GPU step (bench.py) for the ratio")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "emulated_sharded.json"))
     args = ap.parse_args()
@@ -104,7 +107,12 @@ def main():
     if args.world <= 2:
         shapes = [("rows", 1, 1), ("rows", 2, 1), ("rows", 4, 1)]
     if args.shapes:
-        shapes = [(t.split(":")[0], int(t.split(":")[1]), int(t.split(":")[2])) for t in args.shapes]
+        from pytorch_geometric_signed_directed_amd.parallel import split_spec
+
+        def spec(raw):                                   # "2" -> 2 equal pieces, "0.4,0.6" -> uneven ones
+            count, fracs = split_spec(raw)
+            return fracs if fracs is not None else count
+        shapes = [(t.split(":")[0], spec(t.split(":")[1]), spec(t.split(":")[2])) for t in args.shapes]
     out = {"world": args.world, "rank": args.rank, "nodes": args.nodes, "edges": int(ei.size(1)), "hidden": args.hidden,
            "K": args.K, "signed": args.signed, "latency_us": args.latency_us, "single_gpu_ms": args.single_gpu_ms, "runs": []}
     for gbps in args.link_gbps:
