@@ -409,6 +409,51 @@ int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* const* b, i
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Piece layouts (round 5; no reference counterpart: the reference is single-device).  The sharded propagate moves feature
+ * rows in 16-float PIECES: a rank's send buffers hold, per inbound phase, one slot per destination rank with that rank's column
+ * slice of the rows of the phase; its receive buffer of the return exchange holds, per return chunk, one slot per source rank with
+ * that rank's column slice of the products.  `pygsd_piece_layout` describes where element (row t, column c) of an [n_rows, F]
+ * operand lives in such a set of buffers, so that the dense kernels can WRITE the last gradient term straight into the send
+ * buffers (no packing pass) and READ the last Chebyshev term straight out of the receive buffer (no merge pass):
+ *     blk = t / blk_rows,  u = t % blk_rows,  r: lo[r] <= u < lo[r + 1],  j = c / slot_floats,
+ *     slot = (blk + replica) * slots_per_blk + j        (replica = 0 for reads; 0 .. replicas - 1 for stores)
+ *     element offset from the operand pointer = base[r] + (slot * rows[r] + (u - lo[r])) * row_stride + c % slot_floats
+ * Constraints: 1 <= n_chunks <= 4, at most 8 blocks, slot_floats = 16 * 2^k, 16-byte aligned bases / strides.
+ *   send buffers of phase c = [p_r][p_c][phase rows][groups * fw]: blk_rows = rows of the range (one block), lo = phase bounds,
+ *     rows[c] = rows of phase c, slots_per_blk = p_c, replicas = p_r, row_stride = groups * fw, slot_floats = fw, base[c] = the
+ *     phase's buffer; the operand pointer of feature group g is the first buffer + g * fw floats.
+ *   receive buffer of the return = per chunk r [p_r][p_c][chunk rows][groups * fw]: blk_rows = rows of a row block, lo = chunk
+ *     bounds, slots_per_blk = p_c, replicas = 1.
+ * pygsd_magnetic_dense_fwd_pieces_f32 / _bwd_pieces_f32: the fused dense stage with the LAST term's operands a[k1 - 1] / b[k1 - 1]
+ * read through `last_in` and (backward) the last term's gradients da[k1 - 1] / db[k1 - 1] stored through `last_out`; NULL = plain
+ * row-major as in pygsd_magnetic_dense_{fwd,bwd}_f32, whose results they reproduce bit for bit (f_in = 64 or 128 only).
+ * pygsd_gather_pieces_f32: outs[g][t, :] = (zs ? zs[g][t, :] : 0) + the row read through `layout` from srcs[g] -- the merge of a
+ * returned product, with the addend of the adjoint's last step (gX = dT_0 + S^T dT_1) folded in; n_groups <= 4, width a
+ * multiple of 16 floats, ldz / ldo row strides in floats (multiples of 4).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pygsd_piece_layout {
+    int64_t base[4];
+    int32_t lo[5];
+    int32_t rows[4];
+    int32_t n_chunks;
+    int32_t blk_rows;
+    int32_t slots_per_blk;
+    int32_t row_stride;
+    int32_t slot_floats;
+    int32_t replicas;
+} pygsd_piece_layout;
+int pygsd_magnetic_dense_fwd_pieces_f32(const float* const* a, const float* const* b, int32_t k1, const float* w,
+                                        const float* bias, float* out_real, float* out_imag, int32_t n_rows, int32_t f_in,
+                                        int32_t f_out, const pygsd_piece_layout* last_in, void* stream);
+int pygsd_magnetic_dense_bwd_pieces_f32(const float* const* a, const float* const* b, int32_t k1, const float* w,
+                                        const float* g_real, const float* g_imag, int64_t ldg, float* const* da,
+                                        float* const* db, float* dw, float* dbias, int32_t n_rows, int32_t f_in, int32_t f_out,
+                                        void* workspace, size_t workspace_bytes, const pygsd_piece_layout* last_in,
+                                        const pygsd_piece_layout* last_out, void* stream);
+int pygsd_gather_pieces_f32(const float* const* srcs, const pygsd_piece_layout* layout, const float* const* zs, int64_t ldz,
+                            float* const* outs, int64_t ldo, int32_t n_groups, int32_t n_rows, int32_t width, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Node-id validation.  minmax[0] = min(minmax[0], min ids), minmax[1] = max(minmax[1], max ids) (the caller
  * initialises minmax to {INT64_MAX, INT64_MIN}; several lists may be folded into one pair).  The host raises
  * IndexError when an id falls outside [0, num_nodes) -- where the reference's index_select / scatter_add_

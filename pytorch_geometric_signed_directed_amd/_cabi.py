@@ -113,6 +113,13 @@ PROTOTYPES = {
     "pygsd_magnetic_dense_bwd_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                c_int32, c_void_p, c_size_t, c_void_p]),
+    "pygsd_magnetic_dense_fwd_pieces_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                                      c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "pygsd_magnetic_dense_bwd_pieces_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64,
+                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                                      c_int32, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "pygsd_gather_pieces_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                          c_void_p]),
     "pygsd_id_range_i64": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
     "pygsd_stream_copy_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "pygsd_spin_us": (c_int32, [c_double, c_void_p]),
@@ -138,6 +145,57 @@ PROTOTYPES = {
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
 ABI_VERSION = 12
+
+
+class PieceLayoutStruct(ctypes.Structure):
+    """include/pygsd_hip.h: pygsd_piece_layout."""
+    _fields_ = [("base", c_int64 * 4), ("lo", c_int32 * 5), ("rows", c_int32 * 4), ("n_chunks", c_int32),
+                ("blk_rows", c_int32), ("slots_per_blk", c_int32), ("row_stride", c_int32), ("slot_floats", c_int32),
+                ("replicas", c_int32)]
+
+
+class PieceLayout:
+    """Host description of a piece layout (include/pygsd_hip.h, pygsd_piece_layout): where element (row t, column c) of an
+    [n_rows, F] operand lives in the send buffers of an inbound exchange / the receive buffer of a return exchange.
+
+        blk = t // blk_rows, u = t % blk_rows, r: lo[r] <= u < lo[r + 1], j = c // slot_floats
+        slot = (blk + replica) * slots_per_blk + j
+        offset = base[r] + (slot * rows[r] + (u - lo[r])) * row_stride + c % slot_floats         (elements from the operand pointer)
+
+    `offsets` is the restatement of that formula in tensor ops: the CPU tests hold the layouts the engine builds to the
+    tensor-op packing / merging with it, and the GPU tests hold the kernels to it."""
+
+    def __init__(self, base, lo, rows, blk_rows, slots_per_blk, row_stride, slot_floats, replicas=1):
+        self.base, self.lo, self.rows = [int(b) for b in base], [int(v) for v in lo], [int(v) for v in rows]
+        self.blk_rows, self.slots_per_blk = int(blk_rows), int(slots_per_blk)
+        self.row_stride, self.slot_floats, self.replicas = int(row_stride), int(slot_floats), int(replicas)
+        if not (1 <= len(self.rows) <= 4 and len(self.lo) == len(self.rows) + 1 and len(self.base) == len(self.rows)):
+            raise ValueError("a piece layout holds 1..4 chunks")
+
+    def struct(self) -> PieceLayoutStruct:
+        n = len(self.rows)
+        s = PieceLayoutStruct()
+        for r in range(4):
+            s.base[r] = self.base[r] if r < n else 0
+            s.rows[r] = self.rows[r] if r < n else 0
+        for r in range(5):
+            s.lo[r] = self.lo[r] if r <= n else self.lo[n]
+        s.n_chunks, s.blk_rows, s.slots_per_blk = n, self.blk_rows, self.slots_per_blk
+        s.row_stride, s.slot_floats, s.replicas = self.row_stride, self.slot_floats, self.replicas
+        return s
+
+    def offsets(self, n_rows: int, width: int, replica: int = 0):
+        """int64 [n_rows, width]: element offset of every (row, column)."""
+        t = torch.arange(n_rows, dtype=torch.long).view(-1, 1)
+        c = torch.arange(width, dtype=torch.long).view(1, -1)
+        blk, u = t // self.blk_rows, t % self.blk_rows
+        inner = torch.tensor(self.lo[1:-1], dtype=torch.long)
+        r = torch.searchsorted(inner, u.view(-1), right=True).view(-1, 1) if inner.numel() else torch.zeros_like(u)
+        lo = torch.tensor(self.lo[:-1], dtype=torch.long)[r]
+        rows = torch.tensor(self.rows, dtype=torch.long)[r]
+        base = torch.tensor(self.base, dtype=torch.long)[r]
+        slot = (blk + replica) * self.slots_per_blk + c // self.slot_floats
+        return base + (slot * rows + (u - lo)) * self.row_stride + c % self.slot_floats
 
 
 def lib_path():

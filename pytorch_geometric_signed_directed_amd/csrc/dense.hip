@@ -42,6 +42,8 @@ struct DenseFwdArgs {
     float* out_r;
     float* out_i;
     int32_t n_rows, f_in, f_out, k1;
+    pygsd_piece_layout lay;   // PIECES instances: where the rows of a[k1 - 1] / b[k1 - 1] live (common.hpp: piece_row)
+    int32_t lay_shift;        // log2(lay.slot_floats / 16)
 };
 
 // grid = (row blocks, ceil(f_out / 64)); block = 256 threads = 4 wavefronts x 16 rows.
@@ -52,7 +54,10 @@ struct DenseFwdArgs {
 // loads are in flight before its first MFMA.
 // WAVES = 8 when the W slice leaves room for only one block per CU (f_in = 128, K = 2: 104 KB): two
 // wavefronts per SIMD instead of one, so one's row loads overlap the other's MFMAs.
-template <int NT, int FIN, int WAVES>
+// PIECES (round 5, sharded layers, FIN > 0): the LAST term's operands are read through a piece layout -- straight out of the
+// return exchange's receive buffer, 16-float pieces of a row at slot strides (no merge pass in front of this kernel).  The plain
+// instances are untouched by it.
+template <int NT, int FIN, int WAVES, bool PIECES = false>
 __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -89,6 +94,27 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
         auto issue = [&](int tl, int k, float4 (&qa)[NL], float4 (&qb)[NL]) {
             const int r0 = tl << 4;
             const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;      // clamped: stores are masked
+            if constexpr (PIECES) {
+                // address arithmetic only inside the (wavefront-uniform) choice; the loads themselves are common code
+                PieceRow pr;
+                pr.base = static_cast<int64_t>(lrow) * FIN;
+                pr.slot_stride = 0;
+                int sh = 31, mk = 0x7fffffff;                         // row-major: piece q at base + 16 q
+                if (k == p.k1 - 1) {
+                    pr = piece_row(p.lay, lrow);
+                    sh = p.lay_shift;
+                    mk = (1 << sh) - 1;
+                }
+                const float* ap = p.a[k] + 4 * g;
+                const float* bp = p.b[k] + 4 * g;
+#pragma unroll
+                for (int t = 0; t < NL; ++t) {
+                    const int64_t off = piece_offset(pr, t, sh, mk);
+                    qa[t] = ldg4(ap + off);
+                    qb[t] = ldg4(bp + off);
+                }
+                return;
+            }
             const float* ap = p.a[k] + static_cast<int64_t>(lrow) * FIN + 4 * g;
             const float* bp = p.b[k] + static_cast<int64_t>(lrow) * FIN + 4 * g;
 #pragma unroll
@@ -217,6 +243,9 @@ struct DenseBwdArgs {
     const float* w;      // [k1][f_in][f_out]
     float* partial;      // [n_partials][k1 * f_in * f_out + f_out]
     int32_t n_rows, f_in, f_out, k1;
+    // PIECES instances (term k1 - 1 only): a / b read through lay_in, da / db stored through lay_out (every replica)
+    pygsd_piece_layout lay_in, lay_out;
+    int32_t in_on, out_on, in_shift, out_shift;
 };
 
 // grid = (row blocks, k1, ceil(f_in / 64)); block = 256 threads.  Block (x, k, ci) produces
@@ -227,7 +256,10 @@ struct DenseBwdArgs {
 // (rows in the MFMA k-slot, features across the 16 lanes) are produced by a round trip through a
 // wavefront-private LDS region (ds_write_b128 of the row fragments, ds_read_b32 of the column fragments,
 // both conflict-free at a +4-float row pad) instead of 64 scalar global loads per tile.
-template <int NTI, int NTO, bool XPOSE>
+// PIECES (round 5, sharded layers; XPOSE only): the last term's A / B rows come straight out of the return exchange's receive
+// buffer and its dA / dB rows go straight into the next propagate's send buffers (all replicas) -- no merge pass in front of this
+// kernel, no packing pass behind it.
+template <int NTI, int NTO, bool XPOSE, bool PIECES = false>
 __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(DenseBwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -289,9 +321,20 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
             // A_k / B_k rows as float4, then LDS round trip into column fragments
             const float* arow = ak + static_cast<int64_t>(lrow) * p.f_in + c0 + 4 * g;
             const float* brow = bk + static_cast<int64_t>(lrow) * p.f_in + c0 + 4 * g;
+            PieceRow pin;
+            int ish = 31, imk = 0x7fffffff;
+            const bool in_pieces = PIECES && p.in_on && k == p.k1 - 1;      // (block-uniform)
+            if (in_pieces) {
+                pin = piece_row(p.lay_in, lrow);
+                ish = p.in_shift;
+                imk = (1 << ish) - 1;
+                arow = ak + 4 * g;
+                brow = bk + 4 * g;
+            }
 #pragma unroll
             for (int ft = 0; ft < NTI; ++ft) {
-                float4 a4 = ldg4(arow + ft * 16), b4 = ldg4(brow + ft * 16);
+                const int64_t poff = in_pieces ? piece_offset(pin, (c0 >> 4) + ft, ish, imk) : static_cast<int64_t>(ft * 16);
+                float4 a4 = ldg4(arow + poff), b4 = ldg4(brow + poff);
                 if (!lrow_live) {
                     a4 = make_float4(0.f, 0.f, 0.f, 0.f);
                     b4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -403,11 +446,29 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
         }
         // ---- stores last -----------------------------------------------------------------------------
         if (r0 + i < p.n_rows) {
+            if (PIECES && p.out_on && k == p.k1 - 1) {
+                // straight into the send buffers of the propagate that takes this term: one store per replica (destination
+                // row block) of the column slice the piece belongs to
+                const PieceRow po = piece_row(p.lay_out, r0 + i);
+                const int osh = p.out_shift, omk = (1 << osh) - 1;
+                const int64_t rep_stride = static_cast<int64_t>(p.lay_out.slots_per_blk) * po.slot_stride;
 #pragma unroll
-            for (int ft = 0; ft < NTI; ++ft) {
-                const int64_t o = static_cast<int64_t>(r0 + i) * p.f_in + c0 + ft * 16 + 4 * g;
-                *reinterpret_cast<float4*>(dak + o) = make_float4(acc_a[ft][0], acc_a[ft][1], acc_a[ft][2], acc_a[ft][3]);
-                *reinterpret_cast<float4*>(dbk + o) = make_float4(acc_b[ft][0], acc_b[ft][1], acc_b[ft][2], acc_b[ft][3]);
+                for (int ft = 0; ft < NTI; ++ft) {
+                    const int64_t o = piece_offset(po, (c0 >> 4) + ft, osh, omk) + 4 * g;
+                    const float4 va = make_float4(acc_a[ft][0], acc_a[ft][1], acc_a[ft][2], acc_a[ft][3]);
+                    const float4 vb = make_float4(acc_b[ft][0], acc_b[ft][1], acc_b[ft][2], acc_b[ft][3]);
+                    for (int rep = 0; rep < p.lay_out.replicas; ++rep) {
+                        *reinterpret_cast<float4*>(dak + o + rep * rep_stride) = va;
+                        *reinterpret_cast<float4*>(dbk + o + rep * rep_stride) = vb;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ft = 0; ft < NTI; ++ft) {
+                    const int64_t o = static_cast<int64_t>(r0 + i) * p.f_in + c0 + ft * 16 + 4 * g;
+                    *reinterpret_cast<float4*>(dak + o) = make_float4(acc_a[ft][0], acc_a[ft][1], acc_a[ft][2], acc_a[ft][3]);
+                    *reinterpret_cast<float4*>(dbk + o) = make_float4(acc_b[ft][0], acc_b[ft][1], acc_b[ft][2], acc_b[ft][3]);
+                }
             }
         }
     }
@@ -484,30 +545,34 @@ int set_lds(Kern kern, size_t bytes)
     return 0;
 }
 
-template <int NT, int FIN>
+template <int NT, int FIN, bool PIECES = false>
 int launch_fwd_fin(const DenseFwdArgs& a, unsigned gy, size_t lds_bytes, hipStream_t s)
 {
     if (lds_bytes > 80 * 1024) {        // one block per CU: give it 8 wavefronts
-        if (int rc = set_lds(dense_fwd_kernel<NT, FIN, 8>, lds_bytes)) return rc;
-        hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN, 8>), dim3(row_blocks(a.n_rows, 1024), gy), dim3(512), lds_bytes, s, a);
+        if (int rc = set_lds(dense_fwd_kernel<NT, FIN, 8, PIECES>, lds_bytes)) return rc;
+        hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN, 8, PIECES>), dim3(row_blocks(a.n_rows, 1024), gy), dim3(512), lds_bytes, s, a);
         return check_launch("dense_fwd_kernel");
     }
-    if (int rc = set_lds(dense_fwd_kernel<NT, FIN, 4>, lds_bytes)) return rc;
-    hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN, 4>), dim3(row_blocks(a.n_rows, 2048), gy), dim3(256), lds_bytes, s, a);
+    if (int rc = set_lds(dense_fwd_kernel<NT, FIN, 4, PIECES>, lds_bytes)) return rc;
+    hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN, 4, PIECES>), dim3(row_blocks(a.n_rows, 2048), gy), dim3(256), lds_bytes, s, a);
     return check_launch("dense_fwd_kernel");
 }
 
 template <int NT>
-int launch_fwd(const DenseFwdArgs& a, unsigned gy, hipStream_t s)
+int launch_fwd(const DenseFwdArgs& a, unsigned gy, hipStream_t s, bool pieces = false)
 {
     const size_t lds_bytes = static_cast<size_t>(a.k1) * a.f_in * (NT * 16 + kPad) * sizeof(float);
     PYGSD_REQUIRE(lds_bytes <= 160 * 1024 - 1024, "pygsd_magnetic_dense_fwd_f32: W slice needs %zu B of LDS", lds_bytes);
+    if (pieces) {                         // (the entry point admits f_in = 64 / 128 only)
+        if (a.f_in == 64) return launch_fwd_fin<NT, 64, true>(a, gy, lds_bytes, s);
+        return launch_fwd_fin<NT, 128, true>(a, gy, lds_bytes, s);
+    }
     if (a.f_in == 64) return launch_fwd_fin<NT, 64>(a, gy, lds_bytes, s);
     if (a.f_in == 128) return launch_fwd_fin<NT, 128>(a, gy, lds_bytes, s);
     return launch_fwd_fin<NT, 0>(a, gy, lds_bytes, s);
 }
 
-template <int NTI, int NTO>
+template <int NTI, int NTO, bool PIECES = false>
 int launch_bwd(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
 {
     constexpr bool kXpose = true;
@@ -516,9 +581,19 @@ int launch_bwd(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
     const size_t red = static_cast<size_t>(NTI * 16) * (NTO * 16) + NTO * 16;
     if (red > lds_floats) lds_floats = red;
     const size_t lds_bytes = lds_floats * sizeof(float);
-    if (int rc = set_lds(dense_bwd_kernel<NTI, NTO, kXpose>, lds_bytes)) return rc;
-    hipLaunchKernelGGL((dense_bwd_kernel<NTI, NTO, kXpose>), dim3(gx, a.k1, gz), dim3(256), lds_bytes, s, a);
+    if (int rc = set_lds(dense_bwd_kernel<NTI, NTO, kXpose, PIECES>, lds_bytes)) return rc;
+    hipLaunchKernelGGL((dense_bwd_kernel<NTI, NTO, kXpose, PIECES>), dim3(gx, a.k1, gz), dim3(256), lds_bytes, s, a);
     return check_launch("dense_bwd_kernel");
+}
+
+// the piece-layout instances exist for the shapes the sharded layers run: f_in a multiple of 64 (NTI = 4), f_out = 64 / 128
+int dispatch_bwd_pieces(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
+{
+    switch (a.f_out / 16) {
+        case 4: return launch_bwd<4, 4, true>(a, gx, gz, s);
+        case 8: return launch_bwd<4, 8, true>(a, gx, gz, s);
+        default: return fail("pygsd_magnetic_dense_bwd_pieces_f32: f_out=%d (64 or 128 with a piece layout)", a.f_out);
+    }
 }
 
 template <int NTI>
@@ -555,6 +630,13 @@ extern "C" int pygsd_magnetic_dense_fwd_f32(const float* const* a, const float* 
                                             float* out_imag, int32_t n_rows, int32_t f_in, int32_t f_out,
                                             void* stream)
 {
+    return pygsd_magnetic_dense_fwd_pieces_f32(a, b, k1, w, bias, out_real, out_imag, n_rows, f_in, f_out, nullptr, stream);
+}
+
+extern "C" int pygsd_magnetic_dense_fwd_pieces_f32(const float* const* a, const float* const* b, int32_t k1, const float* w,
+                                                   const float* bias, float* out_real, float* out_imag, int32_t n_rows,
+                                                   int32_t f_in, int32_t f_out, const pygsd_piece_layout* last_in, void* stream)
+{
     PYGSD_REQUIRE(pygsd_magnetic_dense_supported(f_in, f_out, k1),
                   "pygsd_magnetic_dense_fwd_f32: unsupported shape f_in=%d f_out=%d k1=%d", f_in, f_out, k1);
     PYGSD_REQUIRE(n_rows >= 0, "pygsd_magnetic_dense_fwd_f32: negative size");
@@ -569,13 +651,19 @@ extern "C" int pygsd_magnetic_dense_fwd_f32(const float* const* a, const float* 
     }
     args.w = w; args.bias = bias; args.out_r = out_real; args.out_i = out_imag;
     args.n_rows = n_rows; args.f_in = f_in; args.f_out = f_out; args.k1 = k1;
+    if (last_in) {
+        PYGSD_REQUIRE((f_in == 64 || f_in == 128) && f_out % kChunk == 0,
+                      "pygsd_magnetic_dense_fwd_pieces_f32: a piece layout needs f_in = 64 / 128 and f_out a multiple of 64");
+        if (int rc = piece_layout_check(last_in, n_rows, f_in, "pygsd_magnetic_dense_fwd_pieces_f32", &args.lay_shift)) return rc;
+        args.lay = *last_in;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_DENSE, s);
     const unsigned gy = (static_cast<unsigned>(f_out) + kChunk - 1) / kChunk;
     // every y-chunk is a full 64 columns except possibly a single-chunk narrow output
     if (f_out >= kChunk) {
         PYGSD_REQUIRE(f_out % kChunk == 0 || gy == 1, "pygsd_magnetic_dense_fwd_f32: f_out=%d not chunkable", f_out);
-        if (f_out % kChunk == 0) return launch_fwd<4>(args, gy, s);
+        if (f_out % kChunk == 0) return launch_fwd<4>(args, gy, s, last_in != nullptr);
     }
     switch (f_out / 16) {
         case 1: return launch_fwd<1>(args, 1, s);
@@ -600,6 +688,17 @@ extern "C" int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* 
                                             int32_t n_rows, int32_t f_in, int32_t f_out, void* workspace,
                                             size_t workspace_bytes, void* stream)
 {
+    return pygsd_magnetic_dense_bwd_pieces_f32(a, b, k1, w, g_real, g_imag, ldg, da, db, dw, dbias, n_rows, f_in, f_out, workspace,
+                                               workspace_bytes, nullptr, nullptr, stream);
+}
+
+extern "C" int pygsd_magnetic_dense_bwd_pieces_f32(const float* const* a, const float* const* b, int32_t k1, const float* w,
+                                                   const float* g_real, const float* g_imag, int64_t ldg, float* const* da,
+                                                   float* const* db, float* dw, float* dbias, int32_t n_rows, int32_t f_in,
+                                                   int32_t f_out, void* workspace, size_t workspace_bytes,
+                                                   const pygsd_piece_layout* last_in, const pygsd_piece_layout* last_out,
+                                                   void* stream)
+{
     PYGSD_REQUIRE(pygsd_magnetic_dense_supported(f_in, f_out, k1),
                   "pygsd_magnetic_dense_bwd_f32: unsupported shape f_in=%d f_out=%d k1=%d", f_in, f_out, k1);
     PYGSD_REQUIRE(n_rows > 0, "pygsd_magnetic_dense_bwd_f32: n_rows must be positive");
@@ -619,12 +718,28 @@ extern "C" int pygsd_magnetic_dense_bwd_f32(const float* const* a, const float* 
     }
     args.gr = g_real; args.gi = g_imag; args.ldg = ldg; args.w = w; args.partial = static_cast<float*>(workspace);
     args.n_rows = n_rows; args.f_in = f_in; args.f_out = f_out; args.k1 = k1;
+    const bool pieces = last_in || last_out;
+    if (pieces) {
+        PYGSD_REQUIRE(f_in % kChunk == 0 && (f_out == 64 || f_out == 128),
+                      "pygsd_magnetic_dense_bwd_pieces_f32: a piece layout needs f_in a multiple of 64 and f_out = 64 / 128");
+        if (last_in) {
+            if (int rc = piece_layout_check(last_in, n_rows, f_in, "pygsd_magnetic_dense_bwd_pieces_f32 (in)", &args.in_shift)) return rc;
+            args.lay_in = *last_in;
+            args.in_on = 1;
+        }
+        if (last_out) {
+            if (int rc = piece_layout_check(last_out, n_rows, f_in, "pygsd_magnetic_dense_bwd_pieces_f32 (out)", &args.out_shift)) return rc;
+            args.lay_out = *last_out;
+            args.out_on = 1;
+        }
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_DENSE_BWD, s);
     const unsigned gx = row_blocks(n_rows, 256);
     const unsigned gz = (static_cast<unsigned>(f_in) + kChunk - 1) / kChunk;
     int rc;
-    if (f_in >= kChunk) rc = dispatch_bwd_nto<4>(args, gx, gz, s);
+    if (pieces) rc = dispatch_bwd_pieces(args, gx, gz, s);
+    else if (f_in >= kChunk) rc = dispatch_bwd_nto<4>(args, gx, gz, s);
     else if (f_in == 48) rc = dispatch_bwd_nto<3>(args, gx, 1, s);
     else if (f_in == 32) rc = dispatch_bwd_nto<2>(args, gx, 1, s);
     else rc = dispatch_bwd_nto<1>(args, gx, 1, s);

@@ -260,6 +260,70 @@ extern "C" int pygsd_pack_slices(const void* const* xs, int32_t groups, int32_t 
 }
 
 namespace {
+struct GatherPiecesArgs {
+    const float* src[4];
+    const float* z[4];
+    float* out[4];
+    pygsd_piece_layout lay;
+    int64_t ldz, ldo;
+    int32_t n_rows, width4, shift;
+};
+
+// out[g][t, :] = (z[g] ? z[g][t, :] : 0) + row t of group g read through the piece layout: the merge of a returned product of the
+// sharded propagate (receive buffer of the return exchange -> [n_rows, F] rows in local order), with the adjoint's last addend
+// folded in.  One float4 per thread, row-major over the output: stores are coalesced, reads are whole 64-byte pieces.
+__global__ __launch_bounds__(256) void gather_pieces_kernel(GatherPiecesArgs a)
+{
+    const int g = blockIdx.y;
+    const float* __restrict__ src = a.src[g];
+    const float* __restrict__ z = a.z[g];
+    float* __restrict__ out = a.out[g];
+    const int mask = (1 << a.shift) - 1;
+    const int64_t total = static_cast<int64_t>(a.n_rows) * a.width4;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; idx < total; idx += static_cast<int64_t>(gridDim.x) * 256) {
+        const int t = static_cast<int>(idx / a.width4);
+        const int c4 = static_cast<int>(idx - static_cast<int64_t>(t) * a.width4);
+        const PieceRow pr = piece_row(a.lay, t);
+        const int64_t off = piece_offset(pr, c4 >> 2, a.shift, mask) + (c4 & 3) * 4;
+        float4 v = *reinterpret_cast<const float4*>(src + off);
+        if (z) {
+            const float4 zz = *reinterpret_cast<const float4*>(z + static_cast<int64_t>(t) * a.ldz + c4 * 4);
+            v = make_float4(zz.x + v.x, zz.y + v.y, zz.z + v.z, zz.w + v.w);
+        }
+        *reinterpret_cast<float4*>(out + static_cast<int64_t>(t) * a.ldo + c4 * 4) = v;
+    }
+}
+}  // namespace
+
+extern "C" int pygsd_gather_pieces_f32(const float* const* srcs, const pygsd_piece_layout* layout, const float* const* zs, int64_t ldz,
+                                       float* const* outs, int64_t ldo, int32_t n_groups, int32_t n_rows, int32_t width, void* stream)
+{
+    PYGSD_REQUIRE(n_groups >= 1 && n_groups <= 4 && n_rows >= 0 && width > 0 && width % 16 == 0,
+                  "pygsd_gather_pieces_f32: 1..4 groups, a width that is a multiple of 16 floats");
+    if (n_rows == 0) return 0;
+    PYGSD_REQUIRE(srcs && layout && outs && ldo >= width && ldo % 4 == 0 && (!zs || (ldz >= width && ldz % 4 == 0)),
+                  "pygsd_gather_pieces_f32: null pointer or row stride");
+    GatherPiecesArgs a{};
+    if (int rc = piece_layout_check(layout, n_rows, width, "pygsd_gather_pieces_f32", &a.shift)) return rc;
+    for (int g = 0; g < n_groups; ++g) {
+        PYGSD_REQUIRE(srcs[g] && outs[g] && aligned16(srcs[g]) && aligned16(outs[g]) && (!zs || !zs[g] || aligned16(zs[g])),
+                      "pygsd_gather_pieces_f32: group %d null or not 16-byte aligned", g);
+        a.src[g] = srcs[g];
+        a.out[g] = outs[g];
+        a.z[g] = zs ? zs[g] : nullptr;
+    }
+    a.lay = *layout;
+    a.ldz = ldz; a.ldo = ldo; a.n_rows = n_rows; a.width4 = width / 4;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope prof(PYGSD_K_ELEMENTWISE, s);
+    const int64_t total = static_cast<int64_t>(n_rows) * a.width4;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(gather_pieces_kernel, dim3(static_cast<unsigned>(blocks < (1 << 20) ? blocks : (1 << 20)), n_groups), dim3(256), 0,
+                       s, a);
+    return check_launch("gather_pieces_kernel");
+}
+
+namespace {
 struct WeightedSumArgs {
     const vec4f* x[8];
     float w[8];

@@ -22,34 +22,88 @@ def _ptr_array(ts: Sequence[Tensor]):
     return (c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
 
-def dense_fwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, bias: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
-    """out_real = sum_k (a_k - b_k) W_k + bias ; out_imag = sum_k (a_k + b_k) W_k + bias."""
+class PieceOperand:
+    """The last term's operand pair of the dense stage living in exchange buffers: `buffer` (fp32, kept alive by whoever holds
+    this), the two groups' first elements `off_a` / `off_b` (floats into it) and the `_cabi.PieceLayout` that places the rows."""
+
+    def __init__(self, buffer: Tensor, off_a: int, off_b: int, layout):
+        self.buffer, self.off_a, self.off_b, self.layout = buffer, int(off_a), int(off_b), layout
+
+    def ptrs(self):
+        return self.buffer.data_ptr() + 4 * self.off_a, self.buffer.data_ptr() + 4 * self.off_b
+
+
+def _ptr_array_with(ts: Sequence[Tensor], last: Optional[int]):
+    ptrs = [t.data_ptr() for t in ts] + ([] if last is None else [last])
+    return (c_void_p * len(ptrs))(*ptrs)
+
+
+def dense_fwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, bias: Optional[Tensor],
+                  last_in: Optional[PieceOperand] = None) -> Tuple[Tensor, Tensor]:
+    """out_real = sum_k (a_k - b_k) W_k + bias ; out_imag = sum_k (a_k + b_k) W_k + bias.
+    last_in (sharded layers): the LAST term's operands are read through a piece layout (pygsd_magnetic_dense_fwd_pieces_f32) --
+    `a` / `b` then hold the k1 - 1 terms before it."""
     k1, f_in, f_out = weight.shape
     for t in list(a) + list(b) + [weight]:
         if t.dtype != torch.float32:
             raise TypeError(f"the fused dense stage computes in float32; got {t.dtype}")
     a = [t.contiguous() for t in a]
     b = [t.contiguous() for t in b]
+    if len(a) != (k1 if last_in is None else k1 - 1) or len(b) != len(a):
+        raise ValueError(f"{k1} Chebyshev terms expected, got {len(a)} (+ a piece operand: {last_in is not None})")
     n = a[0].size(0)
     w = weight.detach().contiguous()
     out_r = torch.empty((n, f_out), dtype=torch.float32, device=w.device)
     out_i = torch.empty_like(out_r)
     bias_c = None if bias is None else bias.detach().contiguous()
     with torch.cuda.device(w.device):
-        check(_cabi.lib().pygsd_magnetic_dense_fwd_f32(_ptr_array(a), _ptr_array(b), k1, ptr(w), ptr(bias_c),
-                                                       ptr(out_r), ptr(out_i), n, f_in, f_out, stream_ptr()),
-              "pygsd_magnetic_dense_fwd_f32")
+        if last_in is None:
+            check(_cabi.lib().pygsd_magnetic_dense_fwd_f32(_ptr_array(a), _ptr_array(b), k1, ptr(w), ptr(bias_c),
+                                                           ptr(out_r), ptr(out_i), n, f_in, f_out, stream_ptr()),
+                  "pygsd_magnetic_dense_fwd_f32")
+        else:
+            pa, pb = last_in.ptrs()
+            lay = last_in.layout.struct()
+            check(_cabi.lib().pygsd_magnetic_dense_fwd_pieces_f32(_ptr_array_with(a, pa), _ptr_array_with(b, pb), k1, ptr(w),
+                                                                  ptr(bias_c), ptr(out_r), ptr(out_i), n, f_in, f_out,
+                                                                  ctypes.byref(lay), stream_ptr()),
+                  "pygsd_magnetic_dense_fwd_pieces_f32")
     return out_r, out_i
 
 
+def gather_pieces(src: PieceOperand, n_rows: int, width: int, z: Optional[Sequence[Tensor]] = None, groups: int = 2):
+    """[(z_g +) group g for g < groups] of a product that lives in a return exchange's receive buffer, as [n_rows, width] rows in
+    local order (pygsd_gather_pieces_f32): the merge, with the addend of the adjoint's steps (dT_{k-1} + S^T dT_k) folded into the
+    same pass.  Group g's rows start `g * (off_b - off_a)` floats behind group 0's."""
+    dev = src.buffer.device
+    outs = [torch.empty((n_rows, width), dtype=torch.float32, device=dev) for _ in range(groups)]
+    zs = None
+    if z is not None:
+        zc = [t.contiguous() for t in z]
+        zs = _ptr_array(zc)
+    step = 4 * (src.off_b - src.off_a)
+    first = src.buffer.data_ptr() + 4 * src.off_a
+    lay = src.layout.struct()
+    with torch.cuda.device(dev):
+        check(_cabi.lib().pygsd_gather_pieces_f32((c_void_p * groups)(*[first + g * step for g in range(groups)]), ctypes.byref(lay),
+                                                  zs, width, _ptr_array(outs), width, groups, n_rows, width, stream_ptr()),
+              "pygsd_gather_pieces_f32")
+    return outs
+
+
 def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor, g_i: Tensor,
-                  rows: Optional[int] = None):
+                  rows: Optional[int] = None, last_in: Optional[PieceOperand] = None, last_out: Optional[PieceOperand] = None):
     """-> (da list, db list, dW [k1, f_in, f_out], dbias [f_out]).
     rows: only the first `rows` rows enter (the sharded layer's real rows; the pad rows behind them are not part of
-    the graph): dW / dbias sum over those rows, da / db keep the full height with zero rows behind."""
+    the graph): dW / dbias sum over those rows, da / db keep the full height with zero rows behind.
+    last_in / last_out (sharded layers, pygsd_magnetic_dense_bwd_pieces_f32): the last term's operands are read through a piece
+    layout (`a` / `b` hold the k1 - 1 terms before it) / its gradients are stored through one -- straight into the send buffers
+    of the propagate that takes them; da[k1 - 1] / db[k1 - 1] are None then."""
     k1, f_in, f_out = weight.shape
     a = [t.contiguous() for t in a]
     b = [t.contiguous() for t in b]
+    if len(a) != (k1 if last_in is None else k1 - 1) or len(b) != len(a):
+        raise ValueError(f"{k1} Chebyshev terms expected, got {len(a)} (+ a piece operand: {last_in is not None})")
     if g_r.size(0) > 1 and g_r.stride(0) == 0 and g_i.stride(0) == 0:
         # one row broadcast to every node (the gradient of a loss that sums over the nodes arrives as an expanded
         # tensor): hand the kernel that row with a zero row stride instead of materialising two [N, F] copies
@@ -60,11 +114,14 @@ def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor,
     n = n_full if rows is None else int(rows)
     dev = weight.device
     w = weight.detach().contiguous()
-    da = [torch.empty((n_full, f_in), dtype=torch.float32, device=dev) for _ in range(k1)]
-    db = [torch.empty((n_full, f_in), dtype=torch.float32, device=dev) for _ in range(k1)]
+    k_plain = k1 if last_out is None else k1 - 1
+    da = [torch.empty((n_full, f_in), dtype=torch.float32, device=dev) for _ in range(k_plain)]
+    db = [torch.empty((n_full, f_in), dtype=torch.float32, device=dev) for _ in range(k_plain)]
     if n < n_full:
         for t in da + db:
             t[n:].zero_()
+    if last_out is not None:
+        da, db = da + [None], db + [None]          # (the send buffers' pad rows hold zeros: nothing ever writes them otherwise)
     if n == 0:                                     # a shard without real rows contributes nothing
         return da, db, torch.zeros((k1, f_in, f_out), dtype=torch.float32, device=dev), \
             torch.zeros(f_out, dtype=torch.float32, device=dev)
@@ -76,10 +133,21 @@ def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor,
         check(lib.pygsd_magnetic_dense_bwd_workspace(n, f_in, f_out, k1, ctypes.byref(need)),
               "pygsd_magnetic_dense_bwd_workspace")
         ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
-        check(lib.pygsd_magnetic_dense_bwd_f32(_ptr_array(a), _ptr_array(b), k1, ptr(w), ptr(g_r), ptr(g_i), ldg,
-                                               _ptr_array(da), _ptr_array(db), ptr(dw), ptr(dbias), n, f_in,
-                                               f_out, ptr(ws), need.value, stream_ptr()),
-              "pygsd_magnetic_dense_bwd_f32")
+        if last_in is None and last_out is None:
+            check(lib.pygsd_magnetic_dense_bwd_f32(_ptr_array(a), _ptr_array(b), k1, ptr(w), ptr(g_r), ptr(g_i), ldg,
+                                                   _ptr_array(da), _ptr_array(db), ptr(dw), ptr(dbias), n, f_in,
+                                                   f_out, ptr(ws), need.value, stream_ptr()),
+                  "pygsd_magnetic_dense_bwd_f32")
+        else:
+            pin = (None, None) if last_in is None else last_in.ptrs()
+            pout = (None, None) if last_out is None else last_out.ptrs()
+            lin = None if last_in is None else last_in.layout.struct()
+            lout = None if last_out is None else last_out.layout.struct()
+            check(lib.pygsd_magnetic_dense_bwd_pieces_f32(
+                _ptr_array_with(a, pin[0]), _ptr_array_with(b, pin[1]), k1, ptr(w), ptr(g_r), ptr(g_i), ldg,
+                _ptr_array_with(da[:k_plain], pout[0]), _ptr_array_with(db[:k_plain], pout[1]), ptr(dw), ptr(dbias), n, f_in, f_out,
+                ptr(ws), need.value, None if lin is None else ctypes.byref(lin), None if lout is None else ctypes.byref(lout),
+                stream_ptr()), "pygsd_magnetic_dense_bwd_pieces_f32")
     return da, db, dw, dbias
 
 

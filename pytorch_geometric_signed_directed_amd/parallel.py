@@ -532,8 +532,41 @@ class PropagateEngine:
         key = (name, tuple(shape), like.dtype, like.device)
         t = self._scratch.get(key)
         if t is None:
-            t = self._scratch[key] = torch.empty(tuple(shape), dtype=like.dtype, device=like.device)
+            # zero-filled once: the pad rows of a send buffer are never written by the dense backward's packed epilogue (it runs
+            # on the real rows only) and must read as zero gradient rows
+            t = self._scratch[key] = torch.zeros(tuple(shape), dtype=like.dtype, device=like.device)
         return t
+
+    # ---- piece layouts (round 5): the dense kernels write / read the exchange buffers directly ------
+    def pieces_ok(self, f: int, like: Tensor) -> bool:
+        """Can the dense kernels address this engine's exchange buffers (include/pygsd_hip.h: pygsd_piece_layout)?  fp32 on the
+        GPU, column slices of 16 * 2^k floats, at most 4 phases / return chunks and 8 row blocks."""
+        if not (like.is_cuda and like.dtype == torch.float32) or f % self.p_c:
+            return False
+        fw = f // self.p_c
+        pieces = fw // 16
+        return (fw % 16 == 0 and pieces & (pieces - 1) == 0 and self.phases <= 4 and self.return_chunks <= 4 and self.p_r <= 8
+                and max(self.phase_rows + self.chunk_rows) * 2 * fw < (1 << 31))
+
+    def send_layout(self, groups: int, f: int, like: Tensor):
+        """(layout, send buffers of all phases): where a local [n_pad, f] operand of `groups` feature groups goes in the inbound
+        exchange's send buffers -- what `_pack_phase` produces, as addresses.  Group g's operand pointer is buffer 0 + g * fw."""
+        from ._cabi import PieceLayout
+        p_r, p_c = (self.p_r, self.p_c) if self.grid else (1, 1)
+        fw = f // p_c
+        lead = (self.plan.world_size,) if self.grid else ()
+        bufs = [self._buf(f"send{c}", lead + (self.phase_rows[c], groups * fw), like) for c in range(self.phases)]
+        esz = like.element_size()
+        base = [(b.data_ptr() - bufs[0].data_ptr()) // esz for b in bufs]
+        return PieceLayout(base, self.phase_bounds, self.phase_rows, self.plan.n_pad, p_c, groups * fw, fw, p_r), bufs
+
+    def return_layout(self, groups: int, fw: int):
+        """Where row t (local order) of a returned product lives in the flat receive buffer of the return exchange
+        [block_rows, groups * fw] -- what `_merge` reads, as addresses (grid only)."""
+        from ._cabi import PieceLayout
+        world = self.plan.world_size
+        base = [world * self.chunk_bounds[r] * groups * fw for r in range(self.return_chunks)]
+        return PieceLayout(base, self.chunk_bounds, self.chunk_rows, self.n_blk, self.p_c, groups * fw, fw, 1)
 
     @staticmethod
     def alignment(world_size: int, p_c: int, phases, return_chunks, force_grid: bool = False) -> int:
@@ -616,6 +649,11 @@ class PropagateEngine:
         (block i', chunk r) of MY range x column slice j' -> per group the [n_pad, F] rows in local order
         i' * n_blk + chunk_bounds[r] + t."""
         fw = recv.size(-1) // groups
+        if groups <= 4 and self.pieces_ok(self.p_c * fw, recv):
+            # one HIP pass whatever the chunk sizes (pygsd_gather_pieces_f32)
+            from .dense import PieceOperand, gather_pieces
+            return gather_pieces(PieceOperand(recv, 0, fw, self.return_layout(groups, fw)), self.plan.n_pad, self.p_c * fw,
+                                 groups=groups)
         if self.chunk_fracs is None:
             v = recv.view(self.return_chunks, self.p_r, self.p_c, self.n_rsub, groups, fw)
             v = v.permute(4, 1, 0, 3, 2, 5).reshape(groups, self.plan.n_pad, self.p_c * fw)
@@ -628,16 +666,25 @@ class PropagateEngine:
         return [out[g] for g in range(groups)]
 
     # ---- the propagate ------------------------------------------------------------------------------
-    def run(self, xs: Sequence[Tensor], op, alpha: float = 1.0) -> List[Tensor]:
+    def run(self, xs: Optional[Sequence[Tensor]], op, alpha: float = 1.0, prepacked=None, merge: bool = True):
         """xs: G local [n_pad, F] feature groups.  op: a dual PhasedOperator (G = 2) or a list of G single ones.
-        Returns G local [n_pad, F] products."""
-        plan, world, groups = self.plan, self.plan.world_size, len(xs)
+        Returns G local [n_pad, F] products.
+        prepacked = (G, F, like) with xs = None: the send buffers already hold the operand (`send_layout`: the dense backward
+        wrote it there) -- no packing pass.  merge = False (grid): the products stay where the return exchange put them -- a FRESH
+        receive buffer, handed back as a dense.PieceOperand whose layout the dense kernels / pygsd_gather_pieces_f32 read."""
+        plan, world = self.plan, self.plan.world_size
+        if prepacked is not None:
+            groups, f, like = prepacked
+            xs = None
+        else:
+            groups, f, like = len(xs), xs[0].size(1), xs[0]
         dual = isinstance(op, PhasedOperator)
         if dual and (not op.dual or groups != 2):
             raise ValueError("a dual operator takes exactly two feature groups")
-        f = xs[0].size(1)
-        quantum = self.p_c * (8 if xs[0].dtype == torch.bfloat16 else 4)
-        if f % quantum and xs[0].is_cuda:
+        if not merge and not self.grid:
+            raise ValueError("merge = False: only the grid layout has a return exchange to read in place")
+        quantum = self.p_c * (8 if like.dtype == torch.bfloat16 else 4)
+        if xs is not None and f % quantum and xs[0].is_cuda:
             # the vector kernels address 16-byte row pieces: zero-pad odd widths (e.g. a 6-wide layer), slice after
             pad = (0, quantum - f % quantum)
             out = self.run([torch.nn.functional.pad(x, pad) for x in xs], op, alpha)
@@ -648,12 +695,13 @@ class PropagateEngine:
         ev = self._events()
         self._mark(ev, "start")
         works, bufs = [], []
-        if xs[0].is_cuda:
+        if xs is not None and xs[0].is_cuda:
             ld = xs[0].stride(0)
             if any(x.stride(1) != 1 or x.stride(0) != ld for x in xs):
                 xs = [x.contiguous() for x in xs]
+        sends = self.send_layout(groups, f, like)[1] if xs is None else None
         for c in range(self.phases):                         # every exchange is issued before any product
-            send = self._pack_phase(xs, c)
+            send = sends[c] if xs is None else self._pack_phase(xs, c)
             buf = self._buf(f"recv{c}", (world, self.phase_rows[c], groups * fw), send)
             works.append(self.ex.all_to_all(buf, send) if self.grid else self.ex.all_gather(buf, send))
             bufs.append(buf)
@@ -663,13 +711,15 @@ class PropagateEngine:
         # already ordered (return chunk, owner, row) -- chunk r of `home` is the all-to-all input as it stands
         returns, recv, home = [], None, None
         if self.grid:
-            home = self._buf("home", (self.block_rows, groups * fw), xs[0])
+            home = self._buf("home", (self.block_rows, groups * fw), like)
             ys = [home[:, g * fw:(g + 1) * fw] for g in range(groups)]
-            recv = self._buf("back", (self.block_rows, groups * fw), xs[0])
+            # read in place by the consumer: a buffer of its own (the forward's is kept for the backward pass)
+            recv = self._buf("back", (self.block_rows, groups * fw), like) if merge else \
+                like.new_empty((self.block_rows, groups * fw))
         else:
             # bf16 storage with more than one phase: the partial products accumulate in fp32 and are rounded ONCE
-            widen = xs[0].dtype == torch.bfloat16 and self.phases > 1
-            ys = [xs[0].new_empty((self.block_rows, fw), dtype=torch.float32 if widen else xs[0].dtype)
+            widen = like.dtype == torch.bfloat16 and self.phases > 1
+            ys = [like.new_empty((self.block_rows, fw), dtype=torch.float32 if widen else like.dtype)
                   for _ in range(groups)]
         for c in range(self.phases):
             works[c].wait()
@@ -691,13 +741,17 @@ class PropagateEngine:
                     returns.append(self.ex.all_to_all(self.chunk_view(recv, r), self.chunk_view(home, r)))
             self._mark(ev, "multiplied")
         if not self.grid:
-            if ys[0].dtype != xs[0].dtype:
-                ys = [y.to(xs[0].dtype) for y in ys]
+            if ys[0].dtype != like.dtype:
+                ys = [y.to(like.dtype) for y in ys]
             self._mark(ev, "end")
             return ys
         for w in returns:
             w.wait()
         self._mark(ev, "returned")
+        if not merge:
+            from .dense import PieceOperand
+            self._mark(ev, "end")
+            return PieceOperand(recv, 0, fw, self.return_layout(groups, fw))
         out = self._merge(recv, groups)
         self._mark(ev, "end")
         return out
@@ -757,6 +811,22 @@ def choose_cols(world_size: int, n_feat: int) -> int:
         if world_size % p_c == 0 and world_size > p_c - 1 + (p_c == 2) and n_feat % (4 * p_c) == 0:
             return p_c
     return 1
+
+
+_MERGE_ON_READ = os.environ.get("PYGSD_SHARD_MERGE_ON_READ", "1") != "0"
+_PACKED_BACKWARD = os.environ.get("PYGSD_SHARD_PACKED_BACKWARD", "1") != "0"
+
+
+def set_exchange_shortcuts(merge_on_read: Optional[bool] = None, packed_backward: Optional[bool] = None):
+    """Round 5's two shortcuts of the sharded magnetic layers (A / B runs, tests): consumers read returned products in place /
+    the dense backward writes the last gradient term into the send buffers.  -> the previous (merge_on_read, packed_backward)."""
+    global _MERGE_ON_READ, _PACKED_BACKWARD
+    prev = (_MERGE_ON_READ, _PACKED_BACKWARD)
+    if merge_on_read is not None:
+        _MERGE_ON_READ = bool(merge_on_read)
+    if packed_backward is not None:
+        _PACKED_BACKWARD = bool(packed_backward)
+    return prev
 
 
 def _env_spec(name: str, default):
@@ -828,6 +898,20 @@ class _ShardedMagneticFn(torch.autograd.Function):
         k1 = weight.size(0)
         eng = layer.engine
         ta, tb = [x_real.contiguous()], [x_imag.contiguous()]
+        ctx.in_place = None
+        if k1 == 2 and layer._reads_in_place(ta[0]):
+            # K = 1 (round 5): T_1 stays where the return exchange put it -- the dense stage (and, in the backward pass, its
+            # weight-gradient product) reads the receive buffer through a piece layout: no merge pass
+            prod = eng.run([ta[0], tb[0]], layer.op_fwd, 1.0, merge=False)
+            out_r, out_i = layer._dense_fwd(ta, tb, weight, bias, last_in=prod)
+            n_local = layer.plan.n_local
+            if n_local < layer.plan.n_pad:
+                out_r[n_local:] = 0
+                out_i[n_local:] = 0
+            ctx.layer, ctx.k1, ctx.has_bias = layer, k1, bias is not None
+            ctx.in_place = (prod.off_a, prod.off_b, prod.layout)
+            ctx.save_for_backward(weight, ta[0], tb[0], prod.buffer)
+            return out_r, out_i
         for k in range(1, k1):
             ya, yb = eng.run([ta[k - 1], tb[k - 1]], layer.op_fwd, 1.0 if k == 1 else 2.0)
             if k >= 2:                                      # T_k = 2 S T_{k-1} - T_{k-2} on the local rows
@@ -851,13 +935,28 @@ class _ShardedMagneticFn(torch.autograd.Function):
         layer, k1 = ctx.layer, ctx.k1
         saved = ctx.saved_tensors
         weight = saved[0]
-        ta, tb = list(saved[1:1 + k1]), list(saved[1 + k1:1 + 2 * k1])
+        eng = layer.engine
+        last_in = last_out = None
+        if ctx.in_place is not None:
+            from .dense import PieceOperand
+            ta, tb = [saved[1]], [saved[2]]
+            last_in = PieceOperand(saved[3], *ctx.in_place)
+        else:
+            ta, tb = list(saved[1:1 + k1]), list(saved[1 + k1:1 + 2 * k1])
+        needs_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        f = ta[0].size(1)
+        if k1 == 2 and needs_dx and layer._writes_packed(ta[0]):
+            # K = 1 (round 5): dT_1 is consumed by the propagate below and by nothing else -- the dense backward stores it
+            # straight into that propagate's send buffers (every replica): no packing pass
+            from .dense import PieceOperand
+            lay, bufs = eng.send_layout(2, f, ta[0])
+            last_out = PieceOperand(bufs[0], 0, lay.slot_floats, lay)
         # (an expanded upstream gradient -- the loss summed the outputs -- stays un-materialised: dense_bwd_raw hands the
         # kernel its one row)
         # upstream gradient on the PAD rows is not part of the graph (the forward zeroes those outputs): the dense
         # backward runs on the real rows only -- dW, db see no pad row whatever the loss or the stacking -- and hands
         # back zero gradient rows for the pad
-        da, db, dw, dbias = layer._dense_bwd(ta, tb, weight, g_r, g_i, layer.plan.n_local)
+        da, db, dw, dbias = layer._dense_bwd(ta, tb, weight, g_r, g_i, layer.plan.n_local, last_in=last_in, last_out=last_out)
         # parameter gradients = sum of the per-shard partials: reduced on the communication stream WHILE the backward
         # propagates below run (they do not depend on it); waited for at the end
         pending = [layer.exchange.all_reduce_async(dw)]
@@ -865,13 +964,25 @@ class _ShardedMagneticFn(torch.autograd.Function):
             dbias = dbias.contiguous()
             pending.append(layer.exchange.all_reduce_async(dbias))
         gx_r = gx_i = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        if needs_dx:
             # d T_{k-1} += 2 S^T d T_k ; d T_{k-2} -= d T_k   (k = K .. 2), then gX = d T_0 + S^T d T_1
-            eng = layer.engine
+            fused_add = layer._reads_in_place(ta[0])      # merge + "d T_{k-1} +" in ONE pass over the receive buffer
             for k in range(k1 - 1, 0, -1):
-                ra, rb = eng.run([da[k], db[k]], layer.op_bwd, 2.0 if k >= 2 else 1.0)
-                da[k - 1] = da[k - 1] + ra
-                db[k - 1] = db[k - 1] + rb
+                alpha = 2.0 if k >= 2 else 1.0
+                if fused_add:
+                    from .dense import gather_pieces
+                    if last_out is not None:               # (k = k1 - 1 = 1: the operand is in the send buffers already)
+                        prod = eng.run(None, layer.op_bwd, alpha, prepacked=(2, f, ta[0]), merge=False)
+                    else:
+                        prod = eng.run([da[k], db[k]], layer.op_bwd, alpha, merge=False)
+                    da[k - 1], db[k - 1] = gather_pieces(prod, layer.plan.n_pad, f, z=[da[k - 1], db[k - 1]])
+                else:
+                    if last_out is not None:               # (row layout: the all-gather's send buffer was written in place)
+                        ra, rb = eng.run(None, layer.op_bwd, alpha, prepacked=(2, f, ta[0]))
+                    else:
+                        ra, rb = eng.run([da[k], db[k]], layer.op_bwd, alpha)
+                    da[k - 1] = da[k - 1] + ra
+                    db[k - 1] = db[k - 1] + rb
                 if k >= 2:
                     da[k - 2] = da[k - 2] - da[k]
                     db[k - 2] = db[k - 2] - db[k]
@@ -1006,22 +1117,52 @@ class ShardedMagNetConv(torch.nn.Module):
         self.op_fwd = self.engine.phased(csr, vf, dual=True)
         self.op_bwd = self.engine.phased(csr, vb, dual=True)
 
+    # ---- round 5: the dense kernels address the exchange buffers themselves (no pack / merge passes) ----------------
+    def _pieces(self, like: Tensor) -> bool:
+        from .dense import dense_supported
+        return (self.engine.grid and self.in_channels in (64, 128) and self.out_channels in (64, 128)
+                and self.engine.pieces_ok(self.in_channels, like)
+                and dense_supported(self.in_channels, self.out_channels, self.weight.size(0)))
+
+    def _reads_in_place(self, like: Tensor) -> bool:
+        """Consumers read returned products where the return exchange put them (PYGSD_SHARD_MERGE_ON_READ=0 switches it off)."""
+        return _MERGE_ON_READ and self._pieces(like)
+
+    def _writes_packed(self, like: Tensor) -> bool:
+        """The dense backward writes dT_K into the send buffers of the propagate that takes it (PYGSD_SHARD_PACKED_BACKWARD=0:
+        off).  Also in the row layout: the all-gather's send buffer is a piece layout of one slot."""
+        from .dense import dense_supported
+        if not _PACKED_BACKWARD:
+            return False
+        if self.engine.grid:
+            return self._pieces(like)
+        return (like.is_cuda and like.dtype == torch.float32 and self.in_channels in (64, 128) and self.out_channels in (64, 128)
+                and self.engine.phases <= 4 and dense_supported(self.in_channels, self.out_channels, self.weight.size(0)))
+
+    @property
+    def merge_on_read(self) -> bool:
+        return self.weight.size(0) == 2 and self._reads_in_place(self.weight)
+
+    @property
+    def packed_backward(self) -> bool:
+        return self.weight.size(0) == 2 and self._writes_packed(self.weight)
+
     # dense stage: the fused MFMA kernels when the shape is tiled by them, library GEMMs otherwise
-    def _dense_fwd(self, ta, tb, weight, bias):
+    def _dense_fwd(self, ta, tb, weight, bias, last_in=None):
         from .dense import dense_fwd_raw, dense_supported
         if ta[0].is_cuda and dense_supported(self.in_channels, self.out_channels, weight.size(0)):
-            return dense_fwd_raw(ta, tb, weight, bias)
+            return dense_fwd_raw(ta, tb, weight, bias, last_in=last_in)
         mm = _dense_mm(ta[0])
         rr = sum(mm(ta[k], weight[k]) for k in range(weight.size(0)))
         ii = sum(mm(tb[k], weight[k]) for k in range(weight.size(0)))
         b = 0 if bias is None else bias
         return rr - ii + b, rr + ii + b
 
-    def _dense_bwd(self, ta, tb, weight, g_r, g_i, rows=None):
+    def _dense_bwd(self, ta, tb, weight, g_r, g_i, rows=None, last_in=None, last_out=None):
         """rows: only the first `rows` rows carry gradient (the rest are pad rows: zero gradient rows come back)."""
         from .dense import dense_bwd_raw, dense_supported
         if ta[0].is_cuda and dense_supported(self.in_channels, self.out_channels, weight.size(0)):
-            return dense_bwd_raw(ta, tb, weight, g_r, g_i, rows)
+            return dense_bwd_raw(ta, tb, weight, g_r, g_i, rows, last_in=last_in, last_out=last_out)
         n = g_r.size(0)
         rows = n if rows is None else rows
         p, m = (g_r + g_i)[:rows], (g_i - g_r)[:rows]

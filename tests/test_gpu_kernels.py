@@ -1452,3 +1452,76 @@ def test_fused_k1_forward_matches_the_two_kernel_form(n, e, bias):
     names = ["out_real", "out_imag", "dx_real", "dx_imag", "dW", "db"]
     for k, (want, got) in enumerate(zip(*res)):
         close(got, want, norm=k >= 4, what=f"fused K=1 forward: {names[k]}")
+
+
+# ------------------------------------------------------------------ piece layouts (round 5: the sharded layers' dense stage)
+def _piece_engine(world, p_c, phases, chunks, n_nodes=20011):
+    from pytorch_geometric_signed_directed_amd.parallel import PropagateEngine, ShardPlan
+    align = PropagateEngine.alignment(world, p_c, phases, chunks)
+    plan = ShardPlan(n_nodes, world, 1, align=align)
+    return plan, PropagateEngine(plan, type("Ex", (), {"world_size": world, "rank": 1})(), p_c, phases, chunks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,p_c,phases,chunks,f", [(8, 4, (0.4, 0.6), (0.5, 0.36, 0.14), 64), (8, 4, 2, 2, 128),
+                                                       (4, 2, (0.3, 0.3, 0.4), (0.8, 0.2), 64), (8, 4, 1, 1, 64)])
+def test_dense_stage_through_piece_layouts_is_bitwise_the_plain_one(world, p_c, phases, chunks, f):
+    """pygsd_magnetic_dense_fwd_pieces_f32 / _bwd_pieces_f32 / pygsd_gather_pieces_f32 (round 5): the last Chebyshev term read
+    straight out of a return exchange's receive buffer, the last gradient term stored straight into an inbound exchange's send
+    buffers (every replica), the merge with its addend in one pass -- against the plain kernels on the merged / un-packed
+    operands, bit for bit, with the engine's own layouts (uneven phases / chunks included) and a row count that is no multiple
+    of the 16-row tiles (the pad rows behind it must stay untouched)."""
+    from pytorch_geometric_signed_directed_amd.dense import PieceOperand, dense_bwd_raw, dense_fwd_raw, gather_pieces
+    d = dev()
+    plan, eng = _piece_engine(world, p_c, phases, chunks)
+    n_pad, n_real, fw = plan.n_pad, plan.n_pad - 37, f // p_c
+    g = torch.Generator().manual_seed(5)
+    x_r, x_i, t_r, t_i = (torch.randn(n_pad, f, generator=g).to(d) for _ in range(4))
+    w = (torch.randn(2, f, f, generator=g) * 0.2).to(d)
+    bias = torch.randn(f, generator=g).to(d)
+    g_r, g_i = torch.randn(n_pad, f, generator=g).to(d), torch.randn(n_pad, f, generator=g).to(d)
+    # T_1 as the return exchange leaves it
+    rl = eng.return_layout(2, fw)
+    off = rl.offsets(n_pad, f).to(d)
+    recv = torch.full((eng.block_rows * 2 * fw,), float("nan"), device=d)
+    recv[off] = t_r
+    recv[off + fw] = t_i
+    recv = recv.view(eng.block_rows, 2 * fw)
+    prod = PieceOperand(recv, 0, fw, rl)
+    # forward
+    want = dense_fwd_raw([x_r, t_r], [x_i, t_i], w, bias)
+    got = dense_fwd_raw([x_r], [x_i], w, bias, last_in=prod)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # the merge, alone and with an addend
+    m_r, m_i = gather_pieces(prod, n_pad, f)
+    assert torch.equal(m_r, t_r) and torch.equal(m_i, t_i)
+    z_r, z_i = gather_pieces(prod, n_pad, f, z=[x_r, x_i])
+    assert torch.equal(z_r, x_r + t_r) and torch.equal(z_i, x_i + t_i)
+    assert [torch.equal(a, b) for a, b in zip(eng._merge(recv, 2), (t_r, t_i))] == [True, True]      # the engine's merge takes the kernel
+    # backward: read T_1 in place, store dT_1 into the send buffers
+    wda, wdb, wdw, wdbias = dense_bwd_raw([x_r, t_r], [x_i, t_i], w, g_r, g_i, rows=n_real)
+    lay, bufs = eng.send_layout(2, f, x_r)
+    for b in bufs:
+        b.fill_(float("nan"))
+    out = PieceOperand(bufs[0], 0, fw, lay)
+    da, db, dw, dbias = dense_bwd_raw([x_r], [x_i], w, g_r, g_i, rows=n_real, last_in=prod, last_out=out)
+    assert da[1] is None and db[1] is None
+    assert torch.equal(da[0], wda[0]) and torch.equal(db[0], wdb[0]) and torch.equal(dw, wdw) and torch.equal(dbias, wdbias)
+    for c in range(eng.phases):                                    # every replica of every phase = what packing dT_1 produces
+        rows = slice(eng.phase_bounds[c], min(eng.phase_bounds[c + 1], n_real))
+        want_pack = eng._pack([wda[1], wdb[1]], c).clone()          # (writes the same persistent buffer: compare copies)
+        lead = want_pack.shape[:-2]
+        hi = rows.stop - rows.start
+        got_c = bufs[c]
+        # _pack just overwrote bufs[c]: run the kernel again and compare the real rows, then the untouched pad rows
+        for b in bufs:
+            b.fill_(float("nan"))
+        dense_bwd_raw([x_r], [x_i], w, g_r, g_i, rows=n_real, last_in=prod, last_out=out)
+        if hi > 0:
+            assert torch.equal(got_c[..., :hi, :], want_pack[..., :hi, :]), (c, lead)
+        assert bool(torch.isnan(got_c[..., max(hi, 0):, :]).all())
+    # mixed use: plain operands in, packed gradients out (the row layout's form) and the reverse
+    da2, db2, dw2, _ = dense_bwd_raw([x_r, t_r], [x_i, t_i], w, g_r, g_i, rows=n_real, last_out=out)
+    assert torch.equal(dw2, wdw) and torch.equal(da2[0], wda[0]) and da2[1] is None
+    da3, db3, dw3, _ = dense_bwd_raw([x_r], [x_i], w, g_r, g_i, rows=n_real, last_in=prod)
+    assert torch.equal(dw3, wdw) and torch.equal(da3[1], wda[1]) and torch.equal(db3[1], wdb[1])

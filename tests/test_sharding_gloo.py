@@ -533,3 +533,42 @@ def test_sharded_digcn_in_the_grid_layout(world, n, f, grid_cols, chunks, block)
     ret = mgr.dict()
     mp.spawn(_digcn_worker, args=(world, _free_port(), n, f, 1, block, ret, grid_cols, chunks), nprocs=world, join=True)
     assert len(ret) == world and max(ret.values()) <= 2e-6, dict(ret)
+
+
+@pytest.mark.parametrize("world,p_c,phases,chunks,f", [(8, 4, (0.4, 0.6), (0.5, 0.36, 0.14), 64), (8, 4, 2, 2, 128),
+                                                       (4, 2, (0.3, 0.3, 0.4), 1, 64), (2, 1, 2, 1, 64)])
+def test_piece_layouts_address_what_packing_and_merging_produce(world, p_c, phases, chunks, f):
+    """Round 5: the dense kernels write the send buffers / read the receive buffer of the exchanges THEMSELVES, through
+    pygsd_piece_layout.  The layouts the engine hands them (`send_layout`, `return_layout`) are held here to the tensor-op
+    packing and merging they replace, through the layout formula restated in `_cabi.PieceLayout.offsets` (the formula the HIP
+    kernels implement; tests/test_gpu_sharded.py holds the kernels to the same)."""
+    grid = p_c > 1
+    align = PropagateEngine.alignment(world, p_c, phases, chunks)
+    plan = ShardPlan(997, world, world - 1, align=align)
+    eng = PropagateEngine(plan, type("Ex", (), {"world_size": world, "rank": world - 1})(), p_c, phases, chunks, C.KERNELS)
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.randn(plan.n_pad, f, generator=g) for _ in range(2)]
+    layout, bufs = eng.send_layout(2, f, xs[0])
+    fw = f // p_c
+    assert layout.slot_floats == fw and layout.replicas == (eng.p_r if grid else 1)
+    esz = 4
+    for rep in range(layout.replicas):
+        off = layout.offsets(plan.n_pad, f, rep)
+        for c in range(eng.phases):
+            packed = eng._pack(xs, c).reshape(-1)
+            assert packed.data_ptr() == bufs[c].data_ptr()
+            rows = slice(eng.phase_bounds[c], eng.phase_bounds[c + 1])
+            local = off[rows] - layout.base[c]
+            assert int(local.min()) >= 0 and int(local.max()) + fw < packed.numel() + fw
+            for grp in range(2):
+                assert torch.equal(packed[local + grp * fw], xs[grp][rows])
+        assert layout.base[c] == (bufs[c].data_ptr() - bufs[0].data_ptr()) // esz
+    if grid:
+        recv = torch.randn(eng.block_rows, 2 * fw, generator=g)
+        merged = eng._merge(recv, 2)
+        rl = eng.return_layout(2, fw)
+        off = rl.offsets(plan.n_pad, f)
+        for grp in range(2):
+            assert torch.equal(recv.reshape(-1)[off + grp * fw], merged[grp])
+        st = rl.struct()
+        assert st.n_chunks == eng.return_chunks and st.blk_rows == eng.n_blk and list(st.lo)[:eng.return_chunks + 1] == eng.chunk_bounds
