@@ -766,6 +766,14 @@ class PropagateEngine:
         self.timing.append([])
         return self.timing[-1]
 
+    def remark_end(self):
+        """Profiling only: move the "end" mark of the last propagate behind what the caller has queued since (the fused merge of a
+        product that `run(..., merge=False)` left in the receive buffer), so that `merge_ms` keeps meaning "from the last arrival
+        to rows in local order" whoever runs the merge."""
+        if self.timing and self.timing[-1] and self.timing[-1][-1][0] == "end":
+            self.timing[-1].pop()
+            self._mark(self.timing[-1], "end")
+
     @staticmethod
     def _mark(ev, name):
         if ev is not None and torch.cuda.is_available():
@@ -976,6 +984,7 @@ class _ShardedMagneticFn(torch.autograd.Function):
                     else:
                         prod = eng.run([da[k], db[k]], layer.op_bwd, alpha, merge=False)
                     da[k - 1], db[k - 1] = gather_pieces(prod, layer.plan.n_pad, f, z=[da[k - 1], db[k - 1]])
+                    eng.remark_end()
                 else:
                     if last_out is not None:               # (row layout: the all-gather's send buffer was written in place)
                         ra, rb = eng.run(None, layer.op_bwd, alpha, prepacked=(2, f, ta[0]))
