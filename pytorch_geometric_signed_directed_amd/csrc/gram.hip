@@ -305,6 +305,181 @@ __global__ __launch_bounds__(256, 2) void tall_gram_bf16_kernel(GramArgs p)
     else gram_pick_bf16<1>(p, cx, cg, lds_b16);
 }
 
+// ---- fp32, round 5: no transposition at all ------------------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 takes ONE value per lane for each operand: lane l supplies A[l % 32][l / 32] and B[l / 32][l % 32].  For
+// dW = X^T G the reduction index k is the ROW, so the A operand of the step over rows (r, r + 1) is X[r + l / 32][c0 + l % 32] --
+// 32 consecutive floats of one row on 32 consecutive lanes -- and the B operand the same read of G: both MFMA operands ARE
+// coalesced global loads (a 128-byte line per half wavefront, every byte used), and the LDS round trip of the 16x16x4 form above
+// (rows in, columns out: 2 wavefront barriers and 12 ds_reads per 32 MFMAs) is gone.  A wavefront keeps the WHOLE [K, F] block
+// of its block pair in registers (NBK x NBF accumulators of 16 registers, <= 12: 192 of the 512 a wavefront may hold at one
+// wavefront per SIMD), so every operand element is fetched exactly once per pass: X is no longer re-read per 128-column chunk of
+// G (1.26 - 1.38 x the algorithmic bytes before, profiles/r4j_configs.json).  The loads of the next D row pairs are in flight
+// while the current D are multiplied (exact fp32, an fmaf chain over the rows in order).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxBlocks32 = 6;          // 32-column blocks of one side handled by a wavefront
+
+struct Gram32Args {
+    const float* x[4];       // first element (row 0) of each 32-column block of this launch's X group ...
+    const float* g[kMaxBlocks32];
+    int64_t ldx[4];          // ... and its row stride in floats
+    int64_t ldg[kMaxBlocks32];
+    float* partial;          // [gridDim.x][k_total * f_total]
+    int64_t n_rows;
+    int32_t k_total, f_total, x_at, g_at;     // where this launch's block sits in dW
+};
+
+template <int NBK, int NBF, int D>
+__global__ __launch_bounds__(256, 1) void tall_gram32_f32_kernel(Gram32Args p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds32[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, c = lane & 31;
+    f32x16 acc[NBK][NBF];
+#pragma unroll
+    for (int a = 0; a < NBK; ++a)
+#pragma unroll
+        for (int b = 0; b < NBF; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+    const float* xp[NBK];
+    const float* gp[NBF];
+#pragma unroll
+    for (int a = 0; a < NBK; ++a) xp[a] = p.x[a] + c;
+#pragma unroll
+    for (int b = 0; b < NBF; ++b) gp[b] = p.g[b] + c;
+    // batches of D row pairs, dealt round-robin over all wavefronts of the grid: neighbouring wavefronts stream neighbouring rows
+    const int64_t n_batches = (p.n_rows + 2 * D - 1) / (2 * D);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
+    int64_t batch = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    float xv[D][NBK], gv[D][NBF], xn[D][NBK], gn[D][NBF];
+    auto fetch = [&](int64_t bt, float (&xo)[D][NBK], float (&go)[D][NBF]) {
+        const int64_t row0 = bt * (2 * D) + half;
+        if ((bt + 1) * (2 * D) <= p.n_rows) {                     // (wavefront-uniform) a full batch: one 64-bit product per block,
+#pragma unroll                                                    // the D row pairs at uniform strides behind it
+            for (int a = 0; a < NBK; ++a) {
+                const float* q = xp[a] + row0 * p.ldx[a];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xo[d][a] = q[static_cast<int64_t>(2 * d) * p.ldx[a]];
+            }
+#pragma unroll
+            for (int b = 0; b < NBF; ++b) {
+                const float* q = gp[b] + row0 * p.ldg[b];
+#pragma unroll
+                for (int d = 0; d < D; ++d) go[d][b] = q[static_cast<int64_t>(2 * d) * p.ldg[b]];
+            }
+            return;
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {                              // the ragged last batch: clamped address, value masked
+            const int64_t row = row0 + 2 * d;
+            const bool live = row < p.n_rows;
+            const int64_t rr = live ? row : 0;
+#pragma unroll
+            for (int a = 0; a < NBK; ++a) {
+                const float v = xp[a][rr * p.ldx[a]];
+                xo[d][a] = live ? v : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < NBF; ++b) {
+                const float v = gp[b][rr * p.ldg[b]];
+                go[d][b] = live ? v : 0.f;
+            }
+        }
+    };
+    if (batch < n_batches) fetch(batch, xv, gv);
+    for (; batch < n_batches; batch += stride) {
+        const int64_t nb = batch + stride < n_batches ? batch + stride : batch;      // (past the end: re-read this batch, L2 hits)
+        fetch(nb, xn, gn);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int a = 0; a < NBK; ++a)
+#pragma unroll
+                for (int b = 0; b < NBF; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[d][a], gv[d][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int a = 0; a < NBK; ++a) xv[d][a] = xn[d][a];
+#pragma unroll
+            for (int b = 0; b < NBF; ++b) gv[d][b] = gn[d][b];
+        }
+    }
+    // C/D layout of 32x32x2: lane (half, c), register v -> dW[32 a + 8 (v / 4) + 4 half + v % 4][32 b + c]; the four wavefronts
+    // of the block add in wave order through LDS, one partial per block
+    constexpr int fo = NBF * 32;
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int a = 0; a < NBK; ++a)
+#pragma unroll
+                for (int b = 0; b < NBF; ++b)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int e = (a * 32 + 8 * (v >> 2) + 4 * half + (v & 3)) * fo + b * 32 + c;
+                        lds32[e] = (turn == 0 ? 0.f : lds32[e]) + acc[a][b][v];
+                    }
+        }
+        __syncthreads();
+    }
+    float* part = p.partial + static_cast<int64_t>(blockIdx.x) * p.k_total * p.f_total;
+    for (int e = tid; e < NBK * 32 * fo; e += 256) {
+        const int row = e / fo, col = e - row * fo;
+        part[static_cast<int64_t>(p.x_at + row) * p.f_total + p.g_at + col] = lds32[e];
+    }
+}
+
+template <int NBK, int NBF>
+int launch_gram32(const Gram32Args& a, unsigned blocks, hipStream_t s)
+{
+    constexpr int D = (NBK + NBF) <= 4 ? 16 : ((NBK + NBF) <= 8 ? 8 : 4);        // <= 64 registers per buffered batch
+    const size_t lds = static_cast<size_t>(NBK) * 32 * NBF * 32 * sizeof(float);
+    if (lds > 64 * 1024)
+        PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram32_f32_kernel<NBK, NBF, D>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((tall_gram32_f32_kernel<NBK, NBF, D>), dim3(blocks), dim3(256), lds, s, a);
+    return check_launch("tall_gram32_f32_kernel");
+}
+
+template <int NBK>
+int pick_gram32(const Gram32Args& a, int nbf, unsigned blocks, hipStream_t s)
+{
+    switch (nbf) {
+        case 1: return launch_gram32<NBK, 1>(a, blocks, s);
+        case 2: return launch_gram32<NBK, 2>(a, blocks, s);
+        case 3: return launch_gram32<NBK, 3>(a, blocks, s);
+        case 4: if constexpr (NBK <= 2) return launch_gram32<NBK, 4>(a, blocks, s); else break;
+        case 6: if constexpr (NBK <= 2) return launch_gram32<NBK, 6>(a, blocks, s); else break;
+        default: break;
+    }
+    return fail("pygsd_tall_gram: no 32x32 instance for %d x %d blocks", NBK, nbf);
+}
+
+// a side's 32-column blocks (every segment a multiple of 32 columns wide): pointer to the block's first column + row stride
+struct Blocks32 {
+    const float* p[16];
+    int64_t ld[16];
+    int n;
+};
+
+// blocks a partial-sum workspace of `budget` bytes admits (one [k_total x f_total] fp32 partial per block)
+unsigned budget_blocks(unsigned want, int64_t n_elem)
+{
+    const int64_t budget = int64_t(64) << 20;
+    int64_t cap = budget / (n_elem * static_cast<int64_t>(sizeof(float)));
+    if (cap < 1) cap = 1;
+    return want > cap ? static_cast<unsigned>(cap) : want;
+}
+
+bool gram32_enabled()
+{
+    static const bool on = [] {
+        const char* e = getenv("PYGSD_GRAM_32X32");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 // out[e] = sum_b partial[b][e] in block order: 64 elements per block, 4 groups of partials combined through LDS
 __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ partial, int n_partials, int64_t n_elem,
                                                           float* __restrict__ out)
@@ -323,12 +498,14 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
     if (grp == 0 && e < n_elem) out[e] = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
 }
 
-unsigned gram_blocks(int64_t n_rows, int rows_per_tile)
+// One [k_total x f_total] fp32 partial per block: the workspace (and the finish kernel's reads) grow with blocks x K x F, so the
+// count is capped by a 64 MB budget as well -- 512 blocks of a 1024 x 2048 product would be 4 GB (ADVICE, round 4).
+unsigned gram_blocks(int64_t n_rows, int rows_per_tile, int64_t n_elem)
 {
     const int64_t tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
     int64_t b = (tiles + 3) / 4;
     if (b > 512) b = 512;                       // 2 blocks per CU; every block walks >= 1 tile per wavefront
-    return static_cast<unsigned>(b < 1 ? 1 : b);
+    return budget_blocks(static_cast<unsigned>(b < 1 ? 1 : b), n_elem);
 }
 
 // a width (multiple of 16) as chunks of 8 / 4 / 2 / 1 tiles, none above `cap`
@@ -354,7 +531,9 @@ extern "C" int pygsd_tall_gram_workspace(int64_t n_rows, int32_t k_total, int32_
     PYGSD_REQUIRE(bytes, "pygsd_tall_gram_workspace: null output");
     PYGSD_REQUIRE(dtype == 0 || dtype == 1, "pygsd_tall_gram_workspace: dtype must be 0 (fp32) or 1 (bf16)");
     PYGSD_REQUIRE(n_rows >= 0 && k_total > 0 && f_total > 0, "pygsd_tall_gram_workspace: sizes must be positive");
-    *bytes = static_cast<size_t>(gram_blocks(n_rows, dtype == 1 ? 32 : 16)) * k_total * f_total * sizeof(float);
+    // (the fp32 32x32 form runs <= 256 blocks: it never needs more than this)
+    *bytes = static_cast<size_t>(gram_blocks(n_rows, dtype == 1 ? 32 : 16, static_cast<int64_t>(k_total) * f_total)) * k_total *
+             f_total * sizeof(float);
     return 0;
 }
 
@@ -396,9 +575,66 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
         PYGSD_HIP_TRY(hipMemsetAsync(out, 0, static_cast<size_t>(n_elem) * sizeof(float), s));
         return 0;
     }
-    const unsigned blocks = gram_blocks(n_rows, dtype == 1 ? 32 : 16);
+    unsigned blocks = gram_blocks(n_rows, dtype == 1 ? 32 : 16, n_elem);
     PYGSD_REQUIRE(workspace && workspace_bytes >= static_cast<size_t>(blocks) * n_elem * sizeof(float),
                   "pygsd_tall_gram: workspace null or too small (pygsd_tall_gram_workspace)");
+    bool all32 = dtype == 0 && gram32_enabled();
+    for (int sgm = 0; sgm < n_x && all32; ++sgm) all32 = x_widths[sgm] % 32 == 0 && ldx[sgm] % 1 == 0;
+    for (int sgm = 0; sgm < n_g && all32; ++sgm) all32 = g_widths[sgm] % 32 == 0;
+    if (all32 && k_total / 32 <= 16 && f_total / 32 <= 16) {
+        // fp32, every segment a multiple of 32 columns: the 32x32x2 form -- operands straight from coalesced loads, every element
+        // fetched once per (X group, G group) pair; groups of <= 4 / 2 / 1 blocks of X against <= 3 / 6 / 6 blocks of G
+        Blocks32 bx{}, bg{};
+        for (int sgm = 0; sgm < n_x; ++sgm)
+            for (int c0 = 0; c0 < x_widths[sgm]; c0 += 32) {
+                bx.p[bx.n] = static_cast<const float*>(xs[sgm]) + c0;
+                bx.ld[bx.n++] = ldx[sgm];
+            }
+        for (int sgm = 0; sgm < n_g; ++sgm)
+            for (int c0 = 0; c0 < g_widths[sgm]; c0 += 32) {
+                bg.p[bg.n] = static_cast<const float*>(gs[sgm]) + c0;
+                bg.ld[bg.n++] = ldg[sgm];
+            }
+        const int gx = bx.n >= 4 ? 4 : (bx.n >= 2 ? 2 : 1);                     // X blocks per group
+        const int gmax = gx == 4 ? 3 : 6;                                       // G blocks per group (gx * gmax <= 12)
+        const int64_t batches = (n_rows + 7) / 8;
+        unsigned b32 = static_cast<unsigned>(batches / 4 < 1 ? 1 : (batches / 4 > 256 ? 256 : batches / 4));   // one block per CU
+        if (b32 > blocks) b32 = blocks;                                         // (the workspace was sized for `blocks`)
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        ProfScope prof(PYGSD_K_DENSE_BWD, st);
+        for (int x0 = 0; x0 < bx.n; x0 += gx) {
+            const int nk = bx.n - x0 >= gx ? gx : (bx.n - x0 >= 2 ? 2 : 1);
+            for (int g0 = 0; g0 < bg.n;) {
+                int nf = bg.n - g0 >= gmax ? gmax : bg.n - g0;
+                if (nf == 5) nf = 4;                                             // (instances: 1, 2, 3, 4, 6 blocks of G)
+                if (nk == 4 && nf > 3) nf = 3;
+                Gram32Args ga{};
+                for (int q = 0; q < nk; ++q) {
+                    ga.x[q] = bx.p[x0 + q];
+                    ga.ldx[q] = bx.ld[x0 + q];
+                }
+                for (int q = 0; q < nf; ++q) {
+                    ga.g[q] = bg.p[g0 + q];
+                    ga.ldg[q] = bg.ld[g0 + q];
+                }
+                ga.partial = static_cast<float*>(workspace);
+                ga.n_rows = n_rows;
+                ga.k_total = k_total;
+                ga.f_total = f_total;
+                ga.x_at = x0 * 32;
+                ga.g_at = g0 * 32;
+                int rc = nk == 4 ? pick_gram32<4>(ga, nf, b32, st) : (nk == 2 ? pick_gram32<2>(ga, nf, b32, st) : pick_gram32<1>(ga, nf, b32, st));
+                if (rc) return rc;
+                g0 += nf;
+            }
+            if (nk < gx) {                                                       // a ragged tail of the X blocks: step by what was taken
+                x0 -= gx - nk;
+            }
+        }
+        hipLaunchKernelGGL(gram_finish_kernel, dim3(static_cast<unsigned>((n_elem + 63) / 64)), dim3(256), 0, st,
+                           static_cast<const float*>(workspace), static_cast<int>(b32), n_elem, out);
+        return check_launch("gram_finish_kernel");
+    }
     a.partial = static_cast<float*>(workspace);
     a.n_rows = n_rows;
     a.k_total = k_total;

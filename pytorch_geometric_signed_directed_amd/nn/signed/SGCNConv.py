@@ -24,7 +24,39 @@ class _SgcnFn(torch.autograd.Function):
     (reference order: aggregate, concatenate, Linear -- SGCNConv.py:101-126)."""
 
     @staticmethod
-    def forward(ctx, x, w_big, bias, o, spec):
+    def assemble(wb, wu, bb, bu, f, o, first_aggr):
+        """[F_x, (2 + m) o] weight and bias of the ONE product: every block of lin_b / lin_u as a column block (zero blocks where
+        a block reads the other half of x), columns [own_b | own_u | a_1 | ... | a_m]; biases ride on the own blocks."""
+        if first_aggr:             # columns: own_b | own_u | agg_b(pos) | agg_u(neg)
+            w_big = torch.cat([wb[:, f:].t(), wu[:, f:].t(), wb[:, :f].t(), wu[:, :f].t()], dim=1)
+            m = 2
+        else:                      # x = [lo | hi]; columns: own_b | own_u | pos_b | neg_b | pos_u | neg_u
+            zeros = wb.new_zeros(f, o)
+            top = torch.cat([wb[:, 2 * f:].t(), zeros, wb[:, :f].t(), zeros, zeros, wu[:, f:2 * f].t()], dim=1)
+            bot = torch.cat([zeros, wu[:, 2 * f:].t(), zeros, wb[:, f:2 * f].t(), wu[:, :f].t(), zeros], dim=1)
+            w_big = torch.cat([top, bot], dim=0)
+            m = 4
+        bias = None if bb is None else torch.cat([bb, bu, bb.new_zeros(m * o)])
+        return w_big, bias
+
+    @staticmethod
+    def split_weight_gradient(dw, f, o, first_aggr):
+        """dW of the one product -> (d lin_b.weight, d lin_u.weight): the blocks `assemble` placed, transposed back; the
+        zero blocks' gradients are dropped (they are constants)."""
+        if first_aggr:             # dw: [f, own_b | own_u | agg_b | agg_u]
+            return (torch.cat([dw[:, 2 * o:3 * o].t(), dw[:, :o].t()], dim=1),
+                    torch.cat([dw[:, 3 * o:4 * o].t(), dw[:, o:2 * o].t()], dim=1))
+        lo, hi = dw[:f], dw[f:]    # rows of x = [lo | hi]; columns own_b | own_u | pos_b | neg_b | pos_u | neg_u
+        return (torch.cat([lo[:, 2 * o:3 * o].t(), hi[:, 3 * o:4 * o].t(), lo[:, :o].t()], dim=1),
+                torch.cat([hi[:, 4 * o:5 * o].t(), lo[:, 5 * o:6 * o].t(), hi[:, o:2 * o].t()], dim=1))
+
+    @staticmethod
+    def forward(ctx, x, wb, wu, bb, bu, f, o, first_aggr, spec):
+        # Round 5: the node takes the layer's OWN parameters.  Composing [own | aggregated] blocks from slices of lin_b / lin_u
+        # under autograd cost, per step, four slice-backward fills + copies and two accumulations per weight, and as many small
+        # launches again for the bias -- a quarter of the C3 step was such glue (profiles/r4j_configs.json: 265 of 1039 us).
+        w_big, bias = _SgcnFn.assemble(wb.detach(), wu.detach(), None if bb is None else bb.detach(),
+                                       None if bu is None else bu.detach(), f, o, first_aggr)
         n = x.size(0)
         # the own block [own_b | own_u] and one contiguous matrix per aggregated block (gathered by whole rows)
         parts = tall_product([x], w_big, False, bias, splits=(2 * o,) + (o,) * len(spec))
@@ -39,7 +71,7 @@ class _SgcnFn(torch.autograd.Function):
                 spmm_rows_into(pat.fwd, None, parts[1 + j], dst, mean=True, z=own[:, half * o:(half + 1) * o])
                 seen.add(half)
         ctx.save_for_backward(x, w_big)
-        ctx.o, ctx.spec, ctx.has_bias = o, spec, bias is not None
+        ctx.o, ctx.f, ctx.first_aggr, ctx.spec, ctx.has_bias = o, f, first_aggr, spec, bias is not None
         return out
 
     @staticmethod
@@ -56,11 +88,14 @@ class _SgcnFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = tall_product([g, ga], w_big, True)          # g W_own^T + g_a W_agg^T in one pass
-        dw = tall_gram([x], [g, ga])                         # [x^T g_out | x^T g_a] in one pass over x, g and g_a
-        dbias = None
-        if ctx.has_bias:
-            dbias = torch.cat([column_sums(g), g.new_zeros(len(spec) * o)])
-        return dx, dw, dbias, None, None
+        d_wb = d_wu = d_bb = d_bu = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw = tall_gram([x], [g, ga])                     # [x^T g_out | x^T g_a] in one pass over x, g and g_a
+            d_wb, d_wu = _SgcnFn.split_weight_gradient(dw, ctx.f, o, ctx.first_aggr)
+        if ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+            sums = column_sums(g)                            # [2 o]: the balanced half's bias, then the unbalanced half's
+            d_bb, d_bu = sums[:o], sums[o:]
+        return dx, d_wb, d_wu, d_bb, d_bu, None, None, None, None
 
 
 class SGCNConv(MessagePassing):
@@ -120,20 +155,10 @@ class SGCNConv(MessagePassing):
         wb, wu = self.lin_b.weight, self.lin_u.weight
         pos = GLOBAL_PATTERNS.get(pos_edge_index, n, n, self.flow)
         neg = GLOBAL_PATTERNS.get(neg_edge_index, n, n, self.flow)
-        if self.first_aggr:             # columns: own_b | own_u | agg_b(pos) | agg_u(neg)
-            w_big = torch.cat([wb[:, f:].t(), wu[:, f:].t(), wb[:, :f].t(), wu[:, :f].t()], dim=1)
-            spec = ((pos, 0), (neg, 1))
-        else:                           # x = [lo | hi]; columns: own_b | own_u | pos_b | neg_b | pos_u | neg_u
-            zeros = wb.new_zeros(f, o)
-            top = torch.cat([wb[:, 2 * f:].t(), zeros, wb[:, :f].t(), zeros, zeros, wu[:, f:2 * f].t()], dim=1)
-            bot = torch.cat([zeros, wu[:, 2 * f:].t(), zeros, wb[:, f:2 * f].t(), wu[:, :f].t(), zeros], dim=1)
-            w_big = torch.cat([top, bot], dim=0)
-            spec = ((pos, 0), (neg, 0), (pos, 1), (neg, 1))
-        bias = None
-        if self.lin_b.bias is not None:
-            bias = torch.cat([self.lin_b.bias, self.lin_u.bias, self.lin_b.bias.new_zeros(len(spec) * o)])
+        spec = ((pos, 0), (neg, 1)) if self.first_aggr else ((pos, 0), (neg, 0), (pos, 1), (neg, 1))
         if o % 4 == 0 and x.dtype == torch.float32 and self.aggr == "mean":
-            return _SgcnFn.apply(x, w_big, bias, o, spec)
+            return _SgcnFn.apply(x, wb, wu, self.lin_b.bias, self.lin_u.bias, f, o, self.first_aggr, spec)
+        w_big, bias = _SgcnFn.assemble(wb, wu, self.lin_b.bias, self.lin_u.bias, f, o, self.first_aggr)   # (under autograd)
         y = tall_linear(x, w_big, bias).split(o, dim=1)    # widths the 16-byte-row kernels do not slice: composed ops
         halves = [y[0], y[1]]
         for j, (pat, half) in enumerate(spec):

@@ -849,12 +849,14 @@ def _env_spec(name: str, default):
     return fracs if fracs is not None else count
 
 
-# Round 5: uneven pieces by default.  The compute stream idles while the FIRST inbound phase is on the wire and while the LAST
-# return chunk travels home; everything in between is covered by a product.  A first phase of ~40 % of the rows is the shortest one
-# whose product still covers the second phase's wire time (product ~ wire per entry on this workload); three return chunks ending
-# in a short one leave ~1/8 of the return behind the last product (tools/emulate_sharded.py sweeps the shapes).
+# Round 5: uneven pieces.  The compute stream idles while the FIRST inbound phase is on the wire: a first phase of ~40 % of the rows
+# is the shortest one whose product still covers the second phase's wire time (product ~ wire per entry on this workload) --
+# rehearsed: 2.04 -> 2.00 ms per step at 8 ranks.  The return does NOT gain from finer or uneven chunks: every exchange carries a
+# fixed cost (issue + arrival latency, ~0.03 - 0.05 ms in the rehearsal) and the return's total wire time is about the last phase's
+# product, so what counts is how early the first chunk leaves, not how short the last one is -- three and four chunks measured
+# 2.06 - 2.14 ms against 2.00 - 2.04 for two equal ones (profiles/r5b_emulated_w8.json).
 DEFAULT_PHASES = (0.4, 0.6)
-DEFAULT_RETURN_CHUNKS = (0.5, 0.36, 0.14)
+DEFAULT_RETURN_CHUNKS = 2
 
 
 def default_pipeline(world_size: int, grid: bool):

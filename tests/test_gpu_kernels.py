@@ -1324,6 +1324,11 @@ GRAM_CASES = [
     ("f32", 1, (16,), (16,), False),
     ("f32", 37, (32, 16), (16, 128, 48), False),       # every chunk size on both sides, ragged tail
     ("f32", 5000, (128,), (32,), True),
+    ("f32", 40003, (128,), (64, 64, 64), False),       # round 5's 32x32 form: 4 X blocks against 6 G blocks (two groups of 3)
+    ("f32", 999, (32,), (160,), True),                 # 1 x 5 blocks -> 4 + 1
+    ("f32", 4097, (96,), (96, 32), False),             # 3 X blocks: 2 + 1; a ragged last batch of row pairs
+    ("f32", 15, (64, 64), (192,), False),              # fewer rows than one batch
+    ("f32", 300000, (64,), (64, 64, 64), False),       # the inception block's shape, enough rows for every wavefront
     ("bf16", 70001, (64,), (64, 128), False),          # C5: bf16 inception block
     ("bf16", 1, (16,), (16,), False),
     ("bf16", 33, (32, 16), (16, 128, 48), True),       # a partial 32-row tile

@@ -136,9 +136,17 @@ def signed_c3(n=500000, entries=10000000, h=64):
     torch.manual_seed(0)
     conv = SGCNConv(h, h // 2, first_aggr=True).to(dev)
 
+    # PYGSD_DENSE_GRAD=1: the upstream gradient is a dense [N, h] matrix handed to backward (what a real loss delivers), instead of
+    # `.sum()` -- whose reduction, ones-fill and materialised broadcast gradient are torch kernels timed with the layer
+    g_up = torch.randn(n, h, generator=g).to(dev)
+    dense_grad = os.environ.get("PYGSD_DENSE_GRAD", "0") == "1"
+
     def step():
         conv.zero_grad(set_to_none=True); x.grad = None
-        conv(x, pos, neg).sum().backward()
+        if dense_grad:
+            torch.autograd.backward(conv(x, pos, neg), g_up)
+        else:
+            conv(x, pos, neg).sum().backward()
     if not want("C3a"):
         ms, prof = None, None
     else:
@@ -149,6 +157,7 @@ def signed_c3(n=500000, entries=10000000, h=64):
         k = prof["spmm"]
         out["C3_sgcnconv_first"] = {"nodes": n, "pos_entries": int(pos.size(1)), "neg_entries": int(neg.size(1)),
                                     "hidden": h, "ms_per_step": ms, "ms_per_step_hipgraph_replay": replayed(step),
+                                    "upstream_gradient": "dense [N, h] handed to backward" if dense_grad else "out.sum()",
                                     "entries_per_s": ei.size(1) / ms * 1e3, "kernels": prof,
                                     "spmm_alg_GBps_fwd_pair": b / (2 * k["ms_per_launch"]) / 1e6 if k["ms_per_launch"] else None}
         out["C3_sgcnconv_first"].update(residency(n * (h // 2) * 4, out["C3_sgcnconv_first"]["spmm_alg_GBps_fwd_pair"]))

@@ -54,15 +54,49 @@ def run_shape(args, edge_index, x_real, x_imag, layout, phases, chunks, link_gbp
         b.record()
         b.synchronize()
         times.append(a.elapsed_time(b))
+    # how long the HOST takes to issue one step (no synchronisation inside the loop): a step of ~2 ms made of ~60 launches, events
+    # and stream switches is paced by the host where this approaches the device time
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    torch.cuda.synchronize()
     layer.engine.profile(True)
     ex.wire_us = 0.0
     for _ in range(args.steps):
         step()
     summary = layer.engine.timing_summary()
+    layer.engine.profile(False)
     wire_ms = ex.wire_us / 1e3 / (2 * args.K * args.steps)         # per propagate
+    # the same step replayed from a hipGraph (hipgraph.capture_step: exchanges on their side stream, played wire times and all):
+    # what the schedule costs the DEVICE once the host is out of the loop
+    graph_ms = graph_err = None
+    if not args.no_graph:
+        try:
+            from pytorch_geometric_signed_directed_amd.hipgraph import capture_step
+            replay = capture_step(step, warmup=2)
+            for _ in range(3):
+                replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(args.steps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                replay()
+                b.record()
+                b.synchronize()
+                ts.append(a.elapsed_time(b))
+            graph_ms = statistics.median(ts)
+            del replay
+        except Exception as exc:  # noqa: BLE001 -- a capture that fails must not cost the eager numbers
+            graph_err = repr(exc)[:300]
+            torch.cuda.synchronize()
     eng = layer.engine
     rec = {"layout": layout, "p_r": eng.p_r, "p_c": eng.p_c, "phases": phases, "return_chunks": chunks,
            "link_gbps": link_gbps, "step_ms_median": statistics.median(times), "step_ms_min": min(times),
+           "host_issue_ms_per_step": host_ms, "step_ms_hipgraph_replay": graph_ms, "hipgraph_error": graph_err,
            "per_propagate": summary, "wire_ms_per_propagate": wire_ms,
            "overlap_fraction": (1.0 - summary["exposed_exchange_ms"] / wire_ms) if wire_ms > 0 else None,
            "phase_rows": eng.phase_rows, "return_chunk_rows": eng.chunk_rows, "merge_on_read": bool(getattr(layer, "merge_on_read", False)),
@@ -89,6 +123,7 @@ def main():
     ap.add_argument("--shapes", nargs="+", default=None, metavar="LAYOUT:C:R",
                     help="pipeline shapes to run, e.g. grid:2:2 rows:1:1 -- C / R a count (equal pieces) or fractions, "
                          "grid:0.4,0.6:0.5,0.36,0.14 (default: the built-in sweep)")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-replayed variant of every shape")
     ap.add_argument("--single-gpu-ms", type=float, default=None, help="measured 1-GPU step (bench.py) for the ratio")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "emulated_sharded.json"))
     args = ap.parse_args()
@@ -123,6 +158,8 @@ def main():
                 rec = {"layout": layout, "phases": phases, "return_chunks": chunks, "link_gbps": gbps, "error": repr(exc)}
             if args.single_gpu_ms and "step_ms_median" in rec:
                 rec["projected_speedup"] = args.single_gpu_ms / rec["step_ms_median"]
+                if rec.get("step_ms_hipgraph_replay"):
+                    rec["projected_speedup_hipgraph_replay"] = args.single_gpu_ms / rec["step_ms_hipgraph_replay"]
             out["runs"].append(rec)
             print(json.dumps(rec), flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
