@@ -329,7 +329,7 @@ struct Gram32Args {
     int32_t k_total, f_total, x_at, g_at;     // where this launch's block sits in dW
 };
 
-template <int NBK, int NBF, int D, bool RING>
+template <int NBK, int NBF, int D>
 __global__ __launch_bounds__(256, 1) void tall_gram32_f32_kernel(Gram32Args p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds32[];
@@ -347,134 +347,62 @@ __global__ __launch_bounds__(256, 1) void tall_gram32_f32_kernel(Gram32Args p)
     for (int a = 0; a < NBK; ++a) xp[a] = p.x[a] + c;
 #pragma unroll
     for (int b = 0; b < NBF; ++b) gp[b] = p.g[b] + c;
-    if constexpr (RING) {
-        // Batches of R = 2 D row pairs, dealt round-robin over all wavefronts of the grid (neighbouring wavefronts stream neighbouring
-        // rows).  The operands of a batch sit in a RING of R register slots: slot s is multiplied and at once re-loaded with row pair s
-        // of the wavefront's NEXT batch, so every load has R pairs of MFMA time (R x NBK x NBF x 64 cycles) to arrive and all R slots'
-        // loads are outstanding all the time -- twice the latency cover of "fetch the next batch, then multiply this one" at the same
-        // register cost (the first version: 0.54 ms at C5a, 0.13 ms at C3a where round 4's kernel took 0.61 / 0.11).
-        constexpr int R = 2 * D;
-        const int64_t n_full = p.n_rows / (2 * R);                      // full batches; the ragged rest is one masked batch at the end
-        const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
-        int64_t batch = static_cast<int64_t>(blockIdx.x) * 4 + wave;
-        float xr[R][NBK], gr[R][NBF];
-        if (batch < n_full) {
-            const int64_t row0 = batch * (2 * R) + half;
-    #pragma unroll
-            for (int sl = 0; sl < R; ++sl) {
-    #pragma unroll
-                for (int a = 0; a < NBK; ++a) xr[sl][a] = xp[a][(row0 + 2 * sl) * p.ldx[a]];
-    #pragma unroll
-                for (int b = 0; b < NBF; ++b) gr[sl][b] = gp[b][(row0 + 2 * sl) * p.ldg[b]];
+    // batches of D row pairs, dealt round-robin over all wavefronts of the grid: neighbouring wavefronts stream neighbouring rows
+    const int64_t n_batches = (p.n_rows + 2 * D - 1) / (2 * D);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
+    int64_t batch = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    float xv[D][NBK], gv[D][NBF], xn[D][NBK], gn[D][NBF];
+    auto fetch = [&](int64_t bt, float (&xo)[D][NBK], float (&go)[D][NBF]) {
+        const int64_t row0 = bt * (2 * D) + half;
+        if ((bt + 1) * (2 * D) <= p.n_rows) {                     // (wavefront-uniform) a full batch: one 64-bit product per block,
+#pragma unroll                                                    // the D row pairs at uniform strides behind it
+            for (int a = 0; a < NBK; ++a) {
+                const float* q = xp[a] + row0 * p.ldx[a];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xo[d][a] = q[static_cast<int64_t>(2 * d) * p.ldx[a]];
+            }
+#pragma unroll
+            for (int b = 0; b < NBF; ++b) {
+                const float* q = gp[b] + row0 * p.ldg[b];
+#pragma unroll
+                for (int d = 0; d < D; ++d) go[d][b] = q[static_cast<int64_t>(2 * d) * p.ldg[b]];
+            }
+            return;
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {                              // the ragged last batch: clamped address, value masked
+            const int64_t row = row0 + 2 * d;
+            const bool live = row < p.n_rows;
+            const int64_t rr = live ? row : 0;
+#pragma unroll
+            for (int a = 0; a < NBK; ++a) {
+                const float v = xp[a][rr * p.ldx[a]];
+                xo[d][a] = live ? v : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < NBF; ++b) {
+                const float v = gp[b][rr * p.ldg[b]];
+                go[d][b] = live ? v : 0.f;
             }
         }
-        while (batch < n_full) {
-            const int64_t next = batch + stride;
-            // (past the wavefront's last batch the slots are re-loaded with this batch again -- L2 hits nobody reads -- instead of
-            // branching around the loads)
-            const int64_t row0 = (next < n_full ? next : batch) * (2 * R) + half;
-            const float* qx[NBK];
-            const float* qg[NBF];
-    #pragma unroll
-            for (int a = 0; a < NBK; ++a) qx[a] = xp[a] + row0 * p.ldx[a];
-    #pragma unroll
-            for (int b = 0; b < NBF; ++b) qg[b] = gp[b] + row0 * p.ldg[b];
-    #pragma unroll
-            for (int sl = 0; sl < R; ++sl) {
-    #pragma unroll
-                for (int a = 0; a < NBK; ++a)
-    #pragma unroll
-                    for (int b = 0; b < NBF; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[sl][a], gr[sl][b], acc[a][b], 0, 0, 0);
-    #pragma unroll
-                for (int a = 0; a < NBK; ++a) xr[sl][a] = qx[a][static_cast<int64_t>(2 * sl) * p.ldx[a]];
-    #pragma unroll
-                for (int b = 0; b < NBF; ++b) gr[sl][b] = qg[b][static_cast<int64_t>(2 * sl) * p.ldg[b]];
-            }
-            batch = next;
-        }
-        // the ragged last batch (fewer than 2 R rows): the one wavefront whose turn it is, row pair by row pair, values masked
-        if (batch == n_full && n_full * (2 * R) < p.n_rows) {
-            for (int sl = 0; sl < R; ++sl) {
-                const int64_t row = n_full * (2 * R) + 2 * sl + half;
-                if (n_full * (2 * R) + 2 * sl >= p.n_rows) break;      // (wavefront-uniform)
-                const bool live = row < p.n_rows;
-                const int64_t rr = live ? row : 0;
-                float xa[NBK], gb[NBF];
-    #pragma unroll
-                for (int a = 0; a < NBK; ++a) {
-                    const float v = xp[a][rr * p.ldx[a]];
-                    xa[a] = live ? v : 0.f;
-                }
-    #pragma unroll
-                for (int b = 0; b < NBF; ++b) {
-                    const float v = gp[b][rr * p.ldg[b]];
-                    gb[b] = live ? v : 0.f;
-                }
-    #pragma unroll
-                for (int a = 0; a < NBK; ++a)
-    #pragma unroll
-                    for (int b = 0; b < NBF; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[a], gb[b], acc[a][b], 0, 0, 0);
-            }
-        }
-    } else {
-        // batches of D row pairs, dealt round-robin over all wavefronts of the grid: neighbouring wavefronts stream neighbouring rows
-        const int64_t n_batches = (p.n_rows + 2 * D - 1) / (2 * D);
-        const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
-        int64_t batch = static_cast<int64_t>(blockIdx.x) * 4 + wave;
-        float xv[D][NBK], gv[D][NBF], xn[D][NBK], gn[D][NBF];
-        auto fetch = [&](int64_t bt, float (&xo)[D][NBK], float (&go)[D][NBF]) {
-            const int64_t row0 = bt * (2 * D) + half;
-            if ((bt + 1) * (2 * D) <= p.n_rows) {                     // (wavefront-uniform) a full batch: one 64-bit product per block,
-    #pragma unroll                                                    // the D row pairs at uniform strides behind it
-                for (int a = 0; a < NBK; ++a) {
-                    const float* q = xp[a] + row0 * p.ldx[a];
-    #pragma unroll
-                    for (int d = 0; d < D; ++d) xo[d][a] = q[static_cast<int64_t>(2 * d) * p.ldx[a]];
-                }
-    #pragma unroll
-                for (int b = 0; b < NBF; ++b) {
-                    const float* q = gp[b] + row0 * p.ldg[b];
-    #pragma unroll
-                    for (int d = 0; d < D; ++d) go[d][b] = q[static_cast<int64_t>(2 * d) * p.ldg[b]];
-                }
-                return;
-            }
-    #pragma unroll
-            for (int d = 0; d < D; ++d) {                              // the ragged last batch: clamped address, value masked
-                const int64_t row = row0 + 2 * d;
-                const bool live = row < p.n_rows;
-                const int64_t rr = live ? row : 0;
-    #pragma unroll
-                for (int a = 0; a < NBK; ++a) {
-                    const float v = xp[a][rr * p.ldx[a]];
-                    xo[d][a] = live ? v : 0.f;
-                }
-    #pragma unroll
-                for (int b = 0; b < NBF; ++b) {
-                    const float v = gp[b][rr * p.ldg[b]];
-                    go[d][b] = live ? v : 0.f;
-                }
-            }
-        };
-        if (batch < n_batches) fetch(batch, xv, gv);
-        for (; batch < n_batches; batch += stride) {
-            const int64_t nb = batch + stride < n_batches ? batch + stride : batch;      // (past the end: re-read this batch, L2 hits)
-            fetch(nb, xn, gn);
-    #pragma unroll
-            for (int d = 0; d < D; ++d)
-    #pragma unroll
-                for (int a = 0; a < NBK; ++a)
-    #pragma unroll
-                    for (int b = 0; b < NBF; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[d][a], gv[d][b], acc[a][b], 0, 0, 0);
-    #pragma unroll
-            for (int d = 0; d < D; ++d) {
-    #pragma unroll
-                for (int a = 0; a < NBK; ++a) xv[d][a] = xn[d][a];
-    #pragma unroll
-                for (int b = 0; b < NBF; ++b) gv[d][b] = gn[d][b];
-            }
+    };
+    if (batch < n_batches) fetch(batch, xv, gv);
+    for (; batch < n_batches; batch += stride) {
+        const int64_t nb = batch + stride < n_batches ? batch + stride : batch;      // (past the end: re-read this batch, L2 hits)
+        fetch(nb, xn, gn);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int a = 0; a < NBK; ++a)
+#pragma unroll
+                for (int b = 0; b < NBF; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[d][a], gv[d][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int a = 0; a < NBK; ++a) xv[d][a] = xn[d][a];
+#pragma unroll
+            for (int b = 0; b < NBF; ++b) gv[d][b] = gn[d][b];
         }
     }
     // C/D layout of 32x32x2: lane (half, c), register v -> dW[32 a + 8 (v / 4) + 4 half + v % 4][32 b + c]; the four wavefronts
@@ -501,36 +429,15 @@ __global__ __launch_bounds__(256, 1) void tall_gram32_f32_kernel(Gram32Args p)
     }
 }
 
-// two forms of the operand prefetch, chosen per instance (PYGSD_GRAM_RING=0 / 1 forces one): the ring of 2 D slots where its
-// registers fit without spills (NBK + NBF <= 6), the double-buffered batch of D pairs for the two largest blocks (12 accumulators)
-bool gram_ring(int nbk, int nbf)
-{
-    static const int forced = [] {
-        const char* e = getenv("PYGSD_GRAM_RING");
-        return e ? (e[0] == '0' ? 0 : 1) : -1;
-    }();
-    if (forced >= 0 && nbk + nbf <= 6) return forced == 1;
-    return nbk + nbf <= 6;
-}
-
 template <int NBK, int NBF>
 int launch_gram32(const Gram32Args& a, unsigned blocks, hipStream_t s)
 {
     constexpr int D = (NBK + NBF) <= 2 ? 16 : ((NBK + NBF) <= 8 ? 8 : 4);        // row pairs per buffered batch
     const size_t lds = static_cast<size_t>(NBK) * 32 * NBF * 32 * sizeof(float);
-    if constexpr (NBK + NBF <= 6) {
-        if (gram_ring(NBK, NBF)) {
-            if (lds > 64 * 1024)
-                PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram32_f32_kernel<NBK, NBF, D, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-            hipLaunchKernelGGL((tall_gram32_f32_kernel<NBK, NBF, D, true>), dim3(blocks), dim3(256), lds, s, a);
-            return check_launch("tall_gram32_f32_kernel");
-        }
-    }
     if (lds > 64 * 1024)
-        PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram32_f32_kernel<NBK, NBF, D, false>),
+        PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram32_f32_kernel<NBK, NBF, D>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL((tall_gram32_f32_kernel<NBK, NBF, D, false>), dim3(blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((tall_gram32_f32_kernel<NBK, NBF, D>), dim3(blocks), dim3(256), lds, s, a);
     return check_launch("tall_gram32_f32_kernel");
 }
 
@@ -564,13 +471,12 @@ unsigned budget_blocks(unsigned want, int64_t n_elem)
     return want > cap ? static_cast<unsigned>(cap) : want;
 }
 
-bool gram32_enabled()
+// 0 = never, 1 = where it measured faster (default), 2 = wherever the shapes admit it (PYGSD_GRAM_32X32 = 0 / unset / 1)
+int gram32_mode()
 {
-    static const bool on = [] {
-        const char* e = getenv("PYGSD_GRAM_32X32");
-        return !(e && e[0] == '0');
-    }();
-    return on;
+    const char* e = getenv("PYGSD_GRAM_32X32");
+    if (!e || !e[0]) return 1;
+    return e[0] == '0' ? 0 : 2;
 }
 
 // out[e] = sum_b partial[b][e] in block order: 64 elements per block, 4 groups of partials combined through LDS
@@ -671,10 +577,20 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
     unsigned blocks = gram_blocks(n_rows, dtype == 1 ? 32 : 16, n_elem);
     PYGSD_REQUIRE(workspace && workspace_bytes >= static_cast<size_t>(blocks) * n_elem * sizeof(float),
                   "pygsd_tall_gram: workspace null or too small (pygsd_tall_gram_workspace)");
-    bool all32 = dtype == 0 && gram32_enabled();
-    for (int sgm = 0; sgm < n_x && all32; ++sgm) all32 = x_widths[sgm] % 32 == 0 && ldx[sgm] % 1 == 0;
+    const int mode32 = gram32_mode();
+    bool all32 = dtype == 0 && mode32 != 0 && k_total / 32 <= 16 && f_total / 32 <= 16;
+    for (int sgm = 0; sgm < n_x && all32; ++sgm) all32 = x_widths[sgm] % 32 == 0;
     for (int sgm = 0; sgm < n_g && all32; ++sgm) all32 = g_widths[sgm] % 32 == 0;
-    if (all32 && k_total / 32 <= 16 && f_total / 32 <= 16) {
+    if (all32 && mode32 == 1) {
+        // Measured (profiles/r5d_gram_forms.json): with 12 accumulator blocks per wavefront -- 64 x 192 or 128 x 96 outputs, the
+        // fp32 inception block's x^T [dx0 | dP_1 | dP_2] -- this form takes 0.53 ms where the LDS-transposing one takes 0.61; with
+        // 8 blocks (SGCNConv's 64 x 128) it loses, 0.126 against 0.111 ms: too few MFMA cycles per batch to cover its loads at one
+        // wavefront per SIMD.  So: only where a wavefront holds at least 10 blocks.
+        const int xb = k_total / 32, gb = f_total / 32;
+        const int gx = xb >= 4 ? 4 : (xb >= 2 ? 2 : 1), gmax = gx == 4 ? 3 : 6;
+        all32 = gx * (gb < gmax ? gb : gmax) >= 10;
+    }
+    if (all32) {
         // fp32, every segment a multiple of 32 columns: the 32x32x2 form -- operands straight from coalesced loads, every element
         // fetched once per (X group, G group) pair; groups of <= 4 / 2 / 1 blocks of X against <= 3 / 6 / 6 blocks of G
         Blocks32 bx{}, bg{};

@@ -398,3 +398,56 @@ def test_c3_sgcn_every_row_and_parameter_gradients_vs_float64(ssbm_c3):
         tag = f"C3 SGCNConv {'first' if first else 'deep'}"
         for a, r, t, what in zip(got, ref32, truth, ("out", "dx") + tuple("d " + nm for nm in names)):
             _check_arbitrated(a, r, t, f"{tag} {what}", norm=what.startswith("d "))
+
+
+def test_c3_sharded_signed_layers_8_ranks_forward_every_row_vs_float64(ssbm_c3):
+    """Round 5 (review: the sharded signed layers were checked at toy sizes only): ShardedSGCNConv (first aggregation, 64 -> 32)
+    and ShardedSIMPA (hop 2, undirected, weighted operators) at BASELINE config 3's stated size -- SSBM 500k nodes / 10M +-
+    entries -- over 8 ranks in the row layout, EVERY row of every rank's output against float64 (and the reference's fp32 op
+    sequence beside it).  The ranks run as threads of one process (parallel.ThreadExchange: the same SPMD code, collectives as
+    rendezvous + copies), forward only: autograd's single worker thread per device cannot rendezvous with itself, and the
+    backward of these layers is autograd's composition of the pieces the 2 - 4-process tests of tests/test_gpu_sharded.py check
+    with gradients (nn/signed/SGCNConv.py:94-126, nn/signed/SIMPA.py:77-139)."""
+    from oracle import ref_layers as R
+    from oracle import sparse_f64_torch as T64
+    from pytorch_geometric_signed_directed_amd.nn import SGCNConv
+    from pytorch_geometric_signed_directed_amd.parallel import ShardedSGCNConv, ShardedSIMPA
+    pos, neg, w_pos, w_neg = ssbm_c3
+    n, h, hop, fill = C3["n"], C3["h"], C3["hop"], C3["fill"]
+    o = h // 2
+    torch.manual_seed(5)
+    sd = {k: v.to(D) for k, v in SGCNConv(h, o, first_aggr=True).state_dict().items()}
+    x, xp, xn = _randn(n, h, seed=61), _randn(n, h, seed=62), _randn(n, h, seed=63)
+    hop_w = {"_w_p": (torch.rand(hop + 1, 1, generator=torch.Generator().manual_seed(70)) + 0.5).to(D),
+             "_w_n": (torch.rand(int((1 + hop) * hop / 2), 1, generator=torch.Generator().manual_seed(71)) + 0.5).to(D)}
+
+    def body(rank, exchange):
+        with torch.no_grad():
+            conv = ShardedSGCNConv(h, o, True, n, pos, neg, device=D, exchange=exchange)
+            conv.load_state_dict(sd)
+            out = conv(conv.shard_rows(x))
+            simpa = ShardedSIMPA(hop, fill, n, pos, w_pos, neg, w_neg, device=D, exchange=exchange)
+            for k, v in hop_w.items():
+                getattr(simpa, k).copy_(v)
+            feat = simpa(simpa.shard_rows(xp), simpa.shard_rows(xn))
+        assert conv.plan.bounds == simpa.plan.bounds
+        return conv.plan, out, feat
+
+    res = C.run_ranks_as_threads(WORLD, body)
+    assert sum(r[0].n_local for r in res) == n
+    got_conv = torch.cat([r[1][:r[0].n_local] for r in res])
+    got_simpa = torch.cat([r[2][:r[0].n_local] for r in res])
+    assert all(float(r[1][r[0].n_local:].abs().sum()) == 0 and float(r[2][r[0].n_local:].abs().sum()) == 0 for r in res)
+    with torch.no_grad():
+        def sgcn(fn, dt):
+            p = {k: v.to(dt) for k, v in sd.items()}
+            return fn(x.to(dt), pos, neg, (p["lin_b.weight"], p["lin_b.bias"]), (p["lin_u.weight"], p["lin_u.bias"]), True, h)
+
+        def simpa_ref(fn, dt):
+            prm = {k: v.to(dt) for k, v in hop_w.items()}
+            return fn(pos, w_pos.to(dt), neg, w_neg.to(dt), xp.to(dt), xn.to(dt), prm, hop, fill, False)
+
+        _check_arbitrated(got_conv, sgcn(R.sgcn_conv, torch.float32), sgcn(T64.sgcn_conv, torch.float64),
+                          "C3 ShardedSGCNConv first, 8 ranks (all rows)")
+        _check_arbitrated(got_simpa, simpa_ref(R.simpa, torch.float32), simpa_ref(T64.simpa, torch.float64),
+                          f"C3 ShardedSIMPA hop {hop}, 8 ranks (all rows)")

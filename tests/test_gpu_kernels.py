@@ -1338,6 +1338,18 @@ GRAM_CASES = [
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,n,xw,gw,sliced", [c for c in GRAM_CASES if c[0] == "f32" and all(w % 32 == 0 for w in c[2] + c[3])])
+def test_tall_gram_32x32_form_matches_float64(dtype, n, xw, gw, sliced, monkeypatch):
+    """Round 5's form of the fp32 weight-gradient product (v_mfma_f32_32x32x2_f32 with both operands straight from coalesced
+    loads, a wavefront holding the whole output block) forced on for every shape whose segments are multiples of 32 columns --
+    by default it only runs where it measured faster (>= 10 accumulator blocks per wavefront)."""
+    monkeypatch.setenv("PYGSD_GRAM_32X32", "1")
+    test_tall_gram_matches_float64(dtype, n, xw, gw, sliced)
+    monkeypatch.setenv("PYGSD_GRAM_32X32", "0")
+    test_tall_gram_matches_float64(dtype, n, xw, gw, sliced)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,n,xw,gw,sliced", GRAM_CASES)
 def test_tall_gram_matches_float64(dtype, n, xw, gw, sliced):
     """[X_0 | ...]^T [G_0 | ...] (dW = x^T dY of the tall linear maps; autograd's mm backward for DiGCNConv.py:66,
