@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 12
+#define PYGSD_ABI_VERSION 13
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -309,6 +309,19 @@ int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, in
                        float diag_shift, void* workspace, size_t workspace_bytes, const int32_t* rowptr,
                        const float* deg, int32_t* col, float* vb_real, float* vb_imag, float* vf_real,
                        float* vf_imag, void* stream);
+/* Round 5: for weighted graphs the bucket plan takes (see pygsd_magop_unit below: <= 2^25 nodes, <= 3000 buckets ...)
+ * pygsd_magop_stage1 no longer sorts the stream globally: it is split once into buckets of consecutive rows that fit a workgroup's
+ * LDS, the weights travelling in a second 4-byte stream, and every row is ordered and merged there by the same wavefront routine
+ * as behind the sort -- same records, same results bit for bit WHERE THE ORDER OF ARRIVAL CANNOT SHOW: a neighbour's run of one or
+ * two entries (a + b = b + a in fp32; the row degree is summed over the column-sorted distinct entries either way).  A run of three
+ * or more entries of one neighbour (an edge listed three times, a reciprocal pair with a duplicate), a row of more than 512
+ * symmetrised entries or an over-full half bucket are counted in d_info[1]; the caller then repeats the first stage with
+ * pygsd_magop_stage1_sorted -- the radix sort on the row bits in front of the merge, rows of up to 4096 entries, duplicates summed
+ * in (direction, list position) order like the reference -- same arguments, same workspace, and runs pygsd_magop_stage2 again.
+ * PYGSD_WEIGHTED_BUILD_FORM=sort in the environment makes pygsd_magop_stage1 itself take the sorted form. */
+int pygsd_magop_stage1_sorted(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
+                              int32_t is_signed, int32_t absolute_degree, int32_t sym, void* workspace,
+                              size_t workspace_bytes, int32_t* rowptr, float* deg, int64_t* d_info, void* stream);
 /* The UNWEIGHTED build in one call (round 4): edge list -> final CSR + the four value arrays.  With unit weights a node's
  * degree is half its number of symmetrised entries (known from the row bounds of the sorted stream), multiplicities and phase
  * arguments are small integers: the wavefront that orders a row parks ONE 8-byte record per distinct neighbour, and after the

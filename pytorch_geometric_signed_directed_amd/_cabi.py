@@ -87,6 +87,8 @@ PROTOTYPES = {
     "pygsd_magop_workspace": (c_int32, [c_int64, c_int32, c_int32, ctypes.POINTER(c_size_t)]),
     "pygsd_magop_stage1": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                      c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pygsd_magop_stage1_sorted": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                            c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_magop_stage2": (c_int32, [c_int64, c_int32, c_int32, c_float, c_int32, c_float, c_float, c_void_p, c_size_t,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_magop_unit": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_float, c_void_p, c_size_t,
@@ -144,7 +146,7 @@ PROTOTYPES = {
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class PieceLayoutStruct(ctypes.Structure):

@@ -264,10 +264,13 @@ constexpr uint32_t kFlag = 0x80000000u;
 // A wavefront orders one row of <= 64 symmetrised entries in registers.  deg_mode: 0 = row sums of A_s, 1 = of |A_s|
 // (signed, absolute_degree off), 2 = of the |w| sums / 2 (signed, absolute_degree on).  `c2` / `w0` are the row's
 // keys (col << 1 | dir) and weights as loaded by lane = list position (prefetched by the caller for several rows).
+// order_free_only (round 5: rows whose entries arrive in NO particular order, bucket_merge_rows_w): a run of three or more entries
+// of one neighbour is reported in `*unordered` instead of trusted -- its fp32 sum depends on the order the reference adds them in;
+// runs of one or two entries do not (a + b = b + a).
 template <typename KT>
 __device__ __forceinline__ void merge_one_row(int32_t r, int32_t beg, int32_t cnt, uint32_t c2, float w0, bool weighted,
                                               int lane, int32_t deg_mode, int32_t* __restrict__ ucnt,
-                                              float* __restrict__ deg, uint4* __restrict__ ent)
+                                              float* __restrict__ deg, uint4* __restrict__ ent, bool* unordered = nullptr)
 {
     const bool have = lane < cnt;
     KT lk = have ? static_cast<KT>((static_cast<KT>(c2) << 6) | static_cast<KT>(lane)) : static_cast<KT>(~static_cast<KT>(0));
@@ -290,6 +293,7 @@ __device__ __forceinline__ void merge_one_row(int32_t r, int32_t beg, int32_t cn
     const uint64_t below = (1ull << lane) - 1ull;
     const int rank = __popcll(H & below);
     const int heads_upto = __popcll(H & (below | (1ull << lane)));
+    if (unordered && __ballot(head && len >= 3)) *unordered = true;
     float s = 0.f, t = 0.f, a = 0.f, d = 0.f;
     if (weighted) {
         const float wv = __shfl(w0, src);                         // weight of the entry this lane holds after the sort
@@ -1454,6 +1458,376 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows(UnitArgs p, BucketP
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 5: the bucket form for REAL-VALUED weights (weighted MagNetConv graphs, MSConv with rated signs): the front of the two-stage
+// pipeline -- edge_keys, the radix sort of (key, weight) pairs on the row bits, key_row_starts, row_merge_wave / _block: 1.2 of its
+// 2.1 ms at the north star -- replaced by the bucket split, with the weight of an entry travelling in a second 4-byte stream at the
+// same index.  What the stages behind it read (one 16-byte record per stream position, row starts, distinct counts, degrees) is
+// produced in the same form, so row_tables / values_entries / diagonal_of_empty_rows run unchanged.
+// Order.  The reference adds the duplicates of an entry in (direction, list position) order and the row degree sequentially in
+// column order.  Buckets and rows are filled by LDS atomics -- no order at all -- so this form only takes what cannot show it:
+// a neighbour's run of ONE or TWO entries (a reciprocal pair, or an edge listed twice: fp32 addition commutes); the degree sum runs
+// over the column-sorted distinct entries and is order-independent by construction.  A run of three or more is counted in info[1]
+// and the host repeats the build behind the radix sort (pygsd_magop_stage1_sorted), as it does for the rows these kernels do not
+// take (more than 512 entries) and for a half bucket that overflows its share of the LDS.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kRoundsW = kTileEdges / (kScatterThreads * kPassBatch);            // batches of one tile per thread: 4
+
+// bucket_scatter with a weight stream: the tile's keys are staged and drained exactly as above; every thread remembers the two
+// staged slots of each of its 16 edges (15 bits each) and, once the keys have left, stages the edges' weights at the same slots and
+// drains them to `wstream` through the same slot -> bucket map.
+__global__ __launch_bounds__(kScatterThreads) void bucket_scatter_w(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                                                    const float* __restrict__ w, int64_t e, int32_t n, BucketPlan pl,
+                                                                    const int32_t* __restrict__ off, uint32_t* __restrict__ stream,
+                                                                    float* __restrict__ wstream)
+{
+    static_assert(2 * kTileEdges == 32 * kScatterThreads, "one 32-slot word of the head map per thread");
+    static_assert(kRoundsW * kScatterThreads * kPassBatch == kTileEdges, "a tile is a whole number of batches");
+    extern __shared__ __attribute__((aligned(8))) uint32_t scatter_lds[];
+    uint32_t* stage = scatter_lds;
+    uint2* hp = reinterpret_cast<uint2*>(stage + 2 * kTileEdges);
+    uint32_t* cur = reinterpret_cast<uint32_t*>(hp + kScatterThreads);
+    uint32_t* gdc = cur + pl.nb;
+    __shared__ uint32_t wsum[kScatterThreads / 64], wsum2[kScatterThreads / 64], total_s;
+    const int st = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    constexpr int PER = (kMaxBuckets + kScatterThreads - 1) / kScatterThreads;
+    uint32_t cnts[PER], goff[PER], mine = 0;
+    hp[t] = make_uint2(0u, 0u);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = t * PER + j;
+        cnts[j] = 0;
+        goff[j] = 0;
+        if (b < pl.nb) {
+            const int32_t* o = off + static_cast<int64_t>(b) * pl.g + st;
+            goff[j] = static_cast<uint32_t>(o[0]);
+            cnts[j] = static_cast<uint32_t>(o[1]) - goff[j];
+        }
+        mine += cnts[j] | (cnts[j] ? 0x10000u : 0u);
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (int q = 0; q < wv; ++q) run += wsum[q];
+    uint32_t slot = run & 0xFFFFu, nz = run >> 16;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = t * PER + j;
+        if (b < pl.nb) {
+            cur[b] = slot;
+            if (cnts[j]) {
+                atomicOr(&hp[slot >> 5].x, 1u << (slot & 31u));
+                gdc[nz++] = goff[j] - slot;
+            }
+        }
+        slot += cnts[j];
+    }
+    if (t == kScatterThreads - 1) total_s = slot;
+    __syncthreads();
+    {
+        const uint32_t pc = __popc(hp[t].x);
+        uint32_t pinc = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(pinc, d);
+            if (lane >= d) pinc += o;
+        }
+        if (lane == 63) wsum2[wv] = pinc;
+        __syncthreads();
+        uint32_t before = pinc - pc;
+        for (int q = 0; q < wv; ++q) before += wsum2[q];
+        hp[t].y = before;
+    }
+    const int64_t lo = static_cast<int64_t>(st) * kTileEdges, hi = lo + kTileEdges < e ? lo + kTileEdges : e;
+    const uint64_t nn = static_cast<uint64_t>(n);
+    const uint32_t rmask = (1u << pl.rl) - 1u;
+    const int sh = pl.cbits + 1;
+    uint32_t slots[kRoundsW * kPassBatch];                         // staged slots of this thread's edges: forward | reversed << 16
+#pragma unroll
+    for (int it = 0; it < kRoundsW; ++it) {
+        int64_t r[kPassBatch], c[kPassBatch];
+#pragma unroll
+        for (int u = 0; u < kPassBatch; ++u) {
+            const int64_t k = lo + (static_cast<int64_t>(it) * kPassBatch + u) * kScatterThreads + t;
+            const bool ok = k < hi;
+            r[u] = ok ? row[k] : 0;                               // (0, 0): a self loop, dropped below
+            c[u] = ok ? col[k] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kPassBatch; ++u) {
+            uint32_t sl = 0xFFFFFFFFu;
+            if (!(static_cast<uint64_t>(r[u]) >= nn || static_cast<uint64_t>(c[u]) >= nn || r[u] == c[u])) {
+                const uint32_t rr = static_cast<uint32_t>(r[u]), cc = static_cast<uint32_t>(c[u]);
+                const uint32_t sf = atomicAdd(&cur[rr >> pl.rl], 1u), sr = atomicAdd(&cur[cc >> pl.rl], 1u);
+                stage[sf] = ((rr & rmask) << sh) | (cc << 1);
+                stage[sr] = ((cc & rmask) << sh) | (rr << 1) | 1u;
+                sl = sf | (sr << 16);
+            }
+            slots[it * kPassBatch + u] = sl;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = total_s;
+    for (uint32_t q = t; q < total; q += kScatterThreads) {
+        const uint2 wq = hp[q >> 5];
+        const uint32_t idx = __popc(wq.x & ((2u << (q & 31u)) - 1u)) + wq.y - 1u;
+        stream[gdc[idx] + q] = stage[q];
+    }
+    __syncthreads();                                              // the keys have left: the staging area takes the weights
+    float* stage_w = reinterpret_cast<float*>(stage);
+#pragma unroll
+    for (int it = 0; it < kRoundsW; ++it) {
+        float wv4[kPassBatch];
+#pragma unroll
+        for (int u = 0; u < kPassBatch; ++u) {
+            const int64_t k = lo + (static_cast<int64_t>(it) * kPassBatch + u) * kScatterThreads + t;
+            wv4[u] = k < hi ? w[k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kPassBatch; ++u) {
+            const uint32_t sl = slots[it * kPassBatch + u];
+            if (sl != 0xFFFFFFFFu) {
+                stage_w[sl & 0xFFFFu] = wv4[u];
+                stage_w[sl >> 16] = wv4[u];
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t q = t; q < total; q += kScatterThreads) {
+        const uint2 wq = hp[q >> 5];
+        const uint32_t idx = __popc(wq.x & ((2u << (q & 31u)) - 1u)) + wq.y - 1u;
+        wstream[gdc[idx] + q] = stage_w[q];
+    }
+}
+
+// A row of 65 .. kUnitRowMax entries of the weighted bucket form, keys (col << 1 | dir) and weights in LDS (`sk`, `sw`), one
+// wavefront.  Rank sort on (key, position in the row): the sorted (key, weight) pairs are parked in the first 8 bytes of the row's
+// 16-byte record slots, read back in chunks of 64 positions -- every head lane sums its run (A_s, Theta_arg, |w|: short loops),
+// the degree runs sequentially over the distinct entries in column order, chunk after chunk -- and only then are the records
+// written (a run may reach into the next chunk: nothing may be overwritten before everything has been read).
+__device__ __forceinline__ void merge_long_row_w(const uint32_t* sk, const float* sw, int cnt, int32_t r, int64_t gbeg, int lane,
+                                                 int32_t deg_mode, int32_t* __restrict__ ucnt, float* __restrict__ deg,
+                                                 uint4* __restrict__ ent, bool* unordered)
+{
+    constexpr int CH = kUnitRowMax / 64;                           // chunks of 64 positions
+    uint2* tmp = reinterpret_cast<uint2*>(ent + gbeg);             // 16-byte slots; the pair (key, weight bits) in the first 8 bytes
+    for (int i = lane; i < cnt; i += 64) {
+        const uint32_t mine = sk[i];
+        int rk = 0;
+        for (int q = 0; q < cnt; ++q) {
+            const uint32_t o = sk[q];
+            rk += (o < mine || (o == mine && q < i)) ? 1 : 0;
+        }
+        tmp[2 * rk] = make_uint2(mine, __float_as_uint(sw[i]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t colv[CH];
+    float sv[CH], tv[CH], av[CH];
+    bool hd[CH];
+    int u = 0, left = 0;
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int i = j * 64 + lane;
+        hd[j] = false;
+        colv[j] = 0u;
+        sv[j] = tv[j] = av[j] = 0.f;
+        if (j * 64 >= cnt) continue;                               // (wavefront-uniform)
+        if (i < cnt) {
+            const uint32_t k2 = tmp[2 * i].x;
+            colv[j] = k2 >> 1;
+            hd[j] = i == 0 || (tmp[2 * (i - 1)].x >> 1) != colv[j];
+        }
+        int len = 0;
+        if (hd[j]) {
+            for (int q = i; q < cnt; ++q) {                        // the run: sorted (direction, position) order
+                const uint2 e = tmp[2 * q];
+                if ((e.x >> 1) != colv[j]) break;
+                const float wq = __uint_as_float(e.y);
+                sv[j] = sv[j] + wq;
+                tv[j] = tv[j] + ((e.x & 1u) ? -wq : wq);
+                av[j] = av[j] + fabsf(wq);
+                ++len;
+            }
+        }
+        if (__ballot(hd[j] && len >= 3)) *unordered = true;
+        // degree: the chunk's distinct entries in column order, appended to the running sum (merge_one_row's compaction)
+        const uint64_t H = __ballot(hd[j]);
+        const int uc = __popcll(H);
+        const uint64_t below = (1ull << lane) - 1ull;
+        const int rank = __popcll(H & below), heads_upto = __popcll(H & (below | (1ull << lane)));
+        const int dest = hd[j] ? rank : uc + (lane - heads_upto);
+        const float dense = __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(degree_source(sv[j], av[j], deg_mode))));
+        for (int k = 0; k < uc; ++k) d = d + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dense), k));
+        u += uc;
+        left += __popcll(__ballot(hd[j] && static_cast<int32_t>(colv[j]) < r));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // every read of the parked pairs precedes the records' stores
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int base_rank = 0, base_rest = 0;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int i = j * 64 + lane;
+        if (j * 64 >= cnt) continue;
+        const uint64_t H = __ballot(hd[j]);
+        const uint64_t below = (1ull << lane) - 1ull;
+        const int rank = base_rank + __popcll(H & below);
+        const int live = cnt - j * 64 < 64 ? cnt - j * 64 : 64;
+        if (i < cnt) {
+            uint4 rec;
+            int64_t pos;
+            if (hd[j]) {
+                rec.x = colv[j] | ((left >= 1 && rank == left - 1) ? kFlag : 0u);
+                rec.y = __float_as_uint(sv[j] / 2.f);
+                rec.z = __float_as_uint(tv[j]);
+                rec.w = static_cast<uint32_t>(r) | ((left == 0 && rank == 0) ? kFlag : 0u);
+                pos = gbeg + rank;
+            } else {
+                rec = make_uint4(0u, 0u, 0u, kNoEntry);
+                pos = gbeg + u + base_rest + (lane - __popcll(H & below));
+            }
+            ent[pos] = rec;
+        }
+        base_rank += __popcll(H);
+        base_rest += live - __popcll(H);
+    }
+    if (lane == 0) {
+        ucnt[r] = u;
+        deg[r] = d;
+    }
+}
+
+// One workgroup per bucket, TWO rounds over its rows (rows 0 .. 2^(rl-1) - 1, then the rest): keys and weights of a round's rows
+// are placed row by row in LDS (8 bytes per entry: half a bucket per round), and each row is ordered and merged by a wavefront with
+// merge_one_row -- the very function the sorted pipeline calls -- so the records, distinct counts and degrees are the ones
+// row_tables / values_entries expect.  Stream positions: the bucket's range, round 0's rows first.
+// LDS: pk[cap / 2], pw[cap / 2], rcnt[2^(rl-1) + 8], roff[2^(rl-1) + 8].
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, const uint32_t* __restrict__ stream,
+                                                               const float* __restrict__ wstream, const int32_t* __restrict__ off,
+                                                               int32_t n, int32_t deg_mode, int32_t* __restrict__ rs,
+                                                               int32_t* __restrict__ ucnt, float* __restrict__ deg,
+                                                               uint4* __restrict__ ent, int64_t* __restrict__ info)
+{
+    constexpr int EPT = 32, WAVES = THREADS / 64;
+    extern __shared__ uint32_t bucket_lds[];
+    const int half_cap = pl.cap / 2, hrow = (1 << pl.rl) >> 1;    // (rl >= 3: a bucket has at least 8 rows)
+    uint32_t* pk = bucket_lds;
+    float* pw = reinterpret_cast<float*>(bucket_lds + half_cap);
+    uint32_t* rcnt = bucket_lds + 2 * half_cap;
+    uint32_t* roff = rcnt + hrow + 8;
+    __shared__ uint32_t wsum[WAVES];
+    __shared__ uint32_t round_total;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int32_t row0 = b << pl.rl;
+    const int32_t b0 = off[static_cast<int64_t>(b) * pl.g], b1 = off[static_cast<int64_t>(b + 1) * pl.g];
+    const int cnt_b = b1 - b0;
+    if (b == pl.nb - 1 && t == 0) {
+        rs[n] = b1;
+        rs[n + 1] = b1;
+        ucnt[n] = 0;                                              // the scan's (n + 1)-th input
+    }
+    if (cnt_b > pl.cap) {                                          // host: the sorted pipeline
+        if (t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
+        return;
+    }
+    uint32_t ek[EPT];
+    float ew[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int i = t + k * THREADS;
+        ek[k] = i < cnt_b ? __builtin_nontemporal_load(stream + b0 + i) : 0u;
+        ew[k] = i < cnt_b ? __builtin_nontemporal_load(wstream + b0 + i) : 0.f;
+    }
+    const int sh = pl.cbits + 1;
+    const uint32_t kmask = (1u << sh) - 1u;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    bool unordered = false;
+    int32_t pos0 = b0;                                             // first stream position of this round's rows
+    for (int round = 0; round < 2; ++round) {
+        for (int i = t; i <= hrow; i += THREADS) rcnt[i] = 0;
+        __syncthreads();
+        const uint32_t rlo = static_cast<uint32_t>(round * hrow);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const uint32_t rl_ = ek[k] >> sh;
+            if (t + k * THREADS < cnt_b && rl_ - rlo < static_cast<uint32_t>(hrow)) atomicAdd(&rcnt[rl_ - rlo], 1u);
+        }
+        __syncthreads();
+        uint32_t mine = t < hrow ? rcnt[t] : 0u, inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        uint32_t base = 0, all = 0;
+        for (int q = 0; q < WAVES; ++q) {
+            if (q < wv) base += wsum[q];
+            all += wsum[q];
+        }
+        const uint32_t excl = base + inc - mine;
+        if (t == 0) round_total = all;
+        const bool fits = all <= static_cast<uint32_t>(half_cap);  // (workgroup-uniform)
+        if (t < hrow) {
+            roff[t] = excl;
+            rcnt[t] = excl;                                        // placement cursor
+            const int32_t r = row0 + static_cast<int32_t>(rlo) + t;
+            if (r < n) rs[r] = pos0 + static_cast<int32_t>(excl);
+        }
+        if (t == 0) roff[hrow] = all;
+        __syncthreads();
+        if (!fits) {                                               // half a bucket that exceeds its share of the LDS: sorted pipeline
+            if (t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
+        } else {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const uint32_t rl_ = ek[k] >> sh;
+                if (t + k * THREADS < cnt_b && rl_ - rlo < static_cast<uint32_t>(hrow)) {
+                    const uint32_t at = atomicAdd(&rcnt[rl_ - rlo], 1u);
+                    pk[at] = ek[k] & kmask;
+                    pw[at] = ew[k];
+                }
+            }
+            __syncthreads();
+            for (int rr = wvu; rr < hrow; rr += WAVES) {
+                const int32_t r = row0 + static_cast<int32_t>(rlo) + rr;
+                if (r >= n) break;
+                const int beg = __builtin_amdgcn_readfirstlane(static_cast<int>(roff[rr]));
+                const int cnt = __builtin_amdgcn_readfirstlane(static_cast<int>(roff[rr + 1])) - beg;
+                if (cnt <= 64) {
+                    const int at = beg + (lane < cnt ? lane : 0);
+                    merge_one_row<uint32_t>(r, pos0 + beg, cnt, pk[cnt ? at : 0], pw[cnt ? at : 0], true, lane, deg_mode, ucnt, deg, ent,
+                                            &unordered);
+                } else if (cnt <= kUnitRowMax) {
+                    merge_long_row_w(pk + beg, pw + beg, cnt, r, static_cast<int64_t>(pos0) + beg, lane, deg_mode, ucnt, deg, ent,
+                                     &unordered);
+                } else {
+                    if (lane == 0) {
+                        atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
+                        ucnt[r] = 0;
+                        deg[r] = 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        pos0 += static_cast<int32_t>(round_total);
+        __syncthreads();
+    }
+    if (__syncthreads_or(unordered) && t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
+}
+
 // rocPRIM's gfx950 default for 64-bit keys sorts 8 bits per pass (3 passes for 20 row bits); 10 bits per pass with
 // 1024-thread blocks needs 2 -- tools/probes/sort_probe.hip, 40 M keys: 0.82 -> 0.64 ms (keys), 1.08 -> 0.85 ms (pairs)
 using RowSortConfig = rocprim::radix_sort_config<
@@ -1483,7 +1857,7 @@ int magop_layout(int64_t e, int32_t n, int weighted, MagopWs* w)
                                           nn + 1, rocprim::plus<int32_t>(), hipStream_t(nullptr)));
     BucketPlan pl;
     size_t table = 0;
-    if (!weighted && bucket_plan(e, n, 0, &pl)) {
+    if (bucket_plan(e, n, 0, &pl)) {                              // (both forms: unit weights and, since round 5, real-valued ones)
         table = static_cast<size_t>(pl.nb) * pl.g + 1;
         size_t scan2 = 0;
         PYGSD_HIP_TRY(rocprim::exclusive_scan(nullptr, scan2, i32, i32, 0, table, rocprim::plus<int32_t>(), hipStream_t(nullptr)));
@@ -1532,9 +1906,11 @@ extern "C" int pygsd_magop_workspace(int64_t n_edges, int32_t n, int32_t weighte
     return 0;
 }
 
-extern "C" int pygsd_magop_stage1(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
-                                  int32_t is_signed, int32_t absolute_degree, int32_t sym, void* workspace,
-                                  size_t workspace_bytes, int32_t* rowptr, float* deg, int64_t* d_info, void* stream)
+// sorted_front: the radix sort on the row bits in front of the row merge (round 3; rows of up to 4096 entries, any duplicates);
+// otherwise weighted graphs the bucket plan takes go through bucket_scatter_w / bucket_merge_rows_w (round 5)
+static int magop_stage1_impl(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
+                             int32_t is_signed, int32_t absolute_degree, int32_t sym, void* workspace,
+                             size_t workspace_bytes, int32_t* rowptr, float* deg, int64_t* d_info, void* stream, bool sorted_front)
 {
     PYGSD_REQUIRE(n >= 0 && n_edges >= 0 && 2 * n_edges < (int64_t(1) << 31), "pygsd_magop_stage1: size out of int32 range");
     PYGSD_REQUIRE(workspace && rowptr && d_info && (n == 0 || deg), "pygsd_magop_stage1: null pointer");
@@ -1564,6 +1940,39 @@ extern "C" int pygsd_magop_stage1(const int64_t* row, const int64_t* col, const 
     PYGSD_HIP_TRY(hipMemsetAsync(d_info, 0, 4 * sizeof(int64_t), s));
     PYGSD_HIP_TRY(hipMemsetAsync(n_long, 0, sizeof(int32_t), s));
     PYGSD_HIP_TRY(hipMemsetAsync(ucnt + n, 0, sizeof(int32_t), s));
+    const int deg_mode = is_signed ? (absolute_degree ? 2 : 1) : 0;
+    BucketPlan pl;
+    const char* wform = getenv("PYGSD_WEIGHTED_BUILD_FORM");      // "sort": the radix-sort front for every graph (measurement / tests)
+    if (weighted && !sorted_front && !(wform && strcmp(wform, "sort") == 0) && n > 0 && n_edges > 0 &&
+        bucket_plan(n_edges, n, 0, &pl)) {
+        int32_t* hist = reinterpret_cast<int32_t*>(base + l.hist);
+        int32_t* off = reinterpret_cast<int32_t*>(base + l.off);
+        uint32_t* stream_k = reinterpret_cast<uint32_t*>(keys_b);
+        hipLaunchKernelGGL(bucket_count, dim3(pl.g), dim3(kPassThreads), 0, s, row, col, static_cast<const float*>(nullptr), 0, n_edges, n,
+                           pl, hist, d_info, 0.f, reinterpret_cast<float*>(base + l.n_long) + 4, dinv);
+        if (int rc = check_launch("bucket_count")) return rc;
+        size_t tb2 = l.scan_tmp_bytes;
+        PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb2, hist, off, 0, static_cast<size_t>(pl.nb) * pl.g + 1,
+                                              rocprim::plus<int32_t>(), s));
+        const size_t lds2 = (static_cast<size_t>(2 * kTileEdges) + 2 * kScatterThreads + 2 * static_cast<size_t>(pl.nb)) * sizeof(uint32_t);
+        static const hipError_t once2 = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_scatter_w),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        PYGSD_HIP_TRY(once2);
+        hipLaunchKernelGGL(bucket_scatter_w, dim3(pl.g), dim3(kScatterThreads), lds2, s, row, col, w, n_edges, n, pl, off, stream_k, w_b);
+        if (int rc = check_launch("bucket_scatter_w")) return rc;
+        const size_t lds = (static_cast<size_t>(pl.cap) + 2 * (((size_t(1) << pl.rl) >> 1) + 8)) * sizeof(uint32_t);
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows_w<1024>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        PYGSD_HIP_TRY(once);
+        hipLaunchKernelGGL(bucket_merge_rows_w<1024>, dim3(pl.nb), dim3(1024), lds, s, pl, stream_k, static_cast<const float*>(w_b), off, n,
+                           deg_mode, rs, ucnt, deg, ent, d_info);
+        if (int rc = check_launch("bucket_merge_rows_w")) return rc;
+        size_t tb3 = l.scan_tmp_bytes;
+        PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb3, rocprim::make_transform_iterator(ucnt, PlusOne()), rowptr, 0,
+                                              static_cast<size_t>(n) + 1, rocprim::plus<int32_t>(), s));
+        hipLaunchKernelGGL(row_tables, dim3(grid_for(n)), dim3(kBlock), 0, s, deg, rs, rowptr, n, sym, dinv, shift, d_info);
+        return check_launch("row_tables");
+    }
     if (n_edges > 0) {
         hipLaunchKernelGGL(edge_keys, dim3(grid_for(n_edges)), dim3(kBlock), 0, s, row, col, w, n_edges, n, keys_a, w_a, d_info);
         if (int rc = check_launch("edge_keys")) return rc;
@@ -1579,7 +1988,6 @@ extern "C" int pygsd_magop_stage1(const int64_t* row, const int64_t* col, const 
     } else {
         PYGSD_HIP_TRY(hipMemsetAsync(rs, 0, sizeof(int32_t) * (static_cast<size_t>(n) + 2), s));
     }
-    const int deg_mode = is_signed ? (absolute_degree ? 2 : 1) : 0;
     if (n > 0) {
         const int64_t per_block = 4 * kRowsPerWave;
         const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n) + per_block - 1) / per_block);
@@ -1600,6 +2008,22 @@ extern "C" int pygsd_magop_stage1(const int64_t* row, const int64_t* col, const 
     hipLaunchKernelGGL(row_tables, dim3(grid_for(n > 0 ? n : 1)), dim3(kBlock), 0, s, deg, rs, rowptr, n, sym, dinv, shift,
                        d_info);
     return check_launch("row_tables");
+}
+
+extern "C" int pygsd_magop_stage1(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
+                                  int32_t is_signed, int32_t absolute_degree, int32_t sym, void* workspace,
+                                  size_t workspace_bytes, int32_t* rowptr, float* deg, int64_t* d_info, void* stream)
+{
+    return magop_stage1_impl(row, col, w, n_edges, n, is_signed, absolute_degree, sym, workspace, workspace_bytes, rowptr, deg, d_info,
+                             stream, false);
+}
+
+extern "C" int pygsd_magop_stage1_sorted(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
+                                         int32_t is_signed, int32_t absolute_degree, int32_t sym, void* workspace,
+                                         size_t workspace_bytes, int32_t* rowptr, float* deg, int64_t* d_info, void* stream)
+{
+    return magop_stage1_impl(row, col, w, n_edges, n, is_signed, absolute_degree, sym, workspace, workspace_bytes, rowptr, deg, d_info,
+                             stream, true);
 }
 
 extern "C" int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, int32_t sym, float lambda_max,

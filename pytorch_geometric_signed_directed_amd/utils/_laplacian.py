@@ -196,7 +196,8 @@ _UNIT_BUILD = os.environ.get("PYGSD_TWO_STAGE_BUILD", "0") != "1"
 
 
 _SIGNED_UNIT_BUILD = os.environ.get("PYGSD_SIGNED_UNIT_BUILD", "1") != "0"
-_NOT_PM1 = TensorMemo(8)  # weight tensors the +-1 build has turned down (weakly held, per in-place version)
+_NOT_PM1 = TensorMemo(8)
+_NOT_BUCKETS = TensorMemo(8)   # (edge_index, edge_weight) pairs the weighted bucket form has turned down (duplicates, hub rows)  # weight tensors the +-1 build has turned down (weakly held, per in-place version)
 
 
 def set_signed_unit_build(on: bool) -> bool:
@@ -320,10 +321,6 @@ def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int
         info = torch.empty(4, dtype=torch.int64, device=dev)
         rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         deg = torch.empty(n, dtype=torch.float32, device=dev)
-        check(lib.pygsd_magop_stage1(ptr(row), ptr(col), ptr(w), e, n, 1 if signed else 0, 1 if absolute_degree else 0,
-                                     sym, ptr(ws), need.value, ptr(rowptr), ptr(deg), ptr(info), stream_ptr()),
-              "pygsd_magop_stage1")
-        host_info, ready = _queue_info_read(info, dev)   # queued behind stage 1; the host waits for THIS, not for stage 2
         # E_s is not known on the host yet -- and is not needed to LAUNCH the second stage: the outputs are allocated
         # at their upper bound (every listed edge distinct, no self loops: 2 E + n; the bound is tight on the graphs this
         # is built for) and narrowed after the one host read below, which then overlaps the second stage instead of
@@ -333,14 +330,30 @@ def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int
         ccol = torch.empty(cap, dtype=torch.int32, device=dev)
         pad = max((cap + 3) // 4 * 4, 4)              # every value array starts on a 16-byte boundary (dwordx4 stores)
         vals = torch.empty((4, pad), dtype=torch.float32, device=dev)
-        check(lib.pygsd_magop_stage2(e, n, 0 if w is None else 1, float(q), sym, float(lambda_max), float(diag_shift),
-                                     ptr(ws), need.value, ptr(rowptr), ptr(deg), ptr(ccol), ptr(vals[0]), ptr(vals[1]),
-                                     ptr(vals[2]), ptr(vals[3]), stream_ptr()), "pygsd_magop_stage2")
-        ready.synchronize()                                       # the one host round-trip
-        es, too_long, bad, bad_id = host_info.tolist()
-        if bad:
-            raise IndexError(f"edge_index holds node id {bad_id}, outside [0, {n}); the HIP path gathers and "
-                             "scatters rows by these ids")
+        # Round 5: a weighted graph first goes through the stage whose front is the bucket split (no global sort).  It takes what
+        # cannot show the order its LDS atomics deliver the entries in -- runs of at most two entries per neighbour, rows of at most
+        # 512 -- and reports anything else in info[1]; the stage behind the radix sort then builds the graph (and the pair of
+        # tensors is remembered, so the next build goes there directly).
+        memo_key = (signed, absolute_degree)
+        sorted_first = w is None or _NOT_BUCKETS.get((edge_index, edge_weight), memo_key) is not None
+        for attempt in ((True,) if sorted_first else (False, True)):
+            stage1 = lib.pygsd_magop_stage1_sorted if attempt else lib.pygsd_magop_stage1
+            check(stage1(ptr(row), ptr(col), ptr(w), e, n, 1 if signed else 0, 1 if absolute_degree else 0,
+                         sym, ptr(ws), need.value, ptr(rowptr), ptr(deg), ptr(info), stream_ptr()),
+                  "pygsd_magop_stage1_sorted" if attempt else "pygsd_magop_stage1")
+            host_info, ready = _queue_info_read(info, dev)   # queued behind stage 1; the host waits for THIS, not for stage 2
+            check(lib.pygsd_magop_stage2(e, n, 0 if w is None else 1, float(q), sym, float(lambda_max), float(diag_shift),
+                                         ptr(ws), need.value, ptr(rowptr), ptr(deg), ptr(ccol), ptr(vals[0]), ptr(vals[1]),
+                                         ptr(vals[2]), ptr(vals[3]), stream_ptr()), "pygsd_magop_stage2")
+            ready.synchronize()                                       # the one host round-trip
+            es, too_long, bad, bad_id = host_info.tolist()
+            if bad:
+                raise IndexError(f"edge_index holds node id {bad_id}, outside [0, {n}); the HIP path gathers and "
+                                 "scatters rows by these ids")
+            if not too_long:
+                break
+            if not attempt:
+                _NOT_BUCKETS.put((edge_index, edge_weight), memo_key, True)
         if too_long:
             return None
         nnz = es + n

@@ -1119,6 +1119,95 @@ def test_signed_unit_operator_build_at_512_rows_per_bucket():
     _same_operator(got, _generic_operator(ei, w, n, True, True, 0.25, "sym", 2.0))
 
 
+def _weighted_graph(n, e, seed, signed, hubs=()):
+    """Random weighted digraph whose symmetrised runs hold at most two entries (what the weighted bucket form takes): reciprocal
+    pairs for one tenth of the edges, exact duplicates for ANOTHER twentieth, self loops, isolated last nodes; optional hub rows of
+    exactly k stream entries."""
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n - 40, (e,), generator=g)
+    dst = torch.randint(0, n - 40, (e,), generator=g)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    # one entry per unordered pair, so that adding a reciprocal / a duplicate makes runs of exactly two
+    key = torch.minimum(src, dst) * n + torch.maximum(src, dst)
+    first = torch.unique(key, return_inverse=True)[1]
+    order = torch.argsort(first, stable=True)
+    uniq = torch.ones_like(first, dtype=torch.bool)
+    uniq[order[1:]] = first[order[1:]] != first[order[:-1]]
+    src, dst = src[uniq], dst[uniq]
+    e = src.numel()
+    for hub, _ in hubs:
+        drop = (src == hub) | (dst == hub)
+        src, dst = src[~drop], dst[~drop]
+    e = src.numel()
+    parts = [torch.stack([src, dst]), torch.stack([dst[:e // 10], src[:e // 10]]),
+             torch.stack([src[e // 2:e // 2 + e // 20], dst[e // 2:e // 2 + e // 20]])]
+    loops = torch.randint(0, n - 40, (e // 50 + 2,), generator=g)
+    parts.append(torch.stack([loops, loops]))
+    for hub, k in hubs:
+        other = torch.randperm(n - 5000, generator=g)[:k] + 4500
+        other = other[other != hub]
+        half = other.numel() // 2
+        parts.append(torch.stack([torch.full((half,), hub), other[:half]]))
+        parts.append(torch.stack([other[half:], torch.full((other.numel() - half,), hub)]))
+    ei = torch.cat(parts, dim=1)
+    ei = ei[:, torch.randperm(ei.size(1), generator=g)]
+    w = torch.rand(ei.size(1), generator=g) + 0.5
+    if signed:
+        w = w * (torch.randint(0, 2, (ei.size(1),), generator=g) * 2 - 1).float()
+    return ei, w
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,e,signed,absdeg,norm,lam", [(50007, 600000, False, True, "sym", 2.0), (50007, 600000, True, True, None, 3.0),
+                                                        (50007, 600000, True, False, "sym", 1.7), (300, 2000, True, True, "sym", 2.0),
+                                                        (600000, 9000000, True, True, "sym", 2.0)])
+def test_weighted_bucket_operator_build_is_bitwise_the_generic_pipeline(n, e, signed, absdeg, norm, lam):
+    """Round 5: real-valued weights through the bucket split (bucket_scatter_w / bucket_merge_rows_w in front of the unchanged second
+    stage; get_magnetic_Laplacian.py:52-85, get_magnetic_signed_Laplacian.py:52-90 with edge weights) -- reciprocal pairs, exact
+    duplicates (runs of two entries: fp32 addition commutes), self loops, isolated nodes, rows of 64 / 65 / 103 / 303 / 512 stream
+    entries (from 65: the rank sort through the record slots), every degree convention, both normalisations; 600 k nodes: buckets of
+    512 rows in two rounds of 256.  Bit-identical to the generic pipeline and from run to run, and TAKEN (nothing was handed to the
+    sorted pipeline)."""
+    from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
+    hubs = ((7, 64), (8, 65), (9, 103), (4000, 303), (n - 50, 512)) if n == 50007 else ()
+    ei, w = _weighted_graph(n, e, seed=n + e, signed=signed, hubs=hubs)
+    d = dev()
+    ei, w = ei.to(d), w.to(d)
+    got = L.fused_operator_csr(ei, w, n, signed, absdeg, 0.25, norm, lam)
+    assert got is not None
+    assert L._NOT_BUCKETS.get((ei, w), (signed, absdeg)) is None      # the bucket form took the graph
+    if hubs:
+        lens = (got[0].rowptr[1:] - got[0].rowptr[:-1]).cpu()
+        assert [int(lens[k]) for k in (7, 8, 9, 4000, n - 50, n - 1)] == [65, 66, 104, 304, 513, 1]
+    _same_operator(L.fused_operator_csr(ei, w, n, signed, absdeg, 0.25, norm, lam), got)
+    _same_operator(got, _generic_operator(ei, w, n, signed, absdeg, 0.25, norm, lam))
+
+
+@pytest.mark.gpu
+def test_weighted_bucket_operator_build_steps_aside(monkeypatch):
+    """What the weighted bucket form must not decide on its own goes to the sorted pipeline and still matches the generic one: an
+    edge listed three times (its fp32 sum depends on the order: the reference's is the list order), a reciprocal pair with a
+    duplicate, a row of 513 entries; the pair of tensors is remembered, and PYGSD_WEIGHTED_BUILD_FORM=sort never tries."""
+    from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
+    n = 50007
+    d = dev()
+    ei, w = _weighted_graph(n, 300000, seed=77, signed=True)
+    g = torch.Generator().manual_seed(8)
+    for extra in (torch.tensor([[3, 3, 3], [9, 9, 9]]), torch.tensor([[20, 21, 20], [21, 20, 21]]),
+                  torch.stack([torch.full((513,), 5), torch.arange(100, 613)])):
+        ei2 = torch.cat([ei, extra], dim=1).to(d)
+        w2 = torch.cat([w, torch.rand(extra.size(1), generator=g) + 0.5]).to(d)
+        want = _generic_operator(ei2, w2, n, True, True, 0.25, "sym", 2.0)
+        assert L._NOT_BUCKETS.get((ei2, w2), (True, True)) is None
+        _same_operator(L.fused_operator_csr(ei2, w2, n, True, True, 0.25, "sym", 2.0), want)
+        assert L._NOT_BUCKETS.get((ei2, w2), (True, True)) is True
+        _same_operator(L.fused_operator_csr(ei2, w2, n, True, True, 0.25, "sym", 2.0), want)
+    monkeypatch.setenv("PYGSD_WEIGHTED_BUILD_FORM", "sort")
+    eid, wd = ei.to(d), w.to(d)
+    _same_operator(L.fused_operator_csr(eid, wd, n, True, True, 0.25, "sym", 2.0), _generic_operator(eid, wd, n, True, True, 0.25, "sym", 2.0))
+
+
 @pytest.mark.gpu
 def test_unit_operator_build_forms_agree_at_512_rows_per_bucket():
     """600 k nodes: buckets of 512 rows, 20 k entries each (the geometry of the north star) -- the two forms of the unweighted build

@@ -24,7 +24,8 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--norm", default="sym", help="sym | none")
 ap.add_argument("--only", default="", help="comma list of legs: fused (= round 4's one-pass unweighted build), two_stage (round 3's), "
                                            "generic, fused_signed (+-1 weights: round 5's one-call build), two_stage_signed, "
-                                           "fused_real_weights, generic_signed")
+                                           "fused_real_weights (round 5: the weighted bucket form), sorted_real_weights (behind the radix sort), "
+                                           "generic_signed")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 NORM = None if args.norm == "none" else "sym"
@@ -79,7 +80,16 @@ def two_stage_signed():
 
 g_w = torch.Generator(device=dev).manual_seed(3)
 w_real = w_s * (torch.rand(w_s.shape, generator=g_w, device=dev) + 0.5)     # real-valued signed weights: the two-stage pipeline
+def sorted_real_weights():
+    os.environ["PYGSD_WEIGHTED_BUILD_FORM"] = "sort"
+    try:
+        return fused(ei_s, w_real, n, True)
+    finally:
+        os.environ.pop("PYGSD_WEIGHTED_BUILD_FORM", None)
+
+
 legs = {"fused": lambda: fused(ei, None, n, False), "two_stage": two_stage, "generic": lambda: generic(ei, None, n, False),
+        "sorted_real_weights": sorted_real_weights,
         "fused_signed": lambda: fused(ei_s, w_s, n, True), "two_stage_signed": two_stage_signed,
         "fused_real_weights": lambda: fused(ei_s, w_real, n, True), "generic_signed": lambda: generic(ei_s, w_s, n, True)}
 only = [s for s in args.only.split(",") if s] or list(legs)
