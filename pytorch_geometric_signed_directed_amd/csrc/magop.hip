@@ -1718,7 +1718,7 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
                                                                int32_t* __restrict__ ucnt, float* __restrict__ deg,
                                                                uint4* __restrict__ ent, int64_t* __restrict__ info)
 {
-    constexpr int EPT = 32, WAVES = THREADS / 64;
+    constexpr int WAVES = THREADS / 64;
     extern __shared__ uint32_t bucket_lds[];
     const int half_cap = pl.cap / 2, hrow = (1 << pl.rl) >> 1;    // (rl >= 3: a bucket has at least 8 rows)
     uint32_t* pk = bucket_lds;
@@ -1740,14 +1740,8 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
         if (t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
         return;
     }
-    uint32_t ek[EPT];
-    float ew[EPT];
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-        const int i = t + k * THREADS;
-        ek[k] = i < cnt_b ? __builtin_nontemporal_load(stream + b0 + i) : 0u;
-        ew[k] = i < cnt_b ? __builtin_nontemporal_load(wstream + b0 + i) : 0.f;
-    }
+    // (the bucket's entries are NOT held in registers across the rounds -- 64 of a 1024-thread workgroup's 128 VGPRs, and the row
+    // routines spilled: each pass re-reads its 80 - 160 KB from the L2 instead)
     const int sh = pl.cbits + 1;
     const uint32_t kmask = (1u << sh) - 1u;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
@@ -1757,10 +1751,9 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
         for (int i = t; i <= hrow; i += THREADS) rcnt[i] = 0;
         __syncthreads();
         const uint32_t rlo = static_cast<uint32_t>(round * hrow);
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const uint32_t rl_ = ek[k] >> sh;
-            if (t + k * THREADS < cnt_b && rl_ - rlo < static_cast<uint32_t>(hrow)) atomicAdd(&rcnt[rl_ - rlo], 1u);
+        for (int i = t; i < cnt_b; i += THREADS) {
+            const uint32_t rl_ = stream[b0 + i] >> sh;
+            if (rl_ - rlo < static_cast<uint32_t>(hrow)) atomicAdd(&rcnt[rl_ - rlo], 1u);
         }
         __syncthreads();
         uint32_t mine = t < hrow ? rcnt[t] : 0u, inc = mine;
@@ -1790,13 +1783,13 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
         if (!fits) {                                               // half a bucket that exceeds its share of the LDS: sorted pipeline
             if (t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
         } else {
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                const uint32_t rl_ = ek[k] >> sh;
-                if (t + k * THREADS < cnt_b && rl_ - rlo < static_cast<uint32_t>(hrow)) {
+            for (int i = t; i < cnt_b; i += THREADS) {
+                const uint32_t key = stream[b0 + i];
+                const uint32_t rl_ = key >> sh;
+                if (rl_ - rlo < static_cast<uint32_t>(hrow)) {
                     const uint32_t at = atomicAdd(&rcnt[rl_ - rlo], 1u);
-                    pk[at] = ek[k] & kmask;
-                    pw[at] = ew[k];
+                    pk[at] = key & kmask;
+                    pw[at] = wstream[b0 + i];
                 }
             }
             __syncthreads();
@@ -1962,7 +1955,7 @@ static int magop_stage1_impl(const int64_t* row, const int64_t* col, const float
         if (int rc = check_launch("bucket_scatter_w")) return rc;
         const size_t lds = (static_cast<size_t>(pl.cap) + 2 * (((size_t(1) << pl.rl) >> 1) + 8)) * sizeof(uint32_t);
         static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows_w<1024>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         PYGSD_HIP_TRY(once);
         hipLaunchKernelGGL(bucket_merge_rows_w<1024>, dim3(pl.nb), dim3(1024), lds, s, pl, stream_k, static_cast<const float*>(w_b), off, n,
                            deg_mode, rs, ucnt, deg, ent, d_info);

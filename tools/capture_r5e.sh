@@ -17,6 +17,6 @@ import csv
 for r in list(csv.DictReader(open("gpurun_out/r5e_prof_build/b_kernel_stats.csv")))[:16]:
     print("%6s %9.1f us  %s" % (r["Calls"], float(r["AverageNs"]) / 1e3, r["Name"][:100]))
 PY
-( timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -x -p no:cacheprovider -k "sharded_signed or c3" > $O/r5e_pytest_c3.log 2>&1; echo "rc=$?" >> $O/r5e_pytest_c3.log )
-tail -6 $O/r5e_pytest_c3.log
-timeout 400 python tools/emulate_sharded_c3.py > $O/r5e_emulated_c3.log 2>&1; cut -c1-420 $O/r5e_emulated_c3.log | tail -3
+
+
+
