@@ -267,7 +267,9 @@ constexpr uint32_t kFlag = 0x80000000u;
 // order_free_only (round 5: rows whose entries arrive in NO particular order, bucket_merge_rows_w): a run of three or more entries
 // of one neighbour is reported in `*unordered` instead of trusted -- its fp32 sum depends on the order the reference adds them in;
 // runs of one or two entries do not (a + b = b + a).
-template <typename KT>
+// SHORT_RUNS (with `unordered`): only the first two entries of a run are summed -- one lane shift instead of the ballot-driven
+// loop over the longest run of the row; a longer run has been reported, the caller discards the build.
+template <typename KT, bool SHORT_RUNS = false>
 __device__ __forceinline__ void merge_one_row(int32_t r, int32_t beg, int32_t cnt, uint32_t c2, float w0, bool weighted,
                                               int lane, int32_t deg_mode, int32_t* __restrict__ ucnt,
                                               float* __restrict__ deg, uint4* __restrict__ ent, bool* unordered = nullptr)
@@ -297,15 +299,29 @@ __device__ __forceinline__ void merge_one_row(int32_t r, int32_t beg, int32_t cn
     float s = 0.f, t = 0.f, a = 0.f, d = 0.f;
     if (weighted) {
         const float wv = __shfl(w0, src);                         // weight of the entry this lane holds after the sort
-        for (int j = 0;; ++j) {                                   // runs are summed in sorted order, like coalesce
-            const bool act = head && j < len;
-            if (!__ballot(act)) break;
-            const float wj = __shfl(wv, lane + j);
-            const int rj = __shfl(static_cast<int>(rev), lane + j);
-            if (act) {
-                s = s + wj;
-                t = t + (rj ? -wj : wj);
-                a = a + fabsf(wj);
+        if constexpr (SHORT_RUNS) {
+            // the same additions in the same order as the loop below, for its first two turns (0 + w_0, then + w_1)
+            const float w1 = __shfl_down(wv, 1);
+            const int r1 = __shfl_down(static_cast<int>(rev), 1);
+            s = s + wv;
+            t = t + (rev ? -wv : wv);
+            a = a + fabsf(wv);
+            if (len >= 2) {
+                s = s + w1;
+                t = t + (r1 ? -w1 : w1);
+                a = a + fabsf(w1);
+            }
+        } else {
+            for (int j = 0;; ++j) {                               // runs are summed in sorted order, like coalesce
+                const bool act = head && j < len;
+                if (!__ballot(act)) break;
+                const float wj = __shfl(wv, lane + j);
+                const int rj = __shfl(static_cast<int>(rev), lane + j);
+                if (act) {
+                    s = s + wj;
+                    t = t + (rj ? -wj : wj);
+                    a = a + fabsf(wj);
+                }
             }
         }
         // degree: SEQUENTIAL sum over the distinct entries in column order (scatter_add_'s order on the reference's
@@ -1736,8 +1752,18 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
         rs[n + 1] = b1;
         ucnt[n] = 0;                                              // the scan's (n + 1)-th input
     }
+    // Whatever this kernel does not merge is reported in info[1] -- and its record slots are marked empty all the same: the host
+    // queues the second stage BEFORE it reads info, and values_entries indexes its tables with what the records name.
+    const uint4 no_entry = make_uint4(0u, 0u, 0u, kNoEntry);
     if (cnt_b > pl.cap) {                                          // host: the sorted pipeline
         if (t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
+        for (int i = t; i < cnt_b; i += THREADS) ent[b0 + i] = no_entry;
+        for (int i = t; i < (1 << pl.rl); i += THREADS)
+            if (row0 + i < n) {
+                rs[row0 + i] = b0;
+                ucnt[row0 + i] = 0;
+                deg[row0 + i] = 0.f;
+            }
         return;
     }
     // (the bucket's entries are NOT held in registers across the rounds -- 64 of a 1024-thread workgroup's 128 VGPRs, and the row
@@ -1782,6 +1808,11 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
         __syncthreads();
         if (!fits) {                                               // half a bucket that exceeds its share of the LDS: sorted pipeline
             if (t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
+            for (uint32_t i = t; i < all; i += THREADS) ent[pos0 + i] = no_entry;
+            if (t < hrow && row0 + static_cast<int32_t>(rlo) + t < n) {
+                ucnt[row0 + rlo + t] = 0;
+                deg[row0 + rlo + t] = 0.f;
+            }
         } else {
             for (int i = t; i < cnt_b; i += THREADS) {
                 const uint32_t key = stream[b0 + i];
@@ -1800,12 +1831,13 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
                 const int cnt = __builtin_amdgcn_readfirstlane(static_cast<int>(roff[rr + 1])) - beg;
                 if (cnt <= 64) {
                     const int at = beg + (lane < cnt ? lane : 0);
-                    merge_one_row<uint32_t>(r, pos0 + beg, cnt, pk[cnt ? at : 0], pw[cnt ? at : 0], true, lane, deg_mode, ucnt, deg, ent,
-                                            &unordered);
+                    merge_one_row<uint32_t, true>(r, pos0 + beg, cnt, pk[cnt ? at : 0], pw[cnt ? at : 0], true, lane, deg_mode, ucnt, deg,
+                                                  ent, &unordered);
                 } else if (cnt <= kUnitRowMax) {
                     merge_long_row_w(pk + beg, pw + beg, cnt, r, static_cast<int64_t>(pos0) + beg, lane, deg_mode, ucnt, deg, ent,
                                      &unordered);
                 } else {
+                    for (int i = lane; i < cnt; i += 64) ent[pos0 + beg + i] = no_entry;
                     if (lane == 0) {
                         atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
                         ucnt[r] = 0;
