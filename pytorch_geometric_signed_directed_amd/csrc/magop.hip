@@ -272,7 +272,8 @@ constexpr uint32_t kFlag = 0x80000000u;
 template <typename KT, bool SHORT_RUNS = false>
 __device__ __forceinline__ void merge_one_row(int32_t r, int32_t beg, int32_t cnt, uint32_t c2, float w0, bool weighted,
                                               int lane, int32_t deg_mode, int32_t* __restrict__ ucnt,
-                                              float* __restrict__ deg, uint4* __restrict__ ent, bool* unordered = nullptr)
+                                              float* __restrict__ deg, uint4* __restrict__ ent, bool* unordered = nullptr,
+                                              float* scratch = nullptr)
 {
     const bool have = lane < cnt;
     KT lk = have ? static_cast<KT>((static_cast<KT>(c2) << 6) | static_cast<KT>(lane)) : static_cast<KT>(~static_cast<KT>(0));
@@ -328,9 +329,32 @@ __device__ __forceinline__ void merge_one_row(int32_t r, int32_t beg, int32_t cn
         // CPU path).  Compact the per-entry sources into lanes 0 .. u-1 (heads go to their rank, the other lanes
         // fill the rest: a permutation), then lane-serial adds.
         const int dest = head ? rank : u + (lane - heads_upto);
-        const float dense = __int_as_float(
-            __builtin_amdgcn_ds_permute(dest << 2, __float_as_int(degree_source(s, a, deg_mode))));
-        for (int k = 0; k < u; ++k) d = d + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dense), k));
+        if (scratch) {
+            // Round 5: through 64 floats of wavefront-private LDS -- the compaction is the store itself, and ONE lane adds the
+            // u values in order, four per ds_read_b128 (the lanes behind the distinct entries hold +0: d + 0 = d bit for bit, d is
+            // never -0).  The readlane loop below costs a taken branch and an SGPR round trip per term: ~1.6 k cycles of a
+            // 40-entry row (bucket_merge_rows_w spent 1.05 ms of the 1.9 ms weighted build in it).
+            scratch[dest] = head ? degree_source(s, a, deg_mode) : 0.f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 0) {
+                for (int k = 0; k < u; k += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(scratch + k);
+                    d = d + v.x;
+                    d = d + v.y;
+                    d = d + v.z;
+                    d = d + v.w;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                      // the next row's stores must not overtake these reads
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            const float dense = __int_as_float(
+                __builtin_amdgcn_ds_permute(dest << 2, __float_as_int(degree_source(s, a, deg_mode))));
+            for (int k = 0; k < u; ++k) d = d + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dense), k));
+        }
     } else {
         // all ones: run sums are small integers and the degree is a sum of at most 64 multiples of 1/2 -- every
         // order of summation gives the same fp32 value, so the row degree is a butterfly instead of 40 serial adds
@@ -376,6 +400,7 @@ __global__ __launch_bounds__(256) void row_merge_wave(
     int64_t m, int32_t deg_mode, int32_t* __restrict__ ucnt, float* __restrict__ deg, uint4* __restrict__ ent,
     int32_t* __restrict__ long_rows, int32_t* __restrict__ n_long)
 {
+    __shared__ __attribute__((aligned(16))) float deg_scratch[4][64];          // merge_one_row's sequential degree sum
     const int lane = threadIdx.x & 63;
     const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * kRowsPerWave;
     if (r0 >= n) return;
@@ -406,7 +431,8 @@ __global__ __launch_bounds__(256) void row_merge_wave(
             if (lane == 0) long_rows[atomicAdd(n_long, 1)] = r;
             continue;
         }
-        merge_one_row<KT>(r, beg[j], cnt[j], c2[j], w0[j], wsorted != nullptr, lane, deg_mode, ucnt, deg, ent);
+        merge_one_row<KT>(r, beg[j], cnt[j], c2[j], w0[j], wsorted != nullptr, lane, deg_mode, ucnt, deg, ent, nullptr,
+                          deg_scratch[__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6))]);
     }
 }
 
@@ -1743,6 +1769,7 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
     uint32_t* roff = rcnt + hrow + 8;
     __shared__ uint32_t wsum[WAVES];
     __shared__ uint32_t round_total;
+    __shared__ __attribute__((aligned(16))) float deg_scratch[WAVES][64];       // merge_one_row's sequential degree sum
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int32_t row0 = b << pl.rl;
     const int32_t b0 = off[static_cast<int64_t>(b) * pl.g], b1 = off[static_cast<int64_t>(b + 1) * pl.g];
@@ -1832,7 +1859,7 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
                 if (cnt <= 64) {
                     const int at = beg + (lane < cnt ? lane : 0);
                     merge_one_row<uint32_t, true>(r, pos0 + beg, cnt, pk[cnt ? at : 0], pw[cnt ? at : 0], true, lane, deg_mode, ucnt, deg,
-                                                  ent, &unordered);
+                                                  ent, &unordered, deg_scratch[wvu]);
                 } else if (cnt <= kUnitRowMax) {
                     merge_long_row_w(pk + beg, pw + beg, cnt, r, static_cast<int64_t>(pos0) + beg, lane, deg_mode, ucnt, deg, ent,
                                      &unordered);
@@ -1986,8 +2013,10 @@ static int magop_stage1_impl(const int64_t* row, const int64_t* col, const float
         hipLaunchKernelGGL(bucket_scatter_w, dim3(pl.g), dim3(kScatterThreads), lds2, s, row, col, w, n_edges, n, pl, off, stream_k, w_b);
         if (int rc = check_launch("bucket_scatter_w")) return rc;
         const size_t lds = (static_cast<size_t>(pl.cap) + 2 * (((size_t(1) << pl.rl) >> 1) + 8)) * sizeof(uint32_t);
+        // (the kernel also holds ~4.5 KB of static LDS: the dynamic part is capped well below 160 KB minus that)
         static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows_w<1024>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
+        PYGSD_REQUIRE(lds <= 148 * 1024, "pygsd_magop_stage1: bucket plan needs %zu B of LDS", lds);
         PYGSD_HIP_TRY(once);
         hipLaunchKernelGGL(bucket_merge_rows_w<1024>, dim3(pl.nb), dim3(1024), lds, s, pl, stream_k, static_cast<const float*>(w_b), off, n,
                            deg_mode, rs, ucnt, deg, ent, d_info);
