@@ -1,15 +1,13 @@
 #!/bin/bash
-# Run ON THE GPU BOX from the repo root: round 4, second capture -- GPU tests, then ONE rocprofv3 kernel-stats run and two PMC
-# passes (FETCH_SIZE, WRITE_SIZE; counters only) per configuration step, each step alone in its process so that a kernel's
-# average belongs to one configuration: C3a SGCNConv, C3b SIMPA, C5a inception block fp32, C5b bf16 (tools/bench_configs.py).
+# Run ON THE GPU BOX from the repo root (TAG=<round tag>): ONE rocprofv3 kernel-stats run and two PMC passes (FETCH_SIZE,
+# WRITE_SIZE; counters only, never combined with a trace) per configuration step, each step alone in its process so that a
+# kernel's average belongs to one configuration: C3a SGCNConv, C3b SIMPA, C5a inception block fp32, C5b bf16
+# (tools/bench_configs.py); tools/configs_summary.py <tag> condenses the result into profiles/<tag>_configs.json.
 set -u
 O=gpurun_out
 T=${TAG:-r4b}
 mkdir -p $O
 export TMPDIR=/tmp
-rm -f $O/parity_errors_*.json
-( timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 > $O/${T}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/${T}_pytest_gpu.log )
-tail -5 $O/${T}_pytest_gpu.log
 C="python tools/bench_configs.py"
 for cfg in C3a C3b C5a C5b; do
   export PYGSD_CONFIGS=$cfg

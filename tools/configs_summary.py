@@ -7,7 +7,7 @@ WRITE_SIZE pass per configuration step, each step alone in its process) into pro
   MEASURED bytes per launch from the counters (FETCH_SIZE x 1024 x 2 [gfx950: 128-byte requests of 16-byte-per-lane reads are
   tallied as 64 bytes, MI355X_MICROARCH.md] + WRITE_SIZE x 1024; memory-side L2 traffic: Infinity-Cache hits included).
 
-and copies the kernel_stats.csv of every step to profiles/<tag>_kernel_stats_<step>.csv.   usage: r4_configs_summary.py [tag]"""
+and copies the kernel_stats.csv of every step to profiles/<tag>_kernel_stats_<step>.csv.   usage: configs_summary.py [tag]"""
 import csv
 import glob
 import json
@@ -21,7 +21,7 @@ OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r4b"
 STEPS = {"C3a": ("C3_sgcnconv_first", 13), "C3b": ("C3_simpa_hop2", 13), "C5a": ("C5_digcn_inception_block_1gpu", 14),
          "C5b": ("C5_digcn_inception_block_1gpu", 14)}          # (key in configs json, timed + warm-up steps run by the tool)
-NAME = re.compile(r"(spmm_\w+<[^>]*>|tall_linear_\w+<[^>]*>|tall_gram_\w+|gram_finish_kernel|gemm_\w+|column_sums\w*(?:<[^>]*>)?|"
+NAME = re.compile(r"(spmm_\w+<[^>]*>|tall_linear_\w+<[^>]*>|tall_gram32_\w+<[^>]*>|tall_gram_\w+|gram_finish_kernel|gemm_\w+|column_sums\w*(?:<[^>]*>)?|"
                   r"dots_kernel|weighted_sum_kernel|Cijk_\w{0,40})")
 
 
@@ -48,7 +48,7 @@ def model(step, cfg, present=()):
         return {**spmm,
                 "tall_linear_f32_kernel<4,8>": (n * (64 + 128) * 4, 2 * n * 64 * 128, "x [own_b | own_u | agg_b | agg_u]"),
                 "tall_linear_f32_kernel<8,4>": (n * (128 + 64) * 4, 2 * n * 128 * 64, "dx = [g | g_a] W^T"),
-                "tall_gram_f32_kernel": (n * (64 + 128) * 4, 2 * n * 64 * 128, "dW = x^T [g | g_a]"),
+                **{k: (n * (64 + 128) * 4, 2 * n * 64 * 128, "dW = x^T [g | g_a]") for k in present if k and k.startswith("tall_gram")},
                 "column_sums_kernel<false>": (n * 64 * 4, None, "bias gradient")}
     if step == "C3b":
         n, h = cfg["nodes"], cfg["hidden"]
@@ -63,7 +63,9 @@ def model(step, cfg, present=()):
                 b, c0, _ = res.get(name, (0.0, 0, ""))
                 res[name] = (b + spmm_bytes(nnz, n, h) * calls, c0 + calls, "")
             res = {k: (b / c, None, f"A_p / A_n products at width {h} ({c} per step; Z operand not counted)") for k, (b, c, _) in res.items()}
-        res.update({"weighted_sum_kernel": (4 * n * h * 4 * 0.5 + 3 * n * h * 4 * 0.5, None, "feat = sum_h w[h] cur_h (3 terms in, 1 out; both halves)"),
+        # (rounds 3-4 priced one of the two launches at 2 terms in: hop 2 has hop + 1 = 3 terms for feat_p AND (1 + hop) hop / 2 = 3
+        # for feat_n -- SIMPA.py:60-61 -- so both read 3 matrices and write 1; the "1.14 x algorithmic" of r4j was this model)
+        res.update({"weighted_sum_kernel": (4 * n * h * 4, None, "feat = sum_h w[h] cur_h (3 terms in, 1 out; either half)"),
                 "dots_kernel": (4 * n * h * 4, None, "hop-weight gradients <g, cur_h>: g and 3 terms read once")})
         return res
     n, nnz = cfg["nodes"], cfg["nnz"]
@@ -75,7 +77,7 @@ def model(step, cfg, present=()):
             (spmm_bytes(nnz, n, 64, s), None, "S_k^T P_k forward and S_k dx_k backward, 26 entries per row"),
             lin[0]: (n * (64 + 192) * s, 2 * n * 64 * 192, "x [W_ln^T | W_1 | W_2]"),
             lin[1]: (n * (192 + 64) * s, 2 * n * 192 * 64, "dx = [dx0 | dP_1 | dP_2] W^T"),
-            f"tall_gram_{t}_kernel": (n * (64 + 192) * s, 2 * n * 64 * 192, "x^T [dx0 | dP_1 | dP_2]"),
+            **{k: (n * (64 + 192) * s, 2 * n * 64 * 192, "x^T [dx0 | dP_1 | dP_2]") for k in present if k and k.startswith("tall_gram")},
             f"column_sums_kernel<{'false' if step == 'C5a' else 'true'}>": (n * 64 * s, None, "bias gradients")}
 
 
