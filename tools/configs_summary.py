@@ -116,6 +116,12 @@ def main():
             for k, v in counters(f"{TAG}_pmc_{step}_{c}").items():
                 pmc.setdefault(k, {}).update(v)
         names = {short(r["Name"]) for r in csv.DictReader(open(stats[0]))}
+        # steps the trace covers: the timed + warm-up steps AND (since the replayed variant is traced too) the hipGraph warm-ups,
+        # capture and replays of tools/bench_configs.py -- read off the SpMM launches, whose number per step is known
+        spmm_calls = sum(int(r["Calls"]) for r in csv.DictReader(open(stats[0])) if (short(r["Name"]) or "").startswith("spmm_"))
+        per_step = {"C3a": 4, "C3b": 12, "C5a": 4, "C5b": 4}[step]
+        if spmm_calls and spmm_calls % per_step == 0:
+            runs = spmm_calls // per_step
         alg = model(step, cfg, names)
         kernels, library = {}, {}
         for row in csv.DictReader(open(stats[0])):

@@ -11,10 +11,11 @@ xr = torch.randn(n, h, generator=g).to(dev).requires_grad_()
 xi = torch.randn(n, h, generator=g).to(dev).requires_grad_()
 torch.manual_seed(0)
 layer = MagNetConv(h, h, 1, 0.25, False, cached=False).to(dev)
+from pytorch_geometric_signed_directed_amd import memo
 def step(rebuild):
     layer.zero_grad(set_to_none=True); xr.grad = xi.grad = None
-    if rebuild:                       # a NEW graph tensor every step: the operator memo cannot hit
-        layer._op_memo = layer._parts_memo = None
+    if rebuild:                       # drop every memoised operator: this forward rebuilds it, as the reference's does
+        memo.clear_all()
     o = layer(xr, xi, ei); (o[0].sum() + o[1].sum()).backward()
 for rebuild in (True, False):
     for _ in range(2): step(rebuild)
