@@ -308,6 +308,10 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the node-sharded layer even with one rank (exercises the RCCL path on 1 GPU)")
     ap.add_argument("--no-parity", action="store_true", help="skip the un-timed parity guard of the sharded mode")
+    ap.add_argument("--cache-input-exchange", action="store_true",
+                    help="sharded mode, OFF by default: memoise the forward propagate's inbound exchange while the input features are "
+                         "the same tensors at the same version (a first layer's features do not change between training steps); "
+                         "recorded in the `exchange` object -- the default line repeats every exchange in every step")
     ap.add_argument("--no-x4", action="store_true",
                     help="do not run the DRAM-bound x4 graph (4M nodes / 80M edges, ~25 s) that feeds "
                          "`roofline.dram_bound_reference`; the tracked capture is replayed instead, labelled so")
@@ -408,7 +412,8 @@ def main():
         def make_sharded(layout, phases, chunks, synchronous):
             ls = ShardedMagNetConv(hidden, hidden, K=1, q=0.25, num_nodes=n, edge_index=edge_index, edge_weight=None,
                                    device=device, layout=layout, phases=phases, return_chunks=chunks,
-                                   grid_cols=args.grid_cols, exchange=DistExchange(synchronous=synchronous))
+                                   grid_cols=args.grid_cols, exchange=DistExchange(synchronous=synchronous),
+                                   cache_input_exchange=args.cache_input_exchange)
             a = ls.shard_rows(x_real).requires_grad_()
             b = ls.shard_rows(x_imag).requires_grad_()
             return ls, a, b
@@ -572,6 +577,7 @@ def main():
                         "return_ms_per_chunk": return_ms, "return_bytes_per_link": back_bytes_per_link,
                         "return_GBps_per_link": [rate(b, t) for b, t in zip(back_bytes_per_link, return_ms)],
                         "assumed_by_the_rehearsal_GBps_per_link": 61.0},
+                    "cache_input_exchange": bool(args.cache_input_exchange),
                     "backend": dist.get_backend(), "blocking_collectives": bool(getattr(layer_s.exchange, "synchronous", False)),
                     "TORCH_NCCL_AVOID_RECORD_STREAMS": os.environ.get("TORCH_NCCL_AVOID_RECORD_STREAMS"),
                     "fallback": fallback_note,

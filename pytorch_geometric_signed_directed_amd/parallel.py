@@ -666,9 +666,13 @@ class PropagateEngine:
         return [out[g] for g in range(groups)]
 
     # ---- the propagate ------------------------------------------------------------------------------
-    def run(self, xs: Optional[Sequence[Tensor]], op, alpha: float = 1.0, prepacked=None, merge: bool = True):
+    def run(self, xs: Optional[Sequence[Tensor]], op, alpha: float = 1.0, prepacked=None, merge: bool = True,
+            input_memo=None):
         """xs: G local [n_pad, F] feature groups.  op: a dual PhasedOperator (G = 2) or a list of G single ones.
         Returns G local [n_pad, F] products.
+        input_memo (a memo.TensorMemo, opt-in): the INBOUND exchange of these very tensors -- same objects, same in-place
+        version -- is not repeated: the received buffers of the last propagate over them are read again.  For operands that do
+        not change between steps (the input features of a first layer on a fixed graph); never for gradients.
         prepacked = (G, F, like) with xs = None: the send buffers already hold the operand (`send_layout`: the dense backward
         wrote it there) -- no packing pass.  merge = False (grid): the products stay where the return exchange put them -- a FRESH
         receive buffer, handed back as a dense.PieceOperand whose layout the dense kernels / pygsd_gather_pieces_f32 read."""
@@ -700,11 +704,21 @@ class PropagateEngine:
             if any(x.stride(1) != 1 or x.stride(0) != ld for x in xs):
                 xs = [x.contiguous() for x in xs]
         sends = self.send_layout(groups, f, like)[1] if xs is None else None
-        for c in range(self.phases):                         # every exchange is issued before any product
-            send = sends[c] if xs is None else self._pack_phase(xs, c)
-            buf = self._buf(f"recv{c}", (world, self.phase_rows[c], groups * fw), send)
-            works.append(self.ex.all_to_all(buf, send) if self.grid else self.ex.all_gather(buf, send))
-            bufs.append(buf)
+        kept = None
+        if input_memo is not None and xs is not None:
+            kept = input_memo.get(tuple(xs), ("inbound", groups, f))
+        if kept is not None:                                 # the same tensors at the same version: what arrived then is still right
+            bufs, works = list(kept), [_Done()] * self.phases
+        else:
+            for c in range(self.phases):                     # every exchange is issued before any product
+                send = sends[c] if xs is None else self._pack_phase(xs, c)
+                shape = (world, self.phase_rows[c], groups * fw)
+                # (a memoised exchange keeps buffers of its own: the engine's are overwritten by the next propagate)
+                buf = self._buf(f"recv{c}", shape, send) if input_memo is None or xs is None else send.new_empty(shape)
+                works.append(self.ex.all_to_all(buf, send) if self.grid else self.ex.all_gather(buf, send))
+                bufs.append(buf)
+            if input_memo is not None and xs is not None:
+                input_memo.put(tuple(xs), ("inbound", groups, f), tuple(bufs))
         self._mark(ev, "packed")
         # the row layout hands its products to the caller (fresh tensors).  The grid's products are written by the
         # SpMM STRAIGHT INTO the return exchange's send buffer: group g = columns [g fw, (g + 1) fw) of rows that are
@@ -912,7 +926,7 @@ class _ShardedMagneticFn(torch.autograd.Function):
         if k1 == 2 and layer._reads_in_place(ta[0]):
             # K = 1 (round 5): T_1 stays where the return exchange put it -- the dense stage (and, in the backward pass, its
             # weight-gradient product) reads the receive buffer through a piece layout: no merge pass
-            prod = eng.run([ta[0], tb[0]], layer.op_fwd, 1.0, merge=False)
+            prod = eng.run([ta[0], tb[0]], layer.op_fwd, 1.0, merge=False, input_memo=layer._input_memo)
             out_r, out_i = layer._dense_fwd(ta, tb, weight, bias, last_in=prod)
             n_local = layer.plan.n_local
             if n_local < layer.plan.n_pad:
@@ -923,7 +937,8 @@ class _ShardedMagneticFn(torch.autograd.Function):
             ctx.save_for_backward(weight, ta[0], tb[0], prod.buffer)
             return out_r, out_i
         for k in range(1, k1):
-            ya, yb = eng.run([ta[k - 1], tb[k - 1]], layer.op_fwd, 1.0 if k == 1 else 2.0)
+            ya, yb = eng.run([ta[k - 1], tb[k - 1]], layer.op_fwd, 1.0 if k == 1 else 2.0,
+                             input_memo=layer._input_memo if k == 1 else None)
             if k >= 2:                                      # T_k = 2 S T_{k-1} - T_{k-2} on the local rows
                 ya, yb = ya - ta[k - 2], yb - tb[k - 2]
             ta.append(ya.contiguous())
@@ -1080,9 +1095,17 @@ class ShardedMagNetConv(torch.nn.Module):
                  absolute_degree: bool = True, layout: str = "auto", grid_cols: Optional[int] = None,
                  phases: Optional[int] = None, return_chunks: Optional[int] = None, balance: bool = True,
                  lambda_max: Optional[float] = None, exchange=None, build: str = "distributed", kernels=None,
-                 operator_rows=None):
+                 operator_rows=None, cache_input_exchange: Optional[bool] = None):
         super().__init__()
+        from .memo import TensorMemo
         from .nn import MagNetConv, MSConv
+        # Opt-in (round 5; PYGSD_SHARD_CACHE_INPUT_EXCHANGE=1): while x_real / x_imag are the same tensors at the same in-place
+        # version -- the input features of a first layer, which do not change between training steps -- the forward propagate's
+        # INBOUND exchange is not repeated (memo.TensorMemo: weakly held, per version; its opt-outs apply).  Exact, not stale: any
+        # write to the features bumps their version.  Off by default: a layer deeper in a model never sees the same tensor twice.
+        if cache_input_exchange is None:
+            cache_input_exchange = os.environ.get("PYGSD_SHARD_CACHE_INPUT_EXCHANGE", "0") == "1"
+        self._input_memo = TensorMemo(2) if cache_input_exchange else None
         self.exchange = exchange if exchange is not None else DistExchange(group)
         self.group = getattr(self.exchange, "group", group)
         world = self.exchange.world_size

@@ -572,3 +572,69 @@ def test_piece_layouts_address_what_packing_and_merging_produce(world, p_c, phas
             assert torch.equal(recv.reshape(-1)[off + grp * fw], merged[grp])
         st = rl.struct()
         assert st.n_chunks == eng.return_chunks and st.blk_rows == eng.n_blk and list(st.lo)[:eng.return_chunks + 1] == eng.chunk_bounds
+
+
+def _cached_input_worker(rank, world, port, ret):
+    """cache_input_exchange=True: the second forward over the same (unmodified) feature tensors must not exchange them again and
+    must give the same outputs and gradients; an in-place edit of the features bumps their version and is seen."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv, all_gather_rows
+        n, f, k = 61, 16, 2
+        g, ei, w = _graph(n, 5, True)
+        xr, xi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+        gr, gi = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+        torch.manual_seed(3)
+        layer = ShardedMagNetConv(f, f, k, 0.25, n, ei, w, layout="grid", phases=(0.4, 0.6), return_chunks=2, kernels=C.KERNELS,
+                                  operator_rows=C.oracle_operator_rows(ei, w, n, 0.25), cache_input_exchange=True)
+        calls = {"n": 0}
+        inner = layer.engine.ex.all_to_all
+
+        def counting(out, inp):
+            calls["n"] += 1
+            return inner(out, inp)
+        layer.engine.ex.all_to_all = counting
+        plan = layer.plan
+        a, b = layer.shard_rows(xr).requires_grad_(), layer.shard_rows(xi).requires_grad_()
+
+        def step():
+            layer.zero_grad(set_to_none=True)
+            a.grad = b.grad = None
+            o_r, o_i = layer(a, b)
+            ((o_r * layer.shard_rows(gr)).sum() + (o_i * layer.shard_rows(gi)).sum()).backward()
+            return [plan.unshard_rows(all_gather_rows(t.detach())) for t in (o_r, o_i, a.grad, b.grad)]
+
+        def oracle(x_r, x_i):
+            c, d = x_r.clone().requires_grad_(), x_i.clone().requires_grad_()
+            op = R.magnet_operator(ei, w, n, 0.25, "sym", 2.0)
+            w_r, w_i = R.magnet_conv(c, d, op, layer.weight.detach(), layer.bias.detach(), duplicate=False)
+            ((w_r * gr).sum() + (w_i * gi).sum()).backward()
+            return [w_r.detach(), w_i.detach(), c.grad, d.grad]
+
+        def err(got, want):
+            return max(float((x - y).abs().max()) / max(1.0, float(y.abs().max())) for x, y in zip(got, want))
+
+        first = step()
+        per_step = calls["n"]                      # K = 2: 2 forward + 2 backward propagates x (2 phases in + 2 chunks back)
+        second = step()
+        saved = 2 * per_step - calls["n"]
+        assert saved == layer.engine.phases, (per_step, calls["n"])     # exactly ONE propagate's inbound phases were not repeated
+        worst = max(err(first, oracle(xr, xi)), err(second, oracle(xr, xi)))
+        with torch.no_grad():
+            a.mul_(1.5)                            # in-place: the version moves, the memo must miss
+        before = calls["n"]
+        third = step()
+        assert calls["n"] - before == per_step
+        worst = max(worst, err(third, oracle(1.5 * xr, xi)))
+        ret[rank] = worst
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cached_input_exchange_is_exact_and_sees_in_place_edits():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cached_input_worker, args=(4, _free_port(), ret), nprocs=4, join=True)
+    assert len(ret) == 4 and max(ret.values()) <= 2e-6, dict(ret)

@@ -33,7 +33,8 @@ def run_shape(args, edge_index, x_real, x_imag, layout, phases, chunks, link_gbp
     ex = EmulatedExchange(args.world, args.rank, link_gbps, args.latency_us)
     torch.manual_seed(0)
     layer = ShardedMagNetConv(args.hidden, args.hidden, args.K, 0.25, args.nodes, edge_index, args.edge_weight, device=dev,
-                              layout=layout, phases=phases, return_chunks=chunks, exchange=ex, signed=args.signed)
+                              layout=layout, phases=phases, return_chunks=chunks, exchange=ex, signed=args.signed,
+                              cache_input_exchange=args.cache_input_exchange)
     xr = layer.shard_rows(x_real).requires_grad_()
     xi = layer.shard_rows(x_imag).requires_grad_()
 
@@ -101,6 +102,7 @@ def run_shape(args, edge_index, x_real, x_imag, layout, phases, chunks, link_gbp
            "overlap_fraction": (1.0 - summary["exposed_exchange_ms"] / wire_ms) if wire_ms > 0 else None,
            "phase_rows": eng.phase_rows, "return_chunk_rows": eng.chunk_rows, "merge_on_read": bool(getattr(layer, "merge_on_read", False)),
            "packed_backward": bool(getattr(layer, "packed_backward", False)),
+           "cache_input_exchange": bool(args.cache_input_exchange),
            "local_operator_entries": layer.local_nnz, "rows_multiplied": eng.block_rows, "n_pad": layer.plan.n_pad}
     del layer
     torch.cuda.empty_cache()
@@ -123,6 +125,9 @@ def main():
     ap.add_argument("--shapes", nargs="+", default=None, metavar="LAYOUT:C:R",
                     help="pipeline shapes to run, e.g. grid:2:2 rows:1:1 -- C / R a count (equal pieces) or fractions, "
                          "grid:0.4,0.6:0.5,0.36,0.14 (default: the built-in sweep)")
+    ap.add_argument("--cache-input-exchange", action="store_true",
+                    help="opt-in of the layer: the forward propagate's INBOUND exchange is memoised while x_real / x_imag are the same "
+                         "tensors at the same version (input features of a first layer: they do not change between steps)")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-replayed variant of every shape")
     ap.add_argument("--single-gpu-ms", type=float, default=None, help="measured 1-GPU step (bench.py) for the ratio")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "emulated_sharded.json"))
