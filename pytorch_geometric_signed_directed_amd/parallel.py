@@ -667,12 +667,14 @@ class PropagateEngine:
 
     # ---- the propagate ------------------------------------------------------------------------------
     def run(self, xs: Optional[Sequence[Tensor]], op, alpha: float = 1.0, prepacked=None, merge: bool = True,
-            input_memo=None):
+            input_memo=None, whole_op=None):
         """xs: G local [n_pad, F] feature groups.  op: a dual PhasedOperator (G = 2) or a list of G single ones.
         Returns G local [n_pad, F] products.
         input_memo (a memo.TensorMemo, opt-in): the INBOUND exchange of these very tensors -- same objects, same in-place
         version -- is not repeated: the received buffers of the last propagate over them are read again.  For operands that do
-        not change between steps (the input features of a first layer on a fixed graph); never for gradients.
+        not change between steps (the input features of a first layer on a fixed graph); never for gradients.  whole_op: the same
+        operator rows as `op` in ONE column block (padded ids); with nothing on the wire there is nothing to overlap, so a memo hit
+        multiplies them in a single walk over the kept rows (the phases' received pieces joined once, when they were kept).
         prepacked = (G, F, like) with xs = None: the send buffers already hold the operand (`send_layout`: the dense backward
         wrote it there) -- no packing pass.  merge = False (grid): the products stay where the return exchange put them -- a FRESH
         receive buffer, handed back as a dense.PieceOperand whose layout the dense kernels / pygsd_gather_pieces_f32 read."""
@@ -707,8 +709,11 @@ class PropagateEngine:
         kept = None
         if input_memo is not None and xs is not None:
             kept = input_memo.get(tuple(xs), ("inbound", groups, f))
+        n_phases, phase_rows = self.phases, self.phase_rows
         if kept is not None:                                 # the same tensors at the same version: what arrived then is still right
-            bufs, works = list(kept), [_Done()] * self.phases
+            bufs, works = list(kept), [_Done()] * len(kept)
+            if len(kept) == 1 and self.phases > 1:           # (joined into one [world, n_pad, W] buffer: one walk with whole_op)
+                op, n_phases, phase_rows = whole_op, 1, [self.plan.n_pad]
         else:
             for c in range(self.phases):                     # every exchange is issued before any product
                 send = sends[c] if xs is None else self._pack_phase(xs, c)
@@ -717,8 +722,6 @@ class PropagateEngine:
                 buf = self._buf(f"recv{c}", shape, send) if input_memo is None or xs is None else send.new_empty(shape)
                 works.append(self.ex.all_to_all(buf, send) if self.grid else self.ex.all_gather(buf, send))
                 bufs.append(buf)
-            if input_memo is not None and xs is not None:
-                input_memo.put(tuple(xs), ("inbound", groups, f), tuple(bufs))
         self._mark(ev, "packed")
         # the row layout hands its products to the caller (fresh tensors).  The grid's products are written by the
         # SpMM STRAIGHT INTO the return exchange's send buffer: group g = columns [g fw, (g + 1) fw) of rows that are
@@ -735,11 +738,11 @@ class PropagateEngine:
             widen = like.dtype == torch.bfloat16 and self.phases > 1
             ys = [like.new_empty((self.block_rows, fw), dtype=torch.float32 if widen else like.dtype)
                   for _ in range(groups)]
-        for c in range(self.phases):
+        for c in range(n_phases):
             works[c].wait()
             self._mark(ev, "arrived")
-            buf = bufs[c].view(world * self.phase_rows[c], groups * fw)
-            last = c == self.phases - 1
+            buf = bufs[c].view(world * phase_rows[c], groups * fw)
+            last = c == n_phases - 1
             spans = [(world * self.chunk_bounds[r], world * self.chunk_bounds[r + 1]) for r in range(self.return_chunks)] \
                 if (last and self.grid) else [(0, self.block_rows)]
             for r, (lo, hi) in enumerate(spans):
@@ -754,6 +757,16 @@ class PropagateEngine:
                 if last and self.grid:                       # chunk r goes home while chunk r + 1 is multiplied
                     returns.append(self.ex.all_to_all(self.chunk_view(recv, r), self.chunk_view(home, r)))
             self._mark(ev, "multiplied")
+        if input_memo is not None and xs is not None and kept is None:
+            # keep what arrived (every piece has been waited for above) -- joined into ONE buffer when the caller has the operator
+            # in one column block, so that the next propagate over these tensors is a single walk
+            keep = tuple(bufs)
+            if whole_op is not None and self.phases > 1:
+                whole = like.new_empty((world, plan.n_pad, groups * fw))
+                for c in range(self.phases):
+                    whole[:, self.phase_bounds[c]:self.phase_bounds[c + 1]] = bufs[c]
+                keep = (whole,)
+            input_memo.put(tuple(xs), ("inbound", groups, f), keep)
         if not self.grid:
             if ys[0].dtype != like.dtype:
                 ys = [y.to(like.dtype) for y in ys]
@@ -926,7 +939,8 @@ class _ShardedMagneticFn(torch.autograd.Function):
         if k1 == 2 and layer._reads_in_place(ta[0]):
             # K = 1 (round 5): T_1 stays where the return exchange put it -- the dense stage (and, in the backward pass, its
             # weight-gradient product) reads the receive buffer through a piece layout: no merge pass
-            prod = eng.run([ta[0], tb[0]], layer.op_fwd, 1.0, merge=False, input_memo=layer._input_memo)
+            prod = eng.run([ta[0], tb[0]], layer.op_fwd, 1.0, merge=False, input_memo=layer._input_memo,
+                           whole_op=layer.op_fwd_whole)
             out_r, out_i = layer._dense_fwd(ta, tb, weight, bias, last_in=prod)
             n_local = layer.plan.n_local
             if n_local < layer.plan.n_pad:
@@ -938,7 +952,7 @@ class _ShardedMagneticFn(torch.autograd.Function):
             return out_r, out_i
         for k in range(1, k1):
             ya, yb = eng.run([ta[k - 1], tb[k - 1]], layer.op_fwd, 1.0 if k == 1 else 2.0,
-                             input_memo=layer._input_memo if k == 1 else None)
+                             input_memo=layer._input_memo if k == 1 else None, whole_op=layer.op_fwd_whole if k == 1 else None)
             if k >= 2:                                      # T_k = 2 S T_{k-1} - T_{k-2} on the local rows
                 ya, yb = ya - ta[k - 2], yb - tb[k - 2]
             ta.append(ya.contiguous())
@@ -1150,6 +1164,8 @@ class ShardedMagNetConv(torch.nn.Module):
         self.local_nnz = csr.nnz
         self.op_fwd = self.engine.phased(csr, vf, dual=True)
         self.op_bwd = self.engine.phased(csr, vb, dual=True)
+        # the forward rows in ONE column block (the arrays the build produced, no copy): what a memoised inbound exchange multiplies
+        self.op_fwd_whole = PhasedOperator([(csr, tuple(vf))], True) if self._input_memo is not None else None
 
     # ---- round 5: the dense kernels address the exchange buffers themselves (no pack / merge passes) ----------------
     def _pieces(self, like: Tensor) -> bool:

@@ -87,7 +87,7 @@ def test_one_gpu_every_row_vs_float64(magnetic):
     _check(layer.bias.grad, want[5], f"{name} one GPU db vs float64", norm=True)
 
 
-@pytest.mark.parametrize("layout", ["auto", "rows"])
+@pytest.mark.parametrize("layout", ["auto", "rows", "auto+cached-inputs"])
 def test_sharded_8_ranks_every_row_vs_float64(magnetic, layout):
     """8 ranks (threads, one device), default pipeline (auto = 2 x 4 grid, 2 phases x 2 return chunks; rows = all-gather
     layout, 2 phases), distributed operator build: EVERY local row of out_real / out_imag / dx_real / dx_imag of every
@@ -101,15 +101,23 @@ def test_sharded_8_ranks_every_row_vs_float64(magnetic, layout):
     sign = None if p_sign is None else FS.dev_tensor(p_sign, D)
     weight, bias = FS.magnetic_params(name)
 
+    # "+cached-inputs" (round 5): the forward's inbound exchange memoised -- the step is run TWICE and the second one, which reads
+    # the kept pieces (joined, multiplied in a single walk with the un-phased operator rows), is the one checked
+    cached = layout.endswith("+cached-inputs")
+    layout = layout.split("+")[0]
+
     def body(rank, exchange):
         layer = ShardedMagNetConv(h, h, k, 0.25, n, ei, sign, device=D, layout=layout, signed=cfg["signed"],
-                                  exchange=exchange)
+                                  exchange=exchange, cache_input_exchange=cached)
         with torch.no_grad():
             layer.weight.copy_(weight)
             layer.bias.copy_(bias)
         plan, eng = layer.plan, layer.engine
         a, b, ga, gb = (FS.shard(p, plan, h, D) for p in feats)
         outs = C.sharded_magnetic_step(layer, a, b, ga, gb)
+        if cached:
+            assert len(layer._input_memo) == 1
+            outs = C.sharded_magnetic_step(layer, a, b, ga, gb)
         return plan, (layer.layout, eng.p_r, eng.p_c, eng.phases, eng.return_chunks), outs, layer.global_nnz
 
     res = C.run_ranks_as_threads(WORLD, body)
