@@ -311,11 +311,12 @@ int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, in
                        float* vf_imag, void* stream);
 /* Round 5: for weighted graphs the bucket plan takes (see pygsd_magop_unit below: <= 2^25 nodes, <= 3000 buckets ...)
  * pygsd_magop_stage1 no longer sorts the stream globally: it is split once into buckets of consecutive rows that fit a workgroup's
- * LDS, the weights travelling in a second 4-byte stream, and every row is ordered and merged there by the same wavefront routine
+ * LDS, the weights travelling in a second 4-byte stream; a workgroup per bucket groups it by row in LDS and writes the row-grouped
+ * (key, weight) streams the sort used to produce -- minus the order inside a row -- and the rows are merged by the same kernels
  * as behind the sort -- same records, same results bit for bit WHERE THE ORDER OF ARRIVAL CANNOT SHOW: a neighbour's run of one or
  * two entries (a + b = b + a in fp32; the row degree is summed over the column-sorted distinct entries either way).  A run of three
- * or more entries of one neighbour (an edge listed three times, a reciprocal pair with a duplicate), a row of more than 512
- * symmetrised entries or an over-full half bucket are counted in d_info[1]; the caller then repeats the first stage with
+ * or more entries of one neighbour (an edge listed three times, a reciprocal pair with a duplicate) or an over-full half bucket
+ * are counted in d_info[1] (as are, in either form, rows of more than 4096 symmetrised entries); the caller then repeats the first stage with
  * pygsd_magop_stage1_sorted -- the radix sort on the row bits in front of the merge, rows of up to 4096 entries, duplicates summed
  * in (direction, list position) order like the reference -- same arguments, same workspace, and runs pygsd_magop_stage2 again.
  * PYGSD_WEIGHTED_BUILD_FORM=sort in the environment makes pygsd_magop_stage1 itself take the sorted form. */

@@ -264,7 +264,7 @@ constexpr uint32_t kFlag = 0x80000000u;
 // A wavefront orders one row of <= 64 symmetrised entries in registers.  deg_mode: 0 = row sums of A_s, 1 = of |A_s|
 // (signed, absolute_degree off), 2 = of the |w| sums / 2 (signed, absolute_degree on).  `c2` / `w0` are the row's
 // keys (col << 1 | dir) and weights as loaded by lane = list position (prefetched by the caller for several rows).
-// order_free_only (round 5: rows whose entries arrive in NO particular order, bucket_merge_rows_w): a run of three or more entries
+// `unordered` (round 5: rows whose entries arrived in NO particular order, behind bucket_place_rows_w): a run of three or more entries
 // of one neighbour is reported in `*unordered` instead of trusted -- its fp32 sum depends on the order the reference adds them in;
 // runs of one or two entries do not (a + b = b + a).
 // SHORT_RUNS (with `unordered`): only the first two entries of a run are summed -- one lane shift instead of the ballot-driven
@@ -333,7 +333,7 @@ __device__ __forceinline__ void merge_one_row(int32_t r, int32_t beg, int32_t cn
             // Round 5: through 64 floats of wavefront-private LDS -- the compaction is the store itself, and ONE lane adds the
             // u values in order, four per ds_read_b128 (the lanes behind the distinct entries hold +0: d + 0 = d bit for bit, d is
             // never -0).  The readlane loop below costs a taken branch and an SGPR round trip per term: ~1.6 k cycles of a
-            // 40-entry row (bucket_merge_rows_w spent 1.05 ms of the 1.9 ms weighted build in it).
+            // 40-entry row.
             scratch[dest] = head ? degree_source(s, a, deg_mode) : 0.f;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -394,11 +394,13 @@ __device__ __forceinline__ void merge_one_row(int32_t r, int32_t beg, int32_t cn
 // flight -- one row per wavefront was latency-bound: ~3 dependent HBM round trips per 40-entry row).
 constexpr int kRowsPerWave = 4;
 
-template <typename KT>
+// ST: element type of the row-grouped stream -- the radix sort's 64-bit keys (low word = col << 1 | dir) or, behind the bucket split
+// of round 5, 4-byte keys of rows whose entries arrived in NO order (UNORDERED: runs of >= 3 entries are reported in info[1]).
+template <typename KT, typename ST = uint64_t, bool UNORDERED = false>
 __global__ __launch_bounds__(256) void row_merge_wave(
-    const uint64_t* __restrict__ keys, const float* __restrict__ wsorted, const int32_t* __restrict__ rs, int32_t n,
+    const ST* __restrict__ keys, const float* __restrict__ wsorted, const int32_t* __restrict__ rs, int32_t n,
     int64_t m, int32_t deg_mode, int32_t* __restrict__ ucnt, float* __restrict__ deg, uint4* __restrict__ ent,
-    int32_t* __restrict__ long_rows, int32_t* __restrict__ n_long)
+    int32_t* __restrict__ long_rows, int32_t* __restrict__ n_long, int64_t* __restrict__ info = nullptr)
 {
     __shared__ __attribute__((aligned(16))) float deg_scratch[4][64];          // merge_one_row's sequential degree sum
     const int lane = threadIdx.x & 63;
@@ -431,14 +433,22 @@ __global__ __launch_bounds__(256) void row_merge_wave(
             if (lane == 0) long_rows[atomicAdd(n_long, 1)] = r;
             continue;
         }
-        merge_one_row<KT>(r, beg[j], cnt[j], c2[j], w0[j], wsorted != nullptr, lane, deg_mode, ucnt, deg, ent, nullptr,
-                          deg_scratch[__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6))]);
+        if constexpr (UNORDERED) {
+            bool unordered = false;
+            merge_one_row<KT, true>(r, beg[j], cnt[j], c2[j], w0[j], wsorted != nullptr, lane, deg_mode, ucnt, deg, ent, &unordered,
+                                    deg_scratch[__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6))]);
+            if (unordered && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
+        } else {
+            merge_one_row<KT>(r, beg[j], cnt[j], c2[j], w0[j], wsorted != nullptr, lane, deg_mode, ucnt, deg, ent, nullptr,
+                              deg_scratch[__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6))]);
+        }
     }
 }
 
 // Rows of 65 .. kBlockRowMax entries: one block per listed row, bitonic sort of (col, dir, position) keys in LDS.
+template <typename ST = uint64_t, bool UNORDERED = false>
 __global__ __launch_bounds__(256) void row_merge_block(
-    const uint64_t* __restrict__ keys, const float* __restrict__ wsorted, const int32_t* __restrict__ rs,
+    const ST* __restrict__ keys, const float* __restrict__ wsorted, const int32_t* __restrict__ rs,
     int32_t deg_mode, int32_t* __restrict__ ucnt, float* __restrict__ deg, uint4* __restrict__ ent,
     const int32_t* __restrict__ long_rows, const int32_t* __restrict__ n_long, int64_t* __restrict__ info)
 {
@@ -512,12 +522,16 @@ __global__ __launch_bounds__(256) void row_merge_block(
             if (!(p < cnt && (p == 0 || (sk[p - 1] >> 13) != (sk[p] >> 13)))) continue;
             const uint64_t colv = sk[p] >> 13;
             float s = 0.f, t = 0.f, a = 0.f;
+            int run = 0;
             for (int q = p; q < cnt && (sk[q] >> 13) == colv; ++q) {
                 const float we = wsorted ? sw[sk[q] & 4095u] : 1.f;
                 s = s + we;
                 t = t + (((sk[q] >> 12) & 1u) ? -we : we);
                 a = a + fabsf(we);
+                ++run;
             }
+            // (rows that arrived in no order: the position inside the row is not the list position -- a run of three is not ours to sum)
+            if (UNORDERED && run >= 3) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
             uint4 rec;
             rec.x = static_cast<uint32_t>(colv) | ((nleft >= 1 && rank == nleft - 1) ? kFlag : 0u);
             rec.y = __float_as_uint(s / 2.f);
@@ -1648,117 +1662,20 @@ __global__ __launch_bounds__(kScatterThreads) void bucket_scatter_w(const int64_
     }
 }
 
-// A row of 65 .. kUnitRowMax entries of the weighted bucket form, keys (col << 1 | dir) and weights in LDS (`sk`, `sw`), one
-// wavefront.  Rank sort on (key, position in the row): the sorted (key, weight) pairs are parked in the first 8 bytes of the row's
-// 16-byte record slots, read back in chunks of 64 positions -- every head lane sums its run (A_s, Theta_arg, |w|: short loops),
-// the degree runs sequentially over the distinct entries in column order, chunk after chunk -- and only then are the records
-// written (a run may reach into the next chunk: nothing may be overwritten before everything has been read).
-__device__ __forceinline__ void merge_long_row_w(const uint32_t* sk, const float* sw, int cnt, int32_t r, int64_t gbeg, int lane,
-                                                 int32_t deg_mode, int32_t* __restrict__ ucnt, float* __restrict__ deg,
-                                                 uint4* __restrict__ ent, bool* unordered)
-{
-    constexpr int CH = kUnitRowMax / 64;                           // chunks of 64 positions
-    uint2* tmp = reinterpret_cast<uint2*>(ent + gbeg);             // 16-byte slots; the pair (key, weight bits) in the first 8 bytes
-    for (int i = lane; i < cnt; i += 64) {
-        const uint32_t mine = sk[i];
-        int rk = 0;
-        for (int q = 0; q < cnt; ++q) {
-            const uint32_t o = sk[q];
-            rk += (o < mine || (o == mine && q < i)) ? 1 : 0;
-        }
-        tmp[2 * rk] = make_uint2(mine, __float_as_uint(sw[i]));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    uint32_t colv[CH];
-    float sv[CH], tv[CH], av[CH];
-    bool hd[CH];
-    int u = 0, left = 0;
-    float d = 0.f;
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-        const int i = j * 64 + lane;
-        hd[j] = false;
-        colv[j] = 0u;
-        sv[j] = tv[j] = av[j] = 0.f;
-        if (j * 64 >= cnt) continue;                               // (wavefront-uniform)
-        if (i < cnt) {
-            const uint32_t k2 = tmp[2 * i].x;
-            colv[j] = k2 >> 1;
-            hd[j] = i == 0 || (tmp[2 * (i - 1)].x >> 1) != colv[j];
-        }
-        int len = 0;
-        if (hd[j]) {
-            for (int q = i; q < cnt; ++q) {                        // the run: sorted (direction, position) order
-                const uint2 e = tmp[2 * q];
-                if ((e.x >> 1) != colv[j]) break;
-                const float wq = __uint_as_float(e.y);
-                sv[j] = sv[j] + wq;
-                tv[j] = tv[j] + ((e.x & 1u) ? -wq : wq);
-                av[j] = av[j] + fabsf(wq);
-                ++len;
-            }
-        }
-        if (__ballot(hd[j] && len >= 3)) *unordered = true;
-        // degree: the chunk's distinct entries in column order, appended to the running sum (merge_one_row's compaction)
-        const uint64_t H = __ballot(hd[j]);
-        const int uc = __popcll(H);
-        const uint64_t below = (1ull << lane) - 1ull;
-        const int rank = __popcll(H & below), heads_upto = __popcll(H & (below | (1ull << lane)));
-        const int dest = hd[j] ? rank : uc + (lane - heads_upto);
-        const float dense = __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(degree_source(sv[j], av[j], deg_mode))));
-        for (int k = 0; k < uc; ++k) d = d + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dense), k));
-        u += uc;
-        left += __popcll(__ballot(hd[j] && static_cast<int32_t>(colv[j]) < r));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // every read of the parked pairs precedes the records' stores
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    int base_rank = 0, base_rest = 0;
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-        const int i = j * 64 + lane;
-        if (j * 64 >= cnt) continue;
-        const uint64_t H = __ballot(hd[j]);
-        const uint64_t below = (1ull << lane) - 1ull;
-        const int rank = base_rank + __popcll(H & below);
-        const int live = cnt - j * 64 < 64 ? cnt - j * 64 : 64;
-        if (i < cnt) {
-            uint4 rec;
-            int64_t pos;
-            if (hd[j]) {
-                rec.x = colv[j] | ((left >= 1 && rank == left - 1) ? kFlag : 0u);
-                rec.y = __float_as_uint(sv[j] / 2.f);
-                rec.z = __float_as_uint(tv[j]);
-                rec.w = static_cast<uint32_t>(r) | ((left == 0 && rank == 0) ? kFlag : 0u);
-                pos = gbeg + rank;
-            } else {
-                rec = make_uint4(0u, 0u, 0u, kNoEntry);
-                pos = gbeg + u + base_rest + (lane - __popcll(H & below));
-            }
-            ent[pos] = rec;
-        }
-        base_rank += __popcll(H);
-        base_rest += live - __popcll(H);
-    }
-    if (lane == 0) {
-        ucnt[r] = u;
-        deg[r] = d;
-    }
-}
-
-// One workgroup per bucket, TWO rounds over its rows (rows 0 .. 2^(rl-1) - 1, then the rest): keys and weights of a round's rows
-// are placed row by row in LDS (8 bytes per entry: half a bucket per round), and each row is ordered and merged by a wavefront with
-// merge_one_row -- the very function the sorted pipeline calls -- so the records, distinct counts and degrees are the ones
-// row_tables / values_entries expect.  Stream positions: the bucket's range, round 0's rows first.
+// One workgroup per bucket, TWO rounds over its rows (rows 0 .. 2^(rl-1) - 1, then the rest): keys and weights of a round's rows are
+// placed row by row in LDS (8 bytes per entry: half a bucket per round) and leave as ONE coalesced copy per stream -- the row-grouped
+// (key, weight) streams the radix sort used to produce, minus the order inside a row.  Merging is NOT done here: a weighted row is a
+// chain of dependent steps (in-register sort, weight hand-off, run sums, a sequential degree sum over ~40 terms), and this kernel --
+// 1024 threads around 130 KB of LDS -- runs four wavefronts per SIMD; its first version merged in place and took 0.85 ms where the
+// unit merge takes 0.30.  The rows go to the sorted pipeline's row_merge_wave / row_merge_block instead: 41 VGPRs, no LDS to speak
+// of, as many wavefronts per SIMD as the chip holds.  Stream positions: the bucket's range, round 0's rows first.
 // LDS: pk[cap / 2], pw[cap / 2], rcnt[2^(rl-1) + 8], roff[2^(rl-1) + 8].
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, const uint32_t* __restrict__ stream,
+__global__ __launch_bounds__(THREADS) void bucket_place_rows_w(BucketPlan pl, const uint32_t* __restrict__ stream,
                                                                const float* __restrict__ wstream, const int32_t* __restrict__ off,
-                                                               int32_t n, int32_t deg_mode, int32_t* __restrict__ rs,
-                                                               int32_t* __restrict__ ucnt, float* __restrict__ deg,
-                                                               uint4* __restrict__ ent, int64_t* __restrict__ info)
+                                                               int32_t n, int32_t* __restrict__ rs, int32_t* __restrict__ ucnt,
+                                                               uint32_t* __restrict__ keys2, float* __restrict__ w2,
+                                                               int64_t* __restrict__ info)
 {
     constexpr int WAVES = THREADS / 64;
     extern __shared__ uint32_t bucket_lds[];
@@ -1766,10 +1683,8 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
     uint32_t* pk = bucket_lds;
     float* pw = reinterpret_cast<float*>(bucket_lds + half_cap);
     uint32_t* rcnt = bucket_lds + 2 * half_cap;
-    uint32_t* roff = rcnt + hrow + 8;
     __shared__ uint32_t wsum[WAVES];
     __shared__ uint32_t round_total;
-    __shared__ __attribute__((aligned(16))) float deg_scratch[WAVES][64];       // merge_one_row's sequential degree sum
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int32_t row0 = b << pl.rl;
     const int32_t b0 = off[static_cast<int64_t>(b) * pl.g], b1 = off[static_cast<int64_t>(b + 1) * pl.g];
@@ -1779,34 +1694,40 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
         rs[n + 1] = b1;
         ucnt[n] = 0;                                              // the scan's (n + 1)-th input
     }
-    // Whatever this kernel does not merge is reported in info[1] -- and its record slots are marked empty all the same: the host
-    // queues the second stage BEFORE it reads info, and values_entries indexes its tables with what the records name.
-    const uint4 no_entry = make_uint4(0u, 0u, 0u, kNoEntry);
-    if (cnt_b > pl.cap) {                                          // host: the sorted pipeline
-        if (t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
-        for (int i = t; i < cnt_b; i += THREADS) ent[b0 + i] = no_entry;
-        for (int i = t; i < (1 << pl.rl); i += THREADS)
-            if (row0 + i < n) {
-                rs[row0 + i] = b0;
-                ucnt[row0 + i] = 0;
-                deg[row0 + i] = 0.f;
-            }
-        return;
-    }
-    // (the bucket's entries are NOT held in registers across the rounds -- 64 of a 1024-thread workgroup's 128 VGPRs, and the row
-    // routines spilled: each pass re-reads its 80 - 160 KB from the L2 instead)
     const int sh = pl.cbits + 1;
     const uint32_t kmask = (1u << sh) - 1u;
-    const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    bool unordered = false;
+    // A bucket (or half of one) that does not fit the LDS is reported in info[1] (host: the sorted pipeline) and handed on as ONE
+    // over-long row of harmless keys: everything behind this kernel stays inside its arrays whatever the host decides later.
+    if (cnt_b > pl.cap) {
+        if (t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
+        for (int i = t; i < cnt_b; i += THREADS) {
+            keys2[b0 + i] = 0u;
+            w2[b0 + i] = 0.f;
+        }
+        for (int i = t; i < (1 << pl.rl); i += THREADS)
+            if (row0 + i < n) rs[row0 + i] = b0;
+        return;
+    }
+    // the bucket's entries, all loads in flight at once (a loop of load -> LDS atomic ran one L2 round trip per entry and pass: the
+    // kernel took 0.46 ms); this kernel merges nothing, so the registers are free for them
+    constexpr int EPT = 32;
+    uint32_t ek[EPT];
+    float ew[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int i = t + k * THREADS;
+        ek[k] = i < cnt_b ? __builtin_nontemporal_load(stream + b0 + i) : 0u;
+        ew[k] = i < cnt_b ? __builtin_nontemporal_load(wstream + b0 + i) : 0.f;
+    }
     int32_t pos0 = b0;                                             // first stream position of this round's rows
     for (int round = 0; round < 2; ++round) {
         for (int i = t; i <= hrow; i += THREADS) rcnt[i] = 0;
         __syncthreads();
         const uint32_t rlo = static_cast<uint32_t>(round * hrow);
-        for (int i = t; i < cnt_b; i += THREADS) {
-            const uint32_t rl_ = stream[b0 + i] >> sh;
-            if (rl_ - rlo < static_cast<uint32_t>(hrow)) atomicAdd(&rcnt[rl_ - rlo], 1u);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const uint32_t rl_ = ek[k] >> sh;
+            if (t + k * THREADS < cnt_b && rl_ - rlo < static_cast<uint32_t>(hrow)) atomicAdd(&rcnt[rl_ - rlo], 1u);
         }
         __syncthreads();
         uint32_t mine = t < hrow ? rcnt[t] : 0u, inc = mine;
@@ -1826,58 +1747,37 @@ __global__ __launch_bounds__(THREADS) void bucket_merge_rows_w(BucketPlan pl, co
         if (t == 0) round_total = all;
         const bool fits = all <= static_cast<uint32_t>(half_cap);  // (workgroup-uniform)
         if (t < hrow) {
-            roff[t] = excl;
             rcnt[t] = excl;                                        // placement cursor
             const int32_t r = row0 + static_cast<int32_t>(rlo) + t;
-            if (r < n) rs[r] = pos0 + static_cast<int32_t>(excl);
+            if (r < n) rs[r] = pos0 + static_cast<int32_t>(fits ? excl : 0u);
         }
-        if (t == 0) roff[hrow] = all;
         __syncthreads();
-        if (!fits) {                                               // half a bucket that exceeds its share of the LDS: sorted pipeline
+        if (!fits) {
             if (t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
-            for (uint32_t i = t; i < all; i += THREADS) ent[pos0 + i] = no_entry;
-            if (t < hrow && row0 + static_cast<int32_t>(rlo) + t < n) {
-                ucnt[row0 + rlo + t] = 0;
-                deg[row0 + rlo + t] = 0.f;
+            for (uint32_t i = t; i < all; i += THREADS) {
+                keys2[pos0 + i] = 0u;
+                w2[pos0 + i] = 0.f;
             }
         } else {
-            for (int i = t; i < cnt_b; i += THREADS) {
-                const uint32_t key = stream[b0 + i];
-                const uint32_t rl_ = key >> sh;
-                if (rl_ - rlo < static_cast<uint32_t>(hrow)) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const uint32_t rl_ = ek[k] >> sh;
+                if (t + k * THREADS < cnt_b && rl_ - rlo < static_cast<uint32_t>(hrow)) {
                     const uint32_t at = atomicAdd(&rcnt[rl_ - rlo], 1u);
-                    pk[at] = key & kmask;
-                    pw[at] = wstream[b0 + i];
+                    pk[at] = ek[k] & kmask;
+                    pw[at] = ew[k];
                 }
             }
             __syncthreads();
-            for (int rr = wvu; rr < hrow; rr += WAVES) {
-                const int32_t r = row0 + static_cast<int32_t>(rlo) + rr;
-                if (r >= n) break;
-                const int beg = __builtin_amdgcn_readfirstlane(static_cast<int>(roff[rr]));
-                const int cnt = __builtin_amdgcn_readfirstlane(static_cast<int>(roff[rr + 1])) - beg;
-                if (cnt <= 64) {
-                    const int at = beg + (lane < cnt ? lane : 0);
-                    merge_one_row<uint32_t, true>(r, pos0 + beg, cnt, pk[cnt ? at : 0], pw[cnt ? at : 0], true, lane, deg_mode, ucnt, deg,
-                                                  ent, &unordered, deg_scratch[wvu]);
-                } else if (cnt <= kUnitRowMax) {
-                    merge_long_row_w(pk + beg, pw + beg, cnt, r, static_cast<int64_t>(pos0) + beg, lane, deg_mode, ucnt, deg, ent,
-                                     &unordered);
-                } else {
-                    for (int i = lane; i < cnt; i += 64) ent[pos0 + beg + i] = no_entry;
-                    if (lane == 0) {
-                        atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
-                        ucnt[r] = 0;
-                        deg[r] = 0.f;
-                    }
-                }
+            for (uint32_t i = t; i < all; i += THREADS) {
+                keys2[pos0 + i] = pk[i];
+                w2[pos0 + i] = pw[i];
             }
         }
         __syncthreads();
         pos0 += static_cast<int32_t>(round_total);
         __syncthreads();
     }
-    if (__syncthreads_or(unordered) && t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(info + 1), 1ull);
 }
 
 // rocPRIM's gfx950 default for 64-bit keys sorts 8 bits per pass (3 passes for 20 row bits); 10 bits per pass with
@@ -1959,7 +1859,8 @@ extern "C" int pygsd_magop_workspace(int64_t n_edges, int32_t n, int32_t weighte
 }
 
 // sorted_front: the radix sort on the row bits in front of the row merge (round 3; rows of up to 4096 entries, any duplicates);
-// otherwise weighted graphs the bucket plan takes go through bucket_scatter_w / bucket_merge_rows_w (round 5)
+// otherwise weighted graphs the bucket plan takes go through bucket_scatter_w / bucket_place_rows_w (round 5) and are merged by
+// the same row kernels reading the row-grouped 4-byte stream
 static int magop_stage1_impl(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
                              int32_t is_signed, int32_t absolute_degree, int32_t sym, void* workspace,
                              size_t workspace_bytes, int32_t* rowptr, float* deg, int64_t* d_info, void* stream, bool sorted_front)
@@ -2013,14 +1914,26 @@ static int magop_stage1_impl(const int64_t* row, const int64_t* col, const float
         hipLaunchKernelGGL(bucket_scatter_w, dim3(pl.g), dim3(kScatterThreads), lds2, s, row, col, w, n_edges, n, pl, off, stream_k, w_b);
         if (int rc = check_launch("bucket_scatter_w")) return rc;
         const size_t lds = (static_cast<size_t>(pl.cap) + 2 * (((size_t(1) << pl.rl) >> 1) + 8)) * sizeof(uint32_t);
-        // (the kernel also holds ~4.5 KB of static LDS: the dynamic part is capped well below 160 KB minus that)
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_merge_rows_w<1024>),
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_place_rows_w<1024>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
-        PYGSD_REQUIRE(lds <= 148 * 1024, "pygsd_magop_stage1: bucket plan needs %zu B of LDS", lds);
         PYGSD_HIP_TRY(once);
-        hipLaunchKernelGGL(bucket_merge_rows_w<1024>, dim3(pl.nb), dim3(1024), lds, s, pl, stream_k, static_cast<const float*>(w_b), off, n,
-                           deg_mode, rs, ucnt, deg, ent, d_info);
-        if (int rc = check_launch("bucket_merge_rows_w")) return rc;
+        PYGSD_REQUIRE(lds <= 148 * 1024, "pygsd_magop_stage1: bucket plan needs %zu B of LDS", lds);
+        // row-grouped streams: keys in the second half of the key buffer (the bucket stream takes 4 of its 8 bytes per entry), weights
+        // in the sort's other weight buffer; the record area (keys_a + ent) is written by the merge kernels behind them
+        uint32_t* keys2 = stream_k + m;
+        hipLaunchKernelGGL(bucket_place_rows_w<1024>, dim3(pl.nb), dim3(1024), lds, s, pl, stream_k, static_cast<const float*>(w_b), off, n,
+                           rs, ucnt, keys2, w_a, d_info);
+        if (int rc = check_launch("bucket_place_rows_w")) return rc;
+        {
+            const int64_t per_block = 4 * kRowsPerWave;
+            const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n) + per_block - 1) / per_block);
+            hipLaunchKernelGGL((row_merge_wave<uint32_t, uint32_t, true>), dim3(grid), dim3(kBlock), 0, s, keys2, static_cast<const float*>(w_a),
+                               rs, n, m, deg_mode, ucnt, deg, ent, long_rows, n_long, d_info);
+            if (int rc = check_launch("row_merge_wave")) return rc;
+            hipLaunchKernelGGL((row_merge_block<uint32_t, true>), dim3(n < 1024 ? 64 : 1024), dim3(kBlock), 0, s, keys2,
+                               static_cast<const float*>(w_a), rs, deg_mode, ucnt, deg, ent, long_rows, n_long, d_info);
+            if (int rc = check_launch("row_merge_block")) return rc;
+        }
         size_t tb3 = l.scan_tmp_bytes;
         PYGSD_HIP_TRY(rocprim::exclusive_scan(base + l.scan_tmp, tb3, rocprim::make_transform_iterator(ucnt, PlusOne()), rowptr, 0,
                                               static_cast<size_t>(n) + 1, rocprim::plus<int32_t>(), s));
@@ -2052,7 +1965,7 @@ static int magop_stage1_impl(const int64_t* row, const int64_t* col, const float
             hipLaunchKernelGGL(row_merge_wave<uint64_t>, dim3(grid), dim3(kBlock), 0, s, keys_b, w_b, rs, n, m > 0 ? m : 1, deg_mode,
                                ucnt, deg, ent, long_rows, n_long);
         if (int rc = check_launch("row_merge_wave")) return rc;
-        hipLaunchKernelGGL(row_merge_block, dim3(n < 1024 ? 64 : 1024), dim3(kBlock), 0, s, keys_b, w_b, rs, deg_mode, ucnt,
+        hipLaunchKernelGGL(row_merge_block<>, dim3(n < 1024 ? 64 : 1024), dim3(kBlock), 0, s, keys_b, w_b, rs, deg_mode, ucnt,
                            deg, ent, long_rows, n_long, d_info);
         if (int rc = check_launch("row_merge_block")) return rc;
     }

@@ -1163,10 +1163,10 @@ def _weighted_graph(n, e, seed, signed, hubs=()):
                                                         (50007, 600000, True, False, "sym", 1.7), (300, 2000, True, True, "sym", 2.0),
                                                         (600000, 9000000, True, True, "sym", 2.0)])
 def test_weighted_bucket_operator_build_is_bitwise_the_generic_pipeline(n, e, signed, absdeg, norm, lam):
-    """Round 5: real-valued weights through the bucket split (bucket_scatter_w / bucket_merge_rows_w in front of the unchanged second
-    stage; get_magnetic_Laplacian.py:52-85, get_magnetic_signed_Laplacian.py:52-90 with edge weights) -- reciprocal pairs, exact
+    """Round 5: real-valued weights through the bucket split (bucket_scatter_w / bucket_place_rows_w + the sorted pipeline's row kernels
+    on the row-grouped 4-byte stream, in front of the unchanged second stage; get_magnetic_Laplacian.py:52-85, get_magnetic_signed_Laplacian.py:52-90 with edge weights) -- reciprocal pairs, exact
     duplicates (runs of two entries: fp32 addition commutes), self loops, isolated nodes, rows of 64 / 65 / 103 / 303 / 512 stream
-    entries (from 65: the rank sort through the record slots), every degree convention, both normalisations; 600 k nodes: buckets of
+    entries (from 65: the block-wide merge), every degree convention, both normalisations; 600 k nodes: buckets of
     512 rows in two rounds of 256.  Bit-identical to the generic pipeline and from run to run, and TAKEN (nothing was handed to the
     sorted pipeline)."""
     from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
@@ -1188,14 +1188,16 @@ def test_weighted_bucket_operator_build_is_bitwise_the_generic_pipeline(n, e, si
 def test_weighted_bucket_operator_build_steps_aside(monkeypatch):
     """What the weighted bucket form must not decide on its own goes to the sorted pipeline and still matches the generic one: an
     edge listed three times (its fp32 sum depends on the order: the reference's is the list order), a reciprocal pair with a
-    duplicate, a row of 513 entries; the pair of tensors is remembered, and PYGSD_WEIGHTED_BUILD_FORM=sort never tries."""
+    duplicate -- also inside a row of more than 64 entries (the block-wide merge); the pair of tensors is remembered, and
+    PYGSD_WEIGHTED_BUILD_FORM=sort never tries.  Hub rows are NOT a reason any more: up to 4096 entries they are merged by the
+    sorted pipeline's block kernel reading the row-grouped stream; beyond that no fused form takes the graph."""
     from pytorch_geometric_signed_directed_amd.utils import _laplacian as L
     n = 50007
     d = dev()
     ei, w = _weighted_graph(n, 300000, seed=77, signed=True)
     g = torch.Generator().manual_seed(8)
-    for extra in (torch.tensor([[3, 3, 3], [9, 9, 9]]), torch.tensor([[20, 21, 20], [21, 20, 21]]),
-                  torch.stack([torch.full((513,), 5), torch.arange(100, 613)])):
+    hub_with_triple = torch.cat([torch.stack([torch.full((300,), 5), torch.arange(100, 400)]), torch.tensor([[5, 5], [100, 100]])], dim=1)
+    for extra in (torch.tensor([[3, 3, 3], [9, 9, 9]]), torch.tensor([[20, 21, 20], [21, 20, 21]]), hub_with_triple):
         ei2 = torch.cat([ei, extra], dim=1).to(d)
         w2 = torch.cat([w, torch.rand(extra.size(1), generator=g) + 0.5]).to(d)
         want = _generic_operator(ei2, w2, n, True, True, 0.25, "sym", 2.0)
@@ -1203,6 +1205,16 @@ def test_weighted_bucket_operator_build_steps_aside(monkeypatch):
         _same_operator(L.fused_operator_csr(ei2, w2, n, True, True, 0.25, "sym", 2.0), want)
         assert L._NOT_BUCKETS.get((ei2, w2), (True, True)) is True
         _same_operator(L.fused_operator_csr(ei2, w2, n, True, True, 0.25, "sym", 2.0), want)
+    for k, taken in ((513, True), (4000, True), (4200, False)):
+        star = torch.stack([torch.full((k,), 6), torch.arange(100, 100 + k)])
+        ei2 = torch.cat([ei, star], dim=1).to(d)
+        w2 = torch.cat([w, torch.rand(k, generator=g) + 0.5]).to(d)
+        got = L.fused_operator_csr(ei2, w2, n, True, True, 0.25, "sym", 2.0)
+        if taken:
+            assert L._NOT_BUCKETS.get((ei2, w2), (True, True)) is None
+            _same_operator(got, _generic_operator(ei2, w2, n, True, True, 0.25, "sym", 2.0))
+        else:
+            assert got is None                                       # the layers then take the generic pipeline
     monkeypatch.setenv("PYGSD_WEIGHTED_BUILD_FORM", "sort")
     eid, wd = ei.to(d), w.to(d)
     _same_operator(L.fused_operator_csr(eid, wd, n, True, True, 0.25, "sym", 2.0), _generic_operator(eid, wd, n, True, True, 0.25, "sym", 2.0))
