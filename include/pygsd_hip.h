@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 13
+#define PYGSD_ABI_VERSION 14
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -517,8 +517,13 @@ int pygsd_dots_f32(const float* g, int64_t ldg, const float* const* xs, int32_t 
  * of SGCNConv (nn/signed/SGCNConv.py:121-126) -- and, with the upstream gradient and the back-propagated aggregates as the
  * segments and w_transposed != 0, their input gradients [g | dP] W^T in one product instead of one GEMM per block plus
  * accumulation passes.
- * dtype: 0 = fp32 (exact: v_mfma_f32_16x16x4_f32), 1 = bf16 storage with fp32 accumulation (v_mfma_f32_16x16x32_bf16), for
- * X, W, bias and Y alike.  xs / ldx / widths: HOST arrays over the n_seg (<= 4) column segments -- device pointer
+ * dtype: 0 = fp32, 1 = bf16 storage with fp32 accumulation (v_mfma_f32_16x16x32_bf16), for X, W, bias and Y alike.
+ * fp32 products take one of two forms (pygsd_tall_f32_form): SPLIT, the default wherever K, f_out and every input segment
+ * are multiples of 32 columns and K * f_out <= 24576 -- each fp32 value as the sum of three bf16 values, the six largest of
+ * the nine partial products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: within 1.7e-7 * sum |x| |w| of the float64
+ * product where an fp32 fmaf chain is within 2.5e-7 (measured, profiles/r5n_split_probe.txt), 2.7x fewer matrix cycles, but
+ * not bitwise any fp32 summation order, and magnitudes above the largest bf16 (3.39e38) overflow; EXACT -- an fmaf chain per
+ * output on v_mfma_f32_16x16x4_f32 -- for every other shape and on request.  xs / ldx / widths: HOST arrays over the n_seg (<= 4) column segments -- device pointer
  * (16-byte aligned), row stride in elements (a multiple of 16 bytes) and width (a multiple of 32 columns for bf16, 16 for
  * fp32).  W[k][n] (k over the concatenated segment columns) sits at w[k * ldw + n], or at w[n * ldw + k] when w_transposed.
  * The f_out = sum of out_widths output columns are written to n_out (<= 8) column segments ys / ldy / out_widths of the same
@@ -528,6 +533,10 @@ int pygsd_dots_f32(const float* g, int64_t ldg, const float* const* xs, int32_t 
  * library GEMMs otherwise.
  * ------------------------------------------------------------------------------------------- */
 int pygsd_tall_linear_supported(int32_t dtype, int32_t k_total, int32_t f_out);
+/* form: 0 = split where the shape allows (default; PYGSD_TALL_F32=exact at load selects 1), 1 = exact everywhere, anything
+ * else = query only.  Returns the form in force before the call.  Process-wide; not meant to be flipped while launches are
+ * being issued from other threads. */
+int pygsd_tall_f32_form(int32_t form);
 int pygsd_tall_linear(const void* const* xs, const int64_t* ldx, const int32_t* widths, int32_t n_seg, const void* w,
                       int64_t ldw, int32_t w_transposed, const void* bias, void* const* ys, const int64_t* ldy,
                       const int32_t* out_widths, int32_t n_out, int64_t n_rows, int32_t dtype, void* stream);

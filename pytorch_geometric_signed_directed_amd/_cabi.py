@@ -131,6 +131,7 @@ PROTOTYPES = {
     "pygsd_dots_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),
     "pygsd_tall_linear_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "pygsd_tall_f32_form": (c_int32, [c_int32]),
     "pygsd_tall_linear": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "pygsd_column_sums_workspace": (c_int32, [c_int64, c_int32, c_int32, ctypes.POINTER(ctypes.c_size_t)]),
@@ -146,7 +147,7 @@ PROTOTYPES = {
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class PieceLayoutStruct(ctypes.Structure):

@@ -194,6 +194,187 @@ __global__ __launch_bounds__(256) void tall_linear_f32_kernel(TallArgs p)
     }
 }
 
+// ---- fp32 storage, products on the bf16 matrix pipe by three-way splitting (round 5) --------------
+// The exact kernel above sits on the power budget, not on a pipe: its memory half alone streams 5.4 TB/s at 2.1 - 2.3 GHz, its
+// matrix half alone reaches 104 - 137 TF, together they run at 1.8 - 1.9 GHz and 0.49 - 0.55 of the HBM peak
+// (tools/probes/tall_probe.hip, profiles/r5m_tall_probe.txt).  v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate; the way out
+// is fewer matrix cycles per product.  Every fp32 value is the sum of three bf16 values up to 2^-24 of its magnitude:
+//   hi = bf16(x),  mid = bf16(x - hi),  lo = bf16(x - hi - mid)          (round to nearest even; both differences are exact)
+// and x w = the nine partial products of the two triples, of which the six largest are kept -- everything down to 2^-16 |x w|:
+//   hi hi,  hi mid,  mid hi,  mid mid,  hi lo,  lo hi            (dropped: mid lo, lo mid <= 2^-24 |x w| each, lo lo <= 2^-32)
+// Each bf16 x bf16 product is exact in fp32 (8 + 8 mantissa bits); v_mfma_f32_16x16x32_bf16 sums 32 of them into an fp32
+// accumulator per instruction.  6 of those (16 cycles each, 32 k-slots) replace 8 of the fp32 form (32 cycles each, 4 k-slots):
+// 2.7x fewer matrix cycles, and the kernel becomes what its memory half is.  Measured error against a float64 product, relative to
+// sum |x| |w| (tools/probes/split_probe.hip -> profiles/r5n_split_probe.txt): 1.3 - 1.7e-7 (0.5 - 0.8e-7 with the five small
+// terms summed in accumulators of their own, as here for f_out <= 64) against 2.1 - 2.5e-7 for the fmaf chain -- the dropped
+// terms are smaller than the chain's own roundings.  NOT bitwise the fmaf chain; a value of magnitude above the largest bf16
+// (3.39e38) overflows its `hi` (the exact kernel would carry it); PYGSD_TALL_F32=exact keeps every fp32 product on the kernel above.
+//
+// Memory side (the kernel is memory-bound now, so these pay: 81 -> 77 us at K = 128 / f_out = 64, 90 -> 78 at 64 / 128, 500 -> 411
+// at 64 / 192 for 2M rows -- same probe):
+//   * whole-line stores: lanes j and j ^ 8 trade one tile of each pair (a DPP rotation by 8 inside the row of 16 lanes), so that a
+//     store instruction writes 8 rows x 128 contiguous bytes instead of 16 rows x 64;
+//   * rows past the end are CLAMPED, not masked (such a lane loaded row n_rows - 1, so what it holds IS that row's result and it
+//     re-writes the same value there): every load and store is issued, the compiler's `s_waitcnt vmcnt(n)` counts are exact;
+//   * two row buffers A, B; a step S(X) = { tile in X: split, MFMAs, stores; load the tile two steps on into X }; the kernel =
+//     load A, B; S(A); S(B); loop { S(A); S(B) }.  With one pair and a `cur = nxt` copy the compiler moved each copy up behind the
+//     last use of cur[kb] and waited there for loads issued at the top of the SAME step; with masked accesses it waits for fewer
+//     operations than are in flight (a possibly-unissued store is not counted), i.e. for the previous tile's stores to be
+//     acknowledged; entering the loop straight from the prologue lowers the loop's counts to the prologue's.  Steady state:
+//     vmcnt(NT + 2 KB) -- the other tile's stores and its replacement's loads stay in flight across the wait.
+// KB = k-blocks of 32 columns, NT = output tiles of 16 (even); W lives in LDS pre-split, in fragment order: [KB][NT][3][64] x 16 B.
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& h, uint4& m, uint4& l)
+{
+    uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = x[2 * e], b = x[2 * e + 1];
+        hh[e] = pack2(a, b);
+        const float ra = a - __uint_as_float(hh[e] << 16), rb = b - __uint_as_float(hh[e] & 0xffff0000u);
+        mm[e] = pack2(ra, rb);
+        const float sa = ra - __uint_as_float(mm[e] << 16), sb = rb - __uint_as_float(mm[e] & 0xffff0000u);
+        ll[e] = pack2(sa, sb);
+    }
+    h = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+    m = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+    l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+}
+
+// the value lane (l ^ 8) holds: a rotation by 8 within each row of 16 lanes (DPP row_ror:8), full VALU rate
+__device__ __forceinline__ float rotate8(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true));
+}
+
+// the two 16-byte pieces lane (j, q) reads of every k-block of row `tile * 16 + j` (clamped)
+template <int KB>
+__device__ __forceinline__ void split_rows_in(const TallArgs& p, int tile, int j, int q, float4 (&dst)[KB][2])
+{
+    int64_t row = static_cast<int64_t>(tile) * 16 + j;
+    row = row < p.n_rows ? row : p.n_rows - 1;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const float* src = static_cast<const float*>(p.x[kb]) + row * p.ld[kb] + 8 * q;
+        dst[kb][0] = *reinterpret_cast<const float4*>(src);
+        dst[kb][1] = *reinterpret_cast<const float4*>(src + 4);
+    }
+}
+
+template <int KB, int NT>
+__device__ __forceinline__ void split_tile_out(const TallArgs& p, const uint4* frag, const float* bias, int tile, int lane,
+                                               const float4 (&cur)[KB][2])
+{
+    constexpr bool kApart = NT <= 4;          // the five small terms in accumulators of their own (registers allow it)
+    const int j = lane & 15, q = lane >> 4;
+    f32x4 acc[NT], small[kApart ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < (kApart ? NT : 1); ++t) small[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" ::: "memory");            // (keeps the W fragments in LDS: see the exact kernel)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const float xs[8] = {cur[kb][0].x, cur[kb][0].y, cur[kb][0].z, cur[kb][0].w,
+                             cur[kb][1].x, cur[kb][1].y, cur[kb][1].z, cur[kb][1].w};
+        uint4 xh4, xm4, xl4;
+        split8(xs, xh4, xm4, xl4);
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, xh4), xm = __builtin_bit_cast(bf16x8, xm4), xl = __builtin_bit_cast(bf16x8, xl4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint4* src = frag + ((kb * NT + t) * 3) * 64 + lane;
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, src[0]), wm = __builtin_bit_cast(bf16x8, src[64]),
+                         wl = __builtin_bit_cast(bf16x8, src[128]);
+            f32x4& s = kApart ? small[t] : acc[t];
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, s, 0, 0, 0);          // smallest first
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, s, 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t], 0, 0, 0);
+        }
+    }
+    if constexpr (kApart) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] += small[t];
+    }
+    // lane (j, q) holds columns [16 t + 4 q, +4) of row j for every tile t; after the trade lanes j < 8 hold tile 2 m of rows
+    // j and j + 8, lanes j >= 8 tile 2 m + 1 of rows j - 8 and j
+    const bool upper = j >= 8;
+    const int64_t last = p.n_rows - 1;
+    int64_t row_a = static_cast<int64_t>(tile) * 16 + (j & 7), row_b = row_a + 8;
+    row_a = row_a < last ? row_a : last;
+    row_b = row_b < last ? row_b : last;
+#pragma unroll
+    for (int m = 0; m < NT / 2; ++m) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + 32 * m + 4 * q);
+        const float4 b1 = *reinterpret_cast<const float4*>(bias + 32 * m + 16 + 4 * q);
+        const float lo[4] = {acc[2 * m][0] + b0.x, acc[2 * m][1] + b0.y, acc[2 * m][2] + b0.z, acc[2 * m][3] + b0.w};
+        const float hi[4] = {acc[2 * m + 1][0] + b1.x, acc[2 * m + 1][1] + b1.y, acc[2 * m + 1][2] + b1.z,
+                             acc[2 * m + 1][3] + b1.w};
+        float va[4], vb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lo_far = rotate8(lo[r]), hi_far = rotate8(hi[r]);     // the values of lane j ^ 8
+            va[r] = upper ? hi_far : lo[r];
+            vb[r] = upper ? hi[r] : lo_far;
+        }
+        // both tiles' addresses from the (scalar) kernel arguments, then a select: selecting the ARGUMENT per lane turns into a
+        // per-lane global load of it, and the wait for that load also waits for the next tile's rows
+        float* const lo_a = static_cast<float*>(p.y[2 * m]) + row_a * p.ldy[2 * m] + 4 * q;
+        float* const hi_a = static_cast<float*>(p.y[2 * m + 1]) + row_a * p.ldy[2 * m + 1] + 4 * q;
+        float* const lo_b = static_cast<float*>(p.y[2 * m]) + row_b * p.ldy[2 * m] + 4 * q;
+        float* const hi_b = static_cast<float*>(p.y[2 * m + 1]) + row_b * p.ldy[2 * m + 1] + 4 * q;
+        *reinterpret_cast<float4*>(upper ? hi_a : lo_a) = make_float4(va[0], va[1], va[2], va[3]);
+        *reinterpret_cast<float4*>(upper ? hi_b : lo_b) = make_float4(vb[0], vb[1], vb[2], vb[3]);
+    }
+}
+
+template <int KB, int NT>
+__global__ __launch_bounds__(256) void tall_linear_f32_split_kernel(TallArgs p)
+{
+    static_assert(NT % 2 == 0, "output tiles are stored in pairs");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* frag = reinterpret_cast<uint4*>(smem);                                          // [KB][NT][3][64] x 8 bf16
+    float* bias = reinterpret_cast<float*>(smem + static_cast<size_t>(KB) * NT * 3 * 64 * 16);   // [NT * 16]
+    const int tid = threadIdx.x;
+    const float* w = static_cast<const float*>(p.w);
+    for (int idx = tid; idx < KB * NT * 64; idx += 256) {
+        const int lane = idx & 63, t = (idx >> 6) % NT, kb = (idx >> 6) / NT;
+        const int64_t n = 16 * t + (lane & 15), k0 = kb * 32 + 8 * (lane >> 4);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p.w_t ? w[n * p.ldw + k0 + e] : w[(k0 + e) * p.ldw + n];
+        uint4 h, m, l;
+        split8(v, h, m, l);
+        uint4* dst = frag + ((kb * NT + t) * 3) * 64 + lane;
+        dst[0] = h; dst[64] = m; dst[128] = l;
+    }
+    for (int c = tid; c < NT * 16; c += 256) bias[c] = p.bias ? static_cast<const float*>(p.bias)[c] : 0.f;
+    __syncthreads();
+
+    const int lane = tid & 63, j = lane & 15, q = lane >> 4;
+    const int n_tiles = (p.n_rows + 15) >> 4;
+    const int stride = static_cast<int>(gridDim.x) * 4;
+    int tile = static_cast<int>(blockIdx.x) * 4 + (tid >> 6);
+    if (tile >= n_tiles) return;
+    const int last_tile = n_tiles - 1;
+    float4 rows_a[KB][2], rows_b[KB][2];
+    split_rows_in<KB>(p, tile, j, q, rows_a);
+    split_rows_in<KB>(p, min(tile + stride, last_tile), j, q, rows_b);
+#define PYGSD_TALL_STEP(ROWS)                                                          \
+    split_tile_out<KB, NT>(p, frag, bias, tile, lane, ROWS);                           \
+    split_rows_in<KB>(p, min(tile + 2 * stride, last_tile), j, q, ROWS);               \
+    tile += stride;                                                                    \
+    if (tile >= n_tiles) return;
+    PYGSD_TALL_STEP(rows_a)
+    PYGSD_TALL_STEP(rows_b)
+    for (;;) {
+        PYGSD_TALL_STEP(rows_a)
+        PYGSD_TALL_STEP(rows_b)
+    }
+#undef PYGSD_TALL_STEP
+}
+
 template <typename Kern>
 int launch_tall(Kern kern, const TallArgs& a, int kb, int nt, hipStream_t s)
 {
@@ -260,6 +441,60 @@ int dispatch_f32(const TallArgs& a, int nt, hipStream_t s)
         default: break;
     }
     return fail("pygsd_tall_linear: unsupported fp32 shape (%d k-blocks x %d tiles)", KB, nt);
+}
+
+// the split kernel's shapes: K and f_out multiples of 32, 3 KB of LDS per (k-block, tile) pair
+bool split_shape_ok(int k_total, int f_out)
+{
+    if (k_total % 32 || f_out % 32) return false;
+    const int kb = k_total / 32, nt = f_out / 16;
+    const bool kb_ok = kb == 1 || kb == 2 || kb == 3 || kb == 4 || kb == 6 || kb == 8;
+    const bool nt_ok = nt == 2 || nt == 4 || nt == 6 || nt == 8 || nt == 12 || nt == 16;
+    return kb_ok && nt_ok && kb * nt <= 48;
+}
+
+// 0 = the split form wherever its shapes allow (default), 1 = every fp32 product as an fmaf chain on v_mfma_f32_16x16x4_f32;
+// PYGSD_TALL_F32=exact sets 1 at load, pygsd_tall_f32_form changes it at run time (measurement / bitwise tests)
+int& tall_f32_form()
+{
+    static int form = [] {
+        const char* e = getenv("PYGSD_TALL_F32");
+        return (e && e[0] == 'e') ? 1 : 0;
+    }();
+    return form;
+}
+bool split_allowed() { return tall_f32_form() == 0; }
+
+template <typename Kern>
+int launch_split(Kern kern, const TallArgs& a, int kb, int nt, hipStream_t s)
+{
+    const size_t lds = static_cast<size_t>(kb) * nt * 3072 + static_cast<size_t>(nt) * 16 * sizeof(float);
+    if (lds > 64 * 1024)
+        PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          static_cast<int>(lds)));
+    size_t per_cu = (160 * 1024) / lds;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t n_tiles = (static_cast<int64_t>(a.n_rows) + 15) / 16;
+    int64_t grid = (n_tiles + 3) / 4;
+    if (grid > static_cast<int64_t>(256 * per_cu)) grid = static_cast<int64_t>(256 * per_cu);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, s, a);
+    return check_launch("tall_linear_f32_split_kernel");
+}
+
+template <int KB>
+int dispatch_split(const TallArgs& a, int nt, hipStream_t s)
+{
+    switch (nt) {
+        case 2: return launch_split(tall_linear_f32_split_kernel<KB, 2>, a, KB, 2, s);
+        case 4: return launch_split(tall_linear_f32_split_kernel<KB, 4>, a, KB, 4, s);
+        case 6: return launch_split(tall_linear_f32_split_kernel<KB, 6>, a, KB, 6, s);
+        case 8: if constexpr (KB <= 6) return launch_split(tall_linear_f32_split_kernel<KB, 8>, a, KB, 8, s); break;
+        case 12: if constexpr (KB <= 4) return launch_split(tall_linear_f32_split_kernel<KB, 12>, a, KB, 12, s); break;
+        case 16: if constexpr (KB <= 3) return launch_split(tall_linear_f32_split_kernel<KB, 16>, a, KB, 16, s); break;
+        default: break;
+    }
+    return fail("pygsd_tall_linear: unsupported split shape (%d k-blocks x %d tiles)", KB, nt);
 }
 
 // ---- column sums -------------------------------------------------------------------------------
@@ -344,6 +579,14 @@ unsigned column_sum_blocks(int64_t n_rows, int f, int v)
 
 using namespace pygsd;
 
+extern "C" int pygsd_tall_f32_form(int32_t form)
+{
+    int& cur = tall_f32_form();
+    const int before = cur;
+    if (form == 0 || form == 1) cur = form;
+    return before;
+}
+
 extern "C" int pygsd_tall_linear_supported(int32_t dtype, int32_t k_total, int32_t f_out)
 {
     return (k_total > 0 && f_out > 0 && shape_ok(dtype, k_total, f_out)) ? 1 : 0;
@@ -378,13 +621,17 @@ extern "C" int pygsd_tall_linear(const void* const* xs, const int64_t* ldx, cons
     if (n_rows == 0) return 0;
     PYGSD_REQUIRE(w && ldw >= (w_transposed ? k_total : f_out), "pygsd_tall_linear: W null or ldw = %lld too small",
                   static_cast<long long>(ldw));
+    // fp32: the split form (bf16 matrix pipe) where its shapes allow -- every input segment whole 32-column blocks
+    bool split = dtype == 0 && split_allowed() && split_shape_ok(k_total, f_out);
+    for (int g = 0; split && g < n_seg; ++g) split = widths[g] % 32 == 0;
+    const int kw_in = split ? 32 : kw;          // columns per input block
     TallArgs a{};
     int kb = 0;
     for (int g = 0; g < n_seg; ++g) {
         PYGSD_REQUIRE(xs[g] && aligned16(xs[g]) && ldx[g] >= widths[g] && ldx[g] % vec == 0,
                       "pygsd_tall_linear: segment %d null, not 16-byte aligned, or row stride %lld not a multiple of 16 bytes "
                       ">= its width", g, static_cast<long long>(ldx[g]));
-        for (int c = 0; c < widths[g]; c += kw, ++kb) {
+        for (int c = 0; c < widths[g]; c += kw_in, ++kb) {
             a.x[kb] = static_cast<const unsigned char*>(xs[g]) + static_cast<size_t>(c) * esz;
             a.ld[kb] = ldx[g];
         }
@@ -404,6 +651,18 @@ extern "C" int pygsd_tall_linear(const void* const* xs, const int64_t* ldx, cons
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_DENSE, s);
     const int nt = f_out / 16;
+    if (split) {
+        switch (kb) {
+            case 1: return dispatch_split<1>(a, nt, s);
+            case 2: return dispatch_split<2>(a, nt, s);
+            case 3: return dispatch_split<3>(a, nt, s);
+            case 4: return dispatch_split<4>(a, nt, s);
+            case 6: return dispatch_split<6>(a, nt, s);
+            case 8: return dispatch_split<8>(a, nt, s);
+            default: break;
+        }
+        return fail("pygsd_tall_linear: unsupported split shape K=%d f_out=%d", k_total, f_out);
+    }
     if (dtype == 1) {
         switch (kb) {
             case 1: return dispatch_bf16<1>(a, nt, s);

@@ -271,6 +271,14 @@ def set_tall_kernels(on: bool) -> bool:
     return prev
 
 
+def set_tall_f32_exact(on: bool) -> bool:
+    """fp32 tall products as an fmaf chain per output on the exact fp32 MFMA (True) or, where the shape allows, by three-way
+    bf16 splitting on the bf16 matrix pipe (False, the default: faster and closer to the float64 product, but not bitwise an
+    fp32 summation order -- include/pygsd_hip.h, pygsd_tall_f32_form).  `PYGSD_TALL_F32=exact` selects the exact form at load.
+    Returns the previous setting; process-wide."""
+    return bool(_cabi.lib().pygsd_tall_f32_form(1 if on else 0))
+
+
 def _row_major16(t: Tensor) -> Tensor:
     """t as the kernels address it: unit column stride, 16-byte aligned rows (column slices of a wider matrix qualify)."""
     vec = 16 // t.element_size()

@@ -1376,6 +1376,67 @@ def test_tall_product_matches_float64(dtype, n, widths, f_out, transposed, with_
     close(lib, want, TOL if dtype == "f32" else 2.0 ** -7 * (1 + len(widths)), what="library route")
 
 
+SPLIT_CASES = [
+    # (rows, segment widths, f_out, transposed W, bias, output splits, wide-range magnitudes)
+    (1, (64,), 64, False, True, None, False),                  # one row: fifteen clamped lanes re-write it
+    (15, (64, 64), 64, True, False, None, False),
+    (17, (32,), 32, False, True, None, False),                 # the smallest split shape, a ragged second tile
+    (4099, (128,), 64, True, False, None, True),               # C3a's input gradient shape, magnitudes over 2^-16 .. 2^15
+    (70001, (64,), 128, False, True, (64, 64), False),         # C3a forward: two output matrices
+    (20000, (64, 64, 64), 64, True, False, None, False),       # C5a's input gradient [dx0 | dP_1 | dP_2] W^T
+    (20000, (64,), 192, False, True, (64, 64, 64), True),      # C5a forward: three output matrices
+    (513, (256,), 64, False, False, None, False),              # K = 256: eight k-blocks, 16 KB of row buffers per wavefront
+]
+
+
+@pytest.mark.parametrize("n,widths,f_out,transposed,with_bias,splits,wide", SPLIT_CASES)
+def test_tall_product_fp32_split_form_against_exact_form_and_float64(n, widths, f_out, transposed, with_bias, splits, wide):
+    """The default fp32 form of pygsd_tall_linear (three-way bf16 splitting on the bf16 matrix pipe, include/pygsd_hip.h) next
+    to the exact form (an fmaf chain per output) on the same inputs, both against float64 relative to sum |x| |w| per output --
+    the natural scale of a dot product's rounding error.  The split form must be inside the 1e-5 bar AND no further from float64
+    than 1.25x the exact form's own worst error (measured: 0.4 - 0.8x of it), on inputs of one magnitude and on inputs whose
+    magnitudes span 2^31; ragged row counts exercise its clamped (unmasked) last tile."""
+    from pytorch_geometric_signed_directed_amd.dense import set_tall_f32_exact, tall_product
+    k = sum(widths)
+    g = torch.Generator().manual_seed(n + k + f_out)
+    w = torch.randn(k, f_out, generator=g) / k ** 0.5
+    segs = [torch.randn(n, wd, generator=g) for wd in widths]
+    if wide:
+        segs = [t * torch.exp2(torch.randint(-16, 16, t.shape, generator=g).float()) for t in segs]
+        w = w * torch.exp2(torch.randint(-8, 8, w.shape, generator=g).float())
+    bias = torch.randn(f_out, generator=g) if with_bias else None
+    x64 = torch.cat([t.double() for t in segs], dim=1)
+    want = x64 @ w.double()
+    scale = x64.abs() @ w.double().abs()
+    if bias is not None:
+        want = want + bias.double()
+        scale = scale + bias.double().abs()
+    segs_d = [t.to(dev()) for t in segs]
+    wdev = (w.t().contiguous() if transposed else w).to(dev())
+    bdev = None if bias is None else bias.to(dev())
+
+    def run():
+        out = tall_product(segs_d, wdev, transposed, bdev, splits=splits)
+        return torch.cat([o.cpu() for o in out], dim=1) if splits is not None else out.cpu()
+
+    prev = set_tall_f32_exact(False)
+    try:
+        split = run()
+        assert torch.equal(run(), split)                       # deterministic
+        set_tall_f32_exact(True)
+        exact = run()
+    finally:
+        set_tall_f32_exact(prev)
+    assert split.shape == (n, f_out) and not torch.equal(split, exact)     # (two forms really ran)
+    err_split = float(((split.double() - want).abs() / scale).max())
+    err_exact = float(((exact.double() - want).abs() / scale).max())
+    if not wide:        # (with magnitudes spanning 2^31 the sums cancel: only the scale-relative error says anything, for either form)
+        close(split, want, TOL, what="split form")
+        close(exact, want, TOL, what="exact form")
+    assert err_split <= max(1.25 * err_exact, 2.0 ** -23), (err_split, err_exact)
+    assert err_split < (1e-6 if wide else 4e-7), err_split
+
+
 @pytest.mark.parametrize("dtype,n,f,sliced", [("f32", 1000, 64, False), ("f32", 5, 4, False), ("f32", 70001, 192, True),
                                               ("bf16", 1000, 64, False), ("bf16", 70001, 128, True), ("bf16", 3, 8, False)])
 def test_column_sums_match_float64(dtype, n, f, sliced):
