@@ -132,6 +132,7 @@ PROTOTYPES = {
                                  c_void_p]),
     "pygsd_tall_linear_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "pygsd_tall_f32_form": (c_int32, [c_int32]),
+    "pygsd_dense_f32_form": (c_int32, [c_int32]),
     "pygsd_tall_linear": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "pygsd_column_sums_workspace": (c_int32, [c_int64, c_int32, c_int32, ctypes.POINTER(ctypes.c_size_t)]),
@@ -147,7 +148,7 @@ PROTOTYPES = {
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class PieceLayoutStruct(ctypes.Structure):

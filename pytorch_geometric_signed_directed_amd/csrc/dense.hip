@@ -1,5 +1,6 @@
-// Fused dense stage of MagNetConv / MSConv on the MFMA matrix cores (exact fp32:
-// v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) -- the only GEMM-shaped work on the path.
+// Fused dense stage of MagNetConv / MSConv on the MFMA matrix cores -- the only GEMM-shaped work on the path.  Exact fp32
+// (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) for the forward and for every backward shape; the backward at f_out = 64 runs by
+// default on the bf16 pipe by three-way splitting (dense_bwd_split_kernel below; pygsd_dense_f32_form).
 //
 //   forward :  out_real = sum_k (A_k - B_k) W_k + b ,  out_imag = sum_k (A_k + B_k) W_k + b
 //              (A_k / B_k = k-th Chebyshev terms of the real / imaginary chain; reference
@@ -22,6 +23,10 @@ namespace pygsd {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxOrder = 4;   // K + 1 <= 4
 constexpr int kChunk = 64;     // output-column / input-column chunk handled by one block
@@ -509,6 +514,339 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
         for (int e = tid; e < fo; e += 256) part[pstride - p.f_out + e] = lds[wsz + e];
 }
 
+// ---- the backward stage on the bf16 matrix pipe by three-way splitting (round 5) -----------------------------------------
+// dense_bwd_kernel<4, 4, true> is paced by its matrix cycles on a chip that is on its power budget (110 TF of exact-fp32 MFMA,
+// 0.59 ms for 2.05 GB at the north-star shape).  As csrc/tall.hip's split kernel (the derivation and the measured error are
+// there): every fp32 operand = hi + mid + lo in bf16, every product = its six largest partial products on the bf16 pipe with
+// fp32 accumulation -- closer to the float64 product than an fp32 fmaf chain, 2.7x fewer matrix cycles.  Same tiling, same
+// loads, same LDS transposition, same stores, same partials and reduction as the exact kernel (f_in chunk 64 = NTI 4, f_out 64 =
+// NTO 4, XPOSE); what changes is the two products:
+//   phase 1  dA | dB tile = [P | M] W_k^T: the reduction runs over the 64 output features = 2 blocks of 32 k-slots for
+//            v_mfma_f32_16x16x32_bf16.  A lane's 8 k-slots of block kb are the columns 32 kb + 16 h + 4 g + r (h < 2, r < 4) --
+//            exactly the two float4 row pieces it already holds (tiles 2 kb and 2 kb + 1); W_k^T sits in LDS pre-split, in
+//            fragment order with the same slot map.
+//   phase 2  dW_k += A^T P + B^T M: the reduction runs over the tile's 16 rows = ONE v_mfma_f32_16x16x16_bf16 per product
+//            term, whose 4 k-slots per lane are rows 4 g + s, s < 4 -- the column fragments the exact kernel feeds to four
+//            successive 16x16x4 MFMAs.
+struct Triple4 { uint2 h, m, l; };       // four fp32 values as 3 x 4 bf16
+
+__device__ __forceinline__ uint32_t bf16_pair(float lo, float hi)       // one v_cvt_pk_bf16_f32, round to nearest even
+{
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+__device__ __forceinline__ Triple4 split4(float x0, float x1, float x2, float x3)
+{
+    Triple4 t;
+    const float x[4] = {x0, x1, x2, x3};
+    uint32_t hh[2], mm[2], ll[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float a = x[2 * e], b = x[2 * e + 1];
+        hh[e] = bf16_pair(a, b);
+        const float ra = a - __uint_as_float(hh[e] << 16), rb = b - __uint_as_float(hh[e] & 0xffff0000u);      // exact
+        mm[e] = bf16_pair(ra, rb);
+        const float sa = ra - __uint_as_float(mm[e] << 16), sb = rb - __uint_as_float(mm[e] & 0xffff0000u);    // exact
+        ll[e] = bf16_pair(sa, sb);
+    }
+    t.h = make_uint2(hh[0], hh[1]);
+    t.m = make_uint2(mm[0], mm[1]);
+    t.l = make_uint2(ll[0], ll[1]);
+    return t;
+}
+
+__device__ __forceinline__ bf16x8 octet(uint2 lo, uint2 hi) { return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)); }
+__device__ __forceinline__ s16x4 quad(uint2 v) { return __builtin_bit_cast(s16x4, v); }
+
+// c += the six largest partial products of (w_h + w_m + w_l)(x_h + x_m + x_l), smallest first
+__device__ __forceinline__ f32x4 mfma6_32(const bf16x8 (&w)[3], const bf16x8 (&x)[3], f32x4 c)
+{
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1], c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 mfma6_16(const Triple4& a, const Triple4& b, f32x4 c)
+{
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(a.l), quad(b.h), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(a.h), quad(b.l), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(a.m), quad(b.m), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(a.m), quad(b.h), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(a.h), quad(b.m), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(a.h), quad(b.h), c, 0, 0, 0);
+}
+
+template <bool PIECES>
+__global__ __launch_bounds__(256, 2) void dense_bwd_split_kernel(DenseBwdArgs p)
+{
+    constexpr int NTI = 4, NTO = 4, fc = 64, fo = 64;
+    constexpr int rs = 64 + kPad;                                  // row stride of the staging region
+    constexpr int kFragFloats = 2 * NTI * 3 * 64 * 4;              // W_k^T fragments: [2 kb][NTI][3][64] x 16 B
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int k = blockIdx.y;
+    const int c0 = static_cast<int>(blockIdx.z) * kChunk;
+    uint4* wfrag = reinterpret_cast<uint4*>(lds);
+    for (int idx = tid; idx < 2 * NTI * 64; idx += 256) {
+        const int lane = idx & 63, ft = (idx >> 6) & 3, kb = idx >> 8;
+        const int i = lane & 15, g = lane >> 4;
+        const float* wrow = p.w + (static_cast<int64_t>(k) * p.f_in + c0 + 16 * ft + i) * p.f_out + 32 * kb + 4 * g;
+        const Triple4 lo = split4(wrow[0], wrow[1], wrow[2], wrow[3]);             // slots 0..3: column 32 kb + 4 g + r
+        const Triple4 hi = split4(wrow[16], wrow[17], wrow[18], wrow[19]);         // slots 4..7: column 32 kb + 16 + 4 g + r
+        uint4* dst = wfrag + ((kb * NTI + ft) * 3) * 64 + lane;
+        dst[0] = make_uint4(lo.h.x, lo.h.y, hi.h.x, hi.h.y);
+        dst[64] = make_uint4(lo.m.x, lo.m.y, hi.m.x, hi.m.y);
+        dst[128] = make_uint4(lo.l.x, lo.l.y, hi.l.x, hi.l.y);
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, i = lane & 15, g = lane >> 4;
+    float* stage = lds + kFragFloats + (tid >> 6) * (2 * 16 * rs);      // wavefront-private: [2][16][rs]
+    const bool do_bias = (k == 0) && (blockIdx.z == 0);
+    const float* ak = p.a[k];
+    const float* bk = p.b[k];
+    float* dak = p.da[k];
+    float* dbk = p.db[k];
+
+    f32x4 acc_w[NTI][NTO];
+    float acc_bias[NTO];
+#pragma unroll
+    for (int ft = 0; ft < NTI; ++ft)
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) acc_w[ft][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt) acc_bias[nt] = 0.f;
+
+    const int n_tiles = (p.n_rows + 15) >> 4;
+    const int stride = static_cast<int>(gridDim.x) * 4;
+    int tile = static_cast<int>(blockIdx.x) * 4 + (tid >> 6);
+    // All of a tile's loads first, as the exact kernel.  (Issuing tile t + 1's loads in the middle of tile t -- behind the dA / dB
+    // stores, in front of phase 2 -- was measured: 0.513 against 0.506 ms; at 256 registers the compiler sinks them back to their
+    // first use.)
+    float4 xg[NTO], yg[NTO], a4[NTI], b4[NTI];
+    const bool in_pieces = PIECES && p.in_on && k == p.k1 - 1;      // (block-uniform)
+    auto rows_in = [&](int tl) {
+        const int r0 = tl << 4;
+        const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;              // clamped; dead rows are zeroed where they are used
+        const float* grp = p.gr + static_cast<int64_t>(lrow) * p.ldg + 4 * g;
+        const float* gip = p.gi + static_cast<int64_t>(lrow) * p.ldg + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) {
+            xg[nt] = ldg4(grp + nt * 16);
+            yg[nt] = ldg4(gip + nt * 16);
+        }
+        const float* arow = ak + static_cast<int64_t>(lrow) * p.f_in + c0 + 4 * g;
+        const float* brow = bk + static_cast<int64_t>(lrow) * p.f_in + c0 + 4 * g;
+        PieceRow pin;
+        int ish = 31, imk = 0x7fffffff;
+        if (in_pieces) {
+            pin = piece_row(p.lay_in, lrow);
+            ish = p.in_shift;
+            imk = (1 << ish) - 1;
+            arow = ak + 4 * g;
+            brow = bk + 4 * g;
+        }
+#pragma unroll
+        for (int ft = 0; ft < NTI; ++ft) {
+            const int64_t poff = in_pieces ? piece_offset(pin, (c0 >> 4) + ft, ish, imk) : static_cast<int64_t>(ft * 16);
+            a4[ft] = ldg4(arow + poff);
+            b4[ft] = ldg4(brow + poff);
+        }
+    };
+    for (; tile < n_tiles; tile += stride) {
+        const int r0 = tile << 4;
+        const bool lrow_live = r0 + i < p.n_rows;
+        rows_in(tile);
+        if (!lrow_live) {                       // rows past the end must contribute nothing to dW
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                yg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                a4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                b4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int ft = 0; ft < NTI; ++ft) {
+            *reinterpret_cast<float4*>(stage + i * rs + ft * 16 + 4 * g) = a4[ft];
+            *reinterpret_cast<float4*>(stage + 16 * rs + i * rs + ft * 16 + 4 * g) = b4[ft];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // column fragments of A_k / B_k: rows 4 g + s of column 16 ft + i (split further down, beside phase 1's MFMAs)
+        float av[NTI][4], bv[NTI][4];
+#pragma unroll
+        for (int ft = 0; ft < NTI; ++ft) {
+            const float* ca = stage + (4 * g) * rs + ft * 16 + i;
+            const float* cb = ca + 16 * rs;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                av[ft][e] = ca[e * rs];
+                bv[ft][e] = cb[e * rs];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // P / M: row fragments -> staging region (the A / B fragments were consumed above) and, split, phase 1's B operands
+        Triple4 pt[NTO], mt[NTO];
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) {
+            const float4 x = xg[nt], y = yg[nt];
+            const float pp[4] = {x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w};
+            const float mm[4] = {y.x - x.x, y.y - x.y, y.z - x.z, y.w - x.w};
+            *reinterpret_cast<float4*>(stage + i * rs + nt * 16 + 4 * g) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            *reinterpret_cast<float4*>(stage + 16 * rs + i * rs + nt * 16 + 4 * g) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            pt[nt] = split4(pp[0], pp[1], pp[2], pp[3]);
+            mt[nt] = split4(mm[0], mm[1], mm[2], mm[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // column fragments of P / M for phase 2: rows 4 g + s of column 16 nt + i
+        float pb[NTO][4], mb[NTO][4];
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) {
+            const float* cp = stage + (4 * g) * rs + nt * 16 + i;
+            const float* cm = cp + 16 * rs;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pb[nt][e] = cp[e * rs];
+                mb[nt][e] = cm[e * rs];
+            }
+        }
+        if (do_bias) {                          // (the exact kernel's order: one add per row slot)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) acc_bias[nt] += pb[nt][e];
+        }
+        // ---- phase 1: dA_k, dB_k tile = [P | M] (16 x 64) . W_k^T (64 x 64).  The six partial products of a term are issued
+        //      TERM-outer, accumulator-inner: consecutive MFMAs write different accumulators (8 of them), so none waits for its
+        //      predecessor's result and a vector instruction scheduled between two of them costs its own slot only.
+        f32x4 acc_a[NTI], acc_b[NTI];
+#pragma unroll
+        for (int ft = 0; ft < NTI; ++ft) {
+            acc_a[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc_b[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        constexpr int kWi[6] = {2, 0, 1, 1, 0, 0}, kXi[6] = {0, 2, 1, 0, 1, 0};      // (w piece, x piece) of the six terms, smallest first
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const bf16x8 px[3] = {octet(pt[2 * kb].h, pt[2 * kb + 1].h), octet(pt[2 * kb].m, pt[2 * kb + 1].m),
+                                  octet(pt[2 * kb].l, pt[2 * kb + 1].l)};
+            const bf16x8 mx[3] = {octet(mt[2 * kb].h, mt[2 * kb + 1].h), octet(mt[2 * kb].m, mt[2 * kb + 1].m),
+                                  octet(mt[2 * kb].l, mt[2 * kb + 1].l)};
+            bf16x8 w[NTI][3];
+#pragma unroll
+            for (int ft = 0; ft < NTI; ++ft) {
+                const uint4* src = wfrag + ((kb * NTI + ft) * 3) * 64 + lane;
+                w[ft][0] = __builtin_bit_cast(bf16x8, src[0]);
+                w[ft][1] = __builtin_bit_cast(bf16x8, src[64]);
+                w[ft][2] = __builtin_bit_cast(bf16x8, src[128]);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int ft = 0; ft < NTI; ++ft) {
+                    acc_a[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ft][kWi[t]], px[kXi[t]], acc_a[ft], 0, 0, 0);
+                    acc_b[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ft][kWi[t]], mx[kXi[t]], acc_b[ft], 0, 0, 0);
+                }
+        }
+        // ---- the tile's dA / dB stores (in front of phase 2: their registers are free for it) ------------------------------
+        if (r0 + i < p.n_rows) {
+            if (PIECES && p.out_on && k == p.k1 - 1) {
+                const PieceRow po = piece_row(p.lay_out, r0 + i);
+                const int osh = p.out_shift, omk = (1 << osh) - 1;
+                const int64_t rep_stride = static_cast<int64_t>(p.lay_out.slots_per_blk) * po.slot_stride;
+#pragma unroll
+                for (int ft = 0; ft < NTI; ++ft) {
+                    const int64_t o = piece_offset(po, (c0 >> 4) + ft, osh, omk) + 4 * g;
+                    const float4 va = make_float4(acc_a[ft][0], acc_a[ft][1], acc_a[ft][2], acc_a[ft][3]);
+                    const float4 vb = make_float4(acc_b[ft][0], acc_b[ft][1], acc_b[ft][2], acc_b[ft][3]);
+                    for (int rep = 0; rep < p.lay_out.replicas; ++rep) {
+                        *reinterpret_cast<float4*>(dak + o + rep * rep_stride) = va;
+                        *reinterpret_cast<float4*>(dbk + o + rep * rep_stride) = vb;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ft = 0; ft < NTI; ++ft) {
+                    const int64_t o = static_cast<int64_t>(r0 + i) * p.f_in + c0 + ft * 16 + 4 * g;
+                    *reinterpret_cast<float4*>(dak + o) = make_float4(acc_a[ft][0], acc_a[ft][1], acc_a[ft][2], acc_a[ft][3]);
+                    *reinterpret_cast<float4*>(dbk + o) = make_float4(acc_b[ft][0], acc_b[ft][1], acc_b[ft][2], acc_b[ft][3]);
+                }
+            }
+        }
+        // ---- phase 2: dW_k[chunk, :] += A_tile^T P + B_tile^T M  (reduction over the 16 rows), term-outer likewise ---------
+        Triple4 at[NTI], bt[NTI];
+#pragma unroll
+        for (int ft = 0; ft < NTI; ++ft) {
+            at[ft] = split4(av[ft][0], av[ft][1], av[ft][2], av[ft][3]);
+            bt[ft] = split4(bv[ft][0], bv[ft][1], bv[ft][2], bv[ft][3]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) {
+            const Triple4 pc = split4(pb[nt][0], pb[nt][1], pb[nt][2], pb[nt][3]);
+            const Triple4 mc = split4(mb[nt][0], mb[nt][1], mb[nt][2], mb[nt][3]);
+            const uint2 pcs[3] = {pc.h, pc.m, pc.l}, mcs[3] = {mc.h, mc.m, mc.l};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int ft = 0; ft < NTI; ++ft) {
+                    const uint2 as[3] = {at[ft].h, at[ft].m, at[ft].l};
+                    acc_w[ft][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(as[kWi[t]]), quad(pcs[kXi[t]]), acc_w[ft][nt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int ft = 0; ft < NTI; ++ft) {
+                    const uint2 bs[3] = {bt[ft].h, bt[ft].m, bt[ft].l};
+                    acc_w[ft][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(bs[kWi[t]]), quad(mcs[kXi[t]]), acc_w[ft][nt], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- combine the 4 wavefronts of the block through LDS (the W fragments are dead now), then one partial ----
+    __syncthreads();
+    const int wave = tid >> 6;
+    constexpr int wsz = fc * fo;
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int ft = 0; ft < NTI; ++ft)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = (ft * 16 + 4 * g + r) * fo + nt * 16 + i;
+                        lds[e] = (turn == 0 ? 0.f : lds[e]) + acc_w[ft][nt][r];
+                    }
+            if (do_bias) {
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    float v = acc_bias[nt];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (g == 0) lds[wsz + nt * 16 + i] = (turn == 0 ? 0.f : lds[wsz + nt * 16 + i]) + v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t pstride = static_cast<int64_t>(p.k1) * p.f_in * p.f_out + p.f_out;
+    float* part = p.partial + static_cast<int64_t>(blockIdx.x) * pstride;
+    float* dst = part + (static_cast<int64_t>(k) * p.f_in + c0) * p.f_out;
+    for (int e = tid; e < wsz; e += 256) dst[e] = lds[e];
+    if (do_bias)
+        for (int e = tid; e < fo; e += 256) part[pstride - p.f_out + e] = lds[wsz + e];
+}
+
 // out[e] = sum_p partial[p][e], fixed order (deterministic): 64 elements per block, 4 partial
 // groups per element combined through LDS.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
@@ -572,9 +910,33 @@ int launch_fwd(const DenseFwdArgs& a, unsigned gy, hipStream_t s, bool pieces = 
     return launch_fwd_fin<NT, 0>(a, gy, lds_bytes, s);
 }
 
+// 0 = the split form wherever its shapes allow (default), 1 = every product an fmaf chain on v_mfma_f32_16x16x4_f32;
+// PYGSD_DENSE_F32=exact sets 1 at load, pygsd_dense_f32_form changes it at run time (measurement / bitwise tests)
+int& dense_f32_form()
+{
+    static int form = [] {
+        const char* e = getenv("PYGSD_DENSE_F32");
+        return (e && e[0] == 'e') ? 1 : 0;
+    }();
+    return form;
+}
+
+template <bool PIECES>
+int launch_bwd_split(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
+{
+    constexpr size_t rs = 64 + kPad;
+    const size_t lds_bytes = (static_cast<size_t>(2 * 4 * 3 * 64 * 4) + 4 * 2 * 16 * rs) * sizeof(float);
+    if (int rc = set_lds(dense_bwd_split_kernel<PIECES>, lds_bytes)) return rc;
+    hipLaunchKernelGGL((dense_bwd_split_kernel<PIECES>), dim3(gx, a.k1, gz), dim3(256), lds_bytes, s, a);
+    return check_launch("dense_bwd_split_kernel");
+}
+
 template <int NTI, int NTO, bool PIECES = false>
 int launch_bwd(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
 {
+    if constexpr (NTI == 4 && NTO == 4) {
+        if (dense_f32_form() == 0) return launch_bwd_split<PIECES>(a, gx, gz, s);
+    }
     constexpr bool kXpose = true;
     constexpr size_t rs = (NTO > NTI ? NTO : NTI) * 16 + kPad;
     size_t lds_floats = static_cast<size_t>(NTO * 16) * (NTI * 16 + kPad) + (kXpose ? 4 * 2 * 16 * rs : 0);
@@ -613,6 +975,14 @@ int dispatch_bwd_nto(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_
 }  // namespace pygsd
 
 using namespace pygsd;
+
+extern "C" int pygsd_dense_f32_form(int32_t form)
+{
+    int& cur = dense_f32_form();
+    const int before = cur;
+    if (form == 0 || form == 1) cur = form;
+    return before;
+}
 
 extern "C" int pygsd_magnetic_dense_supported(int32_t f_in, int32_t f_out, int32_t k1)
 {

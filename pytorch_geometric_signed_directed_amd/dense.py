@@ -271,6 +271,13 @@ def set_tall_kernels(on: bool) -> bool:
     return prev
 
 
+def set_dense_f32_exact(on: bool) -> bool:
+    """The magnetic dense stage's backward products as fmaf chains on the exact fp32 MFMA (True) or, at the shapes that have
+    one, in the split form on the bf16 matrix pipe (False, the default; include/pygsd_hip.h, pygsd_dense_f32_form).
+    `PYGSD_DENSE_F32=exact` selects the exact form at load.  Returns the previous setting; process-wide."""
+    return bool(_cabi.lib().pygsd_dense_f32_form(1 if on else 0))
+
+
 def set_tall_f32_exact(on: bool) -> bool:
     """fp32 tall products as an fmaf chain per output on the exact fp32 MFMA (True) or, where the shape allows, by three-way
     bf16 splitting on the bf16 matrix pipe (False, the default: faster and closer to the float64 product, but not bitwise an

@@ -353,6 +353,61 @@ def test_dense_backward_takes_a_broadcast_gradient_row(f_in, f_out, k1, n):
             assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("f_in,k1,n,broadcast", [(64, 2, 1, False), (64, 2, 37, False), (64, 1, 4099, False), (64, 3, 20000, False),
+                                                 (128, 3, 1030, False), (64, 2, 70001, True)])
+def test_dense_backward_split_form_against_exact_form_and_float64(f_in, k1, n, broadcast):
+    """The default arithmetic of the magnetic dense backward at f_out = 64 (operands as three bf16 pieces, six partial products
+    per product on the bf16 matrix pipe, include/pygsd_hip.h: pygsd_dense_f32_form) next to the exact form (fmaf chains) on the
+    same inputs, both against float64 relative to the sum of |terms| of each output.  dA / dB: inside 1.25x the exact form's own
+    worst error (measured 0.75 - 0.8x); dW (a reduction over all rows, both forms at 1e-8 of the scale): inside 4x; dbias is
+    computed identically (bitwise).  f_in = 128 runs two 64-column chunks; n = 1 / 37 / 4099 end in ragged tiles."""
+    from pytorch_geometric_signed_directed_amd.dense import dense_bwd_raw, set_dense_f32_exact
+    f_out = 64
+    g = torch.Generator().manual_seed(f_in + k1 + n)
+    a = [torch.randn(n, f_in, generator=g).to(dev()) for _ in range(k1)]
+    b = [torch.randn(n, f_in, generator=g).to(dev()) for _ in range(k1)]
+    w = (torch.randn(k1, f_in, f_out, generator=g) / f_in ** 0.5).to(dev())
+    if broadcast:
+        gr, gi = (torch.randn(1, f_out, generator=g).to(dev()).expand(n, f_out) for _ in range(2))
+    else:
+        gr, gi = (torch.randn(n, f_out, generator=g).to(dev()) for _ in range(2))
+    p64, m64, w64 = (gr + gi).double(), (gi - gr).double(), w.double()
+
+    def errors(res):
+        da, db, dw, dbias = res
+        e_rows = e_w = 0.0
+        for k in range(k1):
+            wt = w64[k].t()
+            for got, src in ((da[k], p64), (db[k], m64)):
+                e_rows = max(e_rows, float(((got.double() - src @ wt).abs() / (src.abs() @ wt.abs())).max()))
+            a64, b64 = a[k].double(), b[k].double()
+            want = a64.t() @ p64 + b64.t() @ m64
+            scale = a64.abs().t() @ p64.abs() + b64.abs().t() @ m64.abs()
+            e_w = max(e_w, float(((dw[k].double() - want).abs() / scale).max()))
+            close(dw[k], want, TOL, norm=True, what="dW")
+            close(da[k], p64 @ wt, TOL, what="dA")
+            close(db[k], m64 @ wt, TOL, what="dB")
+        close(dbias, p64.sum(0), TOL, norm=True, what="dbias")
+        return e_rows, e_w
+
+    prev = set_dense_f32_exact(False)
+    try:
+        split = dense_bwd_raw(a, b, w, gr, gi)
+        again = dense_bwd_raw(a, b, w, gr, gi)
+        set_dense_f32_exact(True)
+        exact = dense_bwd_raw(a, b, w, gr, gi)
+    finally:
+        set_dense_f32_exact(prev)
+    for x, y in zip(split[0] + split[1] + [split[2], split[3]], again[0] + again[1] + [again[2], again[3]]):
+        assert torch.equal(x, y)                                    # deterministic
+    assert not torch.equal(split[0][0], exact[0][0])                # (two forms really ran)
+    assert torch.equal(split[3], exact[3])                          # dbias: the same sums in the same order
+    rows_s, w_s = errors(split)
+    rows_e, w_e = errors(exact)
+    assert rows_s <= max(1.25 * rows_e, 2.0 ** -23), (rows_s, rows_e)
+    assert w_s <= max(4.0 * w_e, 2.0 ** -23), (w_s, w_e)
+
+
 def test_dense_supported_predicate():
     from pytorch_geometric_signed_directed_amd.dense import dense_supported
     assert dense_supported(64, 64, 2) and dense_supported(128, 128, 3) and dense_supported(16, 16, 1)
