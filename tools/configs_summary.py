@@ -48,6 +48,9 @@ def model(step, cfg, present=()):
         return {**spmm,
                 "tall_linear_f32_kernel<4,8>": (n * (64 + 128) * 4, 2 * n * 64 * 128, "x [own_b | own_u | agg_b | agg_u]"),
                 "tall_linear_f32_kernel<8,4>": (n * (128 + 64) * 4, 2 * n * 128 * 64, "dx = [g | g_a] W^T"),
+                # round 5's split form (k-blocks of 32): the same products, flops counted as fp32 multiply-adds of the operands
+                "tall_linear_f32_split_kernel<2,8>": (n * (64 + 128) * 4, 2 * n * 64 * 128, "x [own_b | own_u | agg_b | agg_u] (split form)"),
+                "tall_linear_f32_split_kernel<4,4>": (n * (128 + 64) * 4, 2 * n * 128 * 64, "dx = [g | g_a] W^T (split form)"),
                 **{k: (n * (64 + 128) * 4, 2 * n * 64 * 128, "dW = x^T [g | g_a]") for k in present if k and k.startswith("tall_gram")},
                 "column_sums_kernel<false>": (n * 64 * 4, None, "bias gradient")}
     if step == "C3b":
@@ -77,6 +80,9 @@ def model(step, cfg, present=()):
             (spmm_bytes(nnz, n, 64, s), None, "S_k^T P_k forward and S_k dx_k backward, 26 entries per row"),
             lin[0]: (n * (64 + 192) * s, 2 * n * 64 * 192, "x [W_ln^T | W_1 | W_2]"),
             lin[1]: (n * (192 + 64) * s, 2 * n * 192 * 64, "dx = [dx0 | dP_1 | dP_2] W^T"),
+            **({"tall_linear_f32_split_kernel<2,12>": (n * (64 + 192) * 4, 2 * n * 64 * 192, "x [W_ln^T | W_1 | W_2] (split form)"),
+                "tall_linear_f32_split_kernel<6,4>": (n * (192 + 64) * 4, 2 * n * 192 * 64, "dx = [dx0 | dP_1 | dP_2] W^T (split form)")}
+               if step == "C5a" else {}),
             **{k: (n * (64 + 192) * s, 2 * n * 64 * 192, "x^T [dx0 | dP_1 | dP_2]") for k in present if k and k.startswith("tall_gram")},
             f"column_sums_kernel<{'false' if step == 'C5a' else 'true'}>": (n * 64 * s, None, "bias gradients")}
 

@@ -18,7 +18,7 @@ ROUND = os.environ.get("ROUND", "r2")
 
 
 def short(name):
-    m = re.search(r"(spmm_vec_kernel<[^>]*>|spmm_long\w*<[^>]*>|dense_fwd_kernel<[^>]*>|dense_bwd_kernel<[^>]*>|"
+    m = re.search(r"(spmm_vec_kernel<[^>]*>|spmm_long\w*<[^>]*>|dense_fwd_kernel<[^>]*>|dense_bwd_kernel<[^>]*>|dense_bwd_split_kernel<[^>]*>|"
                   r"reduce_partials_kernel)", name)
     return m.group(1).replace(" ", "") if m else None
 
@@ -67,7 +67,8 @@ def main():
                    "hbm_bytes_per_launch": summary["kernels"][dual[0]]["hbm_bytes_per_launch_corrected"],
                    "source": "profiles/" + ROUND + "_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes)"},
                   open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
-    stats = glob.glob(os.path.join(OUT, "prof_stats", "**", "*kernel_stats.csv"), recursive=True)
+    stats = glob.glob(os.path.join(OUT, "prof_stats", "**", ROUND + "_kernel_stats.csv"), recursive=True) or \
+        glob.glob(os.path.join(OUT, "prof_stats", "**", "*kernel_stats.csv"), recursive=True)      # this round's capture first
     if stats:
         shutil.copy(stats[0], os.path.join(PROF, ROUND + "_bench_kernel_stats.csv"))
     line = os.path.join(OUT, "bench_line.json")
