@@ -105,4 +105,8 @@ inline int piece_layout_check(const pygsd_piece_layout* L, int32_t n_rows, int32
 
 inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// 0 = fp32 tall products / weight gradients in the split form (three bf16 pieces per value, bf16 matrix pipe) wherever a shape has
+// one, 1 = exact fp32 MFMA everywhere (csrc/tall.hip; pygsd_tall_f32_form, PYGSD_TALL_F32=exact)
+int& tall_f32_form();
+
 }  // namespace pygsd

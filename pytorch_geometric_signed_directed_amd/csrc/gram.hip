@@ -316,6 +316,29 @@ __global__ __launch_bounds__(256, 2) void tall_gram_bf16_kernel(GramArgs p)
 // G (1.26 - 1.38 x the algorithmic bytes before, profiles/r4j_configs.json).  The loads of the next D row pairs are in flight
 // while the current D are multiplied (exact fp32, an fmaf chain over the rows in order).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// eight fp32 values -> their (hi, mid, lo) bf16 pieces, round to nearest even; x - hi and x - hi - mid are exact (csrc/tall.hip)
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&out)[3])
+{
+    uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = x[2 * e], b = x[2 * e + 1];
+        const f32x2 v0 = {a, b};
+        hh[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v0, bf16x2));
+        const float ra = a - __uint_as_float(hh[e] << 16), rb = b - __uint_as_float(hh[e] & 0xffff0000u);
+        const f32x2 v1 = {ra, rb};
+        mm[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, bf16x2));
+        const float sa = ra - __uint_as_float(mm[e] << 16), sb = rb - __uint_as_float(mm[e] & 0xffff0000u);
+        const f32x2 v2 = {sa, sb};
+        ll[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2));
+    }
+    out[0] = __builtin_bit_cast(bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+    out[1] = __builtin_bit_cast(bf16x8, make_uint4(mm[0], mm[1], mm[2], mm[3]));
+    out[2] = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+}
+
 
 constexpr int kMaxBlocks32 = 6;          // 32-column blocks of one side handled by a wavefront
 
@@ -329,7 +352,7 @@ struct Gram32Args {
     int32_t k_total, f_total, x_at, g_at;     // where this launch's block sits in dW
 };
 
-template <int NBK, int NBF, int D>
+template <int NBK, int NBF, int D, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void tall_gram32_f32_kernel(Gram32Args p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds32[];
@@ -390,13 +413,40 @@ __global__ __launch_bounds__(256, 1) void tall_gram32_f32_kernel(Gram32Args p)
     for (; batch < n_batches; batch += stride) {
         const int64_t nb = batch + stride < n_batches ? batch + stride : batch;      // (past the end: re-read this batch, L2 hits)
         fetch(nb, xn, gn);
+        if constexpr (SPLIT) {
+            // SPLIT (round 5, D = 8): the batch's 16 rows are the 16 k-slots of ONE v_mfma_f32_32x32x16_bf16 -- lane (half, c)'s
+            // slot 8 half + e is the value it loaded for row pair e, on both operands alike -- and every product is the six largest
+            // partial products of its operands' three bf16 pieces (csrc/tall.hip: closer to float64 than the fmaf chain, 2.7x fewer
+            // matrix cycles).  Term-outer, accumulator-inner: consecutive MFMAs write different accumulators.
+            static_assert(!SPLIT || D == 8, "one 32x32x16 step per batch");
+            bf16x8 xt[NBK][3], gt[NBF][3];
 #pragma unroll
-        for (int d = 0; d < D; ++d)
+            for (int a = 0; a < NBK; ++a) {
+                const float v[8] = {xv[0][a], xv[1][a], xv[2][a], xv[3][a], xv[4][a], xv[5][a], xv[6][a], xv[7][a]};
+                split8(v, xt[a]);
+            }
 #pragma unroll
-            for (int a = 0; a < NBK; ++a)
+            for (int b = 0; b < NBF; ++b) {
+                const float v[8] = {gv[0][b], gv[1][b], gv[2][b], gv[3][b], gv[4][b], gv[5][b], gv[6][b], gv[7][b]};
+                split8(v, gt[b]);
+            }
+            constexpr int kXi[6] = {2, 0, 1, 1, 0, 0}, kGi[6] = {0, 2, 1, 0, 1, 0};      // (x piece, g piece), smallest term first
 #pragma unroll
-                for (int b = 0; b < NBF; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[d][a], gv[d][b], acc[a][b], 0, 0, 0);
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int a = 0; a < NBK; ++a)
+#pragma unroll
+                    for (int b = 0; b < NBF; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xt[a][kXi[t]], gt[b][kGi[t]], acc[a][b], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int a = 0; a < NBK; ++a)
+#pragma unroll
+                    for (int b = 0; b < NBF; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[d][a], gv[d][b], acc[a][b], 0, 0, 0);
+        }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
 #pragma unroll
@@ -432,8 +482,15 @@ __global__ __launch_bounds__(256, 1) void tall_gram32_f32_kernel(Gram32Args p)
 template <int NBK, int NBF>
 int launch_gram32(const Gram32Args& a, unsigned blocks, hipStream_t s)
 {
-    constexpr int D = (NBK + NBF) <= 2 ? 16 : ((NBK + NBF) <= 8 ? 8 : 4);        // row pairs per buffered batch
     const size_t lds = static_cast<size_t>(NBK) * 32 * NBF * 32 * sizeof(float);
+    if (tall_f32_form() == 0) {                  // the split form: 8 row pairs = the 16 k-slots of one bf16 MFMA
+        if (lds > 64 * 1024)
+            PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram32_f32_kernel<NBK, NBF, 8, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL((tall_gram32_f32_kernel<NBK, NBF, 8, true>), dim3(blocks), dim3(256), lds, s, a);
+        return check_launch("tall_gram32_f32_kernel (split)");
+    }
+    constexpr int D = (NBK + NBF) <= 2 ? 16 : ((NBK + NBF) <= 8 ? 8 : 4);        // row pairs per buffered batch
     if (lds > 64 * 1024)
         PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram32_f32_kernel<NBK, NBF, D>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));

@@ -453,16 +453,6 @@ bool split_shape_ok(int k_total, int f_out)
     return kb_ok && nt_ok && kb * nt <= 48;
 }
 
-// 0 = the split form wherever its shapes allow (default), 1 = every fp32 product as an fmaf chain on v_mfma_f32_16x16x4_f32;
-// PYGSD_TALL_F32=exact sets 1 at load, pygsd_tall_f32_form changes it at run time (measurement / bitwise tests)
-int& tall_f32_form()
-{
-    static int form = [] {
-        const char* e = getenv("PYGSD_TALL_F32");
-        return (e && e[0] == 'e') ? 1 : 0;
-    }();
-    return form;
-}
 bool split_allowed() { return tall_f32_form() == 0; }
 
 template <typename Kern>
@@ -575,6 +565,17 @@ unsigned column_sum_blocks(int64_t n_rows, int f, int v)
     return static_cast<unsigned>(b < 1 ? 1 : b);
 }
 }  // namespace
+
+// 0 = the split form wherever its shapes allow (default), 1 = every fp32 product as an fmaf chain on v_mfma_f32_16x16x4_f32;
+// PYGSD_TALL_F32=exact sets 1 at load, pygsd_tall_f32_form changes it at run time (measurement / bitwise tests)
+int& tall_f32_form()
+{
+    static int form = [] {
+        const char* e = getenv("PYGSD_TALL_F32");
+        return (e && e[0] == 'e') ? 1 : 0;
+    }();
+    return form;
+}
 }  // namespace pygsd
 
 using namespace pygsd;

@@ -1560,10 +1560,44 @@ def test_tall_gram_32x32_form_matches_float64(dtype, n, xw, gw, sliced, monkeypa
     """Round 5's form of the fp32 weight-gradient product (v_mfma_f32_32x32x2_f32 with both operands straight from coalesced
     loads, a wavefront holding the whole output block) forced on for every shape whose segments are multiples of 32 columns --
     by default it only runs where it measured faster (>= 10 accumulator blocks per wavefront)."""
+    from pytorch_geometric_signed_directed_amd.dense import set_tall_f32_exact
     monkeypatch.setenv("PYGSD_GRAM_32X32", "1")
-    test_tall_gram_matches_float64(dtype, n, xw, gw, sliced)
+    for exact in (False, True):     # its split form (three bf16 pieces per value on v_mfma_f32_32x32x16_bf16, the default) and the exact one
+        prev = set_tall_f32_exact(exact)
+        try:
+            test_tall_gram_matches_float64(dtype, n, xw, gw, sliced)
+        finally:
+            set_tall_f32_exact(prev)
     monkeypatch.setenv("PYGSD_GRAM_32X32", "0")
     test_tall_gram_matches_float64(dtype, n, xw, gw, sliced)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,xw,gw", [(70001, (64,), (64, 64, 64)), (4099, (64,), (128,)), (17, (32,), (32,))])
+def test_tall_gram_split_form_against_exact_form_and_float64(n, xw, gw, monkeypatch):
+    """The 32x32 weight-gradient kernel's two arithmetic forms on the same inputs against float64, relative to sum |x| |g| per
+    output: the split form no further from float64 than 2x the exact form's own worst error (a reduction over all rows: both sit
+    at 1e-8 of the scale and below)."""
+    from pytorch_geometric_signed_directed_amd.dense import set_tall_f32_exact, tall_gram
+    monkeypatch.setenv("PYGSD_GRAM_32X32", "1")
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, sum(xw), generator=g).to(dev())
+    gg = torch.randn(n, sum(gw), generator=g).to(dev())
+    xs = list(x.split(list(xw), dim=1))
+    gs = [t.contiguous() for t in gg.split(list(gw), dim=1)]
+    want = x.double().t() @ gg.double()
+    scale = x.double().abs().t() @ gg.double().abs()
+    errs = {}
+    for exact in (False, True):
+        prev = set_tall_f32_exact(exact)
+        try:
+            got = tall_gram(xs, gs)
+        finally:
+            set_tall_f32_exact(prev)
+        close(got, want, TOL, norm=True, what="tall_gram")
+        errs[exact] = (got, float(((got.double() - want).abs() / scale).max()))
+    assert not torch.equal(errs[False][0], errs[True][0])            # (two forms really ran)
+    assert errs[False][1] <= max(2.0 * errs[True][1], 2.0 ** -23), (errs[False][1], errs[True][1])
 
 
 @pytest.mark.gpu
