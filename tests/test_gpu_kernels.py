@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import ref_layers as R
-from tolerance import close, close_arbitrated
+from tolerance import close, close_arbitrated, single_thread
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -300,19 +300,23 @@ def test_dense_stage_matches_reference_formula(f_in, f_out, k1, n):
     want_r, want_i = rr - ii + bbd, rr + ii + bbd
     ((want_r * gr.double()).sum() + (want_i * gi.double()).sum()).backward()
     d = dev()
-    # the same formula in fp32 on the host: what the reference's own arithmetic achieves against float64
-    rr32 = sum(a[k] @ w[k] for k in range(k1))
-    ii32 = sum(b[k] @ w[k] for k in range(k1))
+    # the same formula in fp32 on the host: what the reference's own arithmetic achieves against float64 (one thread: reproducible)
+    with single_thread():
+        rr32 = sum(a[k] @ w[k] for k in range(k1))
+        ii32 = sum(b[k] @ w[k] for k in range(k1))
     o_r, o_i = dense_fwd_raw([t.to(d) for t in a], [t.to(d) for t in b], w.to(d), bias.to(d))
     close_arbitrated(o_r, rr32 - ii32 + bias, want_r, what="dense out_real")
     close_arbitrated(o_i, rr32 + ii32 + bias, want_i, what="dense out_imag")
     da, db, dw, dbias = dense_bwd_raw([t.to(d) for t in a], [t.to(d) for t in b], w.to(d), gr.to(d), gi.to(d))
     p32, m32 = gr + gi, gi - gr
+    with single_thread():
+        da32 = [p32 @ w[k].t() for k in range(k1)]
+        db32 = [m32 @ w[k].t() for k in range(k1)]
+        dw32 = torch.stack([a[k].t() @ p32 + b[k].t() @ m32 for k in range(k1)])
     for k in range(k1):
-        close_arbitrated(da[k], p32 @ w[k].t(), ad[k].grad, what="dense dA")
-        close_arbitrated(db[k], m32 @ w[k].t(), bd[k].grad, what="dense dB")
+        close_arbitrated(da[k], da32[k], ad[k].grad, what="dense dA")
+        close_arbitrated(db[k], db32[k], bd[k].grad, what="dense dB")
     # reductions over the n rows (tests/tolerance.py): the reference's own fp32 formula arbitrated by float64
-    dw32 = torch.stack([a[k].t() @ p32 + b[k].t() @ m32 for k in range(k1)])
     close_arbitrated(dw, dw32, wd.grad, norm=True, what="dense dW")
     close_arbitrated(dbias, p32.sum(0), bbd.grad, norm=True, what="dense db")
     # no-bias forward

@@ -17,6 +17,7 @@ Every call records the achieved errors; the session writes them to gpurun_out/pa
 numbers quoted in DESIGN.md come from the run, not from the bar.
 """
 import json
+import contextlib
 import os
 
 import numpy as np
@@ -54,6 +55,20 @@ def close(got, want, tol=TOL, norm=False, what=""):
         assert mixed <= tol, (f"{what} |got - want| <= {tol} (1 + |want|) violated: worst {mixed:.3e} "
                               f"(max abs err {abs_err:.3e}, |want| <= {top:.3g})")
     return abs_err
+
+
+@contextlib.contextmanager
+def single_thread():
+    """The host's fp32 reference sequence in ONE thread: the BLAS behind torch.matmul splits a product over however many
+    threads it is given at that moment, and every split is a different rounding -- the same test measured the reference
+    5.9e-6 and 6.3e-6 from float64 on two boxes of the pool, which moves a bar that is a multiple of that distance."""
+    import torch
+    before = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        yield
+    finally:
+        torch.set_num_threads(before)
 
 
 def close_arbitrated(got, reference_sequence, truth64, tol=TOL, what="", norm=False):
