@@ -408,8 +408,8 @@ int pygsd_complex_relu_bwd_f32(const float* real, const float* g_real, const flo
  * (the upstream gradient of a loss that sums the outputs over the nodes: nothing [N, f_out] is materialised).
  * pygsd_magnetic_dense_supported: 1 if (f_in, f_out, k1) is covered by the fused kernels
  * (multiples of 16, f_out in {16,32,48,64,128}, f_in < 64 or a multiple of 64, k1 <= 4).
- * Arithmetic (pygsd_dense_f32_form): the FORWARD is an fmaf chain per output on the exact fp32 MFMA.  The BACKWARD at f_out = 64
- * and f_in a multiple of 64 (every MagNetConv / MSConv layer of hidden width 64) runs in the SPLIT form by default -- operands as
+ * Arithmetic (pygsd_dense_f32_form): the FORWARD is an fmaf chain per output on the exact fp32 MFMA.  The BACKWARD at f_out = 64 / 128
+ * and f_in a multiple of 64 (every MagNetConv / MSConv layer of hidden width 64 or 128) runs in the SPLIT form by default -- operands as
  * three bf16 pieces, six partial products per product on the bf16 matrix pipe, fp32 accumulation (csrc/tall.hip: closer to the
  * float64 product than an fp32 fmaf chain, not bitwise one; magnitudes above 3.39e38 overflow) -- and as fmaf chains for every
  * other shape and on request.

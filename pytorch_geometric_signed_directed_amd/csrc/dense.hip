@@ -1,5 +1,5 @@
 // Fused dense stage of MagNetConv / MSConv on the MFMA matrix cores -- the only GEMM-shaped work on the path.  Exact fp32
-// (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) for the forward and for every backward shape; the backward at f_out = 64 runs by
+// (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) for the forward and for every backward shape; the backward at f_out = 64 / 128 runs by
 // default on the bf16 pipe by three-way splitting (dense_bwd_split_kernel below; pygsd_dense_f32_form).
 //
 //   forward :  out_real = sum_k (A_k - B_k) W_k + b ,  out_imag = sum_k (A_k + B_k) W_k + b
@@ -519,8 +519,8 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_kernel(Dens
 // 0.59 ms for 2.05 GB at the north-star shape).  As csrc/tall.hip's split kernel (the derivation and the measured error are
 // there): every fp32 operand = hi + mid + lo in bf16, every product = its six largest partial products on the bf16 pipe with
 // fp32 accumulation -- closer to the float64 product than an fp32 fmaf chain, 2.7x fewer matrix cycles.  Same tiling, same
-// loads, same LDS transposition, same stores, same partials and reduction as the exact kernel (f_in chunk 64 = NTI 4, f_out 64 =
-// NTO 4, XPOSE); what changes is the two products:
+// loads, same LDS transposition, same stores, same partials and reduction as the exact kernel (f_in chunk 64 = NTI 4, f_out 64 /
+// 128 = NTO 4 / 8, XPOSE); what changes is the two products:
 //   phase 1  dA | dB tile = [P | M] W_k^T: the reduction runs over the 64 output features = 2 blocks of 32 k-slots for
 //            v_mfma_f32_16x16x32_bf16.  A lane's 8 k-slots of block kb are the columns 32 kb + 16 h + 4 g + r (h < 2, r < 4) --
 //            exactly the two float4 row pieces it already holds (tiles 2 kb and 2 kb + 1); W_k^T sits in LDS pre-split, in
@@ -580,18 +580,19 @@ __device__ __forceinline__ f32x4 mfma6_16(const Triple4& a, const Triple4& b, f3
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(a.h), quad(b.h), c, 0, 0, 0);
 }
 
-template <bool PIECES>
-__global__ __launch_bounds__(256, 2) void dense_bwd_split_kernel(DenseBwdArgs p)
+template <int NTO, bool PIECES>
+__global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_split_kernel(DenseBwdArgs p)
 {
-    constexpr int NTI = 4, NTO = 4, fc = 64, fo = 64;
-    constexpr int rs = 64 + kPad;                                  // row stride of the staging region
-    constexpr int kFragFloats = 2 * NTI * 3 * 64 * 4;              // W_k^T fragments: [2 kb][NTI][3][64] x 16 B
+    static_assert(NTO == 4 || NTO == 8, "f_out = 64 or 128");
+    constexpr int NTI = 4, fc = 64, fo = NTO * 16, KBO = NTO / 2;   // KBO: 32-column blocks of the output features
+    constexpr int rs = fo + kPad;                                  // row stride of the staging region (fo >= fc)
+    constexpr int kFragFloats = KBO * NTI * 3 * 64 * 4;            // W_k^T fragments: [KBO][NTI][3][64] x 16 B
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int k = blockIdx.y;
     const int c0 = static_cast<int>(blockIdx.z) * kChunk;
     uint4* wfrag = reinterpret_cast<uint4*>(lds);
-    for (int idx = tid; idx < 2 * NTI * 64; idx += 256) {
+    for (int idx = tid; idx < KBO * NTI * 64; idx += 256) {
         const int lane = idx & 63, ft = (idx >> 6) & 3, kb = idx >> 8;
         const int i = lane & 15, g = lane >> 4;
         const float* wrow = p.w + (static_cast<int64_t>(k) * p.f_in + c0 + 16 * ft + i) * p.f_out + 32 * kb + 4 * g;
@@ -663,9 +664,12 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_split_kernel(DenseBwdArgs p)
         rows_in(tile);
         if (!lrow_live) {                       // rows past the end must contribute nothing to dW
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < NTO; ++t) {
                 xg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
                 yg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int t = 0; t < NTI; ++t) {
                 a4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
                 b4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -708,24 +712,6 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_split_kernel(DenseBwdArgs p)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // column fragments of P / M for phase 2: rows 4 g + s of column 16 nt + i
-        float pb[NTO][4], mb[NTO][4];
-#pragma unroll
-        for (int nt = 0; nt < NTO; ++nt) {
-            const float* cp = stage + (4 * g) * rs + nt * 16 + i;
-            const float* cm = cp + 16 * rs;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pb[nt][e] = cp[e * rs];
-                mb[nt][e] = cm[e * rs];
-            }
-        }
-        if (do_bias) {                          // (the exact kernel's order: one add per row slot)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int nt = 0; nt < NTO; ++nt) acc_bias[nt] += pb[nt][e];
-        }
         // ---- phase 1: dA_k, dB_k tile = [P | M] (16 x 64) . W_k^T (64 x 64).  The six partial products of a term are issued
         //      TERM-outer, accumulator-inner: consecutive MFMAs write different accumulators (8 of them), so none waits for its
         //      predecessor's result and a vector instruction scheduled between two of them costs its own slot only.
@@ -737,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_split_kernel(DenseBwdArgs p)
         }
         constexpr int kWi[6] = {2, 0, 1, 1, 0, 0}, kXi[6] = {0, 2, 1, 0, 1, 0};      // (w piece, x piece) of the six terms, smallest first
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < KBO; ++kb) {
             const bf16x8 px[3] = {octet(pt[2 * kb].h, pt[2 * kb + 1].h), octet(pt[2 * kb].m, pt[2 * kb + 1].m),
                                   octet(pt[2 * kb].l, pt[2 * kb + 1].l)};
             const bf16x8 mx[3] = {octet(mt[2 * kb].h, mt[2 * kb + 1].h), octet(mt[2 * kb].m, mt[2 * kb + 1].m),
@@ -792,8 +778,18 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_split_kernel(DenseBwdArgs p)
         }
 #pragma unroll
         for (int nt = 0; nt < NTO; ++nt) {
-            const Triple4 pc = split4(pb[nt][0], pb[nt][1], pb[nt][2], pb[nt][3]);
-            const Triple4 mc = split4(mb[nt][0], mb[nt][1], mb[nt][2], mb[nt][3]);
+            // column fragments of P / M: rows 4 g + e of column 16 nt + i, read where they are used (held for all tiles at once
+            // they pushed the piece-layout instance over its 256 registers: 92 bytes of scratch per lane)
+            const float* cp = stage + (4 * g) * rs + nt * 16 + i;
+            const float* cm = cp + 16 * rs;
+            const float pb[4] = {cp[0], cp[rs], cp[2 * rs], cp[3 * rs]};
+            const float mb[4] = {cm[0], cm[rs], cm[2 * rs], cm[3 * rs]};
+            if (do_bias) {                      // (the exact kernel's order: one add per row slot)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc_bias[nt] += pb[e];
+            }
+            const Triple4 pc = split4(pb[0], pb[1], pb[2], pb[3]);
+            const Triple4 mc = split4(mb[0], mb[1], mb[2], mb[3]);
             const uint2 pcs[3] = {pc.h, pc.m, pc.l}, mcs[3] = {mc.h, mc.m, mc.l};
 #pragma unroll
             for (int t = 0; t < 6; ++t)
@@ -921,21 +917,21 @@ int& dense_f32_form()
     return form;
 }
 
-template <bool PIECES>
+template <int NTO, bool PIECES>
 int launch_bwd_split(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
 {
-    constexpr size_t rs = 64 + kPad;
-    const size_t lds_bytes = (static_cast<size_t>(2 * 4 * 3 * 64 * 4) + 4 * 2 * 16 * rs) * sizeof(float);
-    if (int rc = set_lds(dense_bwd_split_kernel<PIECES>, lds_bytes)) return rc;
-    hipLaunchKernelGGL((dense_bwd_split_kernel<PIECES>), dim3(gx, a.k1, gz), dim3(256), lds_bytes, s, a);
+    constexpr size_t rs = NTO * 16 + kPad;
+    const size_t lds_bytes = (static_cast<size_t>((NTO / 2) * 4 * 3 * 64 * 4) + 4 * 2 * 16 * rs) * sizeof(float);
+    if (int rc = set_lds(dense_bwd_split_kernel<NTO, PIECES>, lds_bytes)) return rc;
+    hipLaunchKernelGGL((dense_bwd_split_kernel<NTO, PIECES>), dim3(gx, a.k1, gz), dim3(256), lds_bytes, s, a);
     return check_launch("dense_bwd_split_kernel");
 }
 
 template <int NTI, int NTO, bool PIECES = false>
 int launch_bwd(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
 {
-    if constexpr (NTI == 4 && NTO == 4) {
-        if (dense_f32_form() == 0) return launch_bwd_split<PIECES>(a, gx, gz, s);
+    if constexpr (NTI == 4 && (NTO == 4 || NTO == 8)) {
+        if (dense_f32_form() == 0) return launch_bwd_split<NTO, PIECES>(a, gx, gz, s);
     }
     constexpr bool kXpose = true;
     constexpr size_t rs = (NTO > NTI ? NTO : NTI) * 16 + kPad;

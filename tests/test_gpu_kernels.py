@@ -357,16 +357,16 @@ def test_dense_backward_takes_a_broadcast_gradient_row(f_in, f_out, k1, n):
             assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("f_in,k1,n,broadcast", [(64, 2, 1, False), (64, 2, 37, False), (64, 1, 4099, False), (64, 3, 20000, False),
-                                                 (128, 3, 1030, False), (64, 2, 70001, True)])
-def test_dense_backward_split_form_against_exact_form_and_float64(f_in, k1, n, broadcast):
-    """The default arithmetic of the magnetic dense backward at f_out = 64 (operands as three bf16 pieces, six partial products
+@pytest.mark.parametrize("f_in,f_out,k1,n,broadcast", [(64, 64, 2, 1, False), (64, 64, 2, 37, False), (64, 64, 1, 4099, False),
+                                                       (64, 64, 3, 20000, False), (128, 64, 3, 1030, False), (64, 64, 2, 70001, True),
+                                                       (128, 128, 3, 1030, False), (64, 128, 2, 4099, False), (128, 128, 2, 17, True)])
+def test_dense_backward_split_form_against_exact_form_and_float64(f_in, f_out, k1, n, broadcast):
+    """The default arithmetic of the magnetic dense backward at f_out = 64 / 128 (operands as three bf16 pieces, six partial products
     per product on the bf16 matrix pipe, include/pygsd_hip.h: pygsd_dense_f32_form) next to the exact form (fmaf chains) on the
     same inputs, both against float64 relative to the sum of |terms| of each output.  dA / dB: inside 1.25x the exact form's own
     worst error (measured 0.75 - 0.8x); dW (a reduction over all rows, both forms at 1e-8 of the scale): inside 4x; dbias is
     computed identically (bitwise).  f_in = 128 runs two 64-column chunks; n = 1 / 37 / 4099 end in ragged tiles."""
     from pytorch_geometric_signed_directed_amd.dense import dense_bwd_raw, set_dense_f32_exact
-    f_out = 64
     g = torch.Generator().manual_seed(f_in + k1 + n)
     a = [torch.randn(n, f_in, generator=g).to(dev()) for _ in range(k1)]
     b = [torch.randn(n, f_in, generator=g).to(dev()) for _ in range(k1)]

@@ -43,16 +43,15 @@ def errors(res, ta, tb, w, gr, gi, rows):
 
 
 out = {"cases": []}
-for n, timed in ((1000000, True), (100003, False), (37, False)):
+for n, f, k1, timed in ((1000000, 64, 2, True), (1000000, 128, 3, True), (100003, 64, 2, False), (37, 128, 2, False)):
     torch.manual_seed(n)
-    f, k1 = 64, 2
     ta = [torch.randn(n, f, device=dev) for _ in range(k1)]
     tb = [torch.randn(n, f, device=dev) for _ in range(k1)]
     w = torch.randn(k1, f, f, device=dev) * 0.1
     gr, gi = torch.randn(n, f, device=dev), torch.randn(n, f, device=dev)
     one = torch.ones(1, f, device=dev)
     rows = torch.randint(0, n, (min(n, 4096),), device=dev)
-    row = {"n": n}
+    row = {"n": n, "f": f, "k1": k1}
     for name, exact in (("split", False), ("exact", True)):
         prev = set_dense_f32_exact(exact)
         try:
