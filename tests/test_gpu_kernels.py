@@ -1445,6 +1445,8 @@ SPLIT_CASES = [
     (20000, (64, 64, 64), 64, True, False, None, False),       # C5a's input gradient [dx0 | dP_1 | dP_2] W^T
     (20000, (64,), 192, False, True, (64, 64, 64), True),      # C5a forward: three output matrices
     (513, (256,), 64, False, False, None, False),              # K = 256: eight k-blocks, 16 KB of row buffers per wavefront
+    (1000, (64,), 64, False, True, (16, 48), False),           # output matrices that cut a stored pair of 16-column tiles apart
+    (1000, (32, 32), 96, True, False, (48, 16, 32), False),
 ]
 
 
