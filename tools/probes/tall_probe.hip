@@ -10,6 +10,7 @@
 //   MODE 11 as 0 with the fragment reads of step m + 1 issued before the MFMAs of step m
 //   mem_probe<...>: memory only -- product lane order or whole 128-byte lines per load / store instruction, 1 or 2 tiles ahead
 //   LIBRARY: pygsd_tall_linear of the built library through its C entry, 128 rows checked bitwise against the host fmaf chain
+//            (run with PYGSD_TALL_F32=exact for that check: the library's default fp32 form is the split one, which is not a chain)
 //   [MHz]: shader cycles / 100 MHz ticks over block 0's first wavefront (the clock the kernel actually ran at)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/probes/tall_probe tools/probes/tall_probe.hip -ldl && tools/probes/tall_probe
 #include <hip/hip_runtime.h>
