@@ -511,7 +511,7 @@ def main():
     ms_dense_loss = timed_pass("dense_loss")
     dense_g.clear()
     # ---- pass 1d (labelled): the headline's K steps with every dense product as an fp32 fmaf chain on v_mfma_f32_16x16x4_f32.
-    # The dense backward runs by default on the bf16 matrix pipe with its fp32 operands split three ways (include/pygsd_hip.h:
+    # The dense stage runs by default on the bf16 matrix pipe with its fp32 operands split three ways (include/pygsd_hip.h:
     # pygsd_dense_f32_form): fp32-accurate (closer to float64 than the chain), not a reduced precision -- the
     # line carries both so that nobody has to take that on trust.
     from pytorch_geometric_signed_directed_amd.dense import set_dense_f32_exact
@@ -703,12 +703,13 @@ def main():
                                "the loss's own element-wise passes timed with it",
             "ms_per_step_exact_fp32_dense": ms_exact,
             "value_exact_fp32_dense": e / (ms_exact * 1e-3),
-            "dense_arithmetic_note": "fp32 storage, fp32 accumulation everywhere.  Headline: the dense backward's products run on the "
-                                     "bf16 matrix pipe with each fp32 operand split into three bf16 pieces and the six largest "
-                                     "partial products kept (error vs float64 2.3e-7 of the sum of |terms| for dA / dB, where the "
-                                     "fp32 fmaf chain has 3.0e-7: profiles/r5p_dense_bwd_forms.json) -- the library's default; "
+            "dense_arithmetic_note": "fp32 storage, fp32 accumulation everywhere.  Headline: the dense stage's products (forward and "
+                                     "backward) run on the bf16 matrix pipe with each fp32 operand split into three bf16 pieces and "
+                                     "the six largest partial products kept -- error vs float64 relative to the sum of |terms|: "
+                                     "forward 4.6e-8 (fp32 fmaf chain 2.4e-7), backward dA / dB 2.3e-7 (chain 3.0e-7): "
+                                     "profiles/r5s_dense_fwd_forms.json, r5p_dense_bwd_forms.json -- the library's default; "
                                      "`ms_per_step_exact_fp32_dense` = the same K steps with fmaf chains on the exact fp32 MFMA "
-                                     "(PYGSD_DENSE_F32=exact).  SpMM and dense forward are plain fp32 in both",
+                                     "(PYGSD_DENSE_F32=exact).  The SpMM is plain fp32 in both",
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -408,11 +408,13 @@ int pygsd_complex_relu_bwd_f32(const float* real, const float* g_real, const flo
  * (the upstream gradient of a loss that sums the outputs over the nodes: nothing [N, f_out] is materialised).
  * pygsd_magnetic_dense_supported: 1 if (f_in, f_out, k1) is covered by the fused kernels
  * (multiples of 16, f_out in {16,32,48,64,128}, f_in < 64 or a multiple of 64, k1 <= 4).
- * Arithmetic (pygsd_dense_f32_form): the FORWARD is an fmaf chain per output on the exact fp32 MFMA.  The BACKWARD at f_out = 64 / 128
- * and f_in a multiple of 64 (every MagNetConv / MSConv layer of hidden width 64 or 128) runs in the SPLIT form by default -- operands as
- * three bf16 pieces, six partial products per product on the bf16 matrix pipe, fp32 accumulation (csrc/tall.hip: closer to the
- * float64 product than an fp32 fmaf chain, not bitwise one; magnitudes above 3.39e38 overflow) -- and as fmaf chains for every
- * other shape and on request.
+ * Arithmetic (pygsd_dense_f32_form): two forms.  SPLIT, the default where a shape has it -- the forward at f_in = 64 / 128 with
+ * f_out a multiple of 64, the backward at f_out = 64 / 128 with f_in a multiple of 64 (every MagNetConv / MSConv layer of hidden
+ * width 64 or 128): fp32 operands as three bf16 pieces each, the six largest partial products per product on the bf16 matrix
+ * pipe, fp32 accumulation (csrc/tall.hip).  Closer to the float64 result than an fp32 fmaf chain (forward: a fifth of the chain's
+ * error relative to the sum of |terms| -- the partial products of a 32-feature block are summed apart and added to the running
+ * sum once; backward dA / dB: 0.75 of it), not bitwise any fp32 summation order; magnitudes above 3.39e38 overflow.  EXACT -- an
+ * fmaf chain per output on v_mfma_f32_16x16x4_f32 -- for every other shape and on request.
  * ------------------------------------------------------------------------------------------- */
 int pygsd_magnetic_dense_supported(int32_t f_in, int32_t f_out, int32_t k1);
 /* form: 0 = split where the shape allows (default; PYGSD_DENSE_F32=exact at load selects 1), 1 = exact everywhere, anything else

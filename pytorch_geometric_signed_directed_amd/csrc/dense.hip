@@ -1,6 +1,6 @@
-// Fused dense stage of MagNetConv / MSConv on the MFMA matrix cores -- the only GEMM-shaped work on the path.  Exact fp32
-// (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) for the forward and for every backward shape; the backward at f_out = 64 / 128 runs by
-// default on the bf16 pipe by three-way splitting (dense_bwd_split_kernel below; pygsd_dense_f32_form).
+// Fused dense stage of MagNetConv / MSConv on the MFMA matrix cores -- the only GEMM-shaped work on the path.  Two arithmetic forms
+// (pygsd_dense_f32_form): exact fp32 (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) for every shape, and -- the default at hidden
+// widths 64 / 128 -- the bf16 pipe by three-way splitting (dense_fwd_kernel<..., SPLIT>, dense_bwd_split_kernel).
 //
 //   forward :  out_real = sum_k (A_k - B_k) W_k + b ,  out_imag = sum_k (A_k + B_k) W_k + b
 //              (A_k / B_k = k-th Chebyshev terms of the real / imaginary chain; reference
@@ -39,6 +39,27 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// eight fp32 values -> their (hi, mid, lo) bf16 pieces, round to nearest even; x - hi and x - hi - mid are exact (csrc/tall.hip)
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&out)[3])
+{
+    uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = x[2 * e], b = x[2 * e + 1];
+        const f32x2 v0 = {a, b};
+        hh[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v0, bf16x2));
+        const float ra = a - __uint_as_float(hh[e] << 16), rb = b - __uint_as_float(hh[e] & 0xffff0000u);
+        const f32x2 v1 = {ra, rb};
+        mm[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, bf16x2));
+        const float sa = ra - __uint_as_float(mm[e] << 16), sb = rb - __uint_as_float(mm[e] & 0xffff0000u);
+        const f32x2 v2 = {sa, sb};
+        ll[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2));
+    }
+    out[0] = __builtin_bit_cast(bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+    out[1] = __builtin_bit_cast(bf16x8, make_uint4(mm[0], mm[1], mm[2], mm[3]));
+    out[2] = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+}
+
 struct DenseFwdArgs {
     const float* a[kMaxOrder];
     const float* b[kMaxOrder];
@@ -62,7 +83,13 @@ struct DenseFwdArgs {
 // PIECES (round 5, sharded layers, FIN > 0): the LAST term's operands are read through a piece layout -- straight out of the
 // return exchange's receive buffer, 16-float pieces of a row at slot strides (no merge pass in front of this kernel).  The plain
 // instances are untouched by it.
-template <int NT, int FIN, int WAVES, bool PIECES = false>
+// SPLIT (round 5; NT = 4, FIN = 64 / 128): the products on the bf16 matrix pipe by three-way splitting, as dense_bwd_split_kernel
+// and csrc/tall.hip -- D = A - B and S = A + B are formed in fp32 as before, split into three bf16 pieces each, and multiplied
+// with the pre-split W fragments in LDS ([k][32-column block][tile][3][64] x 16 B) by v_mfma_f32_16x16x32_bf16; a lane's 8 k-slots
+// of block kb are the features 32 kb + 16 h + 4 g + r of the two float4 pieces it already loads.  The six partial products of a
+// 32-column block are summed in accumulators of their own and added to the running sums ONCE per block: the running sum is
+// rounded once per 32 features instead of six times.
+template <int NT, int FIN, int WAVES, bool PIECES = false, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -72,9 +99,29 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
     constexpr int ws = nc + kPad;
     const int f_in = FIN > 0 ? FIN : p.f_in;
     const int wrows = p.k1 * f_in;
-    for (int idx = tid; idx < wrows * nc; idx += WAVES * 64) {
-        const int r = idx / nc, c = idx - r * nc;
-        lds[r * ws + c] = p.w[static_cast<int64_t>(r) * p.f_out + n0 + c];
+    if constexpr (SPLIT) {
+        static_assert(!SPLIT || (FIN % 32 == 0 && FIN > 0 && NT % 2 == 0), "split form: whole 32-column blocks, tile pairs");
+        constexpr int KB = FIN / 32;
+        uint4* wfrag = reinterpret_cast<uint4*>(lds);
+        for (int idx = tid; idx < p.k1 * KB * NT * 64; idx += WAVES * 64) {
+            const int lane = idx & 63, nt = (idx >> 6) % NT, kb = ((idx >> 6) / NT) % KB, k = (idx >> 6) / NT / KB;
+            const int i = lane & 15, g = lane >> 4;
+            const float* wcol = p.w + (static_cast<int64_t>(k) * FIN + 32 * kb + 4 * g) * p.f_out + n0 + 16 * nt + i;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = wcol[static_cast<int64_t>(16 * (e >> 2) + (e & 3)) * p.f_out];
+            bf16x8 t[3];
+            split8(v, t);
+            uint4* dst = wfrag + (((k * KB + kb) * NT + nt) * 3) * 64 + lane;
+            dst[0] = __builtin_bit_cast(uint4, t[0]);
+            dst[64] = __builtin_bit_cast(uint4, t[1]);
+            dst[128] = __builtin_bit_cast(uint4, t[2]);
+        }
+    } else {
+        for (int idx = tid; idx < wrows * nc; idx += WAVES * 64) {
+            const int r = idx / nc, c = idx - r * nc;
+            lds[r * ws + c] = p.w[static_cast<int64_t>(r) * p.f_out + n0 + c];
+        }
     }
     __syncthreads();
 
@@ -136,6 +183,45 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
                     acc_i[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+            if constexpr (SPLIT) {
+                constexpr int KB = FIN / 32;
+                constexpr int kWi[6] = {2, 0, 1, 1, 0, 0}, kXi[6] = {0, 2, 1, 0, 1, 0};      // (w piece, x piece), smallest term first
+                const uint4* wf = reinterpret_cast<const uint4*>(lds) + static_cast<size_t>(k) * KB * NT * 3 * 64 + lane;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const float4 a0 = qa[2 * kb], a1 = qa[2 * kb + 1], b0 = qb[2 * kb], b1 = qb[2 * kb + 1];
+                    const float d[8] = {a0.x - b0.x, a0.y - b0.y, a0.z - b0.z, a0.w - b0.w,
+                                        a1.x - b1.x, a1.y - b1.y, a1.z - b1.z, a1.w - b1.w};
+                    const float sm[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w,
+                                         a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+                    bf16x8 dx[3], sx[3];
+                    split8(d, dx);
+                    split8(sm, sx);
+#pragma unroll
+                    for (int np = 0; np < NT / 2; ++np) {            // tile pairs: four independent accumulators per term
+                        bf16x8 w[2][3];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc)
+                                w[j][pc] = __builtin_bit_cast(bf16x8, wf[((kb * NT + 2 * np + j) * 3 + pc) * 64]);
+                        f32x4 tr[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                        f32x4 ti[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                        for (int t = 0; t < 6; ++t)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                tr[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][kWi[t]], dx[kXi[t]], tr[j], 0, 0, 0);
+                                ti[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][kWi[t]], sx[kXi[t]], ti[j], 0, 0, 0);
+                            }
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc_r[2 * np + j] += tr[j];
+                            acc_i[2 * np + j] += ti[j];
+                        }
+                    }
+                }
+            } else {
             const float* wk = lds + (k * FIN + 4 * g) * ws + i;
 #pragma unroll
             for (int t = 0; t < NL; ++t) {
@@ -152,6 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
                         acc_i[nt] = mfma(w, sm[m], acc_i[nt]);
                     }
                 }
+            }
             }
             if (k == p.k1 - 1) {
                 const int r0 = tl << 4;
@@ -879,9 +966,26 @@ int set_lds(Kern kern, size_t bytes)
     return 0;
 }
 
+int& dense_f32_form();
+
 template <int NT, int FIN, bool PIECES = false>
 int launch_fwd_fin(const DenseFwdArgs& a, unsigned gy, size_t lds_bytes, hipStream_t s)
 {
+    if constexpr (NT == 4 && (FIN == 64 || FIN == 128)) {
+        const size_t split_bytes = static_cast<size_t>(a.k1) * (FIN / 32) * NT * 3072;       // pre-split W fragments
+        if (dense_f32_form() == 0 && split_bytes <= 150 * 1024) {
+            if (split_bytes > 80 * 1024) {      // one block per CU: give it 8 wavefronts
+                if (int rc = set_lds(dense_fwd_kernel<NT, FIN, 8, PIECES, true>, split_bytes)) return rc;
+                hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN, 8, PIECES, true>), dim3(row_blocks(a.n_rows, 1024), gy), dim3(512),
+                                   split_bytes, s, a);
+                return check_launch("dense_fwd_kernel (split)");
+            }
+            if (int rc = set_lds(dense_fwd_kernel<NT, FIN, 4, PIECES, true>, split_bytes)) return rc;
+            hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN, 4, PIECES, true>), dim3(row_blocks(a.n_rows, 2048), gy), dim3(256),
+                               split_bytes, s, a);
+            return check_launch("dense_fwd_kernel (split)");
+        }
+    }
     if (lds_bytes > 80 * 1024) {        // one block per CU: give it 8 wavefronts
         if (int rc = set_lds(dense_fwd_kernel<NT, FIN, 8, PIECES>, lds_bytes)) return rc;
         hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN, 8, PIECES>), dim3(row_blocks(a.n_rows, 1024), gy), dim3(512), lds_bytes, s, a);

@@ -272,8 +272,8 @@ def set_tall_kernels(on: bool) -> bool:
 
 
 def set_dense_f32_exact(on: bool) -> bool:
-    """The magnetic dense stage's backward products as fmaf chains on the exact fp32 MFMA (True) or, at the shapes that have
-    one, in the split form on the bf16 matrix pipe (False, the default; include/pygsd_hip.h, pygsd_dense_f32_form).
+    """The magnetic dense stage's products (forward and backward) as fmaf chains on the exact fp32 MFMA (True) or, at the shapes
+    that have one, in the split form on the bf16 matrix pipe (False, the default; include/pygsd_hip.h, pygsd_dense_f32_form).
     `PYGSD_DENSE_F32=exact` selects the exact form at load.  Returns the previous setting; process-wide."""
     return bool(_cabi.lib().pygsd_dense_f32_form(1 if on else 0))
 

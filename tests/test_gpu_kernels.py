@@ -357,6 +357,40 @@ def test_dense_backward_takes_a_broadcast_gradient_row(f_in, f_out, k1, n):
             assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("f_in,f_out,k1,n", [(64, 64, 2, 1), (64, 64, 3, 37), (128, 128, 3, 1030), (64, 128, 2, 4099), (128, 64, 2, 20000)])
+def test_dense_forward_split_form_against_exact_form_and_float64(f_in, f_out, k1, n):
+    """The default arithmetic of the magnetic dense forward at f_in = 64 / 128 and f_out a multiple of 64 (D = A - B and S = A + B
+    split into three bf16 pieces, six partial products per product on the bf16 matrix pipe, the partial products of every
+    32-feature block summed apart and added to the running sums once -- include/pygsd_hip.h: pygsd_dense_f32_form) next to the
+    exact form (an fmaf chain per output), both against float64 relative to the sum of |terms|: the split form must be the CLOSER
+    one (measured: a fifth of the chain's error)."""
+    from pytorch_geometric_signed_directed_amd.dense import dense_fwd_raw, set_dense_f32_exact
+    g = torch.Generator().manual_seed(f_in + 3 * f_out + k1 + n)
+    a = [torch.randn(n, f_in, generator=g).to(dev()) for _ in range(k1)]
+    b = [torch.randn(n, f_in, generator=g).to(dev()) for _ in range(k1)]
+    w = (torch.randn(k1, f_in, f_out, generator=g) / f_in ** 0.5).to(dev())
+    bias = torch.randn(f_out, generator=g).to(dev())
+    w64 = w.double()
+    want_r = sum((a[k].double() - b[k].double()) @ w64[k] for k in range(k1)) + bias.double()
+    want_i = sum((a[k].double() + b[k].double()) @ w64[k] for k in range(k1)) + bias.double()
+    scale = sum((a[k].double().abs() + b[k].double().abs()) @ w64[k].abs() for k in range(k1)) + bias.double().abs()
+    res = {}
+    for exact in (False, True):
+        prev = set_dense_f32_exact(exact)
+        try:
+            o_r, o_i = dense_fwd_raw(a, b, w, bias)
+            if not exact:
+                again = dense_fwd_raw(a, b, w, bias)
+                assert torch.equal(again[0], o_r) and torch.equal(again[1], o_i)          # deterministic
+        finally:
+            set_dense_f32_exact(prev)
+        close(o_r, want_r, TOL, what="out_real")
+        close(o_i, want_i, TOL, what="out_imag")
+        res[exact] = (o_r, max(float(((o_r.double() - want_r).abs() / scale).max()), float(((o_i.double() - want_i).abs() / scale).max())))
+    assert not torch.equal(res[False][0], res[True][0])                # (two forms really ran)
+    assert res[False][1] <= max(res[True][1], 2.0 ** -23), (res[False][1], res[True][1])
+
+
 @pytest.mark.parametrize("f_in,f_out,k1,n,broadcast", [(64, 64, 2, 1, False), (64, 64, 2, 37, False), (64, 64, 1, 4099, False),
                                                        (64, 64, 3, 20000, False), (128, 64, 3, 1030, False), (64, 64, 2, 70001, True),
                                                        (128, 128, 3, 1030, False), (64, 128, 2, 4099, False), (128, 128, 2, 17, True)])

@@ -4,7 +4,7 @@ north-star shape with a dense and with a broadcast upstream gradient, and the er
 rows, relative to the natural scale of each output (sum of |terms|)."""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pytorch_geometric_signed_directed_amd.dense import dense_bwd_raw, set_dense_f32_exact
+from pytorch_geometric_signed_directed_amd.dense import dense_bwd_raw, dense_fwd_raw, set_dense_f32_exact
 dev = torch.device("cuda:0")
 
 
@@ -42,7 +42,36 @@ def errors(res, ta, tb, w, gr, gi, rows):
     return out
 
 
-out = {"cases": []}
+def fwd_errors(res, ta, tb, w, bias, rows):
+    o_r, o_i = res
+    want_r = sum((ta[k][rows].double() - tb[k][rows].double()) @ w[k].double() for k in range(w.size(0))) + bias.double()
+    want_i = sum((ta[k][rows].double() + tb[k][rows].double()) @ w[k].double() for k in range(w.size(0))) + bias.double()
+    scale = sum((ta[k][rows].double().abs() + tb[k][rows].double().abs()) @ w[k].double().abs() for k in range(w.size(0))) \
+        + bias.double().abs()
+    return max(float(((o_r[rows].double() - want_r).abs() / scale).max()), float(((o_i[rows].double() - want_i).abs() / scale).max()))
+
+
+out = {"cases": [], "forward": []}
+for n, f, k1 in ((1000000, 64, 2), (1000000, 128, 3), (1000003, 128, 2), (37, 64, 3)):
+    torch.manual_seed(n + f)
+    ta = [torch.randn(n, f, device=dev) for _ in range(k1)]
+    tb = [torch.randn(n, f, device=dev) for _ in range(k1)]
+    w = torch.randn(k1, f, f, device=dev) / f ** 0.5
+    bias = torch.randn(f, device=dev)
+    rows = torch.randint(0, n, (min(n, 4096),), device=dev)
+    row = {"n": n, "f": f, "k1": k1}
+    for name, exact in (("split", False), ("exact", True)):
+        prev = set_dense_f32_exact(exact)
+        try:
+            res = dense_fwd_raw(ta, tb, w, bias)
+            row[name] = {"error_vs_float64": fwd_errors(res, ta, tb, w, bias, rows)}
+            if n >= 1000000:
+                row[name]["ms"] = round(timeit(lambda: dense_fwd_raw(ta, tb, w, bias)), 4)
+        finally:
+            set_dense_f32_exact(prev)
+    out["forward"].append(row)
+    del ta, tb
+torch.cuda.empty_cache()
 for n, f, k1, timed in ((1000000, 64, 2, True), (1000000, 128, 3, True), (100003, 64, 2, False), (37, 128, 2, False)):
     torch.manual_seed(n)
     ta = [torch.randn(n, f, device=dev) for _ in range(k1)]
