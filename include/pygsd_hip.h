@@ -530,8 +530,9 @@ int pygsd_dots_f32(const float* g, int64_t ldg, const float* const* xs, int32_t 
  * dtype: 0 = fp32, 1 = bf16 storage with fp32 accumulation (v_mfma_f32_16x16x32_bf16), for X, W, bias and Y alike.
  * fp32 products take one of two forms (pygsd_tall_f32_form): SPLIT, the default wherever K, f_out and every input segment
  * are multiples of 32 columns and K * f_out <= 24576 -- each fp32 value as the sum of three bf16 values, the six largest of
- * the nine partial products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: within 1.7e-7 * sum |x| |w| of the float64
- * product where an fp32 fmaf chain is within 2.5e-7 (measured, profiles/r5n_split_probe.txt), 2.7x fewer matrix cycles, but
+ * the nine partial products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the partial products of a 32-column block summed
+ * apart, added to the running sum once): within 0.9e-7 * sum |x| |w| of the float64 product where an fp32 fmaf chain is within
+ * 3.5e-7 (measured, profiles/r5t_tall_forms.json), 2.7x fewer matrix cycles, but
  * not bitwise any fp32 summation order, and magnitudes above the largest bf16 (3.39e38) overflow; EXACT -- an fmaf chain per
  * output on v_mfma_f32_16x16x4_f32 -- for every other shape and on request.  xs / ldx / widths: HOST arrays over the n_seg (<= 4) column segments -- device pointer
  * (16-byte aligned), row stride in elements (a multiple of 16 bytes) and width (a multiple of 32 columns for bf16, 16 for

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void tall_linear_f32_kernel(TallArgs p)
 // 2.7x fewer matrix cycles, and the kernel becomes what its memory half is.  Measured error against a float64 product, relative to
 // sum |x| |w| (tools/probes/split_probe.hip -> profiles/r5n_split_probe.txt): 1.3 - 1.7e-7 (0.5 - 0.8e-7 with the five small
 // terms summed in accumulators of their own, as here for f_out <= 64) against 2.1 - 2.5e-7 for the fmaf chain -- the dropped
-// terms are smaller than the chain's own roundings.  NOT bitwise the fmaf chain; a value of magnitude above the largest bf16
+// terms are smaller than the chain's own roundings (with the per-block partial sums of split_tile_out: 0.6 - 0.8e-7 for every width).
+// NOT bitwise the fmaf chain; a value of magnitude above the largest bf16
 // (3.39e38) overflows its `hi` (the exact kernel would carry it); PYGSD_TALL_F32=exact keeps every fp32 product on the kernel above.
 //
 // Memory side (the kernel is memory-bound now, so these pay: 81 -> 77 us at K = 128 / f_out = 64, 90 -> 78 at 64 / 128, 500 -> 411
@@ -264,13 +265,16 @@ template <int KB, int NT>
 __device__ __forceinline__ void split_tile_out(const TallArgs& p, const uint4* frag, const float* bias, int tile, int lane,
                                                const float4 (&cur)[KB][2])
 {
-    constexpr bool kApart = NT <= 4;          // the five small terms in accumulators of their own (registers allow it)
+    // The six partial products of a 32-column block are summed in accumulators of their own (groups of G tiles) and added to the
+    // running sums ONCE per block: a running sum is rounded once per 32 columns instead of six times -- measured 0.6 - 0.8e-7 of
+    // sum |x| |w| against 1.3 - 1.7e-7 with the terms added straight in and 2.8 - 3.5e-7 for the fmaf chain (tools/tall_forms_probe.py,
+    // profiles/r5t_tall_forms.json).
+    constexpr int G = NT % 4 == 0 ? 4 : 2;
+    constexpr int kWi[6] = {2, 0, 1, 1, 0, 0}, kXi[6] = {0, 2, 1, 0, 1, 0};      // (w piece, x piece) of the six terms, smallest first
     const int j = lane & 15, q = lane >> 4;
-    f32x4 acc[NT], small[kApart ? NT : 1];
+    f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < (kApart ? NT : 1); ++t) small[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("" ::: "memory");            // (keeps the W fragments in LDS: see the exact kernel)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -278,24 +282,27 @@ __device__ __forceinline__ void split_tile_out(const TallArgs& p, const uint4* f
                              cur[kb][1].x, cur[kb][1].y, cur[kb][1].z, cur[kb][1].w};
         uint4 xh4, xm4, xl4;
         split8(xs, xh4, xm4, xl4);
-        const bf16x8 xh = __builtin_bit_cast(bf16x8, xh4), xm = __builtin_bit_cast(bf16x8, xm4), xl = __builtin_bit_cast(bf16x8, xl4);
+        const bf16x8 xp[3] = {__builtin_bit_cast(bf16x8, xh4), __builtin_bit_cast(bf16x8, xm4), __builtin_bit_cast(bf16x8, xl4)};
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const uint4* src = frag + ((kb * NT + t) * 3) * 64 + lane;
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, src[0]), wm = __builtin_bit_cast(bf16x8, src[64]),
-                         wl = __builtin_bit_cast(bf16x8, src[128]);
-            f32x4& s = kApart ? small[t] : acc[t];
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, s, 0, 0, 0);          // smallest first
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, s, 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t], 0, 0, 0);
+        for (int t0 = 0; t0 < NT; t0 += G) {
+            bf16x8 w[G][3];
+            f32x4 part[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const uint4* src = frag + ((kb * NT + t0 + u) * 3) * 64 + lane;
+                w[u][0] = __builtin_bit_cast(bf16x8, src[0]);
+                w[u][1] = __builtin_bit_cast(bf16x8, src[64]);
+                w[u][2] = __builtin_bit_cast(bf16x8, src[128]);
+                part[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int u = 0; u < G; ++u)
+                    part[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][kWi[t]], xp[kXi[t]], part[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < G; ++u) acc[t0 + u] += part[u];
         }
-    }
-    if constexpr (kApart) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] += small[t];
     }
     // lane (j, q) holds columns [16 t + 4 q, +4) of row j for every tile t; after the trade lanes j < 8 hold tile 2 m of rows
     // j and j + 8, lanes j >= 8 tile 2 m + 1 of rows j - 8 and j
