@@ -706,7 +706,7 @@ def main():
             "dense_arithmetic_note": "fp32 storage, fp32 accumulation everywhere.  Headline: the dense stage's products (forward and "
                                      "backward) run on the bf16 matrix pipe with each fp32 operand split into three bf16 pieces and "
                                      "the six largest partial products kept -- error vs float64 relative to the sum of |terms|: "
-                                     "forward 4.6e-8 (fp32 fmaf chain 2.4e-7), backward dA / dB 2.3e-7 (chain 3.0e-7): "
+                                     "forward 4.6e-8 (fp32 fmaf chain 2.4e-7), backward dA / dB 0.9e-7 (chain 3.0e-7): "
                                      "profiles/r5s_dense_fwd_forms.json, r5p_dense_bwd_forms.json -- the library's default; "
                                      "`ms_per_step_exact_fp32_dense` = the same K steps with fmaf chains on the exact fp32 MFMA "
                                      "(PYGSD_DENSE_F32=exact).  The SpMM is plain fp32 in both",

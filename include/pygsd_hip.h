@@ -413,7 +413,7 @@ int pygsd_complex_relu_bwd_f32(const float* real, const float* g_real, const flo
  * width 64 or 128): fp32 operands as three bf16 pieces each, the six largest partial products per product on the bf16 matrix
  * pipe, fp32 accumulation (csrc/tall.hip).  Closer to the float64 result than an fp32 fmaf chain (forward: a fifth of the chain's
  * error relative to the sum of |terms| -- the partial products of a 32-feature block are summed apart and added to the running
- * sum once; backward dA / dB: 0.75 of it), not bitwise any fp32 summation order; magnitudes above 3.39e38 overflow.  EXACT -- an
+ * sum once; backward dA / dB: a third of it), not bitwise any fp32 summation order; magnitudes above 3.39e38 overflow.  EXACT -- an
  * fmaf chain per output on v_mfma_f32_16x16x4_f32 -- for every other shape and on request.
  * ------------------------------------------------------------------------------------------- */
 int pygsd_magnetic_dense_supported(int32_t f_in, int32_t f_out, int32_t k1);

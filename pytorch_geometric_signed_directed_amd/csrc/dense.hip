@@ -799,9 +799,9 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_split_kerne
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- phase 1: dA_k, dB_k tile = [P | M] (16 x 64) . W_k^T (64 x 64).  The six partial products of a term are issued
-        //      TERM-outer, accumulator-inner: consecutive MFMAs write different accumulators (8 of them), so none waits for its
-        //      predecessor's result and a vector instruction scheduled between two of them costs its own slot only.
+        // ---- phase 1: dA_k, dB_k tile = [P | M] (16 x f_out) . W_k^T (f_out x 64).  The six partial products are issued TERM-outer,
+        //      accumulator-inner: consecutive MFMAs write different accumulators, so none waits for its predecessor's result and
+        //      a vector instruction scheduled between two of them costs its own slot only.
         f32x4 acc_a[NTI], acc_b[NTI];
 #pragma unroll
         for (int ft = 0; ft < NTI; ++ft) {
@@ -815,21 +815,34 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_split_kerne
                                   octet(pt[2 * kb].l, pt[2 * kb + 1].l)};
             const bf16x8 mx[3] = {octet(mt[2 * kb].h, mt[2 * kb + 1].h), octet(mt[2 * kb].m, mt[2 * kb + 1].m),
                                   octet(mt[2 * kb].l, mt[2 * kb + 1].l)};
-            bf16x8 w[NTI][3];
+            // the six partial products of this 32-feature block in accumulators of their own (two f_in tiles at a time: four
+            // independent chains), added to the running sums once: a running sum is rounded once per block, not six times
 #pragma unroll
-            for (int ft = 0; ft < NTI; ++ft) {
-                const uint4* src = wfrag + ((kb * NTI + ft) * 3) * 64 + lane;
-                w[ft][0] = __builtin_bit_cast(bf16x8, src[0]);
-                w[ft][1] = __builtin_bit_cast(bf16x8, src[64]);
-                w[ft][2] = __builtin_bit_cast(bf16x8, src[128]);
-            }
+            for (int fp = 0; fp < NTI; fp += 2) {
+                bf16x8 w[2][3];
+                f32x4 part_a[2], part_b[2];
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int ft = 0; ft < NTI; ++ft) {
-                    acc_a[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ft][kWi[t]], px[kXi[t]], acc_a[ft], 0, 0, 0);
-                    acc_b[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ft][kWi[t]], mx[kXi[t]], acc_b[ft], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) {
+                    const uint4* src = wfrag + ((kb * NTI + fp + u) * 3) * 64 + lane;
+                    w[u][0] = __builtin_bit_cast(bf16x8, src[0]);
+                    w[u][1] = __builtin_bit_cast(bf16x8, src[64]);
+                    w[u][2] = __builtin_bit_cast(bf16x8, src[128]);
+                    part_a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    part_b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        part_a[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][kWi[t]], px[kXi[t]], part_a[u], 0, 0, 0);
+                        part_b[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][kWi[t]], mx[kXi[t]], part_b[u], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc_a[fp + u] += part_a[u];
+                    acc_b[fp + u] += part_b[u];
+                }
+            }
         }
         // ---- the tile's dA / dB stores (in front of phase 2: their registers are free for it) ------------------------------
         if (r0 + i < p.n_rows) {
