@@ -205,11 +205,12 @@ __global__ __launch_bounds__(256) void tall_linear_f32_kernel(TallArgs p)
 // Each bf16 x bf16 product is exact in fp32 (8 + 8 mantissa bits); v_mfma_f32_16x16x32_bf16 sums 32 of them into an fp32
 // accumulator per instruction.  6 of those (16 cycles each, 32 k-slots) replace 8 of the fp32 form (32 cycles each, 4 k-slots):
 // 2.7x fewer matrix cycles, and the kernel becomes what its memory half is.  Measured error against a float64 product, relative to
-// sum |x| |w| (tools/probes/split_probe.hip -> profiles/r5n_split_probe.txt): 1.3 - 1.7e-7 (0.5 - 0.8e-7 with the five small
-// terms summed in accumulators of their own, as here for f_out <= 64) against 2.1 - 2.5e-7 for the fmaf chain -- the dropped
-// terms are smaller than the chain's own roundings (with the per-block partial sums of split_tile_out: 0.6 - 0.8e-7 for every width).
-// NOT bitwise the fmaf chain; a value of magnitude above the largest bf16
-// (3.39e38) overflows its `hi` (the exact kernel would carry it); PYGSD_TALL_F32=exact keeps every fp32 product on the kernel above.
+// sum |x| |w|: 1.3 - 1.7e-7 with the six terms added straight into the running sums (tools/probes/split_probe.hip ->
+// profiles/r5n_split_probe.txt), 0.6 - 0.8e-7 with the six terms of every 32-column block summed apart and added once, as
+// split_tile_out does (tools/tall_forms_probe.py -> profiles/r5t_tall_forms.json), against 2.8 - 3.5e-7 for the fmaf chain on the
+// same inputs -- the dropped terms are smaller than the chain's own roundings.  NOT bitwise the fmaf chain; a value of magnitude
+// above the largest bf16 (3.39e38) overflows its `hi` (the exact kernel would carry it); PYGSD_TALL_F32=exact keeps every fp32
+// product on the kernel above.
 //
 // Memory side (the kernel is memory-bound now, so these pay: 81 -> 77 us at K = 128 / f_out = 64, 90 -> 78 at 64 / 128, 500 -> 411
 // at 64 / 192 for 2M rows -- same probe):
