@@ -48,6 +48,84 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi)
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
+// the value lane (l ^ 8) holds: a rotation by 8 within each row of 16 lanes (DPP row_ror:8), full VALU rate
+__device__ __forceinline__ uint32_t rotate8(uint32_t v)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x128, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float rotate8(float v) { return __uint_as_float(rotate8(__float_as_uint(v))); }
+
+// the 16-byte piece lane (j, q) reads of every k-block of row `tile * 16 + j` (clamped)
+template <int KB>
+__device__ __forceinline__ void bf16_rows_in(const TallArgs& p, int tile, int j, int q, uint4 (&dst)[KB])
+{
+    int64_t row = static_cast<int64_t>(tile) * 16 + j;
+    row = row < p.n_rows ? row : p.n_rows - 1;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+        dst[kb] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.x[kb]) + row * p.ld[kb] + 8 * q);
+}
+
+// one tile of the bf16 kernel: MFMAs over the rows in `cur`, bias, rounding, stores
+template <int KB, int NT>
+__device__ __forceinline__ void bf16_tile_out(const TallArgs& p, const uint4* frag, const float* bias, int tile, int lane,
+                                              const uint4 (&cur)[KB])
+{
+    const int j = lane & 15, q = lane >> 4;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, cur[kb]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, frag[(kb * NT + t) * 64 + lane]);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // lane (j, q): tiles 2 m and 2 m + 1 hold columns [32 m + 8 q, 32 m + 8 q + 8) of row 16 tile + j
+    uint4 o[NT / 2];
+#pragma unroll
+    for (int m = 0; m < NT / 2; ++m) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + 32 * m + 8 * q);
+        const float4 b1 = *reinterpret_cast<const float4*>(bias + 32 * m + 8 * q + 4);
+        const f32x4 lo = acc[2 * m], hi = acc[2 * m + 1];
+        o[m].x = pack2(lo[0] + b0.x, lo[1] + b0.y);
+        o[m].y = pack2(lo[2] + b0.z, lo[3] + b0.w);
+        o[m].z = pack2(hi[0] + b1.x, hi[1] + b1.y);
+        o[m].w = pack2(hi[2] + b1.z, hi[3] + b1.w);
+    }
+    const int64_t last = p.n_rows - 1;
+    if constexpr ((NT / 2) % 2 == 0) {
+        // output blocks (32 columns = 64 bytes a row) in pairs: lanes j and j ^ 8 trade one block of each pair, so that a store
+        // instruction writes 8 rows x 128 contiguous bytes wherever the pair is one segment
+        const bool upper = j >= 8;
+        int64_t row_a = static_cast<int64_t>(tile) * 16 + (j & 7), row_b = row_a + 8;
+        row_a = row_a < last ? row_a : last;          // clamped: such a lane holds row n_rows - 1's own result (bf16_rows_in)
+        row_b = row_b < last ? row_b : last;
+#pragma unroll
+        for (int mm = 0; mm < NT / 4; ++mm) {
+            const uint4 lo = o[2 * mm], hi = o[2 * mm + 1];
+            const uint4 lo_far = make_uint4(rotate8(lo.x), rotate8(lo.y), rotate8(lo.z), rotate8(lo.w));
+            const uint4 hi_far = make_uint4(rotate8(hi.x), rotate8(hi.y), rotate8(hi.z), rotate8(hi.w));
+            const uint4 va = upper ? hi_far : lo, vb = upper ? hi : lo_far;
+            uint16_t* const lo_a = static_cast<uint16_t*>(p.y[2 * mm]) + row_a * p.ldy[2 * mm] + 8 * q;
+            uint16_t* const hi_a = static_cast<uint16_t*>(p.y[2 * mm + 1]) + row_a * p.ldy[2 * mm + 1] + 8 * q;
+            uint16_t* const lo_b = static_cast<uint16_t*>(p.y[2 * mm]) + row_b * p.ldy[2 * mm] + 8 * q;
+            uint16_t* const hi_b = static_cast<uint16_t*>(p.y[2 * mm + 1]) + row_b * p.ldy[2 * mm + 1] + 8 * q;
+            *reinterpret_cast<uint4*>(upper ? hi_a : lo_a) = va;
+            *reinterpret_cast<uint4*>(upper ? hi_b : lo_b) = vb;
+        }
+    } else {
+        int64_t row = static_cast<int64_t>(tile) * 16 + j;
+        row = row < last ? row : last;
+#pragma unroll
+        for (int m = 0; m < NT / 2; ++m)
+            *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.y[m]) + row * p.ldy[m] + 8 * q) = o[m];
+    }
+}
+
 // ---- bf16 storage, fp32 accumulation -----------------------------------------------------------
 template <int KB, int NT>
 __global__ __launch_bounds__(256) void tall_linear_bf16_kernel(TallArgs p)
@@ -72,56 +150,30 @@ __global__ __launch_bounds__(256) void tall_linear_bf16_kernel(TallArgs p)
         bias[c] = p.bias ? bf16_value(static_cast<const uint16_t*>(p.bias)[c]) : 0.f;
     __syncthreads();
 
+    // Memory side as the fp32 split kernel below (round 5; the reasons are spelled out there): rows past the end clamped instead of
+    // masked, two row buffers that trade roles with the first pair of steps written out, whole-line stores where the output
+    // blocks come in pairs.  C5b: 0.242 + 0.202 -> 2 x 0.185 ms per step for the two products (profiles/r5u_configs_bf16.json).
     const int lane = tid & 63, j = lane & 15, q = lane >> 4;
     const int n_tiles = (p.n_rows + 15) >> 4;
     const int stride = static_cast<int>(gridDim.x) * 4;
     int tile = static_cast<int>(blockIdx.x) * 4 + (tid >> 6);
-    uint4 cur[KB], nxt[KB];
-    if (tile < n_tiles) {
-        const int64_t row = (tile * 16 + j < p.n_rows) ? tile * 16 + j : p.n_rows - 1;   // clamped: stores are masked
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-            cur[kb] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.x[kb]) + row * p.ld[kb] + 8 * q);
+    if (tile >= n_tiles) return;
+    const int last_tile = n_tiles - 1;
+    uint4 rows_a[KB], rows_b[KB];
+    bf16_rows_in<KB>(p, tile, j, q, rows_a);
+    bf16_rows_in<KB>(p, min(tile + stride, last_tile), j, q, rows_b);
+#define PYGSD_TALL_STEP(ROWS)                                                          \
+    bf16_tile_out<KB, NT>(p, frag, bias, tile, lane, ROWS);                            \
+    bf16_rows_in<KB>(p, min(tile + 2 * stride, last_tile), j, q, ROWS);                \
+    tile += stride;                                                                    \
+    if (tile >= n_tiles) return;
+    PYGSD_TALL_STEP(rows_a)
+    PYGSD_TALL_STEP(rows_b)
+    for (;;) {
+        PYGSD_TALL_STEP(rows_a)
+        PYGSD_TALL_STEP(rows_b)
     }
-    for (; tile < n_tiles; tile += stride) {
-        const int next = tile + stride;
-        if (next < n_tiles) {
-            const int64_t row = (next * 16 + j < p.n_rows) ? next * 16 + j : p.n_rows - 1;
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                nxt[kb] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.x[kb]) + row * p.ld[kb] + 8 * q);
-        }
-        f32x4 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const bf16x8 b = __builtin_bit_cast(bf16x8, cur[kb]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, frag[(kb * NT + t) * 64 + lane]);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
-            }
-        }
-        // lane (j, q): tiles 2 m and 2 m + 1 hold columns [32 m + 8 q, 32 m + 8 q + 8) of row 16 tile + j
-        if (tile * 16 + j < p.n_rows) {
-            const int64_t row = tile * 16 + j;
-#pragma unroll
-            for (int m = 0; m < NT / 2; ++m) {
-                const float4 b0 = *reinterpret_cast<const float4*>(bias + 32 * m + 8 * q);
-                const float4 b1 = *reinterpret_cast<const float4*>(bias + 32 * m + 8 * q + 4);
-                const f32x4 lo = acc[2 * m], hi = acc[2 * m + 1];
-                uint4 o;
-                o.x = pack2(lo[0] + b0.x, lo[1] + b0.y);
-                o.y = pack2(lo[2] + b0.z, lo[3] + b0.w);
-                o.z = pack2(hi[0] + b1.x, hi[1] + b1.y);
-                o.w = pack2(hi[2] + b1.z, hi[3] + b1.w);
-                *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.y[m]) + row * p.ldy[m] + 8 * q) = o;
-            }
-        }
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) cur[kb] = nxt[kb];
-    }
+#undef PYGSD_TALL_STEP
 }
 
 // ---- fp32, exact (an fmaf chain per output) ----------------------------------------------------
@@ -240,12 +292,6 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& h, uint4& m, 
     h = make_uint4(hh[0], hh[1], hh[2], hh[3]);
     m = make_uint4(mm[0], mm[1], mm[2], mm[3]);
     l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
-}
-
-// the value lane (l ^ 8) holds: a rotation by 8 within each row of 16 lanes (DPP row_ror:8), full VALU rate
-__device__ __forceinline__ float rotate8(float v)
-{
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true));
 }
 
 // the two 16-byte pieces lane (j, q) reads of every k-block of row `tile * 16 + j` (clamped)
