@@ -413,8 +413,13 @@ int pygsd_complex_relu_bwd_f32(const float* real, const float* g_real, const flo
  * width 64 or 128): fp32 operands as three bf16 pieces each, the six largest partial products per product on the bf16 matrix
  * pipe, fp32 accumulation (csrc/tall.hip).  Closer to the float64 result than an fp32 fmaf chain (forward: a fifth of the chain's
  * error relative to the sum of |terms| -- the partial products of a 32-feature block are summed apart and added to the running
- * sum once; backward dA / dB: a third of it), not bitwise any fp32 summation order; magnitudes above 3.39e38 overflow.  EXACT -- an
- * fmaf chain per output on v_mfma_f32_16x16x4_f32 -- for every other shape and on request.
+ * sum once; backward dA / dB: a third of it), not bitwise any fp32 summation order.  EXACT -- an fmaf chain per output on
+ * v_mfma_f32_16x16x4_f32 -- for every other shape and on request.
+ * Non-finite values, both forms: +-inf, NaN and magnitudes up to FLT_MAX come out where the reference's sequence of fp32
+ * torch.matmul's puts them (rr = sum A_k W_k, ii = sum B_k W_k, then rr - ii and rr + ii; their autograd).  The pieces of the
+ * split form carry finite values below the largest bf16 (3.39e38) only; a 16-row tile (a weight-gradient element) whose sums
+ * come out non-finite is computed again from the fp32 operands by fmaf chains in the reference's order of operations
+ * (csrc/dense.hip: exact_rows, reduce_dw_checked_kernel; tests/test_gpu_nonfinite.py).
  * ------------------------------------------------------------------------------------------- */
 int pygsd_magnetic_dense_supported(int32_t f_in, int32_t f_out, int32_t k1);
 /* form: 0 = split where the shape allows (default; PYGSD_DENSE_F32=exact at load selects 1), 1 = exact everywhere, anything else
@@ -533,8 +538,13 @@ int pygsd_dots_f32(const float* g, int64_t ldg, const float* const* xs, int32_t 
  * the nine partial products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the partial products of a 32-column block summed
  * apart, added to the running sum once): within 0.9e-7 * sum |x| |w| of the float64 product where an fp32 fmaf chain is within
  * 3.5e-7 (measured, profiles/r5t_tall_forms.json), 2.7x fewer matrix cycles, but
- * not bitwise any fp32 summation order, and magnitudes above the largest bf16 (3.39e38) overflow; EXACT -- an fmaf chain per
- * output on v_mfma_f32_16x16x4_f32 -- for every other shape and on request.  xs / ldx / widths: HOST arrays over the n_seg (<= 4) column segments -- device pointer
+ * not bitwise any fp32 summation order; EXACT -- an fmaf chain per
+ * output on v_mfma_f32_16x16x4_f32 -- for every other shape and on request.  Non-finite values: the three pieces carry finite
+ * values below the largest bf16 (3.39e38) only, so a 16-row tile (pygsd_tall_gram: an element of the result) whose sums come
+ * out non-finite -- an operand held +-inf, NaN or a magnitude beyond that, or the sum itself overflowed -- is computed again
+ * from the fp32 operands by fmaf chains: +-inf and NaN stand where torch.matmul puts them, in either form
+ * (csrc/tall.hip: any_not_finite / exact_tile_store, csrc/gram.hip: gram_finish_kernel; tests/test_gpu_nonfinite.py).
+ * xs / ldx / widths: HOST arrays over the n_seg (<= 4) column segments -- device pointer
  * (16-byte aligned), row stride in elements (a multiple of 16 bytes) and width (a multiple of 32 columns for bf16, 16 for
  * fp32).  W[k][n] (k over the concatenated segment columns) sits at w[k * ldw + n], or at w[n * ldw + k] when w_transposed.
  * The f_out = sum of out_widths output columns are written to n_out (<= 8) column segments ys / ldy / out_widths of the same

@@ -1,5 +1,6 @@
 // Shared host-side plumbing of libpygsd_hip.so: error string, launch checking, kernel-timing recorder.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -107,6 +108,6 @@ inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // 0 = fp32 tall products / weight gradients in the split form (three bf16 pieces per value, bf16 matrix pipe) wherever a shape has
 // one, 1 = exact fp32 MFMA everywhere (csrc/tall.hip; pygsd_tall_f32_form, PYGSD_TALL_F32=exact)
-int& tall_f32_form();
+std::atomic<int>& tall_f32_form();
 
 }  // namespace pygsd

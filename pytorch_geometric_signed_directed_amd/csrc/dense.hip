@@ -128,6 +128,61 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
     const int lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int n_tiles = (p.n_rows + 15) >> 4;
     const int stride = static_cast<int>(gridDim.x) * WAVES;
+    // ---- non-finite sums (round 6) ------------------------------------------------------------------------------------------
+    // The reference forms rr = sum_k A_k W_k and ii = sum_k B_k W_k and then rr - ii, rr + ii (MagNetConv.py:217-247).  On finite
+    // values (A - B) W is the same number up to rounding; on non-finite ones it is not -- W = inf gives rr = ii = +-inf and
+    // rr - ii = NaN where (A - B) inf is +-inf -- and the split form carries finite values below the largest bf16 only (a NaN
+    // piece makes every sum it enters NaN: csrc/tall.hip, any_not_finite).  So a tile that holds a non-finite sum, in either
+    // form, is computed again the reference's way: rr and ii as fmaf chains over the terms and features in order on the fp32
+    // operands, then the difference and the sum.  Rolled loops, eight sums live: the branch costs the kernel no registers.
+    auto not_finite = [&](const f32x4 (&ar)[NT], const f32x4 (&ai)[NT]) {
+        f32x4 z = ar[0] * 0.f;                                    // 0 for a finite sum, NaN for +-inf and NaN
+        z += ai[0] * 0.f;
+#pragma unroll
+        for (int nt = 1; nt < NT; ++nt) {
+            z += ar[nt] * 0.f;
+            z += ai[nt] * 0.f;
+        }
+        const float c = (z[0] + z[1]) + (z[2] + z[3]);
+        return __builtin_amdgcn_ballot_w64(c != c) != 0;          // wavefront-uniform
+    };
+    auto exact_rows = [&](int tl, f32x4 (&ar)[NT], f32x4 (&ai)[NT]) {
+        const int r0 = tl << 4;
+        const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int kk = 0; kk < p.k1; ++kk) {
+                PieceRow pr;
+                pr.base = static_cast<int64_t>(lrow) * f_in;
+                pr.slot_stride = 0;
+                int sh = 31, mk = 0x7fffffff;
+                if constexpr (PIECES) {
+                    if (kk == p.k1 - 1) {
+                        pr = piece_row(p.lay, lrow);
+                        sh = p.lay_shift;
+                        mk = (1 << sh) - 1;
+                    }
+                }
+                const float* wrow = p.w + static_cast<int64_t>(kk) * f_in * p.f_out + n0 + 16 * nt + 4 * g;
+                const float* ak = p.a[kk];
+                const float* bk = p.b[kk];
+#pragma unroll 1
+                for (int f = 0; f < f_in; ++f) {
+                    const int64_t off = piece_offset(pr, f >> 4, sh, mk) + (f & 15);
+                    const float av = ak[off], bv = bk[off];
+                    const float4 w4 = ldg4(wrow + static_cast<int64_t>(f) * p.f_out);
+                    sa[0] = fmaf(av, w4.x, sa[0]); sa[1] = fmaf(av, w4.y, sa[1]);
+                    sa[2] = fmaf(av, w4.z, sa[2]); sa[3] = fmaf(av, w4.w, sa[3]);
+                    sb[0] = fmaf(bv, w4.x, sb[0]); sb[1] = fmaf(bv, w4.y, sb[1]);
+                    sb[2] = fmaf(bv, w4.z, sb[2]); sb[3] = fmaf(bv, w4.w, sb[3]);
+                }
+            }
+            ar[nt] = f32x4{sa[0] - sb[0], sa[1] - sb[1], sa[2] - sb[2], sa[3] - sb[3]};
+            ai[nt] = f32x4{sa[0] + sb[0], sa[1] + sb[1], sa[2] + sb[2], sa[3] + sb[3]};
+        }
+    };
     // (wavefront-uniform, which the compiler cannot see through tid >> 6: without it the term's base pointers p.a[k] are fetched by
     // VECTOR loads, and the wait for them drains every row load in flight)
     int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * WAVES + (tid >> 6));
@@ -242,6 +297,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
             }
             if (k == p.k1 - 1) {
                 const int r0 = tl << 4;
+                if (not_finite(acc_r, acc_i)) exact_rows(tl, acc_r, acc_i);
                 // transposed C/D: lane (i, g), reg r  ->  out[node r0 + i][feature n0 + 16 nt + 4 g + r]
                 if (r0 + i < p.n_rows) {
 #pragma unroll
@@ -307,6 +363,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
                 }
             }
         }
+        if (not_finite(acc_r, acc_i)) exact_rows(tile, acc_r, acc_i);
         // transposed C/D: lane (i, g), reg r  ->  out[node r0 + i][feature n0 + 16 nt + 4 g + r]
         if (r0 + i < p.n_rows) {
 #pragma unroll
@@ -844,7 +901,39 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_split_kerne
                 }
             }
         }
+        // ---- operands the split cannot carry (+-inf, NaN, magnitudes above the largest bf16: csrc/tall.hip, any_not_finite) leave
+        //      NaN in every sum they enter: a tile that holds a non-finite sum is written a second time at the end of this
+        //      iteration (exact_rows_out below).  The weight-gradient sums of phase 2 are looked at where the partials are added
+        //      (reduce_dw_checked_kernel).
+        bool redo;
+        {
+            f32x4 z = acc_a[0] * 0.f;                             // 0 for a finite sum, NaN for +-inf and NaN
+            z += acc_b[0] * 0.f;
+#pragma unroll
+            for (int ft = 1; ft < NTI; ++ft) {
+                z += acc_a[ft] * 0.f;
+                z += acc_b[ft] * 0.f;
+            }
+            const float c = (z[0] + z[1]) + (z[2] + z[3]);
+            redo = __builtin_amdgcn_ballot_w64(c != c) != 0;      // wavefront-uniform, lives in a scalar register
+        }
         // ---- the tile's dA / dB stores (in front of phase 2: their registers are free for it) ------------------------------
+        auto rows_out = [&](int ft, float4 va, float4 vb) {
+            if (PIECES && p.out_on && k == p.k1 - 1) {
+                const PieceRow po = piece_row(p.lay_out, r0 + i);
+                const int osh = p.out_shift, omk = (1 << osh) - 1;
+                const int64_t rep_stride = static_cast<int64_t>(p.lay_out.slots_per_blk) * po.slot_stride;
+                const int64_t o = piece_offset(po, (c0 >> 4) + ft, osh, omk) + 4 * g;
+                for (int rep = 0; rep < p.lay_out.replicas; ++rep) {
+                    *reinterpret_cast<float4*>(dak + o + rep * rep_stride) = va;
+                    *reinterpret_cast<float4*>(dbk + o + rep * rep_stride) = vb;
+                }
+            } else {
+                const int64_t o = static_cast<int64_t>(r0 + i) * p.f_in + c0 + ft * 16 + 4 * g;
+                *reinterpret_cast<float4*>(dak + o) = va;
+                *reinterpret_cast<float4*>(dbk + o) = vb;
+            }
+        };
         if (r0 + i < p.n_rows) {
             if (PIECES && p.out_on && k == p.k1 - 1) {
                 const PieceRow po = piece_row(p.lay_out, r0 + i);
@@ -906,6 +995,30 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_split_kerne
                     acc_w[ft][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(bs[kWi[t]]), quad(mcs[kXi[t]]), acc_w[ft][nt], 0, 0, 0);
                 }
         }
+        // ---- the tile's dA / dB again, from the fp32 operands: fmaf chains over the output features in order (IEEE products and
+        //      sums: inf / -inf / NaN where autograd's matmuls put them), stored over the split form's rows -- same lane, same
+        //      addresses, program order.  Here, where little else is live, with rolled loops and eight sums: no registers.
+        if (redo && r0 + i < p.n_rows) {
+            const float* grow = p.gr + static_cast<int64_t>(r0 + i) * p.ldg;
+            const float* girow = p.gi + static_cast<int64_t>(r0 + i) * p.ldg;
+#pragma unroll 1
+            for (int ft = 0; ft < NTI; ++ft) {
+                const float* wr = p.w + (static_cast<int64_t>(k) * p.f_in + c0 + 16 * ft + 4 * g) * p.f_out;
+                float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int f = 0; f < fo; ++f) {
+                    const float x = grow[f], y = girow[f];
+                    const float pp = x + y, mm = y - x;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float w = wr[static_cast<int64_t>(r) * p.f_out + f];
+                        sa[r] = fmaf(pp, w, sa[r]);
+                        sb[r] = fmaf(mm, w, sb[r]);
+                    }
+                }
+                rows_out(ft, make_float4(sa[0], sa[1], sa[2], sa[3]), make_float4(sb[0], sb[1], sb[2], sb[3]));
+            }
+        }
     }
 
     // ---- combine the 4 wavefronts of the block through LDS (the W fragments are dead now), then one partial ----
@@ -963,6 +1076,52 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (pg == 0 && e < n_elem) out[e] = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
 }
 
+// dW behind dense_bwd_split_kernel: the partials added as reduce_partials_kernel adds them, and every sum that came out
+// non-finite -- an operand the split cannot carry entered it (see that kernel) -- computed again as autograd's matmuls compute it:
+// dW_k[c][f] = sum over the rows, in order, of A_k[r][c] P[r][f] + B_k[r][c] M[r][f] on the fp32 operands, P = G_r + G_i,
+// M = G_i - G_r.  One compare per element when nothing is wrong.
+__global__ __launch_bounds__(256) void reduce_dw_checked_kernel(DenseBwdArgs p, int n_partials, float* __restrict__ out)
+{
+    __shared__ float sm[256];
+    const int tid = threadIdx.x;
+    const int64_t n_elem = static_cast<int64_t>(p.k1) * p.f_in * p.f_out, stride = n_elem + p.f_out;
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * 64 + (tid & 63);
+    const int pg = tid >> 6;
+    float acc = 0.f;
+    if (e < n_elem) {
+#pragma unroll 8
+        for (int q = pg; q < n_partials; q += 4) acc += p.partial[static_cast<int64_t>(q) * stride + e];
+    }
+    sm[tid] = acc;
+    __syncthreads();
+    if (pg == 0 && e < n_elem) {
+        float total = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
+        if (!(__builtin_fabsf(total) < __builtin_inff())) {
+            const int f = static_cast<int>(e % p.f_out), c = static_cast<int>((e / p.f_out) % p.f_in);
+            const int k = static_cast<int>(e / (static_cast<int64_t>(p.f_out) * p.f_in));
+            const float* ak = p.a[0];
+            const float* bk = p.b[0];
+#pragma unroll
+            for (int q = 1; q < kMaxOrder; ++q)
+                if (q == k) {
+                    ak = p.a[q];
+                    bk = p.b[q];
+                }
+            const bool in_pieces = p.in_on && k == p.k1 - 1;
+            const int ish = p.in_shift, imk = (1 << ish) - 1;
+            total = 0.f;
+            for (int r = 0; r < p.n_rows; ++r) {
+                int64_t off = static_cast<int64_t>(r) * p.f_in + c;
+                if (in_pieces) off = piece_offset(piece_row(p.lay_in, r), c >> 4, ish, imk) + (c & 15);
+                const float x = p.gr[static_cast<int64_t>(r) * p.ldg + f], y = p.gi[static_cast<int64_t>(r) * p.ldg + f];
+                total = fmaf(ak[off], x + y, total);
+                total = fmaf(bk[off], y - x, total);
+            }
+        }
+        out[e] = total;
+    }
+}
+
 unsigned row_blocks(int n_rows, unsigned cap)
 {
     unsigned g = (static_cast<unsigned>(n_rows) + 63u) / 64u;
@@ -979,14 +1138,14 @@ int set_lds(Kern kern, size_t bytes)
     return 0;
 }
 
-int& dense_f32_form();
+std::atomic<int>& dense_f32_form();
 
 template <int NT, int FIN, bool PIECES = false>
 int launch_fwd_fin(const DenseFwdArgs& a, unsigned gy, size_t lds_bytes, hipStream_t s)
 {
     if constexpr (NT == 4 && (FIN == 64 || FIN == 128)) {
         const size_t split_bytes = static_cast<size_t>(a.k1) * (FIN / 32) * NT * 3072;       // pre-split W fragments
-        if (dense_f32_form() == 0 && split_bytes <= 150 * 1024) {
+        if (dense_f32_form().load() == 0 && split_bytes <= 150 * 1024) {
             if (split_bytes > 80 * 1024) {      // one block per CU: give it 8 wavefronts
                 if (int rc = set_lds(dense_fwd_kernel<NT, FIN, 8, PIECES, true>, split_bytes)) return rc;
                 hipLaunchKernelGGL((dense_fwd_kernel<NT, FIN, 8, PIECES, true>), dim3(row_blocks(a.n_rows, 1024), gy), dim3(512),
@@ -1025,12 +1184,12 @@ int launch_fwd(const DenseFwdArgs& a, unsigned gy, hipStream_t s, bool pieces = 
 
 // 0 = the split form wherever its shapes allow (default), 1 = every product an fmaf chain on v_mfma_f32_16x16x4_f32;
 // PYGSD_DENSE_F32=exact sets 1 at load, pygsd_dense_f32_form changes it at run time (measurement / bitwise tests)
-int& dense_f32_form()
+std::atomic<int>& dense_f32_form()
 {
-    static int form = [] {
+    static std::atomic<int> form{[] {
         const char* e = getenv("PYGSD_DENSE_F32");
         return (e && e[0] == 'e') ? 1 : 0;
-    }();
+    }()};
     return form;
 }
 
@@ -1044,11 +1203,12 @@ int launch_bwd_split(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_
     return check_launch("dense_bwd_split_kernel");
 }
 
+// `split`: bwd_split_form() of this call (the form switch is read once per entry-point call)
 template <int NTI, int NTO, bool PIECES = false>
-int launch_bwd(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
+int launch_bwd(const DenseBwdArgs& a, unsigned gx, unsigned gz, bool split, hipStream_t s)
 {
     if constexpr (NTI == 4 && (NTO == 4 || NTO == 8)) {
-        if (dense_f32_form() == 0) return launch_bwd_split<NTO, PIECES>(a, gx, gz, s);
+        if (split) return launch_bwd_split<NTO, PIECES>(a, gx, gz, s);
     }
     constexpr bool kXpose = true;
     constexpr size_t rs = (NTO > NTI ? NTO : NTI) * 16 + kPad;
@@ -1062,24 +1222,24 @@ int launch_bwd(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
 }
 
 // the piece-layout instances exist for the shapes the sharded layers run: f_in a multiple of 64 (NTI = 4), f_out = 64 / 128
-int dispatch_bwd_pieces(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
+int dispatch_bwd_pieces(const DenseBwdArgs& a, unsigned gx, unsigned gz, bool split, hipStream_t s)
 {
     switch (a.f_out / 16) {
-        case 4: return launch_bwd<4, 4, true>(a, gx, gz, s);
-        case 8: return launch_bwd<4, 8, true>(a, gx, gz, s);
+        case 4: return launch_bwd<4, 4, true>(a, gx, gz, split, s);
+        case 8: return launch_bwd<4, 8, true>(a, gx, gz, split, s);
         default: return fail("pygsd_magnetic_dense_bwd_pieces_f32: f_out=%d (64 or 128 with a piece layout)", a.f_out);
     }
 }
 
 template <int NTI>
-int dispatch_bwd_nto(const DenseBwdArgs& a, unsigned gx, unsigned gz, hipStream_t s)
+int dispatch_bwd_nto(const DenseBwdArgs& a, unsigned gx, unsigned gz, bool split, hipStream_t s)
 {
     switch (a.f_out / 16) {
-        case 1: return launch_bwd<NTI, 1>(a, gx, gz, s);
-        case 2: return launch_bwd<NTI, 2>(a, gx, gz, s);
-        case 3: return launch_bwd<NTI, 3>(a, gx, gz, s);
-        case 4: return launch_bwd<NTI, 4>(a, gx, gz, s);
-        case 8: return launch_bwd<NTI, 8>(a, gx, gz, s);
+        case 1: return launch_bwd<NTI, 1>(a, gx, gz, split, s);
+        case 2: return launch_bwd<NTI, 2>(a, gx, gz, split, s);
+        case 3: return launch_bwd<NTI, 3>(a, gx, gz, split, s);
+        case 4: return launch_bwd<NTI, 4>(a, gx, gz, split, s);
+        case 8: return launch_bwd<NTI, 8>(a, gx, gz, split, s);
         default: return fail("pygsd_magnetic_dense_bwd_f32: unsupported f_out=%d", a.f_out);
     }
 }
@@ -1091,10 +1251,9 @@ using namespace pygsd;
 
 extern "C" int pygsd_dense_f32_form(int32_t form)
 {
-    int& cur = dense_f32_form();
-    const int before = cur;
-    if (form == 0 || form == 1) cur = form;
-    return before;
+    std::atomic<int>& cur = dense_f32_form();
+    if (form == 0 || form == 1) return cur.exchange(form);
+    return cur.load();
 }
 
 extern "C" int pygsd_magnetic_dense_supported(int32_t f_in, int32_t f_out, int32_t k1)
@@ -1220,17 +1379,23 @@ extern "C" int pygsd_magnetic_dense_bwd_pieces_f32(const float* const* a, const 
     ProfScope prof(PYGSD_K_DENSE_BWD, s);
     const unsigned gx = row_blocks(n_rows, 256);
     const unsigned gz = (static_cast<unsigned>(f_in) + kChunk - 1) / kChunk;
+    // the split form's shapes (launch_bwd): f_in in chunks of 64, f_out = 64 / 128; the switch is read once per call
+    const bool split = dense_f32_form().load() == 0 && f_in >= kChunk && (f_out == 64 || f_out == 128);
     int rc;
-    if (pieces) rc = dispatch_bwd_pieces(args, gx, gz, s);
-    else if (f_in >= kChunk) rc = dispatch_bwd_nto<4>(args, gx, gz, s);
-    else if (f_in == 48) rc = dispatch_bwd_nto<3>(args, gx, 1, s);
-    else if (f_in == 32) rc = dispatch_bwd_nto<2>(args, gx, 1, s);
-    else rc = dispatch_bwd_nto<1>(args, gx, 1, s);
+    if (pieces) rc = dispatch_bwd_pieces(args, gx, gz, split, s);
+    else if (f_in >= kChunk) rc = dispatch_bwd_nto<4>(args, gx, gz, split, s);
+    else if (f_in == 48) rc = dispatch_bwd_nto<3>(args, gx, 1, split, s);
+    else if (f_in == 32) rc = dispatch_bwd_nto<2>(args, gx, 1, split, s);
+    else rc = dispatch_bwd_nto<1>(args, gx, 1, split, s);
     if (rc) return rc;
     // dw [k1][f_in][f_out] followed by dbias [f_out] in the partial layout
     const int64_t n_w = static_cast<int64_t>(k1) * f_in * f_out;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((n_w + 63) / 64)), dim3(256), 0, s,
-                       args.partial, static_cast<int>(gx), n_w + f_out, n_w, dw);
+    if (split)
+        hipLaunchKernelGGL(reduce_dw_checked_kernel, dim3(static_cast<unsigned>((n_w + 63) / 64)), dim3(256), 0, s, args,
+                           static_cast<int>(gx), dw);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((n_w + 63) / 64)), dim3(256), 0, s,
+                           args.partial, static_cast<int>(gx), n_w + f_out, n_w, dw);
     if (int rc2 = check_launch("reduce_partials_kernel")) return rc2;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((f_out + 63) / 64)), dim3(256), 0, s,
                        args.partial + n_w, static_cast<int>(gx), n_w + f_out, static_cast<int64_t>(f_out), dbias);

@@ -419,6 +419,8 @@ __global__ __launch_bounds__(256, 1) void tall_gram32_f32_kernel(Gram32Args p)
             // partial products of its operands' three bf16 pieces (csrc/tall.hip: closer to float64 than the fmaf chain, 2.7x fewer
             // matrix cycles).  Term-outer, accumulator-inner: consecutive MFMAs write different accumulators.
             static_assert(!SPLIT || D == 8, "one 32x32x16 step per batch");
+            // (Operands the split cannot carry -- +-inf, NaN, magnitudes that round to the bf16 infinity -- leave NaN in every sum
+            // they enter; gram_finish_kernel<true> recomputes those sums exactly.  Nothing in this loop tests for them.)
             bf16x8 xt[NBK][3], gt[NBF][3];
 #pragma unroll
             for (int a = 0; a < NBK; ++a) {
@@ -480,10 +482,10 @@ __global__ __launch_bounds__(256, 1) void tall_gram32_f32_kernel(Gram32Args p)
 }
 
 template <int NBK, int NBF>
-int launch_gram32(const Gram32Args& a, unsigned blocks, hipStream_t s)
+int launch_gram32(const Gram32Args& a, unsigned blocks, bool split, hipStream_t s)
 {
     const size_t lds = static_cast<size_t>(NBK) * 32 * NBF * 32 * sizeof(float);
-    if (tall_f32_form() == 0) {                  // the split form: 8 row pairs = the 16 k-slots of one bf16 MFMA
+    if (split) {                  // the split form: 8 row pairs = the 16 k-slots of one bf16 MFMA
         if (lds > 64 * 1024)
             PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram32_f32_kernel<NBK, NBF, 8, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -499,25 +501,18 @@ int launch_gram32(const Gram32Args& a, unsigned blocks, hipStream_t s)
 }
 
 template <int NBK>
-int pick_gram32(const Gram32Args& a, int nbf, unsigned blocks, hipStream_t s)
+int pick_gram32(const Gram32Args& a, int nbf, unsigned blocks, bool split, hipStream_t s)
 {
     switch (nbf) {
-        case 1: return launch_gram32<NBK, 1>(a, blocks, s);
-        case 2: return launch_gram32<NBK, 2>(a, blocks, s);
-        case 3: return launch_gram32<NBK, 3>(a, blocks, s);
-        case 4: if constexpr (NBK <= 2) return launch_gram32<NBK, 4>(a, blocks, s); else break;
-        case 6: if constexpr (NBK <= 2) return launch_gram32<NBK, 6>(a, blocks, s); else break;
+        case 1: return launch_gram32<NBK, 1>(a, blocks, split, s);
+        case 2: return launch_gram32<NBK, 2>(a, blocks, split, s);
+        case 3: return launch_gram32<NBK, 3>(a, blocks, split, s);
+        case 4: if constexpr (NBK <= 2) return launch_gram32<NBK, 4>(a, blocks, split, s); else break;
+        case 6: if constexpr (NBK <= 2) return launch_gram32<NBK, 6>(a, blocks, split, s); else break;
         default: break;
     }
     return fail("pygsd_tall_gram: no 32x32 instance for %d x %d blocks", NBK, nbf);
 }
-
-// a side's 32-column blocks (every segment a multiple of 32 columns wide): pointer to the block's first column + row stride
-struct Blocks32 {
-    const float* p[16];
-    int64_t ld[16];
-    int n;
-};
 
 // blocks a partial-sum workspace of `budget` bytes admits (one [k_total x f_total] fp32 partial per block)
 unsigned budget_blocks(unsigned want, int64_t n_elem)
@@ -536,9 +531,25 @@ int gram32_mode()
     return e[0] == '0' ? 0 : 2;
 }
 
-// out[e] = sum_b partial[b][e] in block order: 64 elements per block, 4 groups of partials combined through LDS
+// a side's 32-column blocks (every segment a multiple of 32 columns wide): pointer to the block's first column + row stride
+struct Blocks32 {
+    const float* p[16];
+    int64_t ld[16];
+    int n;
+};
+
+// out[e] = sum_b partial[b][e] in block order: 64 elements per block, 4 groups of partials combined through LDS.
+// RECHECK (behind the split form, round 6): the split represents finite values below the largest bf16 only -- x = +-inf gives
+// hi = x and x - hi = NaN, a magnitude above 3.39e38 rounds its hi to inf, and inf times a zero PIECE of a nonzero value is NaN
+// where the fp32 product is +-inf (csrc/tall.hip) -- and a NaN piece makes every sum it enters NaN.  So a sum that came out
+// finite had operands the split carries exactly, and one that did not is computed again here as the reference's fp32 product
+// is: an fmaf chain over the rows in order on the fp32 operands, IEEE products and sums, so that inf, -inf and NaN stand where
+// torch.mm puts them.  One compare per output element when nothing is wrong; the chain is as slow as it looks and runs for the
+// elements that need it only.
+template <bool RECHECK>
 __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ partial, int n_partials, int64_t n_elem,
-                                                          float* __restrict__ out)
+                                                          float* __restrict__ out, Blocks32 bx, Blocks32 bg, int f_total,
+                                                          int64_t n_rows)
 {
     __shared__ float sm[256];
     const int tid = threadIdx.x;
@@ -551,7 +562,20 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
     }
     sm[tid] = acc;
     __syncthreads();
-    if (grp == 0 && e < n_elem) out[e] = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
+    if (grp == 0 && e < n_elem) {
+        float total = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
+        if constexpr (RECHECK) {
+            if (!(__builtin_fabsf(total) < __builtin_inff())) {
+                const int k = static_cast<int>(e / f_total), f = static_cast<int>(e - static_cast<int64_t>(k) * f_total);
+                const float* xc = bx.p[k >> 5] + (k & 31);
+                const float* gc = bg.p[f >> 5] + (f & 31);
+                const int64_t sx = bx.ld[k >> 5], sg = bg.ld[f >> 5];
+                total = 0.f;
+                for (int64_t r = 0; r < n_rows; ++r) total = fmaf(xc[r * sx], gc[r * sg], total);
+            }
+        }
+        out[e] = total;
+    }
 }
 
 // One [k_total x f_total] fp32 partial per block: the workspace (and the finish kernel's reads) grow with blocks x K x F, so the
@@ -668,6 +692,7 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
         if (b32 > blocks) b32 = blocks;                                         // (the workspace was sized for `blocks`)
         hipStream_t st = static_cast<hipStream_t>(stream);
         ProfScope prof(PYGSD_K_DENSE_BWD, st);
+        const bool split = tall_f32_form().load() == 0;                         // read once: every launch of this call agrees
         for (int x0 = 0; x0 < bx.n; x0 += gx) {
             const int nk = bx.n - x0 >= gx ? gx : (bx.n - x0 >= 2 ? 2 : 1);
             for (int g0 = 0; g0 < bg.n;) {
@@ -689,7 +714,8 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
                 ga.f_total = f_total;
                 ga.x_at = x0 * 32;
                 ga.g_at = g0 * 32;
-                int rc = nk == 4 ? pick_gram32<4>(ga, nf, b32, st) : (nk == 2 ? pick_gram32<2>(ga, nf, b32, st) : pick_gram32<1>(ga, nf, b32, st));
+                int rc = nk == 4 ? pick_gram32<4>(ga, nf, b32, split, st)
+                                 : (nk == 2 ? pick_gram32<2>(ga, nf, b32, split, st) : pick_gram32<1>(ga, nf, b32, split, st));
                 if (rc) return rc;
                 g0 += nf;
             }
@@ -697,8 +723,12 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
                 x0 -= gx - nk;
             }
         }
-        hipLaunchKernelGGL(gram_finish_kernel, dim3(static_cast<unsigned>((n_elem + 63) / 64)), dim3(256), 0, st,
-                           static_cast<const float*>(workspace), static_cast<int>(b32), n_elem, out);
+        if (split)
+            hipLaunchKernelGGL(gram_finish_kernel<true>, dim3(static_cast<unsigned>((n_elem + 63) / 64)), dim3(256), 0, st,
+                               static_cast<const float*>(workspace), static_cast<int>(b32), n_elem, out, bx, bg, f_total, n_rows);
+        else
+            hipLaunchKernelGGL(gram_finish_kernel<false>, dim3(static_cast<unsigned>((n_elem + 63) / 64)), dim3(256), 0, st,
+                               static_cast<const float*>(workspace), static_cast<int>(b32), n_elem, out, bx, bg, f_total, n_rows);
         return check_launch("gram_finish_kernel");
     }
     a.partial = static_cast<float*>(workspace);
@@ -730,7 +760,8 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
         hipLaunchKernelGGL(tall_gram_f32_kernel, grid, dim3(256), lds, s, a);
     }
     if (int rc = check_launch("tall_gram_kernel")) return rc;
-    hipLaunchKernelGGL(gram_finish_kernel, dim3(static_cast<unsigned>((n_elem + 63) / 64)), dim3(256), 0, s,
-                       static_cast<const float*>(workspace), static_cast<int>(blocks), n_elem, out);
+    hipLaunchKernelGGL(gram_finish_kernel<false>, dim3(static_cast<unsigned>((n_elem + 63) / 64)), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), static_cast<int>(blocks), n_elem, out, Blocks32{}, Blocks32{}, f_total,
+                       n_rows);
     return check_launch("gram_finish_kernel");
 }

@@ -260,9 +260,9 @@ __global__ __launch_bounds__(256) void tall_linear_f32_kernel(TallArgs p)
 // sum |x| |w|: 1.3 - 1.7e-7 with the six terms added straight into the running sums (tools/probes/split_probe.hip ->
 // profiles/r5n_split_probe.txt), 0.6 - 0.8e-7 with the six terms of every 32-column block summed apart and added once, as
 // split_tile_out does (tools/tall_forms_probe.py -> profiles/r5t_tall_forms.json), against 2.8 - 3.5e-7 for the fmaf chain on the
-// same inputs -- the dropped terms are smaller than the chain's own roundings.  NOT bitwise the fmaf chain; a value of magnitude
-// above the largest bf16 (3.39e38) overflows its `hi` (the exact kernel would carry it); PYGSD_TALL_F32=exact keeps every fp32
-// product on the kernel above.
+// same inputs -- the dropped terms are smaller than the chain's own roundings.  NOT bitwise the fmaf chain.  Operands the split
+// cannot carry -- +-inf, NaN, magnitudes above the largest bf16 (3.39e38) -- send their tile to exact fp32 arithmetic (see
+// any_not_finite / exact_tile_store below); PYGSD_TALL_F32=exact keeps every fp32 product on the kernel above.
 //
 // Memory side (the kernel is memory-bound now, so these pay: 81 -> 77 us at K = 128 / f_out = 64, 90 -> 78 at 64 / 128, 500 -> 411
 // at 64 / 192 for 2M rows -- same probe):
@@ -308,6 +308,60 @@ __device__ __forceinline__ void split_rows_in(const TallArgs& p, int tile, int j
     }
 }
 
+// ---- non-finite and out-of-range operands (round 6) ------------------------------------------------------------------------
+// The split is exact arithmetic on FINITE values below the largest bf16.  Outside that range it is not what the reference's
+// torch.matmul computes: x = +-inf gives hi = x and mid = x - hi = NaN; a finite |x| above 3.39e38 rounds its hi to inf (then
+// mid = -inf, lo = NaN); and even with the lower pieces forced to zero, inf times a W piece that happens to be zero (any weight
+// that fits 8 / 16 mantissa bits) is NaN where inf * w is +-inf.  No arrangement of the three pieces repairs the last case, so
+// the guard is on the RESULT: a NaN piece of either operand makes every sum it enters NaN (NaN * 0 = NaN on the matrix pipe as
+// anywhere else), i.e. a tile whose sums are all finite had operands the split represents exactly.  A wavefront whose tile
+// holds a non-finite sum recomputes that tile from the fp32 operands themselves (IEEE products and sums: inf, -inf and NaN come
+// out where an fmaf chain puts them) -- the rows and W re-read from global memory (L2 hits), executed by the tiles that need it
+// only.  The test costs two packed multiply-adds per output tile.
+template <int NT>
+__device__ __forceinline__ bool any_not_finite(const f32x4 (&acc)[NT])
+{
+    f32x4 z = acc[0] * 0.f;                                    // 0 for a finite value, NaN for +-inf and NaN
+#pragma unroll
+    for (int t = 1; t < NT; ++t) z += acc[t] * 0.f;
+    const float c = (z[0] + z[1]) + (z[2] + z[3]);
+    return __builtin_amdgcn_ballot_w64(c != c) != 0;           // wavefront-uniform
+}
+
+// The tile again, exactly, and stored: lane (j, q) owns columns 16 t + 4 q .. + 3 of row j, as in the split form, and walks
+// them as plain fmaf chains over k in order -- rolled loops, four sums and a few addresses live, so that the branch costs the
+// kernel no registers (an MFMA form with its NT accumulators and loads in flight took a wavefront per SIMD from most instances).
+template <int KB, int NT>
+__device__ __forceinline__ void exact_tile_store(const TallArgs& p, const float* bias, int tile, int j, int q)
+{
+    int64_t row = static_cast<int64_t>(tile) * 16 + j;
+    row = row < p.n_rows ? row : p.n_rows - 1;                 // clamped as the split form: such a lane re-writes the last row
+    const float* w = static_cast<const float*>(p.w);
+    const int64_t ws_k = p.w_t ? 1 : p.ldw, ws_n = p.w_t ? p.ldw : 1;
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+        const float* wc = w + (16 * t + 4 * q) * ws_n;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 1
+        for (int kb = 0; kb < KB; ++kb) {
+            const float* xr = static_cast<const float*>(p.x[kb]) + row * p.ld[kb];
+            const float* wk = wc + static_cast<int64_t>(kb) * 32 * ws_k;
+#pragma unroll 1
+            for (int e = 0; e < 32; ++e) {
+                const float xv = xr[e];
+                s0 = fmaf(xv, wk[0], s0);
+                s1 = fmaf(xv, wk[ws_n], s1);
+                s2 = fmaf(xv, wk[2 * ws_n], s2);
+                s3 = fmaf(xv, wk[3 * ws_n], s3);
+                wk += ws_k;
+            }
+        }
+        const float* b = bias + 16 * t + 4 * q;
+        *reinterpret_cast<float4*>(static_cast<float*>(p.y[t]) + row * p.ldy[t] + 4 * q) =
+            make_float4(s0 + b[0], s1 + b[1], s2 + b[2], s3 + b[3]);
+    }
+}
+
 template <int KB, int NT>
 __device__ __forceinline__ void split_tile_out(const TallArgs& p, const uint4* frag, const float* bias, int tile, int lane,
                                                const float4 (&cur)[KB][2])
@@ -350,6 +404,10 @@ __device__ __forceinline__ void split_tile_out(const TallArgs& p, const uint4* f
 #pragma unroll
             for (int u = 0; u < G; ++u) acc[t0 + u] += part[u];
         }
+    }
+    if (any_not_finite<NT>(acc)) {
+        exact_tile_store<KB, NT>(p, bias, tile, j, q);
+        return;
     }
     // lane (j, q) holds columns [16 t + 4 q, +4) of row j for every tile t; after the trade lanes j < 8 hold tile 2 m of rows
     // j and j + 8, lanes j >= 8 tile 2 m + 1 of rows j - 8 and j
@@ -507,7 +565,7 @@ bool split_shape_ok(int k_total, int f_out)
     return kb_ok && nt_ok && kb * nt <= 48;
 }
 
-bool split_allowed() { return tall_f32_form() == 0; }
+bool split_allowed() { return tall_f32_form().load() == 0; }
 
 template <typename Kern>
 int launch_split(Kern kern, const TallArgs& a, int kb, int nt, hipStream_t s)
@@ -622,12 +680,13 @@ unsigned column_sum_blocks(int64_t n_rows, int f, int v)
 
 // 0 = the split form wherever its shapes allow (default), 1 = every fp32 product as an fmaf chain on v_mfma_f32_16x16x4_f32;
 // PYGSD_TALL_F32=exact sets 1 at load, pygsd_tall_f32_form changes it at run time (measurement / bitwise tests)
-int& tall_f32_form()
+// (an atomic: a thread may flip it while another is inside a launch; every entry point reads it once)
+std::atomic<int>& tall_f32_form()
 {
-    static int form = [] {
+    static std::atomic<int> form{[] {
         const char* e = getenv("PYGSD_TALL_F32");
         return (e && e[0] == 'e') ? 1 : 0;
-    }();
+    }()};
     return form;
 }
 }  // namespace pygsd
@@ -636,10 +695,9 @@ using namespace pygsd;
 
 extern "C" int pygsd_tall_f32_form(int32_t form)
 {
-    int& cur = tall_f32_form();
-    const int before = cur;
-    if (form == 0 || form == 1) cur = form;
-    return before;
+    std::atomic<int>& cur = tall_f32_form();
+    if (form == 0 || form == 1) return cur.exchange(form);
+    return cur.load();
 }
 
 extern "C" int pygsd_tall_linear_supported(int32_t dtype, int32_t k_total, int32_t f_out)
