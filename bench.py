@@ -105,6 +105,7 @@ def cpu_baseline(hidden, steps=4, n=100000, e=2000000, threads=None):
     med_c, med_u = statistics.median(t_cached), statistics.median(t_rebuilt)
     edges = ei.size(1)
     return {"value": edges / med_c, "unit": "edges/s", "cores": cores, "cores_available": available, "kind": "port",
+            "cpu_model": cpu_model(),
             "value_uncached": edges / med_u, "operator_build_seconds": build_s,
             "seconds_per_step": {"cached_median": med_c, "cached_min": min(t_cached), "cached_max": max(t_cached),
                                  "uncached_median": med_u, "uncached_min": min(t_rebuilt), "uncached_max": max(t_rebuilt)},
@@ -117,6 +118,110 @@ def cpu_baseline(hidden, steps=4, n=100000, e=2000000, threads=None):
                       f"({med_c:.2f} s/step); `value_uncached` = operator rebuilt every forward (reference default, "
                       f"MagNetConv.py:45), median of {len(t_rebuilt)} ({med_u:.2f} s/step); {cores} of "
                       f"{available} host threads (ATen scatter_add_ anti-scales beyond)"}
+
+
+def cpu_model():
+    """The host CPU's model string ("core count and CPU model stated"): lscpu, else /proc/cpuinfo."""
+    try:
+        for ln in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def baseline_configs(timeout_s=240):
+    """The other single-GPU BASELINE.json configurations, timed in THIS run (a child process of tools/bench_configs.py in its
+    compact mode, after the headline has released the device): C2 MagNetConv 100k / 2M, C3a SGCNConv and C3b SIMPA hop 2 on
+    SSBM 500k / 10M, C4 MSConv K=2 h=128 on SDSBM 1M / 20M (on ONE GPU), C5a / C5b DiGCN inception block fp32 / bf16 on 2M
+    nodes / 52M entries per operator.  Per configuration: fwd+bwd ms per step (eager, operator cached), the dominant kernel
+    class (all of them are SpMM-bound) with its average launch, and that kernel's algorithmic rate as a fraction of the 8 TB/s
+    HBM peak (SURVEY.md 8(d) byte model, tools/bench_configs.py)."""
+    path = os.path.join(ROOT, "gpurun_out", "bench_configs_compact.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    env = dict(os.environ, PYGSD_CONFIGS="C2,C3a,C3b,C4,C5a,C5b", PYGSD_CONFIGS_COMPACT="1", PYGSD_CONFIGS_OUT=path)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.perf_counter()
+    try:
+        if os.path.exists(path):
+            os.unlink(path)
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py")], cwd=ROOT, env=env,
+                             stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        if run.returncode != 0 or not os.path.exists(path):
+            return {"error": f"tools/bench_configs.py rc={run.returncode}: {run.stderr[-300:]}"}
+        with open(path) as fh:
+            raw = json.load(fh)
+    except Exception as exc:  # noqa: BLE001 -- a secondary leg must not cost the headline
+        return {"error": repr(exc)[:300]}
+
+    def dominant(kernels):
+        best = max(kernels.items(), key=lambda kv: kv[1]["launches_per_step"] * kv[1]["ms_per_launch"])
+        return best[0], best[1]
+
+    def entry(rec, ms, gbps_key, what):
+        name, k = dominant(rec["kernels"])
+        gbps = rec.get(gbps_key) if gbps_key else None
+        return {"workload": what, "ms_per_step": ms, "dominant_kernel_class": name,
+                "dominant_kernel_ms_per_step": k["launches_per_step"] * k["ms_per_launch"],
+                "dominant_kernel_launches_per_step": k["launches_per_step"],
+                "spmm_algorithmic_GBps": gbps, "frac": (gbps / HBM_PEAK_GBS) if gbps else None,
+                "gathered_set_MiB": rec.get("gathered_set_MiB")}
+    out = {}
+    r = raw.get("C2_magnetconv_100k_2M_h64")
+    if r:
+        out["C2"] = entry(r, r["ms_per_step"], "spmm2_alg_GBps", "MagNetConv K=1 h=64 fp32, DSBM 100k nodes / 2M edges")
+    r = raw.get("C3_sgcnconv_first")
+    if r:
+        out["C3a"] = entry(r, r["ms_per_step"], "spmm_alg_GBps_fwd_pair", "SGCNConv first_aggr h=64 fp32, SSBM 500k nodes / 10M signed entries")
+    r = raw.get("C3_simpa_hop2")
+    if r:
+        out["C3b"] = entry(r, r["ms_per_step"], "spmm_alg_GBps", "SIMPA hop 2 h=64 fp32, SSBM 500k nodes / 10M signed entries")
+    r = raw.get("C4_msconv_1M_20M_h128_K2_1gpu")
+    if r:
+        out["C4_one_gpu"] = entry(r, r["ms_per_step"], "spmm2_alg_GBps", "MSConv K=2 h=128 fp32, SDSBM 1M nodes / 20M edges, on ONE GPU")
+    c5 = raw.get("C5_digcn_inception_block_1gpu") or {}
+    for tag, key, label in (("C5a", "float32", "fp32"), ("C5b", "bfloat16", "bf16")):
+        r = c5.get(key)
+        if r:
+            out[tag] = entry(r, r["ms_per_block_step"], "spmm_alg_GBps",
+                             f"DiGCN_InceptionBlock h=64 {label}, 2M nodes / {r.get('nnz_per_operator')} entries per operator, on ONE GPU")
+    out["seconds"] = time.perf_counter() - t0
+    out["note"] = ("fwd+bwd per step, eager, operator cached, 10 (C5: 5) steps after warm-up, in a child process of this run "
+                   "(tools/bench_configs.py, compact mode); frac = the SpMM's algorithmic bytes (SURVEY.md 8(d): every operand "
+                   "read once, every result written once) / its average launch / 8 TB/s -- at or below a 256 MiB gathered set "
+                   "that is an on-die rate, not a DRAM rate")
+    return out
+
+
+def rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(t) for t in v) if isinstance(v, tuple) else str(v)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def device_identities(dist, device):
+    """One record per rank -- host, process, HIP device index, device name, UUID and PCI bus id -- gathered over the process
+    group, so that a multi-GPU line proves by itself that its N ranks ran on N distinct GPUs."""
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": dist.get_rank(), "host": socket.gethostname(), "pid": os.getpid(), "device_index": device.index,
+          "name": props.name, "uuid": str(getattr(props, "uuid", None)),
+          "pci_bus_id": (f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}"
+                         if hasattr(props, "pci_bus_id") else None),
+          "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, me)
+    distinct = len({(r["host"], r["uuid"], r["pci_bus_id"]) for r in box})
+    return {"ranks": box, "distinct_devices": distinct}
 
 
 def stream_copy_rate(device, gib=1.0, reps=7):
@@ -151,7 +256,8 @@ def measure_traffic(args, kernel_substring="spmm_vec_kernel"):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    child = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-pmc", "--no-x4", "--steps", "3", "--warmup", "1",
+    child = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-pmc", "--no-x4", "--no-configs", "--steps", "3",
+             "--warmup", "1",
              "--nodes", str(args.nodes), "--edges", str(args.edges), "--hidden", str(args.hidden)]
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -315,6 +421,12 @@ def main():
     ap.add_argument("--no-x4", action="store_true",
                     help="do not run the DRAM-bound x4 graph (4M nodes / 80M edges, ~25 s) that feeds "
                          "`roofline.dram_bound_reference`; the tracked capture is replayed instead, labelled so")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="do not time the other single-GPU BASELINE configurations (C2, C3a, C3b, C4 on one GPU, C5a, C5b; ~40 s in a "
+                         "child process) into the line's `configs` object")
+    ap.add_argument("--cpu-baseline-northstar", action="store_true",
+                    help="run the CPU baseline at the NORTH-STAR size as well (1M nodes / 20M edges: ~100 GB of host memory, "
+                         "minutes) -> `cpu_baseline.northstar`; run once into profiles/, not part of the default line")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure `roofline.traffic` live (two rocprofv3 --pmc passes of a short child run of this "
                          "script); the value is then replayed from profiles/pmc_traffic.json and labelled so")
@@ -588,7 +700,9 @@ def main():
                         "return_GBps_per_link": [rate(b, t) for b, t in zip(back_bytes_per_link, return_ms)],
                         "assumed_by_the_rehearsal_GBps_per_link": 61.0},
                     "cache_input_exchange": bool(args.cache_input_exchange),
-                    "backend": dist.get_backend(), "blocking_collectives": bool(getattr(layer_s.exchange, "synchronous", False)),
+                    "backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": device_identities(dist, device),
+                    "rccl_version": rccl_version(),
+                    "blocking_collectives": bool(getattr(layer_s.exchange, "synchronous", False)),
                     "TORCH_NCCL_AVOID_RECORD_STREAMS": os.environ.get("TORCH_NCCL_AVOID_RECORD_STREAMS"),
                     "fallback": fallback_note,
                     "node_range_sizes": layer_s.plan.sizes, "n_pad": layer_s.plan.n_pad,
@@ -749,8 +863,18 @@ def main():
             line["exchange"] = exchange
         if parity is not None:
             line["parity"] = parity
+        if world == 1 and layer_s is None and not args.no_configs:
+            torch.cuda.empty_cache()         # (the child process needs the device's memory: C4 and C5 hold 10 - 20 GB)
+            line["configs"] = baseline_configs()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hidden)
+            if args.cpu_baseline_northstar:
+                try:
+                    big = cpu_baseline(hidden, steps=2, n=n, e=args.edges)
+                    big["scaled_from"] = "nothing: the north-star size itself"
+                    line["cpu_baseline"]["northstar"] = big
+                except Exception as exc:  # noqa: BLE001 -- host memory
+                    line["cpu_baseline"]["northstar"] = {"error": repr(exc)[:300]}
         result_out.write(json.dumps(line) + "\n")
         result_out.flush()
     if dist is not None:

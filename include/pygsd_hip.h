@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 15
+#define PYGSD_ABI_VERSION 16
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -594,6 +594,15 @@ int pygsd_gemm_f32_workspace(int64_t m, int64_t n, int64_t k, size_t* bytes);
 int pygsd_gemm_f32(const float* a, int64_t sa_m, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_n, const float* bias,
                    float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, int32_t accumulate, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* The same product for bf16 operands (ABI v16): A, B and bias hold bf16, every product is exact in fp32, the sums are fp32
+ * fmaf chains, and the result -- plus an optional fp32 addend Z[m, n] at row stride ldz (NULL: none) -- is stored in fp32
+ * (c_is_f32 != 0) or rounded to bf16 ONCE (c_is_f32 == 0).  The catch-all behind pygsd_tall_linear / pygsd_tall_gram for bf16
+ * widths their MFMA tiles do not take (a 20-, 48- or 320-wide bf16 DiGCNConv: torch.matmul(x, self.weight) of
+ * nn/directed/DiGCNConv.py:66 and its gradients), so that no bf16 product of the path reaches hipBLASLt either.  Several
+ * column segments accumulate through Z in fp32 and are rounded by the last call.  Workspace: pygsd_gemm_f32_workspace. */
+int pygsd_gemm_bf16(const void* a, int64_t sa_m, int64_t sa_k, const void* b, int64_t sb_k, int64_t sb_n, const void* bias,
+                    void* c, int64_t ldc, int32_t c_is_f32, const float* z, int64_t ldz, int64_t m, int64_t n, int64_t k,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* Keeps `stream` busy for `microseconds` (one idle lane polling the constant-rate wall clock).  Measurement
  * only: the single-GPU rehearsal of the sharded propagate (tools/emulate_sharded.py) uses it as the wire time

@@ -144,11 +144,13 @@ PROTOTYPES = {
     "pygsd_gemm_f32_workspace": (c_int32, [c_int64, c_int64, c_int64, ctypes.POINTER(ctypes.c_size_t)]),
     "pygsd_gemm_f32": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                  c_int64, c_int64, c_int32, c_void_p, ctypes.c_size_t, c_void_p]),
+    "pygsd_gemm_bf16": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int32,
+                                  c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, ctypes.c_size_t, c_void_p]),
     "pygsd_prof_enable": (c_int32, [c_int32]),
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class PieceLayoutStruct(ctypes.Structure):
@@ -239,9 +241,54 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed: {msg}")
 
 
+# torch.cuda.current_stream() and `with torch.cuda.device(...)` cost 9 and 8 microseconds of interpreter time each (device-index
+# resolution through is_available / getenv on every call: profiles/r6b_host_profile.txt) -- a third of the host time of a step made
+# of ~15 launches.  The C entry points behind them take a fraction of a microsecond.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
     """Raw hipStream_t of torch's current stream on the current device."""
+    if _raw_stream is not None and _cur_device is not None:
+        return c_void_p(_raw_stream(_cur_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_STREAM_OBJECTS = {}
+
+
+def current_stream():
+    """torch.cuda.current_stream() without its per-call cost: the Stream object of a (device, raw stream) pair is looked up
+    once (torch's streams live in a pool for the life of the process)."""
+    if _raw_stream is None or _cur_device is None:
+        return torch.cuda.current_stream()
+    dev = _cur_device()
+    key = (dev, _raw_stream(dev))
+    s = _STREAM_OBJECTS.get(key)
+    if s is None:
+        s = _STREAM_OBJECTS[key] = torch.cuda.current_stream()
+    return s
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(dev):
+    """`with on_device(t.device):` -- torch.cuda.device(dev), but free when `dev` is the current device already (the
+    one-process-per-GPU case: always)."""
+    idx = getattr(dev, "index", dev)
+    if _cur_device is not None and (idx is None or idx == _cur_device()):
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def ptr(t):
@@ -270,7 +317,7 @@ def check_node_ids(*bounded_lists, what="edge_index"):
         return
     dev = lists[0][1].device
     minmax = torch.tensor([[_I64_MAX, _I64_MIN]] * len(lists), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         for k, (_, t) in enumerate(lists):
             if t.dtype != torch.int64:
                 raise TypeError(f"{what} must be int64 (torch.long), got {t.dtype}")

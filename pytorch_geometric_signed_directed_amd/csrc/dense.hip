@@ -151,7 +151,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
         const int lrow = (r0 + i < p.n_rows) ? r0 + i : p.n_rows - 1;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+            double sa[4] = {0., 0., 0., 0.}, sb[4] = {0., 0., 0., 0.};       // float64 sums, rounded once (csrc/tall.hip)
 #pragma unroll 1
             for (int kk = 0; kk < p.k1; ++kk) {
                 PieceRow pr;
@@ -171,16 +171,25 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
 #pragma unroll 1
                 for (int f = 0; f < f_in; ++f) {
                     const int64_t off = piece_offset(pr, f >> 4, sh, mk) + (f & 15);
-                    const float av = ak[off], bv = bk[off];
+                    const double av = ak[off], bv = bk[off];
                     const float4 w4 = ldg4(wrow + static_cast<int64_t>(f) * p.f_out);
-                    sa[0] = fmaf(av, w4.x, sa[0]); sa[1] = fmaf(av, w4.y, sa[1]);
-                    sa[2] = fmaf(av, w4.z, sa[2]); sa[3] = fmaf(av, w4.w, sa[3]);
-                    sb[0] = fmaf(bv, w4.x, sb[0]); sb[1] = fmaf(bv, w4.y, sb[1]);
-                    sb[2] = fmaf(bv, w4.z, sb[2]); sb[3] = fmaf(bv, w4.w, sb[3]);
+                    const double w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sa[r] = fma(av, w[r], sa[r]);
+                        sb[r] = fma(bv, w[r], sb[r]);
+                    }
                 }
             }
-            ar[nt] = f32x4{sa[0] - sb[0], sa[1] - sb[1], sa[2] - sb[2], sa[3] - sb[3]};
-            ai[nt] = f32x4{sa[0] + sb[0], sa[1] + sb[1], sa[2] + sb[2], sa[3] + sb[3]};
+            // rr and ii rounded to fp32 as the reference holds them, then the difference and the sum in fp32
+            float ra[4], rb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ra[r] = static_cast<float>(sa[r]);
+                rb[r] = static_cast<float>(sb[r]);
+            }
+            ar[nt] = f32x4{ra[0] - rb[0], ra[1] - rb[1], ra[2] - rb[2], ra[3] - rb[3]};
+            ai[nt] = f32x4{ra[0] + rb[0], ra[1] + rb[1], ra[2] + rb[2], ra[3] + rb[3]};
         }
     };
     // (wavefront-uniform, which the compiler cannot see through tid >> 6: without it the term's base pointers p.a[k] are fetched by
@@ -1004,19 +1013,22 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_split_kerne
 #pragma unroll 1
             for (int ft = 0; ft < NTI; ++ft) {
                 const float* wr = p.w + (static_cast<int64_t>(k) * p.f_in + c0 + 16 * ft + 4 * g) * p.f_out;
-                float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+                double sa[4] = {0., 0., 0., 0.}, sb[4] = {0., 0., 0., 0.};   // float64 sums, rounded once (csrc/tall.hip)
 #pragma unroll 1
                 for (int f = 0; f < fo; ++f) {
                     const float x = grow[f], y = girow[f];
-                    const float pp = x + y, mm = y - x;
+                    const double pp = x + y, mm = y - x;                      // P and M in fp32, as autograd forms them
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float w = wr[static_cast<int64_t>(r) * p.f_out + f];
-                        sa[r] = fmaf(pp, w, sa[r]);
-                        sb[r] = fmaf(mm, w, sb[r]);
+                        const double w = wr[static_cast<int64_t>(r) * p.f_out + f];
+                        sa[r] = fma(pp, w, sa[r]);
+                        sb[r] = fma(mm, w, sb[r]);
                     }
                 }
-                rows_out(ft, make_float4(sa[0], sa[1], sa[2], sa[3]), make_float4(sb[0], sb[1], sb[2], sb[3]));
+                rows_out(ft, make_float4(static_cast<float>(sa[0]), static_cast<float>(sa[1]), static_cast<float>(sa[2]),
+                                         static_cast<float>(sa[3])),
+                         make_float4(static_cast<float>(sb[0]), static_cast<float>(sb[1]), static_cast<float>(sb[2]),
+                                     static_cast<float>(sb[3])));
             }
         }
     }
@@ -1109,14 +1121,15 @@ __global__ __launch_bounds__(256) void reduce_dw_checked_kernel(DenseBwdArgs p, 
                 }
             const bool in_pieces = p.in_on && k == p.k1 - 1;
             const int ish = p.in_shift, imk = (1 << ish) - 1;
-            total = 0.f;
+            double sum = 0.;                                  // float64, rounded once: a long fp32 chain is no product
             for (int r = 0; r < p.n_rows; ++r) {
                 int64_t off = static_cast<int64_t>(r) * p.f_in + c;
                 if (in_pieces) off = piece_offset(piece_row(p.lay_in, r), c >> 4, ish, imk) + (c & 15);
                 const float x = p.gr[static_cast<int64_t>(r) * p.ldg + f], y = p.gi[static_cast<int64_t>(r) * p.ldg + f];
-                total = fmaf(ak[off], x + y, total);
-                total = fmaf(bk[off], y - x, total);
+                sum = fma(static_cast<double>(ak[off]), static_cast<double>(x + y), sum);
+                sum = fma(static_cast<double>(bk[off]), static_cast<double>(y - x), sum);
             }
+            total = static_cast<float>(sum);
         }
         out[e] = total;
     }

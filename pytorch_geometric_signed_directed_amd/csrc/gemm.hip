@@ -1,4 +1,5 @@
-// Generic fp32 GEMM  C[M, N] (+)= A[M, K] B[K, N] (+ bias)  for ANY shapes and strides -- the catch-all behind the MFMA
+// Generic GEMM  C[M, N] (+)= A[M, K] B[K, N] (+ bias)  in fp32, or bf16 storage with fp32 accumulation (round 6: the same
+// kernel with 2-byte loads / stores, so that no bf16 width leaves the library either), for ANY shapes and strides -- the catch-all behind the MFMA
 // kernels of csrc/dense.hip / tall.hip / gram.hip, so that no dense product on the path has to leave the library for
 // hipBLASLt / rocBLAS: odd widths (a 10-class head), reductions deeper than the LDS-resident W of tall.hip allows (the
 // 2879-wide first layer of BASELINE config 1: x W and its weight gradient x^T g), transposed views (strides are arguments).
@@ -12,19 +13,43 @@ namespace pygsd {
 namespace {
 
 struct GemmArgs {
-    const float* a;
-    const float* b;
-    const float* bias;
-    float* c;
+    const void* a;           // fp32, or bf16 (BF_IN) -- A, B and bias alike
+    const void* b;
+    const void* bias;
+    void* c;                 // fp32, or bf16 (BF_OUT)
+    const float* z;          // fp32 addend [M][N] at row stride ldz, or null (accumulate onto an fp32 C: z = c)
     float* partial;          // [splits][M][N] when splits > 1
-    int64_t sa_m, sa_k, sb_k, sb_n, ldc;
+    int64_t sa_m, sa_k, sb_k, sb_n, ldc, ldz;
     int64_t m, n, k, k_per_split;
-    int32_t splits, accumulate;
+    int32_t splits;
 };
 
 constexpr int kTile = 64, kStep = 16;
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p)
+template <bool BF>
+__device__ __forceinline__ float load_el(const void* base, int64_t at)
+{
+    if constexpr (BF) return __uint_as_float(static_cast<uint32_t>(static_cast<const uint16_t*>(base)[at]) << 16);
+    else return static_cast<const float*>(base)[at];
+}
+
+// one rounding to nearest even of the fp32 sum (NaN stays NaN)
+__device__ __forceinline__ uint16_t to_bf16(float v)
+{
+    const uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);
+    return static_cast<uint16_t>((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <bool BF>
+__device__ __forceinline__ void store_el(void* base, int64_t at, float v)
+{
+    if constexpr (BF) static_cast<uint16_t*>(base)[at] = to_bf16(v);
+    else static_cast<float*>(base)[at] = v;
+}
+
+template <bool BF_IN, bool BF_OUT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p)
 {
     __shared__ __attribute__((aligned(16))) float as[kStep][kTile + 4];
     __shared__ __attribute__((aligned(16))) float bs[kStep][kTile + 4];
@@ -46,11 +71,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p)
             int mi, ki;
             if (a_along_k) { mi = t >> 2; ki = (t & 3) * 4 + e; } else { ki = t >> 4; mi = (t & 15) * 4 + e; }
             const int64_t gm = m0 + mi, gk = k0 + ki;
-            as[ki][mi] = (gm < p.m && gk < k_hi) ? p.a[gm * p.sa_m + gk * p.sa_k] : 0.f;
+            as[ki][mi] = (gm < p.m && gk < k_hi) ? load_el<BF_IN>(p.a, gm * p.sa_m + gk * p.sa_k) : 0.f;
             int ni, kj;
             if (b_along_n) { kj = t >> 4; ni = (t & 15) * 4 + e; } else { ni = t >> 2; kj = (t & 3) * 4 + e; }
             const int64_t gn = n0 + ni, gk2 = k0 + kj;
-            bs[kj][ni] = (gn < p.n && gk2 < k_hi) ? p.b[gk2 * p.sb_k + gn * p.sb_n] : 0.f;
+            bs[kj][ni] = (gn < p.n && gk2 < k_hi) ? load_el<BF_IN>(p.b, gk2 * p.sb_k + gn * p.sb_n) : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -76,15 +101,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p)
             if (p.splits > 1) {
                 p.partial[(static_cast<int64_t>(blockIdx.z) * p.m + gm) * p.n + gn] = acc[i][j];
             } else {
-                float v = acc[i][j] + (p.bias ? p.bias[gn] : 0.f);
-                if (p.accumulate) v += p.c[gm * p.ldc + gn];
-                p.c[gm * p.ldc + gn] = v;
+                float v = acc[i][j] + (p.bias ? load_el<BF_IN>(p.bias, gn) : 0.f);
+                if (p.z) v += p.z[gm * p.ldz + gn];
+                store_el<BF_OUT>(p.c, gm * p.ldc + gn, v);
             }
         }
     }
 }
 
-// C = (accumulate ? C : 0) + bias + sum_s partial[s], s in order
+// C = (z ? Z : 0) + bias + sum_s partial[s], s in order
+template <bool BF_IN, bool BF_OUT>
 __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmArgs p)
 {
     const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -92,9 +118,9 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmArgs p)
     const int64_t gm = e / p.n, gn = e - gm * p.n;
     float v = 0.f;
     for (int s = 0; s < p.splits; ++s) v += p.partial[static_cast<int64_t>(s) * p.m * p.n + e];
-    if (p.bias) v += p.bias[gn];
-    if (p.accumulate) v += p.c[gm * p.ldc + gn];
-    p.c[gm * p.ldc + gn] = v;
+    if (p.bias) v += load_el<BF_IN>(p.bias, gn);
+    if (p.z) v += p.z[gm * p.ldz + gn];
+    store_el<BF_OUT>(p.c, gm * p.ldc + gn, v);
 }
 
 int pick_splits(int64_t m, int64_t n, int64_t k)
@@ -120,6 +146,27 @@ extern "C" int pygsd_gemm_f32_workspace(int64_t m, int64_t n, int64_t k, size_t*
     return 0;
 }
 
+namespace {
+template <bool BF_IN, bool BF_OUT>
+int launch_gemm(GemmArgs& g, hipStream_t s)
+{
+    const int64_t steps = (g.k + kStep - 1) / kStep;
+    g.k_per_split = ((steps + g.splits - 1) / g.splits) * kStep;
+    if (g.k_per_split == 0) g.k_per_split = kStep;
+    ProfScope prof(PYGSD_K_DENSE, s);
+    const dim3 grid(static_cast<unsigned>((g.m + kTile - 1) / kTile), static_cast<unsigned>((g.n + kTile - 1) / kTile),
+                    static_cast<unsigned>(g.splits));
+    hipLaunchKernelGGL((gemm_kernel<BF_IN, BF_OUT>), grid, dim3(256), 0, s, g);
+    if (int rc = check_launch("gemm_kernel")) return rc;
+    if (g.splits > 1) {
+        hipLaunchKernelGGL((gemm_finish_kernel<BF_IN, BF_OUT>), dim3(static_cast<unsigned>((g.m * g.n + 255) / 256)), dim3(256), 0,
+                           s, g);
+        return check_launch("gemm_finish_kernel");
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" int pygsd_gemm_f32(const float* a, int64_t sa_m, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_n,
                               const float* bias, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, int32_t accumulate,
                               void* workspace, size_t workspace_bytes, void* stream)
@@ -133,19 +180,26 @@ extern "C" int pygsd_gemm_f32(const float* a, int64_t sa_m, int64_t sa_k, const 
     const size_t need = splits > 1 ? static_cast<size_t>(splits) * m * n * sizeof(float) : 0;
     PYGSD_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "pygsd_gemm_f32: workspace too small "
                   "(pygsd_gemm_f32_workspace)");
-    GemmArgs g{a, b, bias, c, static_cast<float*>(workspace), sa_m, sa_k, sb_k, sb_n, ldc, m, n, k, 0, splits, accumulate};
-    const int64_t steps = (k + kStep - 1) / kStep;
-    g.k_per_split = ((steps + splits - 1) / splits) * kStep;
-    if (g.k_per_split == 0) g.k_per_split = kStep;
+    GemmArgs g{a, b, bias, c, accumulate ? c : nullptr, static_cast<float*>(workspace), sa_m, sa_k, sb_k, sb_n, ldc, ldc,
+               m, n, k, 0, splits};
+    return launch_gemm<false, false>(g, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pygsd_gemm_bf16(const void* a, int64_t sa_m, int64_t sa_k, const void* b, int64_t sb_k, int64_t sb_n,
+                               const void* bias, void* c, int64_t ldc, int32_t c_is_f32, const float* z, int64_t ldz, int64_t m,
+                               int64_t n, int64_t k, void* workspace, size_t workspace_bytes, void* stream)
+{
+    PYGSD_REQUIRE(m >= 0 && n >= 0 && k >= 0, "pygsd_gemm_bf16: negative size");
+    if (m == 0 || n == 0) return 0;
+    PYGSD_REQUIRE(c && ldc >= n, "pygsd_gemm_bf16: null output or ldc < n");
+    PYGSD_REQUIRE(k == 0 || (a && b), "pygsd_gemm_bf16: null operand");
+    PYGSD_REQUIRE(!z || ldz >= n, "pygsd_gemm_bf16: addend row stride < n");
+    PYGSD_REQUIRE((m + kTile - 1) / kTile < (1ll << 31) && (n + kTile - 1) / kTile < 65536, "pygsd_gemm_bf16: output too large");
+    const int splits = pick_splits(m, n, k);
+    const size_t need = splits > 1 ? static_cast<size_t>(splits) * m * n * sizeof(float) : 0;
+    PYGSD_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "pygsd_gemm_bf16: workspace too small "
+                  "(pygsd_gemm_f32_workspace)");
+    GemmArgs g{a, b, bias, c, z, static_cast<float*>(workspace), sa_m, sa_k, sb_k, sb_n, ldc, ldz, m, n, k, 0, splits};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    ProfScope prof(PYGSD_K_DENSE, s);
-    const dim3 grid(static_cast<unsigned>((m + kTile - 1) / kTile), static_cast<unsigned>((n + kTile - 1) / kTile),
-                    static_cast<unsigned>(splits));
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, g);
-    if (int rc = check_launch("gemm_f32_kernel")) return rc;
-    if (splits > 1) {
-        hipLaunchKernelGGL(gemm_finish_kernel, dim3(static_cast<unsigned>((m * n + 255) / 256)), dim3(256), 0, s, g);
-        return check_launch("gemm_finish_kernel");
-    }
-    return 0;
+    return c_is_f32 ? launch_gemm<true, false>(g, s) : launch_gemm<true, true>(g, s);
 }

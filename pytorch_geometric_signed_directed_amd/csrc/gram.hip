@@ -30,11 +30,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kMaxChunks = 16;
 
+// A chunk is up to three PARTS of equal width (round 6): column segments that are neighbours in dW but separate matrices in
+// memory -- [g | g_a] of SGCNConv, [dx0 | dP_1 | dP_2] of the inception block -- ride in ONE chunk, so that the other operand's
+// rows are read once for all of them instead of once per segment (measured before: 1.38x / 1.27x the algorithmic bytes at C3a /
+// C5b, profiles/r5v_configs.json).
 struct GramChunk {
-    const void* p;     // first element of the chunk in row 0
+    const void* p;     // first element of the chunk (of its first part) in row 0
     int64_t ld;        // row stride in elements
-    int32_t tiles;     // 16-column tiles: 1, 2, 4 (X and G) or 8 (G)
+    int32_t tiles;     // 16-column tiles: 1, 2, 4 (X and G), 8 or 12 (G)
     int32_t at;        // first row (X chunks) / column (G chunks) of this chunk in dW
+    const void* p1;    // parts 1 and 2 (part_tiles < tiles): the same, for columns [part_tiles * 16, ...) and [2 part_tiles * 16, ...)
+    const void* p2;
+    int64_t ld1, ld2;
+    int32_t part_tiles;   // tiles per part; == tiles for a chunk of one part
 };
 
 struct GramArgs {
@@ -58,13 +66,21 @@ template <int NT>
 __device__ __forceinline__ void load_rows_f32(const GramChunk& c, int64_t r0, int64_t n_rows, int lane, float4 (&v)[NT])
 {
     constexpr int LPR = NT * 4;            // 16-byte pieces (lanes) per row
-    const float* base = static_cast<const float*>(c.p);
+    const int part_cols = c.part_tiles * 16;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int piece = t * 64 + lane;                      // piece-major over the 16 x LPR pieces of the tile
-        const int row = piece / LPR, col = (piece % LPR) * 4;
+        const int row = piece / LPR;
+        int col = (piece % LPR) * 4;
+        const float* base = static_cast<const float*>(c.p);
+        int64_t ld = c.ld;
+        if (col >= part_cols) {                               // (only chunks of several parts: NT == 8)
+            col -= part_cols;
+            base = static_cast<const float*>(c.p1);
+            ld = c.ld1;
+        }
         v[t] = make_float4(0.f, 0.f, 0.f, 0.f);               // rows past the end contribute nothing
-        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const float4*>(base + (r0 + row) * c.ld + col);
+        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const float4*>(base + (r0 + row) * ld + col);
     }
 }
 
@@ -172,13 +188,25 @@ template <int NT>
 __device__ __forceinline__ void load_rows_bf16(const GramChunk& c, int64_t r0, int64_t n_rows, int lane, uint4 (&v)[NT])
 {
     constexpr int LPR = NT * 2;            // 16-byte pieces (lanes) per row
-    const uint16_t* base = static_cast<const uint16_t*>(c.p);
+    const int part_p8 = c.part_tiles * 2;  // 8-column pieces per part
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int piece = t * 64 + lane;                      // piece-major over the 32 x LPR pieces of the tile
         const int row = piece / LPR, c8 = piece % LPR;        // 8-column piece c8 of the row
+        const uint16_t* base = static_cast<const uint16_t*>(c.p);
+        int64_t ld = c.ld;
+        int local = c8;
+        if (c8 >= 2 * part_p8) {                              // (only chunks of several parts: NT == 8 / 12)
+            local = c8 - 2 * part_p8;
+            base = static_cast<const uint16_t*>(c.p2);
+            ld = c.ld2;
+        } else if (c8 >= part_p8) {
+            local = c8 - part_p8;
+            base = static_cast<const uint16_t*>(c.p1);
+            ld = c.ld1;
+        }
         v[t] = make_uint4(0u, 0u, 0u, 0u);
-        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const uint4*>(base + (r0 + row) * c.ld + c8 * 8);
+        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const uint4*>(base + (r0 + row) * ld + local * 8);
     }
 }
 
@@ -287,9 +315,15 @@ __device__ __forceinline__ void gram_block_bf16(const GramArgs& p, const GramChu
     }
 }
 
-template <int NTK>
+template <int NTK, bool WIDE>
 __device__ __forceinline__ void gram_pick_bf16(const GramArgs& p, const GramChunk& cx, const GramChunk& cg, unsigned char* lds)
 {
+    if constexpr (WIDE) {
+        if (cg.tiles == 12) {
+            gram_block_bf16<NTK, 12>(p, cx, cg, lds);
+            return;
+        }
+    }
     if (cg.tiles == 8) gram_block_bf16<NTK, 8>(p, cx, cg, lds);
     else if (cg.tiles == 4) gram_block_bf16<NTK, 4>(p, cx, cg, lds);
     else if (cg.tiles == 2) gram_block_bf16<NTK, 2>(p, cx, cg, lds);
@@ -300,9 +334,20 @@ __global__ __launch_bounds__(256, 2) void tall_gram_bf16_kernel(GramArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_b16[];
     const GramChunk cx = p.x[blockIdx.x / p.n_g], cg = p.g[blockIdx.x % p.n_g];
-    if (cx.tiles == 4) gram_pick_bf16<4>(p, cx, cg, lds_b16);
-    else if (cx.tiles == 2) gram_pick_bf16<2>(p, cx, cg, lds_b16);
-    else gram_pick_bf16<1>(p, cx, cg, lds_b16);
+    if (cx.tiles == 4) gram_pick_bf16<4, false>(p, cx, cg, lds_b16);
+    else if (cx.tiles == 2) gram_pick_bf16<2, false>(p, cx, cg, lds_b16);
+    else gram_pick_bf16<1, false>(p, cx, cg, lds_b16);
+}
+
+// the same with G chunks of 12 tiles (three 64-column parts: the inception block's [dx0 | dP_1 | dP_2]): 192 accumulator registers
+// against 64 columns of X -- one wavefront per SIMD, every operand row read ONCE
+__global__ __launch_bounds__(256, 1) void tall_gram_bf16_wide_kernel(GramArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_b16w[];
+    const GramChunk cx = p.x[blockIdx.x / p.n_g], cg = p.g[blockIdx.x % p.n_g];
+    if (cx.tiles == 4) gram_pick_bf16<4, true>(p, cx, cg, lds_b16w);
+    else if (cx.tiles == 2) gram_pick_bf16<2, true>(p, cx, cg, lds_b16w);
+    else gram_pick_bf16<1, true>(p, cx, cg, lds_b16w);
 }
 
 // ---- fp32, round 5: no transposition at all ------------------------------------------------------------------------------
@@ -543,8 +588,8 @@ struct Blocks32 {
 // hi = x and x - hi = NaN, a magnitude above 3.39e38 rounds its hi to inf, and inf times a zero PIECE of a nonzero value is NaN
 // where the fp32 product is +-inf (csrc/tall.hip) -- and a NaN piece makes every sum it enters NaN.  So a sum that came out
 // finite had operands the split carries exactly, and one that did not is computed again here as the reference's fp32 product
-// is: an fmaf chain over the rows in order on the fp32 operands, IEEE products and sums, so that inf, -inf and NaN stand where
-// torch.mm puts them.  One compare per output element when nothing is wrong; the chain is as slow as it looks and runs for the
+// is: an fma chain over the rows in order on the fp32 operands (summed in float64, rounded once), IEEE products and sums, so
+// that inf, -inf and NaN stand where torch.mm puts them.  One compare per output element when nothing is wrong; the chain is as slow as it looks and runs for the
 // elements that need it only.
 template <bool RECHECK>
 __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ partial, int n_partials, int64_t n_elem,
@@ -570,8 +615,9 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
                 const float* xc = bx.p[k >> 5] + (k & 31);
                 const float* gc = bg.p[f >> 5] + (f & 31);
                 const int64_t sx = bx.ld[k >> 5], sg = bg.ld[f >> 5];
-                total = 0.f;
-                for (int64_t r = 0; r < n_rows; ++r) total = fmaf(xc[r * sx], gc[r * sg], total);
+                double sum = 0.;                              // float64, rounded once: a million-term fp32 chain is no product
+                for (int64_t r = 0; r < n_rows; ++r) sum = fma(static_cast<double>(xc[r * sx]), static_cast<double>(gc[r * sg]), sum);
+                total = static_cast<float>(sum);
             }
         }
         out[e] = total;
@@ -596,10 +642,46 @@ int cut_chunks(const void* base, int64_t ld, int width, size_t esz, int at, int 
         const int left = (width - col) / 16;
         const int tiles = (left >= 8 && cap >= 8) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
         if (have >= kMaxChunks) return -1;
-        out[have++] = GramChunk{static_cast<const unsigned char*>(base) + static_cast<size_t>(col) * esz, ld, tiles, at + col};
+        out[have++] = GramChunk{static_cast<const unsigned char*>(base) + static_cast<size_t>(col) * esz, ld, tiles, at + col,
+                                nullptr, nullptr, 0, 0, tiles};
         col += tiles * 16;
     }
     return have;
+}
+
+// G chunks that are whole segments of one width and neighbours in dW become PARTS of one chunk: two (fp32: <= 8 tiles) or up to
+// three (bf16: <= 12 tiles).  `whole[c]` != 0: chunk c is all of its segment.  Returns the new chunk count.
+int join_parts(GramChunk* g, const int* whole, int n, int max_tiles)
+{
+    int out = 0;
+    for (int c = 0; c < n;) {
+        GramChunk cur = g[c];
+        int parts = 1;
+        const int t = cur.tiles;
+        if (whole[c] && (t == 1 || t == 2 || t == 4)) {
+            while (c + parts < n && parts < 3 && whole[c + parts] && g[c + parts].tiles == t &&
+                   g[c + parts].at == cur.at + parts * t * 16) {
+                const int joined = (parts + 1) * t;
+                if (joined > max_tiles || !(joined == 2 || joined == 4 || joined == 8 || joined == 12)) break;
+                ++parts;
+            }
+            // three parts only as 3 x 4 tiles; (3 x 1, 3 x 2 have no instance: the loop above stops at 2 there, via `joined`)
+            if (parts == 3 && t != 4) parts = 2;
+        }
+        if (parts >= 2) {
+            cur.p1 = g[c + 1].p;
+            cur.ld1 = g[c + 1].ld;
+        }
+        if (parts == 3) {
+            cur.p2 = g[c + 2].p;
+            cur.ld2 = g[c + 2].ld;
+        }
+        cur.part_tiles = t;
+        cur.tiles = parts * t;
+        g[out++] = cur;
+        c += parts;
+    }
+    return out;
 }
 }  // namespace
 }  // namespace pygsd
@@ -628,6 +710,7 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
     const size_t esz = dtype == 1 ? 2 : 4;
     const int vec = dtype == 1 ? 8 : 4;
     GramArgs a{};
+    int g_whole[kMaxChunks] = {};
     int nx = 0, ng = 0, k_total = 0, f_total = 0;
     for (int s = 0; s < n_x; ++s) {
         PYGSD_REQUIRE(x_widths[s] > 0 && x_widths[s] % 16 == 0, "pygsd_tall_gram: X segment %d is %d columns wide (multiples "
@@ -645,10 +728,13 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
         PYGSD_REQUIRE(n_rows == 0 || (gs[s] && aligned16(gs[s]) && ldg[s] >= g_widths[s] && ldg[s] % vec == 0),
                       "pygsd_tall_gram: G segment %d null, not 16-byte aligned, or row stride not a multiple of 16 bytes >= its "
                       "width", s);
+        const int before = ng;
         ng = cut_chunks(gs[s], ldg[s], g_widths[s], esz, f_total, 8, a.g, ng);
         PYGSD_REQUIRE(ng > 0, "pygsd_tall_gram: more than %d column chunks in G", kMaxChunks);
+        for (int c = before; c < ng; ++c) g_whole[c] = (ng - before == 1) ? 1 : 0;
         f_total += g_widths[s];
     }
+    ng = join_parts(a.g, g_whole, ng, dtype == 1 ? 12 : 8);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n_elem = static_cast<int64_t>(k_total) * f_total;
     if (n_rows == 0) {
@@ -747,10 +833,17 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
     if (dtype == 1) {
         size_t lds = static_cast<size_t>(4) * (tk + tf) * 1024;                        // 4 wavefronts x [tile][32][16] bf16
         if (lds < combine) lds = combine;
-        if (lds > 64 * 1024)
-            PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram_bf16_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        hipLaunchKernelGGL(tall_gram_bf16_kernel, grid, dim3(256), lds, s, a);
+        if (tf == 12) {                       // a three-part chunk: the one-wavefront-per-SIMD instance holds its 192 accumulators
+            if (lds > 64 * 1024)
+                PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram_bf16_wide_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            hipLaunchKernelGGL(tall_gram_bf16_wide_kernel, grid, dim3(256), lds, s, a);
+        } else {
+            if (lds > 64 * 1024)
+                PYGSD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tall_gram_bf16_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            hipLaunchKernelGGL(tall_gram_bf16_kernel, grid, dim3(256), lds, s, a);
+        }
     } else {
         size_t lds = static_cast<size_t>(4) * 16 * ((tk * 16 + 4) + (tf * 16 + 4)) * sizeof(float);   // 4 x [16][cols + 4]
         if (lds < combine) lds = combine;

@@ -328,9 +328,12 @@ __device__ __forceinline__ bool any_not_finite(const f32x4 (&acc)[NT])
     return __builtin_amdgcn_ballot_w64(c != c) != 0;           // wavefront-uniform
 }
 
-// The tile again, exactly, and stored: lane (j, q) owns columns 16 t + 4 q .. + 3 of row j, as in the split form, and walks
-// them as plain fmaf chains over k in order -- rolled loops, four sums and a few addresses live, so that the branch costs the
-// kernel no registers (an MFMA form with its NT accumulators and loads in flight took a wavefront per SIMD from most instances).
+// The tile again, from the fp32 operands, and stored: lane (j, q) owns columns 16 t + 4 q .. + 3 of row j, as in the split form,
+// and walks them as fma chains over k in order -- rolled loops, four sums and a few addresses live, so that the branch costs
+// the kernel no registers (an MFMA form with its NT accumulators and loads in flight took a wavefront per SIMD from most
+// instances).  The sums are kept in float64 and rounded once (a sequential fp32 chain of a few hundred terms sits at the 1e-5
+// bar by itself; time is no object here): IEEE products and sums either way -- inf x 0 = NaN, inf - inf = NaN, a sum beyond
+// FLT_MAX rounds to inf.
 template <int KB, int NT>
 __device__ __forceinline__ void exact_tile_store(const TallArgs& p, const float* bias, int tile, int j, int q)
 {
@@ -341,24 +344,25 @@ __device__ __forceinline__ void exact_tile_store(const TallArgs& p, const float*
 #pragma unroll 1
     for (int t = 0; t < NT; ++t) {
         const float* wc = w + (16 * t + 4 * q) * ws_n;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll 1
         for (int kb = 0; kb < KB; ++kb) {
             const float* xr = static_cast<const float*>(p.x[kb]) + row * p.ld[kb];
             const float* wk = wc + static_cast<int64_t>(kb) * 32 * ws_k;
 #pragma unroll 1
             for (int e = 0; e < 32; ++e) {
-                const float xv = xr[e];
-                s0 = fmaf(xv, wk[0], s0);
-                s1 = fmaf(xv, wk[ws_n], s1);
-                s2 = fmaf(xv, wk[2 * ws_n], s2);
-                s3 = fmaf(xv, wk[3 * ws_n], s3);
+                const double xv = xr[e];
+                s0 = fma(xv, static_cast<double>(wk[0]), s0);
+                s1 = fma(xv, static_cast<double>(wk[ws_n]), s1);
+                s2 = fma(xv, static_cast<double>(wk[2 * ws_n]), s2);
+                s3 = fma(xv, static_cast<double>(wk[3 * ws_n]), s3);
                 wk += ws_k;
             }
         }
         const float* b = bias + 16 * t + 4 * q;
         *reinterpret_cast<float4*>(static_cast<float*>(p.y[t]) + row * p.ldy[t] + 4 * q) =
-            make_float4(s0 + b[0], s1 + b[1], s2 + b[2], s3 + b[3]);
+            make_float4(static_cast<float>(s0 + b[0]), static_cast<float>(s1 + b[1]), static_cast<float>(s2 + b[2]),
+                        static_cast<float>(s3 + b[3]));
     }
 }
 

@@ -56,7 +56,7 @@ def dense_fwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, bias: Option
     out_r = torch.empty((n, f_out), dtype=torch.float32, device=w.device)
     out_i = torch.empty_like(out_r)
     bias_c = None if bias is None else bias.detach().contiguous()
-    with torch.cuda.device(w.device):
+    with _cabi.on_device(w.device):
         if last_in is None:
             check(_cabi.lib().pygsd_magnetic_dense_fwd_f32(_ptr_array(a), _ptr_array(b), k1, ptr(w), ptr(bias_c),
                                                            ptr(out_r), ptr(out_i), n, f_in, f_out, stream_ptr()),
@@ -84,7 +84,7 @@ def gather_pieces(src: PieceOperand, n_rows: int, width: int, z: Optional[Sequen
     step = 4 * (src.off_b - src.off_a)
     first = src.buffer.data_ptr() + 4 * src.off_a
     lay = src.layout.struct()
-    with torch.cuda.device(dev):
+    with _cabi.on_device(dev):
         check(_cabi.lib().pygsd_gather_pieces_f32((c_void_p * groups)(*[first + g * step for g in range(groups)]), ctypes.byref(lay),
                                                   zs, width, _ptr_array(outs), width, groups, n_rows, width, stream_ptr()),
               "pygsd_gather_pieces_f32")
@@ -128,7 +128,7 @@ def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor,
     dw = torch.empty((k1, f_in, f_out), dtype=torch.float32, device=dev)
     dbias = torch.empty(f_out, dtype=torch.float32, device=dev)
     lib = _cabi.lib()
-    with torch.cuda.device(dev):
+    with _cabi.on_device(dev):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_magnetic_dense_bwd_workspace(n, f_in, f_out, k1, ctypes.byref(need)),
               "pygsd_magnetic_dense_bwd_workspace")
@@ -197,7 +197,7 @@ def spmm2_k1_dense_raw(csr, va: Tensor, vb: Tensor, x_real: Tensor, x_imag: Tens
     bd = None if bias is None else bias.detach().contiguous()
     ta, tb = torch.empty_like(xa), torch.empty_like(xb)
     out_r, out_i = torch.empty((n, 64), dtype=torch.float32, device=xa.device), torch.empty((n, 64), dtype=torch.float32, device=xa.device)
-    with torch.cuda.device(xa.device):
+    with _cabi.on_device(xa.device):
         check(_cabi.lib().pygsd_spmm2_k1_dense_f32(ptr(csr.rowptr), ptr(csr.col), ptr(va), ptr(vb), ptr(xa), ptr(xb), 64, ptr(ta),
                                                    ptr(tb), 64, ptr(w), ptr(bd), ptr(out_r), ptr(out_i), 64, n, csr.nnz,
                                                    stream_ptr()), "pygsd_spmm2_k1_dense_f32")
@@ -332,7 +332,7 @@ def tall_product(segments: Sequence[Tensor], w: Tensor, transposed: bool = False
     ys = (c_void_p * m)(*[t.data_ptr() for t in outs])
     ldy = (ctypes.c_int64 * m)(*[t.stride(0) for t in outs])
     owid = (ctypes.c_int32 * m)(*[t.size(1) for t in outs])
-    with torch.cuda.device(x0.device):
+    with _cabi.on_device(x0.device):
         check(_cabi.lib().pygsd_tall_linear(xs, lds, wid, k, ptr(wd), wd.stride(0), 1 if transposed else 0, ptr(bd), ys, ldy,
                                             owid, m, n, code, stream_ptr()), "pygsd_tall_linear")
     return outs[0] if splits is None else outs
@@ -350,6 +350,9 @@ def column_sums(x: Tensor) -> Tensor:
             # split reduction adds the row ranges in a fixed order (the row of ones is a stride-0 view, never materialised)
             ones = torch.ones(1, dtype=torch.float32, device=x.device).expand(1, x.size(0))
             return gemm(ones, x).view(-1)
+        if _TALL_KERNELS and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and x.size(0) > 0 and x.size(1) > 0:
+            ones = torch.ones(1, dtype=torch.bfloat16, device=x.device).expand(1, x.size(0))      # (the same, bf16 storage)
+            return gemm_bf16(ones, x, out_dtype=torch.float32).view(-1).to(x.dtype)
         if x.is_cuda and x.dim() == 2 and x.size(0) >= 4096:          # a tall reduction outside the kernels' shapes
             _cabi.note_library_route("column_sums", f"{tuple(x.shape)} {x.dtype}")
         return x.sum(0)
@@ -359,7 +362,7 @@ def column_sums(x: Tensor) -> Tensor:
     n, f = xd.shape
     out = torch.empty(f, dtype=torch.float32, device=x.device)
     lib = _cabi.lib()
-    with torch.cuda.device(x.device):
+    with _cabi.on_device(x.device):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_column_sums_workspace(n, f, code, ctypes.byref(need)), "pygsd_column_sums_workspace")
         ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
@@ -412,15 +415,24 @@ class _TallLinear(torch.autograd.Function):
 
 
 def _gemm_fallback(segments, w, transposed, bias, k_total, f_out):
-    """[X_0 | X_1 | ...] W (+ bias) for shapes pygsd_tall_linear does not tile: the generic HIP GEMM (fp32, any shape),
-    else -- counted and announced (_cabi.note_library_route) -- library GEMMs."""
+    """[X_0 | X_1 | ...] W (+ bias) for shapes pygsd_tall_linear does not tile: the generic HIP GEMM (fp32 or bf16 storage,
+    any shape), else -- counted and announced (_cabi.note_library_route) -- library GEMMs."""
     x0 = segments[0]
-    if _TALL_KERNELS and x0.is_cuda and x0.dtype == torch.float32 and w.dtype == torch.float32 \
-            and all(t.dim() == 2 and t.dtype == torch.float32 for t in segments) and (bias is None or bias.dtype == torch.float32):
+    dt = x0.dtype
+    if _TALL_KERNELS and x0.is_cuda and dt in (torch.float32, torch.bfloat16) and w.dtype == dt \
+            and all(t.dim() == 2 and t.dtype == dt for t in segments) and (bias is None or bias.dtype == dt):
         y, at = None, 0
-        for t in segments:
+        if dt == torch.float32:
+            for t in segments:
+                blk = w[:, at:at + t.size(1)].t() if transposed else w[at:at + t.size(1)]
+                y = gemm(t, blk, bias=bias if y is None else None, out=y, accumulate=y is not None)
+                at += t.size(1)
+            return y
+        # bf16: the segments accumulate in an fp32 buffer; the last product adds it, the bias, and rounds to bf16 once
+        for i, t in enumerate(segments):
             blk = w[:, at:at + t.size(1)].t() if transposed else w[at:at + t.size(1)]
-            y = gemm(t, blk, bias=bias if y is None else None, out=y, accumulate=y is not None)
+            last = i == len(segments) - 1
+            y = gemm_bf16(t, blk, bias=bias if last else None, addend=y, out_dtype=dt if last else torch.float32)
             at += t.size(1)
         return y
     if x0.is_cuda:                    # (CPU tensors only reach this through the gloo restatements of the sharded tests)
@@ -436,6 +448,31 @@ def _gemm_fallback(segments, w, transposed, bias, k_total, f_out):
     return y
 
 
+def gemm_bf16(a: Tensor, b: Tensor, bias: Optional[Tensor] = None, addend: Optional[Tensor] = None,
+              out_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+    """a [M, K] @ b [K, N] (+ bias [N]) (+ addend [M, N] fp32) for bf16 operands of ANY shapes and strides (pygsd_gemm_bf16):
+    exact products, fp32 fmaf chains, the result in fp32 or rounded to bf16 once."""
+    m, k = a.shape
+    n = b.size(1)
+    a, b = a.detach(), b.detach()
+    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    if m == 0 or n == 0:
+        return out
+    z = None if addend is None else addend.detach()
+    if z is not None and (z.dtype != torch.float32 or z.stride(1) != 1):
+        z = z.float().contiguous()
+    lib = _cabi.lib()
+    with _cabi.on_device(a.device):
+        need = ctypes.c_size_t(0)
+        check(lib.pygsd_gemm_f32_workspace(m, n, k, ctypes.byref(need)), "pygsd_gemm_f32_workspace")
+        ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=a.device)
+        check(lib.pygsd_gemm_bf16(ptr(a), a.stride(0), a.stride(1), ptr(b), b.stride(0), b.stride(1),
+                                  ptr(None if bias is None else bias.detach().contiguous()), ptr(out), out.stride(0),
+                                  1 if out_dtype == torch.float32 else 0, ptr(z), 0 if z is None else z.stride(0), m, n, k,
+                                  ptr(ws), need.value, stream_ptr()), "pygsd_gemm_bf16")
+    return out
+
+
 def gemm(a: Tensor, b: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     """a [M, K] @ b [K, N] (+ bias [N]) in exact fp32 (fmaf chains) for ANY shapes and strides (views, transposes):
     pygsd_gemm_f32, the generic tiled kernel behind the shapes the MFMA kernels do not take (odd widths, K > 256, the
@@ -449,7 +486,7 @@ def gemm(a: Tensor, b: Tensor, bias: Optional[Tensor] = None, out: Optional[Tens
     if m == 0 or n == 0:
         return out
     lib = _cabi.lib()
-    with torch.cuda.device(a.device):
+    with _cabi.on_device(a.device):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_gemm_f32_workspace(m, n, k, ctypes.byref(need)), "pygsd_gemm_f32_workspace")
         ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=a.device)
@@ -465,14 +502,15 @@ class _Matmul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         ctx.save_for_backward(a, b)
-        return gemm(a, b)
+        return gemm(a, b) if a.dtype == torch.float32 else gemm_bf16(a, b)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        ga = gemm(g, b.t()) if ctx.needs_input_grad[0] else None
-        gb = gemm(a.t(), g) if ctx.needs_input_grad[1] else None
+        mm = gemm if a.dtype == torch.float32 else gemm_bf16
+        ga = mm(g, b.t()) if ctx.needs_input_grad[0] else None
+        gb = mm(a.t(), g) if ctx.needs_input_grad[1] else None
         return ga, gb
 
 
@@ -480,7 +518,8 @@ def matmul(a: Tensor, b: Tensor) -> Tensor:
     """a [M, K] @ b [K, N] for fp32 device matrices of any shape / stride through pygsd_gemm_f32 (differentiable): the
     small or odd-shaped products around the path -- cluster flows P^T (A P), volumes, 1..6-column read-outs -- that the
     libraries run at ~100 GB/s (rocBLAS gemv on a 5 * 10^5 x 32 operand: 4.5 ms).  Other inputs: torch.matmul, counted."""
-    if (_TALL_KERNELS and a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and b.dtype == torch.float32):
+    if (_TALL_KERNELS and a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
+            and a.dtype in (torch.float32, torch.bfloat16)):
         return _Matmul.apply(a, b)
     if a.is_cuda and max(a.size(-2), a.size(-1)) >= 4096:
         _cabi.note_library_route("matmul", f"{tuple(a.shape)} @ {tuple(b.shape)} {a.dtype}")
@@ -515,7 +554,7 @@ def tall_gram(xs, gs) -> Tensor:
         out = torch.empty((k_total, f_total), dtype=torch.float32, device=x0.device)
         arr = lambda ts, fn, ct: (ct * len(ts))(*[fn(t) for t in ts])  # noqa: E731
         lib = _cabi.lib()
-        with torch.cuda.device(x0.device):
+        with _cabi.on_device(x0.device):
             need = ctypes.c_size_t(0)
             check(lib.pygsd_tall_gram_workspace(n, k_total, f_total, code, ctypes.byref(need)), "pygsd_tall_gram_workspace")
             ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=x0.device)
@@ -529,6 +568,8 @@ def tall_gram(xs, gs) -> Tensor:
     g = gs[0] if len(gs) == 1 else torch.cat(gs, dim=1)
     if _TALL_KERNELS and x.is_cuda and dtype == torch.float32 and g.dtype == torch.float32:
         return gemm(x.t(), g)                       # generic HIP GEMM, reduction over the rows split over the blocks
+    if _TALL_KERNELS and x.is_cuda and dtype == torch.bfloat16 and g.dtype == torch.bfloat16:
+        return gemm_bf16(x.t(), g, out_dtype=torch.float32).to(dtype)      # (fp32 sums, rounded once -- as the fused path)
     if x.is_cuda:
         _cabi.note_library_route("tall_gram", f"{tuple(x.shape)}^T {tuple(g.shape)} {dtype}")
     slab = _TallLinear.SLAB

@@ -68,10 +68,8 @@ class DiGCNConv(MessagePassing):
         _cabi.require_gpu(x, edge_index, edge_weight)
         if x.dim() == 2:
             projected = tall_linear(x, self.weight)
-        else:                                   # [..., N, F] batches: a broadcasting library product, counted
-            if x.is_cuda:
-                _cabi.note_library_route("DiGCNConv batched x W", f"{tuple(x.shape)} {x.dtype}")
-            projected = torch.matmul(x, self.weight)
+        else:                                   # [..., N, F] batches: W is shared, so the batch is one tall product
+            projected = tall_linear(x.reshape(-1, x.size(-1)), self.weight).view(*x.shape[:-1], self.weight.size(1))
         return self.aggregate_projected(projected, edge_index, edge_weight)
 
     # -- MessagePassing hooks (generic propagate path) -------------------------------------------------

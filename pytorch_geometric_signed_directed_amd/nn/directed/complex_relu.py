@@ -16,7 +16,7 @@ class _ComplexRelu(torch.autograd.Function):
             raise ValueError("complex_relu: real and imag must have the same shape")
         real, imag = real.contiguous(), imag.contiguous()
         o_r, o_i = torch.empty_like(real), torch.empty_like(imag)
-        with torch.cuda.device(real.device):
+        with _cabi.on_device(real.device):
             check(_cabi.lib().pygsd_complex_relu_f32(ptr(real), ptr(imag), ptr(o_r), ptr(o_i), real.numel(),
                                                      stream_ptr()), "pygsd_complex_relu_f32")
         ctx.save_for_backward(real)
@@ -27,7 +27,7 @@ class _ComplexRelu(torch.autograd.Function):
         (real,) = ctx.saved_tensors
         g_r, g_i = g_r.contiguous(), g_i.contiguous()
         o_r, o_i = torch.empty_like(g_r), torch.empty_like(g_i)
-        with torch.cuda.device(real.device):
+        with _cabi.on_device(real.device):
             check(_cabi.lib().pygsd_complex_relu_bwd_f32(ptr(real), ptr(g_r), ptr(g_i), ptr(o_r), ptr(o_i),
                                                          real.numel(), stream_ptr()),
                   "pygsd_complex_relu_bwd_f32")

@@ -36,7 +36,7 @@ class _GatAggregate(torch.autograd.Function):
         csr = pat.fwd
         alpha = torch.empty(csr.nnz, dtype=torch.float32, device=h.device)
         if csr.nnz:
-            with torch.cuda.device(h.device):
+            with _cabi.on_device(h.device):
                 hubs, keep = segment_long_rows_arg(csr)
                 check(_cabi.lib().pygsd_gat_alpha_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(a_src), ptr(a_dst),
                                                           csr.n_rows, float(slope), ptr(alpha), hubs, stream_ptr()),
@@ -62,7 +62,7 @@ class _GatAggregate(torch.autograd.Function):
                 all(t.data_ptr() % 16 == 0 for t in (g, hh, oo)):
             # vectorised path: ds in by-target slot order, d a_dst from the same pass
             da_dst = torch.empty(fwd.n_rows, dtype=torch.float32, device=h.device)
-            with torch.cuda.device(h.device):
+            with _cabi.on_device(h.device):
                 hubs, keep = segment_long_rows_arg(fwd)
                 check(_cabi.lib().pygsd_gat_alpha_bwd_csr_v2_f32(ptr(fwd.rowptr), ptr(fwd.col), ptr(a_src), ptr(a_dst),
                                                                  float(ctx.slope), ptr(alpha), ptr(hh), ldh, ptr(g),
@@ -75,7 +75,7 @@ class _GatAggregate(torch.autograd.Function):
             return gh, segment_sum_raw(bwd.rowptr, m, ds, bwd.n_rows, bwd), da_dst, None, None
         a_coo = torch.empty_like(ds)
         if fwd.nnz:
-            with torch.cuda.device(h.device):
+            with _cabi.on_device(h.device):
                 hubs, keep = segment_long_rows_arg(fwd)
                 check(_cabi.lib().pygsd_gat_alpha_bwd_csr_f32(ptr(fwd.rowptr), ptr(fwd.col), ptr(fwd.perm), ptr(a_src),
                                                               ptr(a_dst), float(ctx.slope), ptr(alpha), ptr(hh), ldh,

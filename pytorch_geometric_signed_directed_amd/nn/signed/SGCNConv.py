@@ -132,11 +132,9 @@ class SGCNConv(MessagePassing):
         w = lin.weight                                  # [out_dim, (len(aggregated) + 1) * in_dim]
         if own.dim() == 2:
             lin_fn = tall_linear
-        else:                                           # [..., N, F] batches: a broadcasting library product, counted
+        else:                                           # [..., N, F] batches: the Linear is shared, so the batch is one tall product
             def lin_fn(t, wt, b=None):
-                if t.is_cuda:
-                    _cabi.note_library_route("SGCNConv batched Linear", f"{tuple(t.shape)} {t.dtype}")
-                return F.linear(t, wt.t(), b)
+                return tall_linear(t.reshape(-1, t.size(-1)), wt, b).view(*t.shape[:-1], wt.size(1))
         if self.in_dim > self.out_dim:
             out = lin_fn(own, w[:, len(aggregated) * f:].t(), lin.bias)
             for k, (feat, ei) in enumerate(aggregated):

@@ -28,7 +28,7 @@ def weighted_sum(tensors, weights, out=None):
         ldo = out.stride(0)
     ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors])
     ws = (ctypes.c_float * k)(*[float(w) for w in weights])
-    with torch.cuda.device(out.device):
+    with _cabi.on_device(out.device):
         _cabi.check(_cabi.lib().pygsd_weighted_sum_f32(ptrs, ws, k, rows, cols, _cabi.ptr(out), ldo, _cabi.stream_ptr()),
                     "pygsd_weighted_sum_f32")
     return out
@@ -44,7 +44,7 @@ def dots(g, tensors):
     out = torch.empty(k, dtype=torch.float32, device=g.device)
     ws = torch.empty(8192, dtype=torch.float32, device=g.device)
     ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors])
-    with torch.cuda.device(g.device):
+    with _cabi.on_device(g.device):
         _cabi.check(_cabi.lib().pygsd_dots_f32(_cabi.ptr(g), cols, ptrs, k, rows, cols, _cabi.ptr(out), _cabi.ptr(ws),
                                                ws.numel() * 4, _cabi.stream_ptr()), "pygsd_dots_f32")
     return out

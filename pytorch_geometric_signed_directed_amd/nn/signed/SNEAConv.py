@@ -55,7 +55,7 @@ class _SneaShares(torch.autograd.Function):
         share0 = torch.zeros(n, dtype=torch.float32, device=s0.device)
         share1 = torch.zeros(n, dtype=torch.float32, device=s0.device) if typed else None
         if g.fwd.nnz:
-            with torch.cuda.device(s0.device):
+            with _cabi.on_device(s0.device):
                 hubs, keep = segment_long_rows_arg(g.fwd)
                 check(_cabi.lib().pygsd_snea_alpha_csr_f32(ptr(g.fwd.rowptr), ptr(g.fwd.col), ptr(g.etype), ptr(s0),
                                                            ptr(s1), ptr(d0), ptr(d1), ptr(bias), n, ptr(alpha),
@@ -83,7 +83,7 @@ class _SneaShares(torch.autograd.Function):
         dd0 = torch.zeros(n, dtype=torch.float32, device=dev)
         dd1 = torch.zeros(n, dtype=torch.float32, device=dev) if typed else None
         if nnz:
-            with torch.cuda.device(dev):
+            with _cabi.on_device(dev):
                 hubs, keep = segment_long_rows_arg(g.fwd)
                 check(_cabi.lib().pygsd_snea_alpha_bwd_csr_f32(ptr(g.fwd.rowptr), ptr(g.fwd.col), ptr(g.etype), ptr(s0),
                                                                ptr(s1), ptr(d0), ptr(d1), ptr(bias), ptr(alpha),

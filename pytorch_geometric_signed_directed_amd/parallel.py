@@ -297,7 +297,8 @@ class _StreamEvent:
         self.event = event
 
     def wait(self):
-        torch.cuda.current_stream().wait_event(self.event)
+        from ._cabi import current_stream
+        current_stream().wait_event(self.event)
         return True
 
 
@@ -326,7 +327,7 @@ class EmulatedExchange:
 
     def _play(self, out: Tensor, src: Tensor, bytes_per_link: float):
         ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream())
+        ready.record(self._cabi.current_stream())
         us = self.latency_us + bytes_per_link / (self.link_gbps * 1e3) if self.world_size > 1 else 0.0
         self.wire_us += us
         with torch.cuda.stream(self.stream):
@@ -632,7 +633,7 @@ class PropagateEngine:
         out = self._buf(f"send{c}", lead + (n_sub, groups * (f // p_c)), xs[0])
         first = self.phase_bounds[c] * ld * esz
         ptrs = (_cabi.c_void_p * groups)(*[x.data_ptr() + first for x in xs])
-        with torch.cuda.device(xs[0].device):
+        with _cabi.on_device(xs[0].device):
             _cabi.check(_cabi.lib().pygsd_pack_slices(ptrs, groups, n_sub, f * esz, ld * esz, p_r, p_c, 1,
                                                       _cabi.ptr(out), _cabi.stream_ptr()), "pygsd_pack_slices")
         return out

@@ -26,7 +26,7 @@ class _SegmentSoftmax(torch.autograd.Function):
             raise ValueError(f"segment_softmax: {logits.numel()} logits for {csr.nnz} CSR entries")
         alpha = torch.empty_like(logits)
         if csr.nnz:
-            with torch.cuda.device(logits.device):
+            with _cabi.on_device(logits.device):
                 hubs, keep = segment_long_rows_arg(csr)
                 check(_cabi.lib().pygsd_segment_softmax_csr_f32(ptr(csr.rowptr), ptr(logits), csr.n_rows, ptr(alpha),
                                                                 hubs, stream_ptr()), "pygsd_segment_softmax_csr_f32")
@@ -43,7 +43,7 @@ class _SegmentSoftmax(torch.autograd.Function):
         g = g.float().contiguous()
         out = torch.empty_like(alpha)
         if csr.nnz:
-            with torch.cuda.device(alpha.device):
+            with _cabi.on_device(alpha.device):
                 hubs, keep = segment_long_rows_arg(csr)
                 check(_cabi.lib().pygsd_segment_softmax_bwd_csr_f32(ptr(csr.rowptr), ptr(alpha), ptr(g), csr.n_rows,
                                                                     ptr(out), hubs, stream_ptr()),
@@ -67,7 +67,7 @@ class _SegmentSum(torch.autograd.Function):
             return out
         out = torch.zeros(csr.n_rows, dtype=torch.float32, device=vals.device)
         if csr.nnz and csr.n_rows:
-            with torch.cuda.device(vals.device):
+            with _cabi.on_device(vals.device):
                 check(_cabi.lib().pygsd_csr_row_sum_f32(ptr(csr.rowptr), None, ptr(vals), csr.n_rows, ptr(out),
                                                         stream_ptr()), "pygsd_csr_row_sum_f32")
         ctx.save_for_backward(rows)

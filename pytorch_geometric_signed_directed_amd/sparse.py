@@ -108,7 +108,7 @@ def csr_from_coo(seg: Tensor, other: Tensor, n_seg: int, n_other: int, validate:
     nnz = seg.numel()
     dev = seg.device
     lib = _cabi.lib()
-    with torch.cuda.device(dev):
+    with _cabi.on_device(dev):
         rowptr = torch.empty(n_seg + 1, dtype=torch.int32, device=dev)
         col = torch.empty(nnz, dtype=torch.int32, device=dev)
         perm = torch.empty(nnz, dtype=torch.int32, device=dev)
@@ -126,7 +126,7 @@ def segment_sum_raw(rowptr: Tensor, perm: Optional[Tensor], w: Tensor, n_rows: i
     segment-parallel path."""
     out = torch.zeros(n_rows, dtype=torch.float32, device=w.device)
     if w.numel() and n_rows:
-        with torch.cuda.device(w.device):
+        with _cabi.on_device(w.device):
             hubs, keep = segment_long_rows_arg(csr) if csr is not None else (None, None)
             check(_cabi.lib().pygsd_segment_sum_f32(ptr(rowptr), ptr(perm), ptr(w), n_rows, ptr(out), hubs, stream_ptr()),
                   "pygsd_segment_sum_f32")
@@ -141,7 +141,7 @@ def gather_values(src: Tensor, perm: Tensor) -> Tensor:
     if src.dtype != torch.float32:
         src = src.float()
     out = torch.empty(perm.numel(), dtype=torch.float32, device=src.device)
-    with torch.cuda.device(src.device):
+    with _cabi.on_device(src.device):
         check(_cabi.lib().pygsd_gather_f32(ptr(src), ptr(perm), perm.numel(), ptr(out), stream_ptr()),
               "pygsd_gather_f32")
     return out
@@ -272,7 +272,7 @@ def _spmm_bf16_raw(csr: CSR, val: Optional[Tensor], x: Tensor, ldx: int, z: Opti
                         None if bias is None else bias.float())
         return y32.to(torch.bfloat16)
     y = torch.empty((csr.n_rows, f), dtype=torch.bfloat16, device=x.device)
-    with torch.cuda.device(x.device):
+    with _cabi.on_device(x.device):
         check(_cabi.lib().pygsd_spmm_csr_bf16(ptr(csr.rowptr), ptr(csr.col), ptr(val), ptr(x), ldx, ptr(y), f, zp,
                                               ldz, csr.n_rows, f, float(alpha), float(beta), 1 if mean else 0,
                                               stream_ptr()), "pygsd_spmm_csr_bf16")
@@ -318,7 +318,7 @@ def _spmm_raw(csr: CSR, val: Optional[Tensor], x: Tensor, z: Optional[Tensor], a
         if bias.data_ptr() % 16:
             bias = bias.clone()
         zp, beta = ptr(bias), 1.0
-    with torch.cuda.device(x.device):
+    with _cabi.on_device(x.device):
         hubs, keep = _long_rows_arg(csr, f, False)
         check(_cabi.lib().pygsd_spmm_csr_f32(ptr(csr.rowptr), ptr(csr.col), ptr(val), ptr(x), ldx, ptr(y),
                                              max(f, 1), zp, ldz, csr.n_rows, f, float(alpha), float(beta),
@@ -372,7 +372,7 @@ def _spmm2_raw(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tensor, z
     blocks = [(0, f)]
     if f >= 128 and f % 64 == 0 and csr.n_cols * f * 8 >= _COLBLOCK_BYTES:
         blocks = [(o, 64) for o in range(0, f, 64)]
-    with torch.cuda.device(xa.device):
+    with _cabi.on_device(xa.device):
         lib = _cabi.lib()
         for off, width in blocks:
             hubs, keep = _long_rows_arg(csr, width, True)
@@ -421,7 +421,7 @@ def spmm2_rows_into(csr: CSR, val_a: Tensor, val_b: Tensor, xa: Tensor, xb: Tens
         return
     off_y = 4 * row_lo * ldy
     pya, pyb = c_void_p(ya.data_ptr() + off_y), c_void_p(yb.data_ptr() + off_y)
-    with torch.cuda.device(xa.device):
+    with _cabi.on_device(xa.device):
         check(_cabi.lib().pygsd_spmm2_csr_f32(c_void_p(csr.rowptr.data_ptr() + 4 * row_lo), ptr(csr.col), ptr(val_a),
                                               ptr(val_b), ptr(xa), ptr(xb), lda, pya, pyb, ldy,
                                               pya if accumulate else None, pyb if accumulate else None,
@@ -466,7 +466,7 @@ def spmm_rows_into(csr: CSR, val: Optional[Tensor], x: Tensor, y: Tensor, row_lo
         z, ldz, beta = c_void_p(z.data_ptr()), z.stride(0), 1.0
     else:
         z, ldz, beta = (py, ldy, 1.0) if accumulate else (None, 0, 0.0)
-    with torch.cuda.device(x.device):
+    with _cabi.on_device(x.device):
         if mixed:
             check(_cabi.lib().pygsd_spmm_csr_bf16_acc_f32(rp, ptr(csr.col), ptr(val), ptr(x), ldx, py, ldy, z, ldz, n_rows, f,
                                                           float(alpha), beta, stream_ptr()), "pygsd_spmm_csr_bf16_acc_f32")
@@ -487,7 +487,7 @@ def _sddmm_raw(ia: Tensor, ib: Tensor, a: Tensor, b: Tensor) -> Tensor:
     a, lda = _rows(a.float())
     b, ldb = _rows(b.float())
     out = torch.empty(ia.numel(), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with _cabi.on_device(a.device):
         check(_cabi.lib().pygsd_sddmm_coo_f32(ptr(ia), ptr(ib), ia.numel(), ptr(a), lda, ptr(b), ldb,
                                               a.size(1), ptr(out), stream_ptr()), "pygsd_sddmm_coo_f32")
     return out

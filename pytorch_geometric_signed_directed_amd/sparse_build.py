@@ -23,7 +23,7 @@ def sort_keys(keys: Tensor, key_bits: int) -> Tuple[Tensor, Tensor]:
     if n == 0:
         return out, perm
     lib = _cabi.lib()
-    with torch.cuda.device(keys.device):
+    with _cabi.on_device(keys.device):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_sort_keys_u64_workspace(n, ctypes.byref(need)), "pygsd_sort_keys_u64_workspace")
         ws = torch.empty(need.value, dtype=torch.uint8, device=keys.device)

@@ -53,7 +53,7 @@ def laplacian_parts(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, s
         if w.numel() != e:
             raise ValueError(f"edge_weight has {w.numel()} entries for {e} edges")
     lib = _cabi.lib()
-    with torch.cuda.device(dev):
+    with _cabi.on_device(dev):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_maglap_workspace(e, ctypes.byref(need)), "pygsd_maglap_workspace")
         ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
@@ -115,7 +115,7 @@ def assemble_operator_csr(parts: LaplacianParts, off_real: Tensor, off_imag: Ten
     rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
     col = torch.empty(nnz, dtype=torch.int32, device=dev)
     vals = torch.empty((4, max(nnz, 1)), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _cabi.on_device(dev):
         check(_cabi.lib().pygsd_maglap_assemble_csr(ptr(parts.index[0]) if es else None,
                                                     ptr(parts.index[1]) if es else None, ptr(off_real), ptr(off_imag),
                                                     ptr(mir_real), ptr(mir_imag), ptr(diag), ptr(parts.off_ptr), es, n,
@@ -152,7 +152,7 @@ def laplacian_values(parts: LaplacianParts, q, normalization: Optional[str], mir
     mir_r = torch.empty_like(parts.a_sym) if mirror else None
     mir_i = torch.empty_like(parts.a_sym) if mirror else None
     if es:
-        with torch.cuda.device(parts.a_sym.device):
+        with _cabi.on_device(parts.a_sym.device):
             check(_cabi.lib().pygsd_maglap_values(ptr(parts.index[0]), ptr(parts.index[1]), ptr(parts.a_sym),
                                                   ptr(parts.theta), ptr(parts.deg), es, qf, 1 if sym else 0,
                                                   ptr(off_r), ptr(off_i), ptr(mir_r), ptr(mir_i), stream_ptr()),
@@ -229,7 +229,7 @@ def _unit_operator_csr(row: Tensor, col: Tensor, e: int, n: int, sym: int, q: fl
     from ..sparse import CSR
     dev = row.device
     lib = _cabi.lib()
-    with torch.cuda.device(dev):
+    with _cabi.on_device(dev):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_magop_workspace(e, n, 0, ctypes.byref(need)), "pygsd_magop_workspace")
         ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
@@ -314,7 +314,7 @@ def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int
         if built is not None:
             return built
         _NOT_PM1.put((edge_weight,), (signed, absolute_degree), True)
-    with torch.cuda.device(dev):
+    with _cabi.on_device(dev):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_magop_workspace(e, n, 0 if w is None else 1, ctypes.byref(need)), "pygsd_magop_workspace")
         ws = torch.empty(need.value, dtype=torch.uint8, device=dev)

@@ -41,7 +41,7 @@ def add_remaining_self_loops(edge_index: Tensor, edge_attr: Optional[Tensor], fi
     _cabi.check_node_ids((n, row), (n, col))     # the loop scan indexes last[] by these ids
     w = _f32(edge_attr)
     lib = _cabi.lib()
-    with torch.cuda.device(dev):
+    with _cabi.on_device(dev):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_self_loops_workspace(e, ctypes.byref(need)), "pygsd_self_loops_workspace")
         ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
@@ -63,7 +63,7 @@ def _degree(index_row: Tensor, other: Tensor, w: Tensor, n: int) -> Tensor:
     """deg[r] = sum of w over the entries with index_row == r, in COO order."""
     csr = csr_from_coo(index_row, other, n, n)
     deg = torch.empty(n, dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _cabi.on_device(w.device):
         check(_cabi.lib().pygsd_csr_row_sum_f32(ptr(csr.rowptr), ptr(csr.perm), ptr(w), n, ptr(deg), stream_ptr()),
               "pygsd_csr_row_sum_f32")
     return deg
@@ -71,7 +71,7 @@ def _degree(index_row: Tensor, other: Tensor, w: Tensor, n: int) -> Tensor:
 
 def _scale(edge_index: Tensor, w: Tensor, deg: Tensor, mode: int) -> Tensor:
     out = torch.empty_like(w)
-    with torch.cuda.device(w.device):
+    with _cabi.on_device(w.device):
         check(_cabi.lib().pygsd_degree_scale_f32(ptr(edge_index[0]), ptr(edge_index[1]), ptr(w), ptr(deg),
                                                  w.numel(), mode, ptr(out), stream_ptr()), "pygsd_degree_scale_f32")
     return out

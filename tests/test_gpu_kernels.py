@@ -1833,3 +1833,64 @@ def test_dense_stage_through_piece_layouts_is_bitwise_the_plain_one(world, p_c, 
     assert torch.equal(dw2, wdw) and torch.equal(da2[0], wda[0]) and da2[1] is None
     da3, db3, dw3, _ = dense_bwd_raw([x_r], [x_i], w, g_r, g_i, rows=n_real, last_in=prod)
     assert torch.equal(dw3, wdw) and torch.equal(da3[1], wda[1]) and torch.equal(db3[1], wdb[1])
+
+
+ODD_WIDTHS = (20, 48, 80, 160, 320)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("k", ODD_WIDTHS)
+def test_no_width_of_a_tall_linear_map_reaches_a_library(dtype, k):
+    """Round 6: behind the MFMA tiles of pygsd_tall_linear / pygsd_tall_gram / pygsd_column_sums sits a generic HIP GEMM for
+    bf16 as well as fp32 (pygsd_gemm_bf16), so x W + b of ANY width (DiGCNConv.py:66 at 20, 48, 80, 160 or 320 columns) and
+    its three gradients take zero hipBLASLt / rocBLAS / torch-reduction routes -- and agree with float64 on the same
+    (already rounded) operands: fp32 to the suite's bar, bf16 to one rounding of the fp32 sum."""
+    from pytorch_geometric_signed_directed_amd import _cabi
+    from pytorch_geometric_signed_directed_amd.dense import tall_linear
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    n = 5000                                                    # (tall reductions count as routes from 4096 rows)
+    for f_out in ODD_WIDTHS:
+        g = torch.Generator().manual_seed(1000 * k + f_out)
+        x = torch.randn(n, k, generator=g).to(td)
+        w = (torch.randn(k, f_out, generator=g) / k ** 0.5).to(td)
+        b = torch.randn(f_out, generator=g).to(td)
+        gy = torch.randn(n, f_out, generator=g).to(td)
+        xd, wd, bd = (t.to(dev()).requires_grad_() for t in (x, w, b))
+        _cabi.reset_library_routes()
+        y = tall_linear(xd, wd, bd)
+        y.backward(gy.to(dev()))
+        torch.cuda.synchronize()
+        assert _cabi.library_routes() == {}, (dtype, k, f_out, _cabi.library_routes())
+        x64, w64, b64 = (t.double().requires_grad_() for t in (x, w, b))
+        (x64 @ w64 + b64).backward(gy.double())
+        tol = TOL if dtype == "f32" else 2.0 ** -8
+        assert y.dtype == td and xd.grad.dtype == td and wd.grad.dtype == td and bd.grad.dtype == td
+        close(y, x64 @ w64 + b64, tol, what=f"odd-width tall_linear forward {k}x{f_out} {dtype}")
+        close(xd.grad, x64.grad, tol, what=f"odd-width dX {k}x{f_out} {dtype}")
+        close(wd.grad, w64.grad, tol, norm=True, what=f"odd-width dW {k}x{f_out} {dtype}")
+        close(bd.grad, b64.grad, tol, norm=True, what=f"odd-width db {k}x{f_out} {dtype}")
+
+
+@pytest.mark.gpu
+def test_generic_bf16_gemm_strides_addend_and_rounding():
+    """pygsd_gemm_bf16 by itself: transposed views, an fp32 addend, fp32 and bf16 outputs, a split reduction -- against float64."""
+    from pytorch_geometric_signed_directed_amd.dense import gemm_bf16
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(70, 33, generator=g).bfloat16().to(dev())
+    b = torch.randn(33, 21, generator=g).bfloat16().to(dev())
+    z = torch.randn(70, 21, generator=g).to(dev())
+    bias = torch.randn(21, generator=g).bfloat16().to(dev())
+    want = a.double() @ b.double() + z.double() + bias.double()
+    got32 = gemm_bf16(a, b, bias=bias, addend=z, out_dtype=torch.float32)
+    assert got32.dtype == torch.float32
+    close(got32, want, TOL, what="generic bf16 GEMM, fp32 result")
+    got16 = gemm_bf16(a, b, bias=bias, addend=z)
+    assert got16.dtype == torch.bfloat16
+    assert torch.equal(got16, got32.bfloat16())                 # ONE rounding of the same fp32 sums
+    at = torch.randn(33, 70, generator=g).bfloat16().to(dev())  # A as a transposed view
+    close(gemm_bf16(at.t(), b, out_dtype=torch.float32), at.double().t() @ b.double(), TOL, what="transposed A")
+    tall_a = torch.randn(20000, 20, generator=g).bfloat16().to(dev())
+    tall_b = torch.randn(20000, 48, generator=g).bfloat16().to(dev())
+    close(gemm_bf16(tall_a.t(), tall_b, out_dtype=torch.float32), tall_a.double().t() @ tall_b.double(), TOL, norm=True,
+          what="split reduction over 20000 rows")

@@ -247,9 +247,9 @@ def test_magnetic_dense_default_form_carries_non_finite_values_as_the_reference_
         gr[n - 1, 0] = INF
         gi[n - 1, 0] = INF                # M = inf - inf = NaN, P = inf
     def reference(dtype):
-        at = [t.to(dtype).requires_grad_() for t in a]
-        bt = [t.to(dtype).requires_grad_() for t in b]
-        wt, biast = w.to(dtype).requires_grad_(), bias.to(dtype).requires_grad_()
+        at = [t.detach().clone().to(dtype).requires_grad_() for t in a]
+        bt = [t.detach().clone().to(dtype).requires_grad_() for t in b]
+        wt, biast = w.detach().clone().to(dtype).requires_grad_(), bias.detach().clone().to(dtype).requires_grad_()
         with single_thread():
             rr = sum(at[k] @ wt[k] for k in range(k1))
             ii = sum(bt[k] @ wt[k] for k in range(k1))

@@ -18,6 +18,10 @@ out = {}
 # e.g. PYGSD_CONFIGS=C3,C5 -- or one step alone for a profile whose kernel averages belong to ONE configuration:
 # C3a (SGCNConv), C3b (SIMPA), C5a (inception block fp32), C5b (bf16)
 ONLY = [t for t in os.environ.get("PYGSD_CONFIGS", "").split(",") if t]
+# PYGSD_CONFIGS_COMPACT=1 (bench.py's `configs` leg): the eager fwd+bwd step of every configuration and its kernel classes only --
+# no cached=False variants, no hipGraph replays, no with-loss variant
+COMPACT = os.environ.get("PYGSD_CONFIGS_COMPACT", "0") == "1"
+OUT_PATH = os.environ.get("PYGSD_CONFIGS_OUT")
 
 
 def want(tag):
@@ -45,6 +49,8 @@ def timed(step, iters=10, warm=3):
 def replayed(step, iters=20):
     """The same step captured into a hipGraph (hipgraph.capture_step) and replayed: the step without its host launch path
     (a few dozen launches of tens of microseconds each).  None when the capture fails."""
+    if COMPACT:
+        return None
     from pytorch_geometric_signed_directed_amd.hipgraph import capture_step
     try:
         g = capture_step(step)
@@ -106,6 +112,11 @@ def magnetic(name, cls, n, e, h, K, signed, **kw):
                  "spmm2_alg_GBps": (b / (k["ms_per_launch"] * k["launches_per_step"] / (2 * K)) / 1e6
                                     if k["ms_per_launch"] else None)}
     out[name].update(residency(2 * n * h * 4, out[name]["spmm2_alg_GBps"]))
+    if COMPACT:
+        print(name, json.dumps(out[name]), flush=True)
+        del layer, xr, xi, ei
+        torch.cuda.empty_cache()
+        return
     # reference default: cached=False, operator rebuilt on every forward
     layer_u = cls(h, h, K, 0.25, False, cached=False, **kw).to(dev)
     layer_u.load_state_dict(layer.state_dict())
@@ -175,9 +186,15 @@ def signed_c3(n=500000, entries=10000000, h=64):
         simpa.zero_grad(set_to_none=True); xp.grad = xn.grad = None
         simpa(pos, wp, neg, wn, xp, xn).sum().backward()
     ms, prof = timed(step2)
+    # 6 products forward + their 6 transposes backward, 4 on A_p and 2 on A_n each way, all at width h with values
+    k = prof["spmm"]
+    b_step = 2 * (4 * spmm_bytes(pos.size(1) + n, n, h) + 2 * spmm_bytes(neg.size(1) + n, n, h))
+    spmm_ms = k["ms_per_launch"] * k["launches_per_step"]
     out["C3_simpa_hop2"] = {"nodes": n, "hidden": h, "pos_entries": int(pos.size(1)), "neg_entries": int(neg.size(1)), "ms_per_step": ms,
+                            "spmm_alg_GBps": b_step / spmm_ms / 1e6 if spmm_ms else None,
                             "ms_per_step_hipgraph_replay": replayed(step2), "entries_per_s": ei.size(1) / ms * 1e3,
                             "kernels": prof, "note": "6 SpMM fwd + 6 bwd (4 on A_p, 2 on A_n) per step; the reference's unused last-hop product is skipped"}
+    out["C3_simpa_hop2"].update(residency(n * h * 4, out["C3_simpa_hop2"]["spmm_alg_GBps"]))
     print("C3_simpa_hop2", json.dumps(out["C3_simpa_hop2"]), flush=True)
     torch.cuda.empty_cache()
 
@@ -219,7 +236,7 @@ def digcn_c5(n=2000000, e=25000000, h=64):
             ib.zero_grad(set_to_none=True); x.grad = None
             x0, x1, x2 = ib(x, ops[0][0], ops[0][1], ops[1][0], ops[1][1])
             (x0 + x1 + x2).float().sum().backward()
-        ms_loss, _ = timed(step_with_loss, iters=5, warm=2)
+        ms_loss = None if COMPACT else timed(step_with_loss, iters=5, warm=2)[0]
         ms, prof = timed(step, iters=5, warm=2)
         nnz = ops[0][0].size(1)
         s_el = 2 if dtype == torch.bfloat16 else 4
@@ -248,4 +265,4 @@ if want("northstar"):
 if want("C5") or want("C5a") or want("C5b"):
     digcn_c5()
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/configs.json" if not ONLY else "gpurun_out/configs_partial.json", "w"), indent=1)
+json.dump(out, open(OUT_PATH or ("gpurun_out/configs.json" if not ONLY else "gpurun_out/configs_partial.json"), "w"), indent=1)

@@ -4,7 +4,7 @@
 # with sys/hip/hsa traces), all into gpurun_out/; tools/pmc_summary.py then condenses them into profiles/.
 set -u
 R=${ROUND:-r2}
-B="python bench.py --no-cpu-baseline --no-pmc --no-x4"
+B="python bench.py --no-cpu-baseline --no-pmc --no-x4 --no-configs"
 O=gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
