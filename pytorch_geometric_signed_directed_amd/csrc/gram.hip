@@ -39,9 +39,8 @@ struct GramChunk {
     int64_t ld;        // row stride in elements
     int32_t tiles;     // 16-column tiles: 1, 2, 4 (X and G), 8 or 12 (G)
     int32_t at;        // first row (X chunks) / column (G chunks) of this chunk in dW
-    const void* p1;    // parts 1 and 2 (part_tiles < tiles): the same, for columns [part_tiles * 16, ...) and [2 part_tiles * 16, ...)
-    const void* p2;
-    int64_t ld1, ld2;
+    int64_t d1, d2;    // parts 1 and 2 (part_tiles < tiles): ELEMENT offset of their first column in row 0 from `p`, for columns
+                       // [part_tiles * 16, ...) and [2 part_tiles * 16, ...); all parts share the row stride
     int32_t part_tiles;   // tiles per part; == tiles for a chunk of one part
 };
 
@@ -67,20 +66,17 @@ __device__ __forceinline__ void load_rows_f32(const GramChunk& c, int64_t r0, in
 {
     constexpr int LPR = NT * 4;            // 16-byte pieces (lanes) per row
     const int part_cols = c.part_tiles * 16;
+    const float* base = static_cast<const float*>(c.p);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int piece = t * 64 + lane;                      // piece-major over the 16 x LPR pieces of the tile
         const int row = piece / LPR;
-        int col = (piece % LPR) * 4;
-        const float* base = static_cast<const float*>(c.p);
-        int64_t ld = c.ld;
-        if (col >= part_cols) {                               // (only chunks of several parts: NT == 8)
-            col -= part_cols;
-            base = static_cast<const float*>(c.p1);
-            ld = c.ld1;
-        }
+        const int col = (piece % LPR) * 4;
+        // (chunks of two parts only: NT == 8.  Offsets, not a choice of pointers: a per-lane choice among the struct's pointer
+        // fields is compiled into an indexed read of a private copy of the struct -- 136 bytes of scratch per lane)
+        const int64_t part = (col >= part_cols) ? c.d1 - part_cols : 0;
         v[t] = make_float4(0.f, 0.f, 0.f, 0.f);               // rows past the end contribute nothing
-        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const float4*>(base + (r0 + row) * ld + col);
+        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const float4*>(base + (r0 + row) * c.ld + col + part);
     }
 }
 
@@ -189,24 +185,16 @@ __device__ __forceinline__ void load_rows_bf16(const GramChunk& c, int64_t r0, i
 {
     constexpr int LPR = NT * 2;            // 16-byte pieces (lanes) per row
     const int part_p8 = c.part_tiles * 2;  // 8-column pieces per part
+    const uint16_t* base = static_cast<const uint16_t*>(c.p);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int piece = t * 64 + lane;                      // piece-major over the 32 x LPR pieces of the tile
         const int row = piece / LPR, c8 = piece % LPR;        // 8-column piece c8 of the row
-        const uint16_t* base = static_cast<const uint16_t*>(c.p);
-        int64_t ld = c.ld;
-        int local = c8;
-        if (c8 >= 2 * part_p8) {                              // (only chunks of several parts: NT == 8 / 12)
-            local = c8 - 2 * part_p8;
-            base = static_cast<const uint16_t*>(c.p2);
-            ld = c.ld2;
-        } else if (c8 >= part_p8) {
-            local = c8 - part_p8;
-            base = static_cast<const uint16_t*>(c.p1);
-            ld = c.ld1;
-        }
+        // (chunks of several parts only: NT == 8 / 12; offsets, not a choice of pointers -- see load_rows_f32)
+        int64_t part = (c8 >= part_p8) ? c.d1 - part_p8 * 8 : 0;
+        part = (c8 >= 2 * part_p8) ? c.d2 - 2 * part_p8 * 8 : part;
         v[t] = make_uint4(0u, 0u, 0u, 0u);
-        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const uint4*>(base + (r0 + row) * ld + local * 8);
+        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const uint4*>(base + (r0 + row) * c.ld + c8 * 8 + part);
     }
 }
 
@@ -643,15 +631,15 @@ int cut_chunks(const void* base, int64_t ld, int width, size_t esz, int at, int 
         const int tiles = (left >= 8 && cap >= 8) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
         if (have >= kMaxChunks) return -1;
         out[have++] = GramChunk{static_cast<const unsigned char*>(base) + static_cast<size_t>(col) * esz, ld, tiles, at + col,
-                                nullptr, nullptr, 0, 0, tiles};
+                                0, 0, tiles};
         col += tiles * 16;
     }
     return have;
 }
 
-// G chunks that are whole segments of one width and neighbours in dW become PARTS of one chunk: two (fp32: <= 8 tiles) or up to
-// three (bf16: <= 12 tiles).  `whole[c]` != 0: chunk c is all of its segment.  Returns the new chunk count.
-int join_parts(GramChunk* g, const int* whole, int n, int max_tiles)
+// G chunks that are whole segments of one width and one row stride, neighbours in dW, become PARTS of one chunk: two (fp32:
+// <= 8 tiles) or up to three (bf16: <= 12 tiles).  `whole[c]` != 0: chunk c is all of its segment.  Returns the new chunk count.
+int join_parts(GramChunk* g, const int* whole, int n, int max_tiles, size_t esz)
 {
     int out = 0;
     for (int c = 0; c < n;) {
@@ -659,23 +647,19 @@ int join_parts(GramChunk* g, const int* whole, int n, int max_tiles)
         int parts = 1;
         const int t = cur.tiles;
         if (whole[c] && (t == 1 || t == 2 || t == 4)) {
-            while (c + parts < n && parts < 3 && whole[c + parts] && g[c + parts].tiles == t &&
+            while (c + parts < n && parts < 3 && whole[c + parts] && g[c + parts].tiles == t && g[c + parts].ld == cur.ld &&
                    g[c + parts].at == cur.at + parts * t * 16) {
                 const int joined = (parts + 1) * t;
                 if (joined > max_tiles || !(joined == 2 || joined == 4 || joined == 8 || joined == 12)) break;
                 ++parts;
             }
-            // three parts only as 3 x 4 tiles; (3 x 1, 3 x 2 have no instance: the loop above stops at 2 there, via `joined`)
-            if (parts == 3 && t != 4) parts = 2;
         }
-        if (parts >= 2) {
-            cur.p1 = g[c + 1].p;
-            cur.ld1 = g[c + 1].ld;
-        }
-        if (parts == 3) {
-            cur.p2 = g[c + 2].p;
-            cur.ld2 = g[c + 2].ld;
-        }
+        auto offset = [&](const GramChunk& other) {
+            return (static_cast<const unsigned char*>(other.p) - static_cast<const unsigned char*>(cur.p)) /
+                   static_cast<int64_t>(esz);
+        };
+        if (parts >= 2) cur.d1 = offset(g[c + 1]);
+        if (parts == 3) cur.d2 = offset(g[c + 2]);
         cur.part_tiles = t;
         cur.tiles = parts * t;
         g[out++] = cur;
@@ -734,7 +718,7 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
         for (int c = before; c < ng; ++c) g_whole[c] = (ng - before == 1) ? 1 : 0;
         f_total += g_widths[s];
     }
-    ng = join_parts(a.g, g_whole, ng, dtype == 1 ? 12 : 8);
+    ng = join_parts(a.g, g_whole, ng, dtype == 1 ? 12 : 8, esz);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n_elem = static_cast<int64_t>(k_total) * f_total;
     if (n_rows == 0) {

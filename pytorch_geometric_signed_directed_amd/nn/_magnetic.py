@@ -226,7 +226,7 @@ class MagneticChebConv(MessagePassing):
             # the case every uncached forward pays for: one fused pass, edge list -> compute layout (csrc/magop.hip)
             qf = float(q.detach().item()) if isinstance(q, torch.Tensor) else float(q)
             built = fused_operator_csr(edge_index, edge_weight, num_nodes, q=qf, normalization=normalization,
-                                       lambda_max=float(lambda_max), **self._laplacian_kwargs())
+                                       lambda_max=float(lambda_max), site=self, **self._laplacian_kwargs())
             if built is not None:
                 csr, vf, vb, deg = built
                 diag = torch.ones_like(deg) if normalization is not None else deg

@@ -382,7 +382,9 @@ def take_rows(csr: CSR, values: Sequence[Tensor], row_ids: Tensor) -> Tuple[CSR,
 
 def cut_points(total: int, count: int, fracs: Optional[Sequence[float]] = None) -> List[int]:
     """count + 1 ascending bounds of [0, total): equal pieces (total must divide) or -- `fracs`, positive, any sum -- pieces
-    in those proportions, every piece at least one row while total >= count (an exchange of zero rows is no exchange)."""
+    in those proportions, every piece at least one row while total >= count (an exchange of zero rows is no exchange).  With
+    fewer rows than pieces (a shard of a toy graph) some pieces ARE empty: their exchanges move nothing and their products
+    launch nothing (the kernels return on zero rows; tests/test_sharding_gloo.py runs such a plan)."""
     if fracs is None:
         if total % count:
             raise ValueError(f"{total} rows do not split into {count} equal pieces")
@@ -405,7 +407,13 @@ def split_spec(spec) -> Tuple[int, Optional[Tuple[float, ...]]]:
     product) -> (count, fractions or None).  A string "2" / "0.4,0.6" (environment) is parsed the same way."""
     if isinstance(spec, str):
         parts = [t for t in spec.replace(":", ",").split(",") if t.strip()]
-        spec = int(parts[0]) if len(parts) == 1 and parts[0].strip().isdigit() else [float(t) for t in parts]
+        if len(parts) == 1:                  # one number is a COUNT ("2", "2.0"); "0.5" alone is neither a count nor a split
+            value = float(parts[0])
+            if value != int(value) or value < 1:
+                raise ValueError(f"pipeline depth {spec!r}: a count (\"2\") or at least two fractions (\"0.4,0.6\")")
+            spec = int(value)
+        else:
+            spec = [float(t) for t in parts]
     if isinstance(spec, (int,)) or (hasattr(spec, "__int__") and not hasattr(spec, "__len__")):
         return max(int(spec), 1), None
     fr = tuple(float(f) for f in spec)
@@ -539,15 +547,17 @@ class PropagateEngine:
         return t
 
     # ---- piece layouts (round 5): the dense kernels write / read the exchange buffers directly ------
-    def pieces_ok(self, f: int, like: Tensor) -> bool:
+    def pieces_ok(self, f: int, like: Tensor, groups: int = 2) -> bool:
         """Can the dense kernels address this engine's exchange buffers (include/pygsd_hip.h: pygsd_piece_layout)?  fp32 on the
-        GPU, column slices of 16 * 2^k floats, at most 4 phases / return chunks and 8 row blocks."""
+        GPU, column slices of 16 * 2^k floats, at most 4 phases / return chunks and 8 row blocks, and every slot (rows of a
+        phase / chunk x the `groups` feature groups side by side) below 2^31 floats -- piece_layout_check's bound; callers fall
+        back to the tensor-op pack / merge beyond it."""
         if not (like.is_cuda and like.dtype == torch.float32) or f % self.p_c:
             return False
         fw = f // self.p_c
         pieces = fw // 16
         return (fw % 16 == 0 and pieces & (pieces - 1) == 0 and self.phases <= 4 and self.return_chunks <= 4 and self.p_r <= 8
-                and max(self.phase_rows + self.chunk_rows) * 2 * fw < (1 << 31))
+                and max(self.phase_rows + self.chunk_rows) * max(groups, 2) * fw < (1 << 31))
 
     def send_layout(self, groups: int, f: int, like: Tensor):
         """(layout, send buffers of all phases): where a local [n_pad, f] operand of `groups` feature groups goes in the inbound
@@ -650,7 +660,7 @@ class PropagateEngine:
         (block i', chunk r) of MY range x column slice j' -> per group the [n_pad, F] rows in local order
         i' * n_blk + chunk_bounds[r] + t."""
         fw = recv.size(-1) // groups
-        if groups <= 4 and self.pieces_ok(self.p_c * fw, recv):
+        if groups <= 4 and self.pieces_ok(self.p_c * fw, recv, groups):
             # one HIP pass whatever the chunk sizes (pygsd_gather_pieces_f32)
             from .dense import PieceOperand, gather_pieces
             return gather_pieces(PieceOperand(recv, 0, fw, self.return_layout(groups, fw)), self.plan.n_pad, self.p_c * fw,
@@ -1188,7 +1198,8 @@ class ShardedMagNetConv(torch.nn.Module):
         if self.engine.grid:
             return self._pieces(like)
         return (like.is_cuda and like.dtype == torch.float32 and self.in_channels in (64, 128) and self.out_channels in (64, 128)
-                and self.engine.phases <= 4 and dense_supported(self.in_channels, self.out_channels, self.weight.size(0)))
+                and self.engine.phases <= 4 and max(self.engine.phase_rows) * 2 * self.in_channels < (1 << 31)
+                and dense_supported(self.in_channels, self.out_channels, self.weight.size(0)))
 
     @property
     def merge_on_read(self) -> bool:
@@ -1305,7 +1316,7 @@ class _GradSync:
         for k, prm in enumerate(self._sync_params):
             prm.register_hook(lambda grad, k=k: self._remember(grad, k))
 
-    def _remember(self, grad, k):
+    def _begin_pass(self):
         task = torch._C._current_graph_task_id()
         if task != self._sync_task:
             # a new backward pass.  Shares left over from a pass that aborted after its first hook (OOM, an exception
@@ -1313,6 +1324,22 @@ class _GradSync:
             # later exchange; the callback is queued once per graph task, whatever state the last one ended in.
             self._sync_task, self._sync_local, self._sync_seen = task, {}, {}
             torch.autograd.Variable._execution_engine.queue_callback(self._exchange_gradients)
+
+    def _arm(self, out):
+        """Called on what forward() returns.  The end-of-pass exchange is a COLLECTIVE: every rank has to run it in every
+        backward pass that reaches this layer -- also a rank none of whose parameters receives a gradient in that pass (its
+        peers would wait in the all-reduces for ever).  A hook on the layer's outputs queues the callback as soon as the pass
+        reaches the layer, whatever happens to the parameters afterwards."""
+        def hook(grad):
+            self._begin_pass()
+            return grad
+        for t in (out if isinstance(out, tuple) else (out,)):
+            if t.requires_grad:
+                t.register_hook(hook)
+        return out
+
+    def _remember(self, grad, k):
+        self._begin_pass()
         if k not in self._sync_seen:
             held = self._sync_params[k].grad
             self._sync_seen[k] = (held, None if held is None else held._version)
@@ -1323,16 +1350,24 @@ class _GradSync:
     def _exchange_gradients(self):
         local, seen = self._sync_local, self._sync_seen
         self._sync_local, self._sync_seen, self._sync_task = {}, {}, None
+        if not self._sync_params:
+            return
         with torch.no_grad():
+            # which parameters received a share on ANY rank: one small all-reduce and the pass's one host read.  A parameter no
+            # rank used keeps the `.grad` it had -- None under zero_grad(set_to_none=True), exactly as in the single-device
+            # reference, so that an optimiser skips it (an explicit zero gradient would still be decayed / given momentum).
+            flags = torch.tensor([1.0 if k in local else 0.0 for k in range(len(self._sync_params))], dtype=torch.float32,
+                                 device=self._sync_params[0].device)
+            used = self.exchange.all_reduce(flags).tolist()
             stale = None
             for k, prm in enumerate(self._sync_params):                  # fixed order on every rank
+                if used[k] == 0:
+                    continue
                 mine = local.get(k)
-                if mine is None:                       # a parameter that got no gradient here still takes part
+                if mine is None:                       # other ranks' shares of a parameter this rank's graph skipped
                     total = self.exchange.all_reduce(torch.zeros_like(prm))
-                    # other ranks' shares of a parameter this rank's graph skipped.  With `.grad` still None (the default
-                    # zero_grad(set_to_none=True)) the total BECOMES the gradient: every rank has to end the pass with the
-                    # same `.grad`, or the replicated parameters drift apart at the next optimiser step.  (No host read
-                    # decides this: where no rank had a share the gradient is an explicit zero on all of them alike.)
+                    # with `.grad` still None the total BECOMES the gradient: every rank has to end the pass with the same
+                    # `.grad`, or the replicated parameters drift apart at the next optimiser step
                     if prm.grad is not None:
                         prm.grad.add_(total)
                     elif prm.requires_grad:
@@ -1390,7 +1425,7 @@ class ShardedDiGCNConv(_GradSync, torch.nn.Module):
         from .dense import tall_linear
         out = self.aggregate(tall_linear(x_local, self.weight))
         out = out if self.bias is None else out + self.bias
-        return _zero_pad_rows(self.plan, out)
+        return self._arm(_zero_pad_rows(self.plan, out))
 
 
 def _dense_mm(like: Tensor):
@@ -1450,7 +1485,7 @@ class ShardedDiGCNInceptionBlock(_GradSync, torch.nn.Module):
                                        [self.op1.op_bwd, self.op2.op_bwd], p1, p2)
         if self.conv1.bias is not None:
             x1, x2 = x1 + self.conv1.bias, x2 + self.conv2.bias
-        return tuple(_zero_pad_rows(self.plan, t) for t in (x0, x1, x2))
+        return self._arm(tuple(_zero_pad_rows(self.plan, t) for t in (x0, x1, x2)))
 
 
 class ShardedSGCNConv(_GradSync, torch.nn.Module):
@@ -1507,7 +1542,7 @@ class ShardedSGCNConv(_GradSync, torch.nn.Module):
         halves = [y[:, :o], y[:, o:2 * o]]
         for (_, half), a in zip(spec, agg):
             halves[half] = halves[half] + a
-        return _zero_pad_rows(self.plan, torch.cat(halves, dim=1))
+        return self._arm(_zero_pad_rows(self.plan, torch.cat(halves, dim=1)))
 
 
 class ShardedSIMPA(_GradSync, torch.nn.Module):
@@ -1581,10 +1616,10 @@ class ShardedSIMPA(_GradSync, torch.nn.Module):
     def forward(self, x_p: Tensor, x_n: Tensor, x_pt: Optional[Tensor] = None, x_nt: Optional[Tensor] = None) -> Tensor:
         """Local rows in (x_p, x_n[, x_pt, x_nt]: [n_pad, F]), local rows of [feat_p | feat_n (| target streams)] out."""
         if self._undirected:
-            return _zero_pad_rows(self.plan, self._stream("p", "n", x_p, x_n, self._w_p, self._w_n))
+            return self._arm(_zero_pad_rows(self.plan, self._stream("p", "n", x_p, x_n, self._w_p, self._w_n)))
         source = self._stream("p", "n", x_p, x_n, self._w_sp, self._w_sn)
         target = self._stream("tp", "tn", x_pt, x_nt, self._w_tp, self._w_tn)
-        return _zero_pad_rows(self.plan, torch.cat([source, target], dim=1))
+        return self._arm(_zero_pad_rows(self.plan, torch.cat([source, target], dim=1)))
 
 
 # ------------------------------------------------------------------------------------------------

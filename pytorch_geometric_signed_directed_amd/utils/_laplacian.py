@@ -196,8 +196,12 @@ _UNIT_BUILD = os.environ.get("PYGSD_TWO_STAGE_BUILD", "0") != "1"
 
 
 _SIGNED_UNIT_BUILD = os.environ.get("PYGSD_SIGNED_UNIT_BUILD", "1") != "0"
-_NOT_PM1 = TensorMemo(8)
-_NOT_BUCKETS = TensorMemo(8)   # (edge_index, edge_weight) pairs the weighted bucket form has turned down (duplicates, hub rows)  # weight tensors the +-1 build has turned down (weakly held, per in-place version)
+_NOT_PM1 = TensorMemo(8)       # weight tensors the +-1 build has turned down (weakly held, per in-place version)
+_NOT_BUCKETS = TensorMemo(8)   # (edge_index, edge_weight) pairs the weighted bucket form has turned down (duplicates, hub rows)
+# A call site (a layer) whose builds the +-1 form has turned down this many times in a row -- fresh real-valued weight tensors
+# on every uncached forward, which the per-tensor memo above cannot recognise -- stops offering them: each refusal costs a
+# counting pass, a scan and a host round trip in front of the build that then runs.
+_PM1_SITE_REFUSALS = 2
 
 
 def set_signed_unit_build(on: bool) -> bool:
@@ -274,7 +278,7 @@ def _unit_operator_csr(row: Tensor, col: Tensor, e: int, n: int, sym: int, q: fl
 
 def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, signed: bool,
                        absolute_degree: bool, q: float, normalization: Optional[str], lambda_max: float,
-                       diag_shift: float = -1.0):
+                       diag_shift: float = -1.0, site=None):
     """Edge list -> compute layout of 2 L / lambda_max + diag_shift I in one pass through csrc/magop.hip
     (pygsd_magop_stage1 / _stage2): what `laplacian_parts` -> `laplacian_values(mirror=True)` ->
     `assemble_operator_csr` produce, without their int64 COO intermediates and with the node-id range check and
@@ -282,7 +286,8 @@ def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int
     layers rebuild on every uncached forward, MagNetConv.py:157-181).
 
     Returns (CSR, (vf_real, vf_imag), (vb_real, vb_imag), deg), or None when a node has more than 4096 symmetrised
-    entries (the caller then takes the generic pipeline, which has a path for such rows)."""
+    entries (the caller then takes the generic pipeline, which has a path for such rows).
+    site: the calling layer; it remembers (as `_pm1_refusals`) how often in a row its weights were not +-1."""
     from ..sparse import CSR
     _cabi.require_gpu(edge_index, edge_weight)
     if edge_index.dtype != torch.int64:
@@ -306,14 +311,19 @@ def fused_operator_csr(edge_index: Tensor, edge_weight: Optional[Tensor], n: int
         if built is not None:
             return built
         # a node with more than 512 symmetrised entries: the two-stage pipeline below has a path for rows up to 4096
-    elif w is not None and _UNIT_BUILD and _SIGNED_UNIT_BUILD and _NOT_PM1.get((edge_weight,), (signed, absolute_degree)) is None:
+    elif (w is not None and _UNIT_BUILD and _SIGNED_UNIT_BUILD and getattr(site, "_pm1_refusals", 0) < _PM1_SITE_REFUSALS
+          and _NOT_PM1.get((edge_weight,), (signed, absolute_degree)) is None):
         # weights that are all +-1 (SDSBM / SSBM signs, explicit unit weights) take the one-call build as well; the DEVICE decides
         # (its first kernel validates the weights -- no host read of them), and a weight tensor that was turned down once is not
         # offered again while it is the same tensor at the same version (memo.TensorMemo)
         built = _unit_operator_csr(row, col, e, n, sym, q, lambda_max, diag_shift, w, signed, absolute_degree)
         if built is not None:
+            if site is not None:
+                site._pm1_refusals = 0
             return built
         _NOT_PM1.put((edge_weight,), (signed, absolute_degree), True)
+        if site is not None:                     # `site`: the layer this build is for (any object that takes an attribute)
+            site._pm1_refusals = getattr(site, "_pm1_refusals", 0) + 1
     with _cabi.on_device(dev):
         need = ctypes.c_size_t(0)
         check(lib.pygsd_magop_workspace(e, n, 0 if w is None else 1, ctypes.byref(need)), "pygsd_magop_workspace")

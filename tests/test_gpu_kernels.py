@@ -1591,6 +1591,12 @@ GRAM_CASES = [
     ("bf16", 33, (32, 16), (16, 128, 48), True),       # a partial 32-row tile
     ("bf16", 4099, (64, 64), (192,), False),
     ("bf16", 1000, (16,), (32,), True),
+    # round 6: neighbouring whole segments of one width ride in ONE chunk (two parts fp32, up to three bf16)
+    ("bf16", 70001, (64,), (64, 64, 64), False),       # C5b: x^T [dx0 | dP_1 | dP_2], 12 tiles against 4: every row read once
+    ("bf16", 5000, (64,), (64, 64, 64), True),         # the same as column slices of one wider matrix
+    ("bf16", 4099, (32, 32), (32, 32, 16, 16, 16), False),   # pairs of 2 and of 1 tiles, a third 16 left alone
+    ("f32", 5000, (64,), (64, 64), True),              # C3a's pair as column slices
+    ("f32", 3001, (16, 48), (32, 32, 64, 64, 16), False),
 ]
 
 

@@ -115,6 +115,9 @@ def test_uneven_pipeline_pieces():
     assert split_spec(2) == (2, None) and split_spec("3") == (3, None)
     assert split_spec((0.4, 0.6)) == (2, (0.4, 0.6)) and split_spec("0.5,0.3,0.2") == (3, (0.5, 0.3, 0.2))
     assert split_spec((1.0,)) == (1, None)
+    assert split_spec("2.0") == (2, None)                                     # one number is a count, however it is written
+    with pytest.raises(ValueError):
+        split_spec("0.5")                                                     # ... and a lone fraction is neither
     assert PropagateEngine.alignment(8, 4, (0.4, 0.6), (0.5, 0.3, 0.2)) == 2 and PropagateEngine.alignment(8, 4, 2, 2) == 4
     world, n_pad = 3, 11
     n = world * n_pad
@@ -458,6 +461,62 @@ def test_parameter_gradients_do_not_depend_on_the_order_autograd_produces_them_i
     ret = mgr.dict()
     mp.spawn(_grad_sync_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert len(ret) == 2 and max(ret.values()) <= 4e-6, dict(ret)
+
+
+def _unused_parameter_worker(rank, world, port, ret):
+    """Ranks that use DIFFERENT parameters in one pass, and parameters no rank uses: a parameter some rank used ends the pass
+    with the same summed `.grad` on every rank; one that NO rank used keeps `.grad` = None, as on a single device (an optimiser
+    skips it -- an explicit zero would still be decayed / given momentum)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytorch_geometric_signed_directed_amd.parallel import ShardedDiGCNInceptionBlock
+        C.patch_device_builders()
+        n, f = 40, 8
+        g, ei, w = _graph(n, 9, True)
+        _, ei2, w2 = _graph(n, 10, False)
+        w, w2 = w / 8, w2 / 8
+        x, go = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+        torch.manual_seed(3)
+        layer = ShardedDiGCNInceptionBlock(f, f, n, ei, w, ei2, w2, kernels=C.KERNELS)
+        with torch.no_grad():
+            for prm in layer.parameters():
+                prm.uniform_(-0.5, 0.5)
+                dist.broadcast(prm.data, 0)
+        gl = layer.shard_rows(go)
+        # pass A: no rank's loss sees the Linear branch -> its parameters keep `.grad` = None on every rank
+        layer.zero_grad(set_to_none=True)
+        x0, x1, x2 = layer(layer.shard_rows(x))
+        (x1 * gl).sum().backward()
+        none_ok = layer.ln.weight.grad is None and layer.ln.bias.grad is None and layer.conv1.weight.grad is not None
+        # pass B: every rank's loss sees the conv1 branch (its backward is a collective: SPMD), only rank 0's the Linear branch
+        # (local rows, no exchange): rank 1 has no share of ln.* but ends the pass with rank 0's
+        layer.zero_grad(set_to_none=True)
+        x0, x1, x2 = layer(layer.shard_rows(x))
+        (((x1 + x0) if rank == 0 else x1) * gl).sum().backward()
+        sd = {k: v.detach().clone().requires_grad_() for k, v in layer.named_parameters()}
+        lo, hi = layer.plan.bounds[0], layer.plan.bounds[1]
+        want_lin = x @ sd["ln.weight"].t() + sd["ln.bias"]
+        want_c1 = R.digcn_conv(x, ei, w, sd["conv1.weight"], sd["conv1.bias"])
+        # the un-sharded equivalent: conv1's branch on all rows, the Linear on rank 0's rows
+        ((want_c1 * go).sum() + (want_lin * go)[lo:hi].sum()).backward()
+        worst = 0.0
+        for k, prm in layer.named_parameters():
+            if not k.startswith("conv2"):          # (conv2 rides in conv1's product node: its share is an explicit zero)
+                worst = max(worst, float((prm.grad - sd[k].grad).abs().max()) / max(1.0, float(sd[k].grad.abs().max())))
+        ret[rank] = (worst, none_ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_parameters_no_rank_used_keep_no_gradient_and_partly_used_ones_agree():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_unused_parameter_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert len(ret) == 2, dict(ret)
+    for worst, none_ok in ret.values():
+        assert worst <= 4e-6 and none_ok, dict(ret)
 
 
 @pytest.mark.parametrize("world,n,f,phases,block", [(2, 50, 8, 1, False), (3, 61, 4, 2, False), (2, 50, 8, 1, True),
