@@ -388,6 +388,123 @@ def dram_bound_reference(device, hidden, copy_rate, scale=4, steps=6):
         return rec
 
 
+def exchange_report(args, layer_s, xr_loc, xi_loc, dist, device, world, hidden, sync, reduce_max, fallback_note):
+    """The `exchange` object of a sharded run: schedule, per-propagate compute-stream split (the engine's timing of the
+    instrumented pass), every collective of one propagate timed ALONE, and who ran where (world size, RCCL version, one device
+    identity per rank)."""
+    summary = layer_s.engine.timing_summary() or {}
+    layer_s.engine.profile(False)
+    # the exchanges alone (nothing to overlap with): every collective of one propagate timed on its own -- the
+    # first multi-GPU run calibrates the link rate the single-GPU rehearsal assumed (61 GB/s per direction)
+    eng = layer_s.engine
+    esz = xr_loc.element_size()
+
+    def timed_collective(fn):
+        ts = []
+        for _ in range(5):
+            sync()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn().wait()
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        return reduce_max(statistics.median(ts))
+
+    inbound_ms, return_ms, in_bytes_per_link, back_bytes_per_link = [], [], [], []
+    for c in range(eng.phases):                       # (the pieces may be uneven: round 5's default schedule)
+        send_c = eng._pack([xr_loc.detach(), xi_loc.detach()], c).clone()
+        buf_c = send_c.new_empty((world, eng.phase_rows[c], send_c.size(-1)))
+        inbound_ms.append(timed_collective(lambda: eng.ex.all_to_all(buf_c, send_c) if eng.grid
+                                           else eng.ex.all_gather(buf_c, send_c)))
+        in_bytes_per_link.append((send_c[0].numel() if eng.grid else send_c.numel()) * esz)
+    if eng.grid:
+        fw2 = 2 * (hidden // eng.p_c)
+        for r in range(eng.return_chunks):
+            back = xr_loc.new_zeros((world, eng.chunk_rows[r], fw2))
+            recv = torch.empty_like(back)
+            back_bytes_per_link.append(back[0].numel() * esz)
+            return_ms.append(timed_collective(lambda: eng.ex.all_to_all(recv, back)))
+    alone_total = sum(inbound_ms) + sum(return_ms)
+
+    def rate(nbytes, ms):
+        return nbytes / (ms * 1e-3) / 1e9 if ms and world > 1 else None
+    exchange = {"layout": layer_s.layout, "p_r": eng.p_r, "p_c": eng.p_c, "phases": eng.phases,
+                "return_chunks": eng.return_chunks, "phase_rows": eng.phase_rows,
+                "return_chunk_rows": eng.chunk_rows if eng.grid else None, "propagates_per_step": 2,
+                "propagate_ms": summary.get("total_ms"), "product_ms": summary.get("product_ms"),
+                "pack_ms": summary.get("pack_ms"), "merge_ms": summary.get("merge_ms"),
+                "exposed_exchange_ms": summary.get("exposed_exchange_ms"),
+                "exchange_alone_ms": alone_total,
+                "collectives_alone": {
+                    "inbound_ms_per_phase": inbound_ms, "inbound_bytes_per_link": in_bytes_per_link,
+                    "inbound_GBps_per_link": [rate(b, t) for b, t in zip(in_bytes_per_link, inbound_ms)],
+                    "return_ms_per_chunk": return_ms, "return_bytes_per_link": back_bytes_per_link,
+                    "return_GBps_per_link": [rate(b, t) for b, t in zip(back_bytes_per_link, return_ms)],
+                    "assumed_by_the_rehearsal_GBps_per_link": 61.0},
+                "cache_input_exchange": bool(args.cache_input_exchange),
+                "backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": device_identities(dist, device),
+                "rccl_version": rccl_version(),
+                "blocking_collectives": bool(getattr(layer_s.exchange, "synchronous", False)),
+                "TORCH_NCCL_AVOID_RECORD_STREAMS": os.environ.get("TORCH_NCCL_AVOID_RECORD_STREAMS"),
+                "fallback": fallback_note,
+                "node_range_sizes": layer_s.plan.sizes, "n_pad": layer_s.plan.n_pad,
+                "note": "per propagate, compute-stream time of rank 0: product = partial SpMM launches, exposed = "
+                        "the compute stream waiting for an inbound phase or the return; exchange_alone = the same "
+                        "collectives with nothing to overlap"}
+    return exchange
+
+
+def parity_guard(layer_s, xr_loc, xi_loc, x_real, x_imag, edge_index, n, hidden, rank, device):
+    """Un-timed parity guard of the sharded mode: sampled rows of the sharded outputs and input gradients, and the
+    all-reduced dW / db, against the UN-SHARDED HIP layer run on rank 0 with the same parameters (that layer is held
+    to a float64 evaluation at this size by tests/test_gpu_fullsize.py).  In the JSON line; rc != 0 above the bar.
+    """
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv
+    parity = None
+    k_rows = min(1024, n)
+    gen = torch.Generator().manual_seed(12345)
+    rows = torch.sort(torch.randperm(n, generator=gen)[:k_rows]).values
+    layer_s.zero_grad(set_to_none=True)
+    xr_loc.grad = xi_loc.grad = None
+    o_r, o_i = layer_s(xr_loc, xi_loc)
+    (o_r.sum() + o_i.sum()).backward()
+    plan = layer_s.plan
+    mine = (rows >= plan.lo) & (rows < plan.hi)
+    loc = (rows[mine] - plan.lo).to(device)
+    got = torch.zeros((k_rows, 4 * hidden), dtype=torch.float32, device=device)
+    got[mine.to(device)] = torch.cat([t.detach()[loc] for t in (o_r, o_i, xr_loc.grad, xi_loc.grad)], dim=1)
+    layer_s.exchange.all_reduce(got)                  # every sampled row is owned by exactly one rank
+    if rank == 0:
+        ref = MagNetConv(hidden, hidden, K=1, q=0.25, trainable_q=False, cached=True).to(device)
+        with torch.no_grad():
+            ref.weight.copy_(layer_s.weight)
+            ref.bias.copy_(layer_s.bias)
+        a = x_real.detach().clone().requires_grad_()
+        b = x_imag.detach().clone().requires_grad_()
+        w_r, w_i = ref(a, b, edge_index)
+        (w_r.sum() + w_i.sum()).backward()
+        idx = rows.to(device)
+        want = torch.cat([t.detach()[idx] for t in (w_r, w_i, a.grad, b.grad)], dim=1).double()
+        d = (got.double() - want).abs()
+        mixed = float((d / (1.0 + want.abs())).max())
+
+        def norm_err(x, y):
+            return float((x.double() - y.double()).abs().max()) / max(1.0, float(y.abs().max()))
+        dw_err = norm_err(layer_s.weight.grad, ref.weight.grad)
+        db_err = norm_err(layer_s.bias.grad, ref.bias.grad)
+        ok = mixed <= 1e-5 and dw_err <= 1e-5 and db_err <= 1e-5
+        parity = {"ok": ok, "rows": int(k_rows), "max_err_rows": mixed, "max_abs_err_rows": float(d.max()),
+                  "max_abs_want": float(want.abs().max()), "dW_norm_err": dw_err, "db_norm_err": db_err,
+                  "bar": "|d| <= 1e-5 (1 + |want|) per element of out_real / out_imag / dx_real / dx_imag on the "
+                         "sampled rows; max-norm 1e-5 for dW / db", "against": "un-sharded HIP MagNetConv on rank 0, "
+                         "same parameters, same inputs (float64-verified at this size by tests/test_gpu_fullsize.py)",
+                  "operator_nnz_matches": bool(layer_s.global_nnz == ref._operator.nnz)}
+        parity["ok"] = bool(parity["ok"] and parity["operator_nnz_matches"])
+        del ref, a, b, w_r, w_i
+    return parity
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -649,113 +766,10 @@ def main():
     _cabi.prof_reset()
     exchange = None
     if layer_s is not None:
-        summary = layer_s.engine.timing_summary() or {}
-        layer_s.engine.profile(False)
-        # the exchanges alone (nothing to overlap with): every collective of one propagate timed on its own -- the
-        # first multi-GPU run calibrates the link rate the single-GPU rehearsal assumed (61 GB/s per direction)
-        eng = layer_s.engine
-        esz = xr_loc.element_size()
-
-        def timed_collective(fn):
-            ts = []
-            for _ in range(5):
-                sync()
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                fn().wait()
-                b.record()
-                b.synchronize()
-                ts.append(a.elapsed_time(b))
-            return reduce_max(statistics.median(ts))
-
-        inbound_ms, return_ms, in_bytes_per_link, back_bytes_per_link = [], [], [], []
-        for c in range(eng.phases):                       # (the pieces may be uneven: round 5's default schedule)
-            send_c = eng._pack([xr_loc.detach(), xi_loc.detach()], c).clone()
-            buf_c = send_c.new_empty((world, eng.phase_rows[c], send_c.size(-1)))
-            inbound_ms.append(timed_collective(lambda: eng.ex.all_to_all(buf_c, send_c) if eng.grid
-                                               else eng.ex.all_gather(buf_c, send_c)))
-            in_bytes_per_link.append((send_c[0].numel() if eng.grid else send_c.numel()) * esz)
-        if eng.grid:
-            fw2 = 2 * (hidden // eng.p_c)
-            for r in range(eng.return_chunks):
-                back = xr_loc.new_zeros((world, eng.chunk_rows[r], fw2))
-                recv = torch.empty_like(back)
-                back_bytes_per_link.append(back[0].numel() * esz)
-                return_ms.append(timed_collective(lambda: eng.ex.all_to_all(recv, back)))
-        alone_total = sum(inbound_ms) + sum(return_ms)
-
-        def rate(nbytes, ms):
-            return nbytes / (ms * 1e-3) / 1e9 if ms and world > 1 else None
-        exchange = {"layout": layer_s.layout, "p_r": eng.p_r, "p_c": eng.p_c, "phases": eng.phases,
-                    "return_chunks": eng.return_chunks, "phase_rows": eng.phase_rows,
-                    "return_chunk_rows": eng.chunk_rows if eng.grid else None, "propagates_per_step": 2,
-                    "propagate_ms": summary.get("total_ms"), "product_ms": summary.get("product_ms"),
-                    "pack_ms": summary.get("pack_ms"), "merge_ms": summary.get("merge_ms"),
-                    "exposed_exchange_ms": summary.get("exposed_exchange_ms"),
-                    "exchange_alone_ms": alone_total,
-                    "collectives_alone": {
-                        "inbound_ms_per_phase": inbound_ms, "inbound_bytes_per_link": in_bytes_per_link,
-                        "inbound_GBps_per_link": [rate(b, t) for b, t in zip(in_bytes_per_link, inbound_ms)],
-                        "return_ms_per_chunk": return_ms, "return_bytes_per_link": back_bytes_per_link,
-                        "return_GBps_per_link": [rate(b, t) for b, t in zip(back_bytes_per_link, return_ms)],
-                        "assumed_by_the_rehearsal_GBps_per_link": 61.0},
-                    "cache_input_exchange": bool(args.cache_input_exchange),
-                    "backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": device_identities(dist, device),
-                    "rccl_version": rccl_version(),
-                    "blocking_collectives": bool(getattr(layer_s.exchange, "synchronous", False)),
-                    "TORCH_NCCL_AVOID_RECORD_STREAMS": os.environ.get("TORCH_NCCL_AVOID_RECORD_STREAMS"),
-                    "fallback": fallback_note,
-                    "node_range_sizes": layer_s.plan.sizes, "n_pad": layer_s.plan.n_pad,
-                    "note": "per propagate, compute-stream time of rank 0: product = partial SpMM launches, exposed = "
-                            "the compute stream waiting for an inbound phase or the return; exchange_alone = the same "
-                            "collectives with nothing to overlap"}
-
-    # ---- un-timed parity guard of the sharded mode: sampled rows of the sharded outputs and input gradients, and the
-    # all-reduced dW / db, against the UN-SHARDED HIP layer run on rank 0 with the same parameters (that layer is held
-    # to a float64 evaluation at this size by tests/test_gpu_fullsize.py).  In the JSON line; rc != 0 above the bar.
+        exchange = exchange_report(args, layer_s, xr_loc, xi_loc, dist, device, world, hidden, sync, reduce_max, fallback_note)
     parity = None
     if layer_s is not None and not args.no_parity:
-        k_rows = min(1024, n)
-        gen = torch.Generator().manual_seed(12345)
-        rows = torch.sort(torch.randperm(n, generator=gen)[:k_rows]).values
-        layer_s.zero_grad(set_to_none=True)
-        xr_loc.grad = xi_loc.grad = None
-        o_r, o_i = layer_s(xr_loc, xi_loc)
-        (o_r.sum() + o_i.sum()).backward()
-        plan = layer_s.plan
-        mine = (rows >= plan.lo) & (rows < plan.hi)
-        loc = (rows[mine] - plan.lo).to(device)
-        got = torch.zeros((k_rows, 4 * hidden), dtype=torch.float32, device=device)
-        got[mine.to(device)] = torch.cat([t.detach()[loc] for t in (o_r, o_i, xr_loc.grad, xi_loc.grad)], dim=1)
-        layer_s.exchange.all_reduce(got)                  # every sampled row is owned by exactly one rank
-        if rank == 0:
-            ref = MagNetConv(hidden, hidden, K=1, q=0.25, trainable_q=False, cached=True).to(device)
-            with torch.no_grad():
-                ref.weight.copy_(layer_s.weight)
-                ref.bias.copy_(layer_s.bias)
-            a = x_real.detach().clone().requires_grad_()
-            b = x_imag.detach().clone().requires_grad_()
-            w_r, w_i = ref(a, b, edge_index)
-            (w_r.sum() + w_i.sum()).backward()
-            idx = rows.to(device)
-            want = torch.cat([t.detach()[idx] for t in (w_r, w_i, a.grad, b.grad)], dim=1).double()
-            d = (got.double() - want).abs()
-            mixed = float((d / (1.0 + want.abs())).max())
-
-            def norm_err(x, y):
-                return float((x.double() - y.double()).abs().max()) / max(1.0, float(y.abs().max()))
-            dw_err = norm_err(layer_s.weight.grad, ref.weight.grad)
-            db_err = norm_err(layer_s.bias.grad, ref.bias.grad)
-            ok = mixed <= 1e-5 and dw_err <= 1e-5 and db_err <= 1e-5
-            parity = {"ok": ok, "rows": int(k_rows), "max_err_rows": mixed, "max_abs_err_rows": float(d.max()),
-                      "max_abs_want": float(want.abs().max()), "dW_norm_err": dw_err, "db_norm_err": db_err,
-                      "bar": "|d| <= 1e-5 (1 + |want|) per element of out_real / out_imag / dx_real / dx_imag on the "
-                             "sampled rows; max-norm 1e-5 for dW / db", "against": "un-sharded HIP MagNetConv on rank 0, "
-                             "same parameters, same inputs (float64-verified at this size by tests/test_gpu_fullsize.py)",
-                      "operator_nnz_matches": bool(layer_s.global_nnz == ref._operator.nnz)}
-            parity["ok"] = bool(parity["ok"] and parity["operator_nnz_matches"])
-            del ref, a, b, w_r, w_i
-
+        parity = parity_guard(layer_s, xr_loc, xi_loc, x_real, x_imag, edge_index, n, hidden, rank, device)
     if rank == 0:
         nnz = op_nnz()                      # E_s + N (folded diagonal)
         e_s = nnz - n
