@@ -218,10 +218,13 @@ def device_identities(dist, device):
           "pci_bus_id": (f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}"
                          if hasattr(props, "pci_bus_id") else None),
           "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
-    box = [None] * dist.get_world_size()
-    dist.all_gather_object(box, me)
-    distinct = len({(r["host"], r["uuid"], r["pci_bus_id"]) for r in box})
-    return {"ranks": box, "distinct_devices": distinct}
+    try:                                  # (an identity record must never cost the run its result line)
+        box = [None] * dist.get_world_size()
+        dist.all_gather_object(box, me)
+        distinct = len({(r["host"], r["uuid"], r["pci_bus_id"]) for r in box})
+        return {"ranks": box, "distinct_devices": distinct}
+    except Exception as exc:  # noqa: BLE001
+        return {"ranks": [me], "distinct_devices": None, "error": repr(exc)[:200]}
 
 
 def stream_copy_rate(device, gib=1.0, reps=7):

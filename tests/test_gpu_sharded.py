@@ -279,6 +279,10 @@ def test_bench_self_launches_its_ranks(gpus):
     for key in ("product_ms", "exposed_exchange_ms", "exchange_alone_ms", "collectives_alone", "fallback"):
         assert key in rec["exchange"], rec["exchange"]
     assert rec["exchange"]["fallback"] is None
+    # who ran where (round 6): the line proves its N ranks by itself -- one identity record per rank (here all on the test GPU)
+    assert rec["exchange"]["world_size"] == gpus and len(rec["exchange"]["devices"]["ranks"]) == gpus, rec["exchange"]
+    assert sorted(r["rank"] for r in rec["exchange"]["devices"]["ranks"]) == list(range(gpus))
+    assert all(r["uuid"] and r["name"] for r in rec["exchange"]["devices"]["ranks"]), rec["exchange"]["devices"]
     # the un-timed parity guard: sampled rows of the sharded run against the un-sharded HIP layer, in the line
     assert rec["parity"]["ok"] and rec["parity"]["rows"] == 1024 and rec["parity"]["max_err_rows"] <= 1e-5, rec["parity"]
 
