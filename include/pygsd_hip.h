@@ -604,6 +604,14 @@ int pygsd_gemm_bf16(const void* a, int64_t sa_m, int64_t sa_k, const void* b, in
                     void* c, int64_t ldc, int32_t c_is_f32, const float* z, int64_t ldz, int64_t m, int64_t n, int64_t k,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* A 64-bit fingerprint of `bytes` bytes at `data` (device memory, 4-byte aligned) into *out (device): the sum of a mixed
+ * function of every 4-byte word and its position -- order-independent across blocks (deterministic), position-dependent.
+ * The host side (memo.py) compares it with the fingerprint taken when an operator was memoised: the reference re-derives its
+ * operators from the CURRENT contents of edge_index / edge_weight on every uncached forward (nn/directed/MagNetConv.py:157-181,
+ * nn/directed/DGCNConv.py:76-97, nn/general/conv_base.py:86-114), so a memo hit must also survive writes that bypass torch's
+ * version counter (`t.data[...] = ...`).  No reference counterpart (the reference has no memo). */
+int pygsd_fingerprint_u64(const void* data, size_t bytes, uint64_t* out, void* stream);
+
 /* Keeps `stream` busy for `microseconds` (one idle lane polling the constant-rate wall clock).  Measurement
  * only: the single-GPU rehearsal of the sharded propagate (tools/emulate_sharded.py) uses it as the wire time
  * of an xGMI exchange on its communication stream.  No reference counterpart. */

@@ -146,6 +146,7 @@ PROTOTYPES = {
                                  c_int64, c_int64, c_int32, c_void_p, ctypes.c_size_t, c_void_p]),
     "pygsd_gemm_bf16": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                   c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, ctypes.c_size_t, c_void_p]),
+    "pygsd_fingerprint_u64": (c_int32, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "pygsd_prof_enable": (c_int32, [c_int32]),
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
@@ -293,6 +294,19 @@ def on_device(dev):
 
 def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
+
+
+def fingerprint(t):
+    """64-bit content fingerprint of a device tensor, as an int64[1] device tensor (pygsd_fingerprint_u64; queued, no host
+    read).  Non-contiguous views are fingerprinted through a contiguous copy."""
+    src = t.detach()
+    if not src.is_contiguous():
+        src = src.contiguous()
+    out = torch.empty(1, dtype=torch.int64, device=src.device)
+    with on_device(src.device):
+        check(lib().pygsd_fingerprint_u64(c_void_p(src.data_ptr()), src.numel() * src.element_size(), c_void_p(out.data_ptr()),
+                                          stream_ptr()), "pygsd_fingerprint_u64")
+    return out
 
 
 def require_gpu(*tensors):

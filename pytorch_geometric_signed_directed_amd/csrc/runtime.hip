@@ -495,6 +495,79 @@ extern "C" int pygsd_id_range_i64(const int64_t* ids, int64_t n, int64_t* minmax
     return check_launch("id_range_kernel");
 }
 
+// ---- content fingerprint (round 6: memo.py's check that a memoised operator's key tensors still hold what they held) --------
+// 64 bits over the bytes of a buffer: the sum over the 4-byte words w_i of splitmix64((i << 32) | w_i) -- a sum, so the blocks
+// may add in any order (integer atomics: deterministic), and position-dependent, so a permutation does not cancel.  16-byte
+// loads where the buffer is 16-byte aligned (160 MB of edge_index: ~0.04 ms), 4-byte loads otherwise; a 1..3-byte tail is
+// folded in by one thread.  Not cryptographic: a changed buffer collides with its old self with probability 2^-64.
+namespace {
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void fingerprint_kernel(const unsigned char* data, long long n_words, int tail_bytes,
+                                                          unsigned long long* out)
+{
+    const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    unsigned long long h = 0;
+    if constexpr (VEC) {
+        const uint4* v = reinterpret_cast<const uint4*>(data);
+        const long long n_vec = n_words >> 2;
+        for (long long i = tid; i < n_vec; i += stride) {
+            const uint4 q = v[i];
+            const unsigned long long b = static_cast<unsigned long long>(4 * i) << 32;
+            h += mix64(b | q.x) + mix64((b + (1ull << 32)) | q.y) + mix64((b + (2ull << 32)) | q.z) + mix64((b + (3ull << 32)) | q.w);
+        }
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(data);
+        for (long long i = (n_vec << 2) + tid; i < n_words; i += stride) h += mix64((static_cast<unsigned long long>(i) << 32) | w[i]);
+    } else {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(data);
+        for (long long i = tid; i < n_words; i += stride) h += mix64((static_cast<unsigned long long>(i) << 32) | w[i]);
+    }
+    if (tid == 0 && tail_bytes > 0) {
+        uint32_t last = 0;
+        for (int b = 0; b < tail_bytes; ++b) last |= static_cast<uint32_t>(data[4 * n_words + b]) << (8 * b);
+        h += mix64((static_cast<unsigned long long>(n_words) << 32) | last) + static_cast<unsigned long long>(tail_bytes);
+    }
+    // one atomic per BLOCK (8192 wavefronts adding to one address took 0.4 ms by themselves -- measured on SIMPA's step)
+    __shared__ unsigned long long part[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long total = (part[0] + part[1]) + (part[2] + part[3]);
+        if (total != 0) atomicAdd(out, total);
+    }
+}
+}  // namespace
+
+extern "C" int pygsd_fingerprint_u64(const void* data, size_t bytes, uint64_t* out, void* stream)
+{
+    PYGSD_REQUIRE(out, "pygsd_fingerprint_u64: null output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PYGSD_HIP_TRY(hipMemsetAsync(out, 0, sizeof(uint64_t), s));
+    if (bytes == 0) return 0;
+    PYGSD_REQUIRE(data && (reinterpret_cast<uintptr_t>(data) & 3u) == 0, "pygsd_fingerprint_u64: null or not 4-byte aligned buffer");
+    const long long n_words = static_cast<long long>(bytes / 4);
+    const int tail = static_cast<int>(bytes % 4);
+    long long blocks = (n_words / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);       // two blocks per CU keep ~3 TB/s of 16-byte loads in flight
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(out);
+    const unsigned char* d = static_cast<const unsigned char*>(data);
+    if (aligned16(data))
+        hipLaunchKernelGGL(fingerprint_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, d, n_words, tail, o);
+    else
+        hipLaunchKernelGGL(fingerprint_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, d, n_words, tail, o);
+    return check_launch("fingerprint_kernel");
+}
+
 extern "C" int pygsd_version(void) { return PYGSD_ABI_VERSION; }
 
 extern "C" const char* pygsd_last_error(void) { return last_error().c_str(); }

@@ -20,6 +20,7 @@ import torch
 from torch.nn import Parameter
 
 from .. import _cabi
+from .. import memo
 from ..memo import TensorMemo
 from ..message_passing import MessagePassing
 from ..dense import FixedSpmm2, MagneticConvFunction, dense_supported, tall_linear
@@ -315,8 +316,9 @@ class MagneticChebConv(MessagePassing):
                                                     self._lambda_max_eigsh(edge_index, edge_weight, None))
             if lambda_max is None:
                 lambda_max = 2.0
-            self._operator = self._operator_for(edge_index, x_real.size(self.node_dim), edge_weight,
-                                                self.q, self.normalization, lambda_max, x_real.dtype)
+            with memo.verified(edge_index, edge_weight, lambda_max if isinstance(lambda_max, torch.Tensor) else None):
+                self._operator = self._operator_for(edge_index, x_real.size(self.node_dim), edge_weight,
+                                                    self.q, self.normalization, lambda_max, x_real.dtype)
 
         op = self._operator
         fixed = op.csr is not None            # operator values carry no gradient (q not trainable)

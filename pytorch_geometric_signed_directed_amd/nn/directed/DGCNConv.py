@@ -4,7 +4,7 @@ from typing import Optional
 
 from torch import Tensor
 
-from ... import _cabi
+from ... import _cabi, memo
 from ...memo import TensorMemo
 from ...message_passing import MessagePassing
 from ...sparse import Pattern, spmm
@@ -52,6 +52,7 @@ class DGCNConv(MessagePassing):
                                                    self.add_self_loops, x.dtype)
                 # gcn_norm range-checked the ids it was given: its output needs no second device -> host read
                 if not self.cached and not (src_weight is not None and src_weight.requires_grad):
+                    memo.own(*[t for t in (edge_index, edge_weight) if t is not src_index and t is not src_weight])
                     pattern = Pattern(edge_index, n, n, self.flow, validate=False)
                     self._memo_store(src_index, src_weight, n, edge_weight, pattern)
                 if self.cached:

@@ -6,6 +6,7 @@ their concatenation.  State: `_w_s`, `_w_t` of shape [hop + 1, 1], all ones at r
 import torch
 from torch.nn import Parameter
 
+from ... import memo
 from ..general.conv_base import Conv_Base, flipped_edge_index
 
 
@@ -35,7 +36,9 @@ class DIMPA(torch.nn.Module):
 
     def forward(self, x_s: torch.Tensor, x_t: torch.Tensor, edge_index: torch.Tensor,
                 edge_weight: torch.Tensor) -> torch.Tensor:
-        flipped = flipped_edge_index(edge_index)          # memoised: keeps the operator caches of the flipped list warm
-        along = lambda v: self.conv_layer(v, edge_index, edge_weight)       # noqa: E731
-        against = lambda v: self.conv_layer(v, flipped, edge_weight)       # noqa: E731
-        return torch.cat([_hop_polynomial(along, self._w_s, x_s), _hop_polynomial(against, self._w_t, x_t)], dim=1)
+        with memo.verified(edge_index, edge_weight):      # one content check for every memo lookup of this forward
+            flipped = flipped_edge_index(edge_index)      # memoised: keeps the operator caches of the flipped list warm
+            memo.trust(flipped)                           # (this package's own tensor)
+            along = lambda v: self.conv_layer(v, edge_index, edge_weight)       # noqa: E731
+            against = lambda v: self.conv_layer(v, flipped, edge_weight)       # noqa: E731
+            return torch.cat([_hop_polynomial(along, self._w_s, x_s), _hop_polynomial(against, self._w_t, x_t)], dim=1)

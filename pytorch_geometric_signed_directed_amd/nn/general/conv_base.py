@@ -5,6 +5,7 @@ from typing import Optional
 from torch import Tensor
 
 from ... import _cabi
+from ... import memo
 from ...memo import TensorMemo
 from ...message_passing import MessagePassing
 from ...sparse import GLOBAL_PATTERNS, spmm
@@ -21,6 +22,7 @@ def flipped_edge_index(edge_index: Tensor) -> Tensor:
     out = _FLIP_MEMO.get((edge_index,))
     if out is None:
         out = _FLIP_MEMO.put((edge_index,), None, edge_index[[1, 0]])
+        memo.own(out)                      # (no caller holds it: lookups keyed on it need no content check)
     return out
 
 
@@ -55,20 +57,24 @@ class Conv_Base(MessagePassing):
         if hit is None:
             hit = self._norm_memo.put((edge_index, edge_weight), n,
                                       conv_norm_rw(edge_index, self.fill_value, edge_weight, n, self.add_self_loops, dtype))
+            # this package's own tensors from here on -- unless the normalisation handed the caller's back unchanged
+            memo.own(*[t for t in hit if t is not edge_index and t is not edge_weight])
         return hit
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> Tensor:
         _cabi.require_gpu(x, edge_index, edge_weight)
         n = x.size(self.node_dim)
-        if self.normalize:
-            if edge_weight is not None and edge_weight.requires_grad:
-                edge_index, edge_weight = conv_norm_rw(edge_index, self.fill_value, edge_weight, n,
-                                                       self.add_self_loops, x.dtype)
-            else:
-                edge_index, edge_weight = self._normalised(edge_index, edge_weight, n, x.dtype)
-        # a normalised edge list comes out of conv_norm_rw, which range-checked the ids it was given: no second
-        # device -> host read for the pattern (one synchronisation per uncached call, not two)
-        pattern = GLOBAL_PATTERNS.get(edge_index, n, n, self.flow, validate=not self.normalize)
+        with memo.verified(edge_index, edge_weight):       # one content check of the caller's tensors for both lookups below
+            if self.normalize:
+                if edge_weight is not None and edge_weight.requires_grad:
+                    edge_index, edge_weight = conv_norm_rw(edge_index, self.fill_value, edge_weight, n,
+                                                           self.add_self_loops, x.dtype)
+                else:
+                    edge_index, edge_weight = self._normalised(edge_index, edge_weight, n, x.dtype)
+            # a normalised edge list comes out of conv_norm_rw, which range-checked the ids it was given: no second
+            # device -> host read for the pattern (one synchronisation per uncached call, not two); it is this package's own
+            # tensor, so the pattern lookup keyed on it needs no content check either
+            pattern = GLOBAL_PATTERNS.get(edge_index, n, n, self.flow, validate=not self.normalize, trusted=self.normalize)
         return spmm(pattern, x, edge_weight)
 
     def message(self, x_j: Tensor, edge_weight: Optional[Tensor]) -> Tensor:

@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
-from ... import _cabi
+from ... import _cabi, memo
 from ...message_passing import MessagePassing
 from ...dense import column_sums, tall_gram, tall_linear, tall_product
 from ...sparse import GLOBAL_PATTERNS, spmm, spmm_rows_into
@@ -165,6 +165,12 @@ class SGCNConv(MessagePassing):
 
     def forward(self, x: Union[Tensor, Tuple[Tensor, Tensor]], pos_edge_index: Tensor,
                 neg_edge_index: Tensor) -> Tensor:
+        # (one content check of the two edge lists for all pattern lookups of this forward: memo.verified)
+        with memo.verified(pos_edge_index if isinstance(pos_edge_index, Tensor) else None,
+                           neg_edge_index if isinstance(neg_edge_index, Tensor) else None):
+            return self._forward(x, pos_edge_index, neg_edge_index)
+
+    def _forward(self, x, pos_edge_index, neg_edge_index):
         if (isinstance(x, Tensor) and x.dim() == 2 and self.in_dim >= self.out_dim
                 and isinstance(pos_edge_index, Tensor) and isinstance(neg_edge_index, Tensor)):
             _cabi.require_gpu(x, pos_edge_index, neg_edge_index)

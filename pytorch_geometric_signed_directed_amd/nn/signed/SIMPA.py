@@ -6,6 +6,7 @@ import torch
 from torch.nn import Parameter
 
 from ... import _cabi
+from ... import memo
 from ...memo import TensorMemo
 from ...sparse import GLOBAL_PATTERNS, _spmm_raw
 from ..general.conv_base import Conv_Base, flipped_edge_index
@@ -50,7 +51,7 @@ def dots(g, tensors):
     return out
 
 
-_HOST_WEIGHTS = TensorMemo(16)
+_HOST_WEIGHTS = TensorMemo(16, verify=False)      # (its own contract: see _host_weights)
 
 
 def _host_weights(w):
@@ -242,7 +243,7 @@ class SIMPA(torch.nn.Module):
             handles = []
             for conv, ei, w in ((self.conv_layer_p, ei_p, w_p), (self.conv_layer_n, ei_n, w_n)):
                 nei, nw = conv._normalised(ei, w, n, x_pos.dtype)          # conv_norm_rw, memoised on the graph tensors
-                handles.append((GLOBAL_PATTERNS.get(nei, n, n, conv.flow, validate=False), nw))
+                handles.append((GLOBAL_PATTERNS.get(nei, n, n, conv.flow, validate=False, trusted=True), nw))
             return _StreamFn.apply(x_pos, x_neg, wp, wn, handles[0], handles[1], self._hop_p - 1)    # [feat_p | feat_n]
         feat_p = wp[0] * x_pos
         feat_n = None
@@ -270,10 +271,13 @@ class SIMPA(torch.nn.Module):
                 x_p: torch.FloatTensor, x_n: torch.FloatTensor,
                 x_pt: Optional[torch.FloatTensor] = None,
                 x_nt: Optional[torch.FloatTensor] = None) -> torch.FloatTensor:
-        if self._undirected:
-            return self._stream(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, x_p, x_n, self._w_p, self._w_n)
-        source = self._stream(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, x_p, x_n, self._w_sp, self._w_sn)
-        target = self._stream(flipped_edge_index(edge_index_p), edge_weight_p,
-                              flipped_edge_index(edge_index_n), edge_weight_n,
-                              x_pt, x_nt, self._w_tp, self._w_tn)
+        # one content check of the four graph tensors for every memo lookup of this forward (memo.verified); the flipped lists
+        # are this package's own tensors, derived inside the scope
+        with memo.verified(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n):
+            if self._undirected:
+                return self._stream(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, x_p, x_n, self._w_p, self._w_n)
+            source = self._stream(edge_index_p, edge_weight_p, edge_index_n, edge_weight_n, x_p, x_n, self._w_sp, self._w_sn)
+            flip_p, flip_n = flipped_edge_index(edge_index_p), flipped_edge_index(edge_index_n)
+            memo.trust(flip_p, flip_n)
+            target = self._stream(flip_p, edge_weight_p, flip_n, edge_weight_n, x_pt, x_nt, self._w_tp, self._w_tn)
         return torch.cat([source, target], dim=1)               # [sp | sn | tp | tn], SIMPA.py:142

@@ -1130,7 +1130,7 @@ class ShardedMagNetConv(torch.nn.Module):
         # write to the features bumps their version.  Off by default: a layer deeper in a model never sees the same tensor twice.
         if cache_input_exchange is None:
             cache_input_exchange = os.environ.get("PYGSD_SHARD_CACHE_INPUT_EXCHANGE", "0") == "1"
-        self._input_memo = TensorMemo(2) if cache_input_exchange else None
+        self._input_memo = TensorMemo(2, verify=False) if cache_input_exchange else None      # (opt-in: identity + version)
         self.exchange = exchange if exchange is not None else DistExchange(group)
         self.group = getattr(self.exchange, "group", group)
         world = self.exchange.world_size

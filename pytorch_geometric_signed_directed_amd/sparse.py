@@ -22,7 +22,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import _cabi
+from . import _cabi, memo
 from ._cabi import check, ptr, stream_ptr
 from .memo import TensorMemo
 
@@ -235,9 +235,11 @@ class Pattern:
         """`w` (COO order) re-ordered for the `which` in {'fwd','bwd'} CSR; cached per tensor version."""
         if w is None:
             return None
+        if memo.verify():
+            memo.check_unchanged(w)                  # strict mode: the permuted copy below is only as good as w's contents
         key = (id(w), which)
         hit = self._vcache.get(key)
-        if hit is not None and hit[0]() is w and hit[1] == w._version:
+        if hit is not None and hit[0]() is w and hit[1] == (w._version, memo.content_epoch()):
             return hit[2]
         if w.numel() != self.nnz:
             raise ValueError(f"edge value array has {w.numel()} entries, pattern has {self.nnz}")
@@ -245,7 +247,7 @@ class Pattern:
         out = gather_values(w.detach().reshape(-1), csr.perm)
         if len(self._vcache) > 16:
             self._vcache.clear()
-        self._vcache[key] = (weakref.ref(w), w._version, out)
+        self._vcache[key] = (weakref.ref(w), (w._version, memo.content_epoch()), out)
         return out
 
 
@@ -645,9 +647,9 @@ class PatternCache:
     def __init__(self, capacity: int = 8):
         self._memo = TensorMemo(capacity)
 
-    def get(self, edge_index: Tensor, n_in: int, n_out: int, flow: str, validate: bool = True) -> Pattern:
+    def get(self, edge_index: Tensor, n_in: int, n_out: int, flow: str, validate: bool = True, trusted: bool = False) -> Pattern:
         key = (int(n_in), int(n_out), flow)
-        pat = self._memo.get((edge_index,), key)
+        pat = self._memo.get((edge_index,), key, trusted=trusted)
         if pat is None:
             pat = self._memo.put((edge_index,), key, Pattern(edge_index, n_in, n_out, flow, validate))
         return pat

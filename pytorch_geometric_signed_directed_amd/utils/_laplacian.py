@@ -196,8 +196,8 @@ _UNIT_BUILD = os.environ.get("PYGSD_TWO_STAGE_BUILD", "0") != "1"
 
 
 _SIGNED_UNIT_BUILD = os.environ.get("PYGSD_SIGNED_UNIT_BUILD", "1") != "0"
-_NOT_PM1 = TensorMemo(8)       # weight tensors the +-1 build has turned down (weakly held, per in-place version)
-_NOT_BUCKETS = TensorMemo(8)   # (edge_index, edge_weight) pairs the weighted bucket form has turned down (duplicates, hub rows)
+_NOT_PM1 = TensorMemo(8, verify=False)       # (which build to try first: never a wrong result) weight tensors the +-1 build has turned down (weakly held, per in-place version)
+_NOT_BUCKETS = TensorMemo(8, verify=False)   # (edge_index, edge_weight) pairs the weighted bucket form has turned down (duplicates, hub rows)
 # A call site (a layer) whose builds the +-1 form has turned down this many times in a row -- fresh real-valued weight tensors
 # on every uncached forward, which the per-tensor memo above cannot recognise -- stops offering them: each refusal costs a
 # counting pass, a scan and a host round trip in front of the build that then runs.

@@ -1900,3 +1900,34 @@ def test_generic_bf16_gemm_strides_addend_and_rounding():
     tall_b = torch.randn(20000, 48, generator=g).bfloat16().to(dev())
     close(gemm_bf16(tall_a.t(), tall_b, out_dtype=torch.float32), tall_a.double().t() @ tall_b.double(), TOL, norm=True,
           what="split reduction over 20000 rows")
+
+
+@pytest.mark.gpu
+def test_content_fingerprint_sees_any_change_and_nothing_else():
+    """pygsd_fingerprint_u64 (memo.py's content check): equal bytes -> equal fingerprints whatever the alignment of the buffer;
+    one changed element, two swapped elements, one appended byte -> different ones; deterministic across launches."""
+    from pytorch_geometric_signed_directed_amd import _cabi
+    g = torch.Generator().manual_seed(4)
+    base = torch.randint(0, 2 ** 31, (2, 100003), generator=g).to(dev())
+
+    def fp(t):
+        return int(_cabi.fingerprint(t).item())
+    a = fp(base)
+    assert a == fp(base) == fp(base.clone())                       # deterministic, content only
+    shifted = torch.empty(base.numel() + 1, dtype=torch.int64, device=dev())[1:].view(2, -1)     # 8-byte (not 16-byte) aligned storage
+    shifted.copy_(base)
+    assert shifted.data_ptr() % 16 == 8 and fp(shifted) == a
+    one = base.clone()
+    one[1, 77777] += 1
+    assert fp(one) != a
+    swapped = base.clone()
+    swapped[0, 5], swapped[0, 6] = base[0, 6].clone(), base[0, 5].clone()
+    assert (base[0, 5] == base[0, 6]) or fp(swapped) != a          # position-dependent: a permutation does not cancel
+    floats = torch.randn(999, generator=g).to(dev())
+    assert fp(floats) != fp(floats * 1.0000001) or True            # (may round to the same floats)
+    assert fp(floats) == fp(floats.clone()) != fp(floats[:-1])
+    bytes_ = torch.arange(0, 203, dtype=torch.uint8, device=dev())             # a 3-byte tail
+    assert fp(bytes_) == fp(bytes_.clone()) != fp(torch.cat([bytes_[:-1], bytes_[-1:] + 1]))
+    assert fp(torch.empty(0, device=dev())) == 0
+    strided = base.t()                                             # non-contiguous view: fingerprinted through a copy
+    assert fp(strided) == fp(strided.contiguous())

@@ -991,9 +991,11 @@ def test_uncached_layer_reuses_the_operator_only_for_unmodified_graph_tensors():
 
 
 def test_operator_memo_opt_out_and_weak_keys():
-    """memo.py's contract: a write that bypasses the version counter (`.data`) is NOT seen by the memo (documented
-    hazard) and IS seen with the memo switched off (ctor kwarg, process switch); the memo holds its key tensors
-    weakly, so dropping the graph drops the cached operator."""
+    """memo.py's contract.  By default a write that bypasses the version counter (`.data`) is NOT seen by the memo (documented
+    hazard); in STRICT mode (round 6: memo.set_verify(True) / PYGSD_MEMO_VERIFY=1) it is -- the layer fingerprints its graph
+    tensors before it consults its memos (memo.verified) and rebuilds, like the reference; the opt-outs (ctor kwarg, process
+    switch, clear_all) rebuild in either mode.  The memo holds its key tensors weakly, so dropping the graph drops the
+    cached operator."""
     import gc
     import weakref
     from pytorch_geometric_signed_directed_amd import memo
@@ -1008,6 +1010,7 @@ def test_operator_memo_opt_out_and_weak_keys():
     off.load_state_dict(on.state_dict())
     a1, b1 = on(xr, xi, ei, w), off(xr, xi, ei, w)
     assert torch.equal(a1[0], b1[0])
+    assert not memo.verify()                           # the default: identity + version + storage
     version = w._version
     w.data.mul_(3.0)                                   # bypasses the version counter
     assert w._version == version
@@ -1018,7 +1021,28 @@ def test_operator_memo_opt_out_and_weak_keys():
     want = fresh(xr, xi, ei.clone(), w.clone())
     close(b2[0], want[0]); close(b2[1], want[1])       # opt-out rebuilds, like the reference
     assert not torch.equal(b2[0], b1[0])
-    memo.clear_all()                                   # ... and so does an explicit clear
+    prev = memo.set_verify(True)                       # STRICT mode: hits are verified by content
+    try:
+        memo.clear_all()
+        first = on(xr, xi, ei, w)                      # builds, and takes the fingerprints
+        close(first[0], want[0])
+        op_before = on._operator
+        on(xr, xi, ei, w)
+        assert on._operator is op_before               # unchanged contents: still a hit
+        w.data.mul_(0.5)
+        assert w._version == version
+        seen = on(xr, xi, ei, w)                       # the changed contents are seen, the operator rebuilt
+        want_w = fresh(xr, xi, ei.clone(), w.clone())
+        close(seen[0], want_w[0]); close(seen[1], want_w[1])
+        assert on._operator is not op_before
+        ei.data[0, 0] = (ei[0, 0] + 1) % 40            # an edge_index written behind the counter is seen as well
+        moved = on(xr, xi, ei, w)
+        want_moved = fresh(xr, xi, ei.clone(), w.clone())
+        close(moved[0], want_moved[0]); close(moved[1], want_moved[1])
+    finally:
+        memo.set_verify(prev)
+    want = want_moved
+    memo.clear_all()                                   # ... and an explicit clear rebuilds in either mode
     a3 = on(xr, xi, ei, w)
     close(a3[0], want[0])
     try:
@@ -1038,6 +1062,63 @@ def test_operator_memo_opt_out_and_weak_keys():
     del tmp
     gc.collect()
     assert ref() is None and len(on._op_memo) == 0 and len(GLOBAL_PATTERNS) == before - 1
+
+
+def test_strict_memo_mode_sees_data_writes_in_every_uncached_layer():
+    """memo.set_verify(True): SGCNConv, Conv_Base / SIMPA, DGCNConv and DiGCNConv (cached=False) after a `.data` write to their
+    edge lists / weights give what a fresh layer gives on the new contents -- in the default mode at least one of them does not
+    (the documented hazard), which is what shows the check is doing the work."""
+    from pytorch_geometric_signed_directed_amd import memo
+    from pytorch_geometric_signed_directed_amd.nn import DGCNConv, SGCNConv, SIMPA
+    from pytorch_geometric_signed_directed_amd.nn.directed.DiGCNConv import DiGCNConv
+    g = torch.Generator().manual_seed(23)
+    n, e, f = 300, 2400, 16
+    x = torch.randn(n, f, generator=g).to(D)
+
+    def graph():
+        ei = torch.randint(0, n, (2, e), generator=torch.Generator().manual_seed(5)).to(D)
+        w = (torch.rand(e, generator=torch.Generator().manual_seed(6)) + 0.5).to(D)
+        return ei, w
+
+    torch.manual_seed(1)
+    sgcn, simpa, dgcn = SGCNConv(f, 8, first_aggr=True).to(D), SIMPA(2, 0.5).to(D), DGCNConv().to(D)
+    digcn = DiGCNConv(f, 8, cached=False).to(D)
+
+    def outputs(ei, w, pos, neg, wp, wn):
+        return [sgcn(x, pos, neg), simpa(pos, wp, neg, wn, x, x), dgcn(x, ei, w), digcn(x, ei, w)]
+
+    def mutate(ei, w, pos, neg, wp, wn):
+        ei.data[1, :50] = (ei[1, :50] + 7) % n
+        w.data.mul_(1.5)
+        pos.data[0, :20] = (pos[0, :20] + 3) % n
+        neg.data[1, :20] = (neg[1, :20] + 11) % n
+        wp.data.add_(0.25)
+        wn.data.mul_(2.0)
+
+    stale_seen = False
+    for strict in (False, True):
+        prev = memo.set_verify(strict)
+        try:
+            memo.clear_all()
+            ei, w = graph()
+            pos, neg = ei[:, : e // 2].contiguous(), ei[:, e // 2:].contiguous()
+            wp, wn = w[: e // 2].contiguous(), w[e // 2:].contiguous()
+            outputs(ei, w, pos, neg, wp, wn)                      # memos filled (and, in strict mode, fingerprints taken)
+            versions = [t._version for t in (ei, w, pos, neg, wp, wn)]
+            mutate(ei, w, pos, neg, wp, wn)
+            assert versions == [t._version for t in (ei, w, pos, neg, wp, wn)]
+            got = outputs(ei, w, pos, neg, wp, wn)
+            memo.clear_all()
+            want = outputs(ei.clone(), w.clone(), pos.clone(), neg.clone(), wp.clone(), wn.clone())
+            same = [bool(torch.allclose(a, b, rtol=0, atol=1e-5)) for a, b in zip(got, want)]
+            if strict:
+                assert all(same), same
+            else:
+                stale_seen = not all(same)
+        finally:
+            memo.set_verify(prev)
+            memo.clear_all()
+    assert stale_seen
 
 
 @pytest.mark.parametrize("first,in_dim,out_dim,bias", [(True, 64, 32, True), (False, 32, 32, True), (True, 16, 48, True),
