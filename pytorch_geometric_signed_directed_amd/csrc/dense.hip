@@ -404,7 +404,12 @@ struct DenseBwdArgs {
     // PIECES instances (term k1 - 1 only): a / b read through lay_in, da / db stored through lay_out (every replica)
     pygsd_piece_layout lay_in, lay_out;
     int32_t in_on, out_on, in_shift, out_shift;
+    // split form: tiles whose dA / dB sums came out non-finite, per wavefront of the product kernel -- [gx][k1][gz][4][kBadSlot]
+    // int32 behind the partials: [0] = how many (every wavefront writes it), [1 ..] = the first kBadSlot - 1 tile numbers
+    int32_t* bad;
 };
+
+constexpr int kBadSlot = 8;
 
 // grid = (row blocks, k1, ceil(f_in / 64)); block = 256 threads.  Block (x, k, ci) produces
 // dA_k[:, chunk ci], dB_k[:, chunk ci] for its rows and one partial of dW_k[chunk ci, :] (+ db when
@@ -782,6 +787,9 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_split_kerne
     // stores, in front of phase 2 -- was measured: 0.513 against 0.506 ms; at 256 registers the compiler sinks them back to their
     // first use.)
     float4 xg[NTO], yg[NTO], a4[NTI], b4[NTI];
+    int n_bad = 0;                                                  // (wavefront-uniform: a scalar register)
+    int32_t* const bad_slot = p.bad + ((((static_cast<int64_t>(blockIdx.x) * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * 4 +
+                                        (tid >> 6)) * kBadSlot);
     const bool in_pieces = PIECES && p.in_on && k == p.k1 - 1;      // (block-uniform)
     auto rows_in = [&](int tl) {
         const int r0 = tl << 4;
@@ -910,39 +918,7 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_split_kerne
                 }
             }
         }
-        // ---- operands the split cannot carry (+-inf, NaN, magnitudes above the largest bf16: csrc/tall.hip, any_not_finite) leave
-        //      NaN in every sum they enter: a tile that holds a non-finite sum is written a second time at the end of this
-        //      iteration (exact_rows_out below).  The weight-gradient sums of phase 2 are looked at where the partials are added
-        //      (reduce_dw_checked_kernel).
-        bool redo;
-        {
-            f32x4 z = acc_a[0] * 0.f;                             // 0 for a finite sum, NaN for +-inf and NaN
-            z += acc_b[0] * 0.f;
-#pragma unroll
-            for (int ft = 1; ft < NTI; ++ft) {
-                z += acc_a[ft] * 0.f;
-                z += acc_b[ft] * 0.f;
-            }
-            const float c = (z[0] + z[1]) + (z[2] + z[3]);
-            redo = __builtin_amdgcn_ballot_w64(c != c) != 0;      // wavefront-uniform, lives in a scalar register
-        }
         // ---- the tile's dA / dB stores (in front of phase 2: their registers are free for it) ------------------------------
-        auto rows_out = [&](int ft, float4 va, float4 vb) {
-            if (PIECES && p.out_on && k == p.k1 - 1) {
-                const PieceRow po = piece_row(p.lay_out, r0 + i);
-                const int osh = p.out_shift, omk = (1 << osh) - 1;
-                const int64_t rep_stride = static_cast<int64_t>(p.lay_out.slots_per_blk) * po.slot_stride;
-                const int64_t o = piece_offset(po, (c0 >> 4) + ft, osh, omk) + 4 * g;
-                for (int rep = 0; rep < p.lay_out.replicas; ++rep) {
-                    *reinterpret_cast<float4*>(dak + o + rep * rep_stride) = va;
-                    *reinterpret_cast<float4*>(dbk + o + rep * rep_stride) = vb;
-                }
-            } else {
-                const int64_t o = static_cast<int64_t>(r0 + i) * p.f_in + c0 + ft * 16 + 4 * g;
-                *reinterpret_cast<float4*>(dak + o) = va;
-                *reinterpret_cast<float4*>(dbk + o) = vb;
-            }
-        };
         if (r0 + i < p.n_rows) {
             if (PIECES && p.out_on && k == p.k1 - 1) {
                 const PieceRow po = piece_row(p.lay_out, r0 + i);
@@ -966,6 +942,27 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_split_kerne
                     *reinterpret_cast<float4*>(dbk + o) = make_float4(acc_b[ft][0], acc_b[ft][1], acc_b[ft][2], acc_b[ft][3]);
                 }
             }
+        }
+        // ---- operands the split cannot carry (+-inf, NaN, magnitudes above the largest bf16: csrc/tall.hip, any_not_finite) leave
+        //      NaN in every sum they enter.  A tile that holds a non-finite sum is NOTED (its number goes into this wavefront's
+        //      slot of p.bad) and computed again from the fp32 operands by the kernel that adds the partials
+        //      (reduce_dw_checked_kernel), which also looks at the weight-gradient sums of phase 2.  Behind the stores, which
+        //      wait for the same sums, and WITHOUT a branch: the tile number is stored every time -- to entry 0, which the count
+        //      overwrites at the end, unless the tile is bad.  (A recomputation inside this loop cost 10 registers and 5 - 10 %;
+        //      a branch in front of the stores still 5 %: it keeps phase 2's operand splits from being scheduled under the last
+        //      MFMAs of phase 1 -- profiles/r6_dense_forms.json.)
+        {
+            f32x4 z = acc_a[0] * 0.f;                             // 0 for a finite sum, NaN for +-inf and NaN
+            z += acc_b[0] * 0.f;
+#pragma unroll
+            for (int ft = 1; ft < NTI; ++ft) {
+                z += acc_a[ft] * 0.f;
+                z += acc_b[ft] * 0.f;
+            }
+            const float c = (z[0] + z[1]) + (z[2] + z[3]);
+            const int bad = __builtin_amdgcn_ballot_w64(c != c) != 0 ? 1 : 0;     // wavefront-uniform
+            n_bad += bad;
+            bad_slot[bad ? (n_bad < kBadSlot ? n_bad : kBadSlot - 1) : 0] = tile;   // (all lanes, one address, one value)
         }
         // ---- phase 2: dW_k[chunk, :] += A_tile^T P + B_tile^T M  (reduction over the 16 rows), term-outer likewise ---------
         Triple4 at[NTI], bt[NTI];
@@ -1004,34 +1001,8 @@ __global__ __launch_bounds__(256, (NTO <= 4 ? 2 : 1)) void dense_bwd_split_kerne
                     acc_w[ft][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(quad(bs[kWi[t]]), quad(mcs[kXi[t]]), acc_w[ft][nt], 0, 0, 0);
                 }
         }
-        // ---- the tile's dA / dB again, from the fp32 operands: fmaf chains over the output features in order (IEEE products and
-        //      sums: inf / -inf / NaN where autograd's matmuls put them), stored over the split form's rows -- same lane, same
-        //      addresses, program order.  Here, where little else is live, with rolled loops and eight sums: no registers.
-        if (redo && r0 + i < p.n_rows) {
-            const float* grow = p.gr + static_cast<int64_t>(r0 + i) * p.ldg;
-            const float* girow = p.gi + static_cast<int64_t>(r0 + i) * p.ldg;
-#pragma unroll 1
-            for (int ft = 0; ft < NTI; ++ft) {
-                const float* wr = p.w + (static_cast<int64_t>(k) * p.f_in + c0 + 16 * ft + 4 * g) * p.f_out;
-                double sa[4] = {0., 0., 0., 0.}, sb[4] = {0., 0., 0., 0.};   // float64 sums, rounded once (csrc/tall.hip)
-#pragma unroll 1
-                for (int f = 0; f < fo; ++f) {
-                    const float x = grow[f], y = girow[f];
-                    const double pp = x + y, mm = y - x;                      // P and M in fp32, as autograd forms them
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const double w = wr[static_cast<int64_t>(r) * p.f_out + f];
-                        sa[r] = fma(pp, w, sa[r]);
-                        sb[r] = fma(mm, w, sb[r]);
-                    }
-                }
-                rows_out(ft, make_float4(static_cast<float>(sa[0]), static_cast<float>(sa[1]), static_cast<float>(sa[2]),
-                                         static_cast<float>(sa[3])),
-                         make_float4(static_cast<float>(sb[0]), static_cast<float>(sb[1]), static_cast<float>(sb[2]),
-                                     static_cast<float>(sb[3])));
-            }
-        }
     }
+    bad_slot[0] = n_bad;                                           // (every wavefront, every launch: the slots are never cleared)
 
     // ---- combine the 4 wavefronts of the block through LDS (the W fragments are dead now), then one partial ----
     __syncthreads();
@@ -1132,6 +1103,80 @@ __global__ __launch_bounds__(256) void reduce_dw_checked_kernel(DenseBwdArgs p, 
             total = static_cast<float>(sum);
         }
         out[e] = total;
+    }
+    // ---- the tiles the product kernel noted (non-finite dA / dB sums): 16 rows x 64 input features of term k again, from the
+    //      fp32 operands -- dA_k[r][c] = sum_f P[r][f] W_k[c][f], dB_k likewise with M -- as fma chains over f in order, summed
+    //      in float64 and rounded once (IEEE products and sums: inf / -inf / NaN where autograd's matmuls put them), stored
+    //      where the product kernel stored them (every replica of a piece layout).  A slot that overflowed (more noted tiles than
+    //      it holds) has ALL tiles of its wavefront redone.  One 4-byte read per slot when nothing is wrong.
+    const int gz = (p.f_in + kChunk - 1) / kChunk;
+    const int n_slots = n_partials * p.k1 * gz * 4;
+    const int n_tiles = (p.n_rows + 15) >> 4;
+    // (the counts of 256 slots are read at once, one per thread: walking them one after the other put 16 dependent load
+    // latencies -- 20 us -- behind a 5 us reduction)
+    __shared__ int counts[256];
+    for (int base = static_cast<int>(blockIdx.x) * 256; base < n_slots; base += static_cast<int>(gridDim.x) * 256) {
+        const int mine = base + tid;
+        const int cnt = mine < n_slots ? p.bad[static_cast<int64_t>(mine) * kBadSlot] : 0;
+        if (!__syncthreads_or(cnt != 0)) continue;                         // nothing noted in these 256 slots (the usual case)
+        counts[tid] = cnt;
+        __syncthreads();
+      for (int s_in = 0; s_in < 256; ++s_in) {
+        const int count = counts[s_in];
+        if (count == 0) continue;                                          // (block-uniform)
+        const int slot = base + s_in;
+        const int32_t* sl = p.bad + static_cast<int64_t>(slot) * kBadSlot;
+        const int wave = slot & 3, z = (slot >> 2) % gz, k = ((slot >> 2) / gz) % p.k1, bx = (slot >> 2) / gz / p.k1;
+        const int c0 = z * kChunk;
+        const bool all = count >= kBadSlot;
+        const int n_list = all ? (n_tiles - (bx * 4 + wave) + n_partials * 4 - 1) / (n_partials * 4) : count;
+        for (int j = 0; j < n_list; ++j) {
+            const int tile = all ? bx * 4 + wave + j * n_partials * 4 : sl[1 + j];
+            const int row = (tile << 4) + (tid >> 4), cq = (tid & 15) * 4;     // 16 rows x 16 column quads
+            if (row >= p.n_rows || c0 + cq >= p.f_in) continue;
+            const float* grow = p.gr + static_cast<int64_t>(row) * p.ldg;
+            const float* girow = p.gi + static_cast<int64_t>(row) * p.ldg;
+            const float* wr = p.w + (static_cast<int64_t>(k) * p.f_in + c0 + cq) * p.f_out;
+            double sa[4] = {0., 0., 0., 0.}, sb[4] = {0., 0., 0., 0.};
+            for (int f = 0; f < p.f_out; ++f) {
+                const float x = grow[f], y = girow[f];
+                const double pp = x + y, mm = y - x;                       // P and M in fp32, as autograd forms them
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double w = wr[static_cast<int64_t>(r) * p.f_out + f];
+                    sa[r] = fma(pp, w, sa[r]);
+                    sb[r] = fma(mm, w, sb[r]);
+                }
+            }
+            const float4 va = make_float4(static_cast<float>(sa[0]), static_cast<float>(sa[1]), static_cast<float>(sa[2]),
+                                          static_cast<float>(sa[3]));
+            const float4 vb = make_float4(static_cast<float>(sb[0]), static_cast<float>(sb[1]), static_cast<float>(sb[2]),
+                                          static_cast<float>(sb[3]));
+            float* dak = p.da[0];
+            float* dbk = p.db[0];
+#pragma unroll
+            for (int q = 1; q < kMaxOrder; ++q)
+                if (q == k) {
+                    dak = p.da[q];
+                    dbk = p.db[q];
+                }
+            if (p.out_on && k == p.k1 - 1) {
+                const PieceRow po = piece_row(p.lay_out, row);
+                const int osh = p.out_shift, omk = (1 << osh) - 1;
+                const int64_t rep_stride = static_cast<int64_t>(p.lay_out.slots_per_blk) * po.slot_stride;
+                const int64_t o = piece_offset(po, (c0 + cq) >> 4, osh, omk) + (cq & 15);
+                for (int rep = 0; rep < p.lay_out.replicas; ++rep) {
+                    *reinterpret_cast<float4*>(dak + o + rep * rep_stride) = va;
+                    *reinterpret_cast<float4*>(dbk + o + rep * rep_stride) = vb;
+                }
+            } else {
+                const int64_t o = static_cast<int64_t>(row) * p.f_in + c0 + cq;
+                *reinterpret_cast<float4*>(dak + o) = va;
+                *reinterpret_cast<float4*>(dbk + o) = vb;
+            }
+        }
+      }
+        __syncthreads();                                                   // (counts[] is rewritten by the next pass)
     }
 }
 
@@ -1333,7 +1378,9 @@ extern "C" int pygsd_magnetic_dense_bwd_workspace(int32_t n_rows, int32_t f_in, 
 {
     PYGSD_REQUIRE(bytes, "pygsd_magnetic_dense_bwd_workspace: null output");
     const size_t per = static_cast<size_t>(k1) * f_in * f_out + f_out;
-    *bytes = per * sizeof(float) * row_blocks(n_rows, 256);
+    const size_t gx = row_blocks(n_rows, 256), gz = (static_cast<size_t>(f_in) + kChunk - 1) / kChunk;
+    // the partials, then the split form's per-wavefront slots of noted tiles (DenseBwdArgs::bad)
+    *bytes = per * sizeof(float) * gx + gx * static_cast<size_t>(k1 > 0 ? k1 : 1) * gz * 4 * kBadSlot * sizeof(int32_t);
     return 0;
 }
 
@@ -1372,6 +1419,8 @@ extern "C" int pygsd_magnetic_dense_bwd_pieces_f32(const float* const* a, const 
         args.a[k] = a[k]; args.b[k] = b[k]; args.da[k] = da[k]; args.db[k] = db[k];
     }
     args.gr = g_real; args.gi = g_imag; args.ldg = ldg; args.w = w; args.partial = static_cast<float*>(workspace);
+    args.bad = reinterpret_cast<int32_t*>(static_cast<float*>(workspace) +
+                                          (static_cast<size_t>(k1) * f_in * f_out + f_out) * row_blocks(n_rows, 256));
     args.n_rows = n_rows; args.f_in = f_in; args.f_out = f_out; args.k1 = k1;
     const bool pieces = last_in || last_out;
     if (pieces) {
