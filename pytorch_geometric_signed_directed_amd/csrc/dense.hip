@@ -306,18 +306,27 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_kernel(DenseFwdArgs p)
             }
             if (k == p.k1 - 1) {
                 const int r0 = tl << 4;
-                if (not_finite(acc_r, acc_i)) exact_rows(tl, acc_r, acc_i);
+                // (decided here, acted on BEHIND the stores, which wait for the same sums: a branch in front of them is a barrier for
+                // the scheduler -- the same lane then stores the tile a second time over the same addresses, in program order)
+                const bool redo = not_finite(acc_r, acc_i);
                 // transposed C/D: lane (i, g), reg r  ->  out[node r0 + i][feature n0 + 16 nt + 4 g + r]
-                if (r0 + i < p.n_rows) {
+                auto store_tile = [&]() {
+                    if (r0 + i < p.n_rows) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int col = n0 + nt * 16 + 4 * g;
-                        const int64_t o = static_cast<int64_t>(r0 + i) * p.f_out + col;
-                        *reinterpret_cast<float4*>(p.out_r + o) = make_float4(acc_r[nt][0] + bv[nt].x, acc_r[nt][1] + bv[nt].y,
-                                                                              acc_r[nt][2] + bv[nt].z, acc_r[nt][3] + bv[nt].w);
-                        *reinterpret_cast<float4*>(p.out_i + o) = make_float4(acc_i[nt][0] + bv[nt].x, acc_i[nt][1] + bv[nt].y,
-                                                                              acc_i[nt][2] + bv[nt].z, acc_i[nt][3] + bv[nt].w);
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const int col = n0 + nt * 16 + 4 * g;
+                            const int64_t o = static_cast<int64_t>(r0 + i) * p.f_out + col;
+                            *reinterpret_cast<float4*>(p.out_r + o) = make_float4(acc_r[nt][0] + bv[nt].x, acc_r[nt][1] + bv[nt].y,
+                                                                                  acc_r[nt][2] + bv[nt].z, acc_r[nt][3] + bv[nt].w);
+                            *reinterpret_cast<float4*>(p.out_i + o) = make_float4(acc_i[nt][0] + bv[nt].x, acc_i[nt][1] + bv[nt].y,
+                                                                                  acc_i[nt][2] + bv[nt].z, acc_i[nt][3] + bv[nt].w);
+                        }
                     }
+                };
+                store_tile();
+                if (redo) {
+                    exact_rows(tl, acc_r, acc_i);
+                    store_tile();
                 }
             }
         };

@@ -409,9 +409,16 @@ __device__ __forceinline__ void split_tile_out(const TallArgs& p, const uint4* f
             for (int u = 0; u < G; ++u) acc[t0 + u] += part[u];
         }
     }
-    if (any_not_finite<NT>(acc)) {
-        exact_tile_store<KB, NT>(p, bias, tile, j, q);
-        return;
+    // Decided here.  Up to 8 output tiles it is acted on BEHIND the stores, which wait for the same sums: a branch in front of them
+    // kept the stores and the next tile's loads from being scheduled under the last MFMAs (8 - 14 % on the C3a products,
+    // profiles/r6j_configs.json).  With 12 / 16 output tiles the store epilogue is long and holding the decision across it costs
+    // more than the branch (K = 64 -> 192: 0.52 against 0.43 ms, profiles/r6_guard_placement.txt): there the tile leaves early.
+    const bool redo = any_not_finite<NT>(acc);
+    if constexpr (NT >= 12) {
+        if (redo) {
+            exact_tile_store<KB, NT>(p, bias, tile, j, q);
+            return;
+        }
     }
     // lane (j, q) holds columns [16 t + 4 q, +4) of row j for every tile t; after the trade lanes j < 8 hold tile 2 m of rows
     // j and j + 8, lanes j >= 8 tile 2 m + 1 of rows j - 8 and j
@@ -442,6 +449,10 @@ __device__ __forceinline__ void split_tile_out(const TallArgs& p, const uint4* f
         float* const hi_b = static_cast<float*>(p.y[2 * m + 1]) + row_b * p.ldy[2 * m + 1] + 4 * q;
         *reinterpret_cast<float4*>(upper ? hi_a : lo_a) = make_float4(va[0], va[1], va[2], va[3]);
         *reinterpret_cast<float4*>(upper ? hi_b : lo_b) = make_float4(vb[0], vb[1], vb[2], vb[3]);
+    }
+    // the tile again over the split form's rows: the same wavefront's later stores to the same addresses
+    if constexpr (NT < 12) {
+        if (redo) exact_tile_store<KB, NT>(p, bias, tile, j, q);
     }
 }
 

@@ -5,7 +5,7 @@
 # (tools/capture_configs.sh); the operator-build probe with its kernel stats and counters; the magnetic configurations; the
 # sharded rehearsals.  Summaries are condensed into profiles/ afterwards, off the box: tools/pmc_summary.py, tools/configs_summary.py.
 set -u
-R=${ROUND:-r5}
+R=${ROUND:-r6}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
@@ -28,9 +28,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 PYGSD_CONFIGS=northstar,C2,C4 timeout 500 python tools/bench_configs.py > $O/${R}_configs_magnetic.log 2>&1; cp $O/configs_partial.json $O/${R}_configs_magnetic.json
 timeout 300 python tools/uncached_step.py > $O/${R}_uncached_step.log 2>&1
-timeout 600 python tools/emulate_sharded.py --world 8 --single-gpu-ms 6.92 --shapes grid:0.4,0.6:2 grid:2:2 grid:1:1 rows:1:1 --out $O/${R}_emulated_sharded_w8.json > $O/${R}_emulated_sharded_w8.log 2>&1
-PYGSD_SHARD_MERGE_ON_READ=0 PYGSD_SHARD_PACKED_BACKWARD=0 timeout 300 python tools/emulate_sharded.py --world 8 --single-gpu-ms 6.92 --shapes grid:0.4,0.6:2 grid:2:2 --out $O/${R}_emulated_sharded_w8_no_shortcuts.json > $O/${R}_emulated_sharded_w8_no_shortcuts.log 2>&1
-timeout 400 python tools/emulate_sharded.py --world 4 --single-gpu-ms 6.92 --shapes grid:0.4,0.6:2 grid:2:2 rows:1:1 --out $O/${R}_emulated_sharded_w4.json > $O/${R}_emulated_sharded_w4.log 2>&1
+timeout 600 python tools/emulate_sharded.py --world 8 --single-gpu-ms 6.74 --shapes grid:0.4,0.6:2 grid:2:2 grid:1:1 rows:1:1 --out $O/${R}_emulated_sharded_w8.json > $O/${R}_emulated_sharded_w8.log 2>&1
+PYGSD_SHARD_MERGE_ON_READ=0 PYGSD_SHARD_PACKED_BACKWARD=0 timeout 300 python tools/emulate_sharded.py --world 8 --single-gpu-ms 6.74 --shapes grid:0.4,0.6:2 grid:2:2 --out $O/${R}_emulated_sharded_w8_no_shortcuts.json > $O/${R}_emulated_sharded_w8_no_shortcuts.log 2>&1
+timeout 400 python tools/emulate_sharded.py --world 4 --single-gpu-ms 6.74 --shapes grid:0.4,0.6:2 grid:2:2 rows:1:1 --out $O/${R}_emulated_sharded_w4.json > $O/${R}_emulated_sharded_w4.log 2>&1
 timeout 400 python tools/emulate_sharded.py --world 8 --signed --hidden 128 --K 2 --single-gpu-ms 30.0 --shapes grid:0.4,0.6:2 grid:2:2 --out $O/${R}_emulated_sharded_c4.json > $O/${R}_emulated_sharded_c4.log 2>&1
 grep -E "^northstar|^C2|^C4" $O/${R}_configs_magnetic.log | cut -c1-300
 cat $O/${R}_build_probe.log | cut -c1-160
