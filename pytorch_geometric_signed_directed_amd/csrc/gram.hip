@@ -622,13 +622,13 @@ unsigned gram_blocks(int64_t n_rows, int rows_per_tile, int64_t n_elem)
     return budget_blocks(static_cast<unsigned>(b < 1 ? 1 : b), n_elem);
 }
 
-// a width (multiple of 16) as chunks of 8 / 4 / 2 / 1 tiles, none above `cap`
+// a width (multiple of 16) as chunks of 12 / 8 / 4 / 2 / 1 tiles, none above `cap`
 int cut_chunks(const void* base, int64_t ld, int width, size_t esz, int at, int cap, GramChunk* out, int have)
 {
     int col = 0;
     while (col < width) {
         const int left = (width - col) / 16;
-        const int tiles = (left >= 8 && cap >= 8) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
+        const int tiles = (left >= 12 && cap >= 12) ? 12 : (left >= 8 && cap >= 8) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
         if (have >= kMaxChunks) return -1;
         out[have++] = GramChunk{static_cast<const unsigned char*>(base) + static_cast<size_t>(col) * esz, ld, tiles, at + col,
                                 0, 0, tiles};
@@ -694,6 +694,9 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
     const size_t esz = dtype == 1 ? 2 : 4;
     const int vec = dtype == 1 ? 8 : 4;
     GramArgs a{};
+    // widest G chunk: 8 tiles, bf16 12 (the one-wavefront-per-SIMD instance; PYGSD_GRAM_WIDE=0 keeps 8 -- measurement / A-B)
+    const char* wide_env = getenv("PYGSD_GRAM_WIDE");
+    const int g_cap = (dtype == 1 && !(wide_env && wide_env[0] == '0')) ? 12 : 8;
     int g_whole[kMaxChunks] = {};
     int nx = 0, ng = 0, k_total = 0, f_total = 0;
     for (int s = 0; s < n_x; ++s) {
@@ -713,12 +716,12 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
                       "pygsd_tall_gram: G segment %d null, not 16-byte aligned, or row stride not a multiple of 16 bytes >= its "
                       "width", s);
         const int before = ng;
-        ng = cut_chunks(gs[s], ldg[s], g_widths[s], esz, f_total, 8, a.g, ng);
+        ng = cut_chunks(gs[s], ldg[s], g_widths[s], esz, f_total, g_cap, a.g, ng);
         PYGSD_REQUIRE(ng > 0, "pygsd_tall_gram: more than %d column chunks in G", kMaxChunks);
         for (int c = before; c < ng; ++c) g_whole[c] = (ng - before == 1) ? 1 : 0;
         f_total += g_widths[s];
     }
-    ng = join_parts(a.g, g_whole, ng, dtype == 1 ? 12 : 8, esz);
+    ng = join_parts(a.g, g_whole, ng, g_cap, esz);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n_elem = static_cast<int64_t>(k_total) * f_total;
     if (n_rows == 0) {
