@@ -29,19 +29,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kMaxChunks = 16;
+constexpr int kNoPart = 1 << 20;      // GramChunk::c1 / c2 of a chunk without that part
 
-// A chunk is up to three PARTS of equal width (round 6): column segments that are neighbours in dW but separate matrices in
-// memory -- [g | g_a] of SGCNConv, [dx0 | dP_1 | dP_2] of the inception block -- ride in ONE chunk, so that the other operand's
-// rows are read once for all of them instead of once per segment (measured before: 1.38x / 1.27x the algorithmic bytes at C3a /
-// C5b, profiles/r5v_configs.json).
+// A chunk is up to three PARTS (round 6): column segments that are neighbours in dW but separate matrices in memory -- [g | g_a] of
+// SGCNConv, [dx0 | dP] of the inception block (64 + 128 columns, different row strides) -- ride in ONE chunk, so that the other
+// operand's rows are read once for all of them instead of once per segment (measured before: 1.38x / 1.27x the algorithmic bytes
+// at C3a / C5b, profiles/r5v_configs.json).
 struct GramChunk {
     const void* p;     // first element of the chunk (of its first part) in row 0
-    int64_t ld;        // row stride in elements
+    int64_t ld;        // row stride in elements (of the first part)
     int32_t tiles;     // 16-column tiles: 1, 2, 4 (X and G), 8 or 12 (G)
     int32_t at;        // first row (X chunks) / column (G chunks) of this chunk in dW
-    int64_t d1, d2;    // parts 1 and 2 (part_tiles < tiles): ELEMENT offset of their first column in row 0 from `p`, for columns
-                       // [part_tiles * 16, ...) and [2 part_tiles * 16, ...); all parts share the row stride
-    int32_t part_tiles;   // tiles per part; == tiles for a chunk of one part
+    // parts 1 and 2 start at COLUMN c1 / c2 of the chunk (a value past the chunk's width: no such part); their first element in
+    // row 0 sits d1 / d2 ELEMENTS from `p` and their row stride is ld + dl1 / ld + dl2.  (Offsets and differences, not pointers
+    // and strides: a per-lane choice among struct fields is compiled into an indexed read of a private copy of the struct.)
+    int64_t d1, d2, dl1, dl2;
+    int32_t c1, c2;
 };
 
 struct GramArgs {
@@ -65,18 +68,18 @@ template <int NT>
 __device__ __forceinline__ void load_rows_f32(const GramChunk& c, int64_t r0, int64_t n_rows, int lane, float4 (&v)[NT])
 {
     constexpr int LPR = NT * 4;            // 16-byte pieces (lanes) per row
-    const int part_cols = c.part_tiles * 16;
     const float* base = static_cast<const float*>(c.p);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int piece = t * 64 + lane;                      // piece-major over the 16 x LPR pieces of the tile
         const int row = piece / LPR;
         const int col = (piece % LPR) * 4;
-        // (chunks of two parts only: NT == 8.  Offsets, not a choice of pointers: a per-lane choice among the struct's pointer
-        // fields is compiled into an indexed read of a private copy of the struct -- 136 bytes of scratch per lane)
-        const int64_t part = (col >= part_cols) ? c.d1 - part_cols : 0;
+        int64_t part = (col >= c.c1) ? c.d1 - c.c1 : 0;       // (chunks of several parts only)
+        int64_t ld = c.ld + ((col >= c.c1) ? c.dl1 : 0);
+        part = (col >= c.c2) ? c.d2 - c.c2 : part;
+        ld = (col >= c.c2) ? c.ld + c.dl2 : ld;
         v[t] = make_float4(0.f, 0.f, 0.f, 0.f);               // rows past the end contribute nothing
-        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const float4*>(base + (r0 + row) * c.ld + col + part);
+        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const float4*>(base + (r0 + row) * ld + col + part);
     }
 }
 
@@ -180,21 +183,26 @@ __global__ __launch_bounds__(256, 2) void tall_gram_f32_kernel(GramArgs p)
 
 // ---- bf16 storage, fp32 accumulation ------------------------------------------------------------
 // rows of one 32-row tile -> image [tile][32 rows][16 cols]: NT 16-byte loads per lane, a row's 16 NT columns on 2 NT lanes
-template <int NT>
+// DL: parts may have row strides of their own (the one-wavefront-per-SIMD instance only: the stride select costs the two-wave
+// instance the registers it does not have -- 3 spills)
+template <int NT, bool DL>
 __device__ __forceinline__ void load_rows_bf16(const GramChunk& c, int64_t r0, int64_t n_rows, int lane, uint4 (&v)[NT])
 {
     constexpr int LPR = NT * 2;            // 16-byte pieces (lanes) per row
-    const int part_p8 = c.part_tiles * 2;  // 8-column pieces per part
     const uint16_t* base = static_cast<const uint16_t*>(c.p);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int piece = t * 64 + lane;                      // piece-major over the 32 x LPR pieces of the tile
-        const int row = piece / LPR, c8 = piece % LPR;        // 8-column piece c8 of the row
-        // (chunks of several parts only: NT == 8 / 12; offsets, not a choice of pointers -- see load_rows_f32)
-        int64_t part = (c8 >= part_p8) ? c.d1 - part_p8 * 8 : 0;
-        part = (c8 >= 2 * part_p8) ? c.d2 - 2 * part_p8 * 8 : part;
+        const int row = piece / LPR, col = (piece % LPR) * 8; // 8-column piece of the row
+        int64_t part = (col >= c.c1) ? c.d1 - c.c1 : 0;       // (chunks of several parts only; see GramChunk)
+        part = (col >= c.c2) ? c.d2 - c.c2 : part;
+        int64_t ld = c.ld;
+        if constexpr (DL) {
+            ld = c.ld + ((col >= c.c1) ? c.dl1 : 0);
+            ld = (col >= c.c2) ? c.ld + c.dl2 : ld;
+        }
         v[t] = make_uint4(0u, 0u, 0u, 0u);
-        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const uint4*>(base + (r0 + row) * c.ld + c8 * 8 + part);
+        if (r0 + row < n_rows) v[t] = *reinterpret_cast<const uint4*>(base + (r0 + row) * ld + col + part);
     }
 }
 
@@ -235,7 +243,7 @@ __device__ __forceinline__ void column_fragments(uint32_t first_block_addr, int 
     }
 }
 
-template <int NTK, int NTF>
+template <int NTK, int NTF, bool WIDE = false>
 __device__ __forceinline__ void gram_block_bf16(const GramArgs& p, const GramChunk& cx, const GramChunk& cg, unsigned char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
@@ -253,15 +261,15 @@ __device__ __forceinline__ void gram_block_bf16(const GramArgs& p, const GramChu
     int64_t tile = static_cast<int64_t>(blockIdx.y) * 4 + wave;
     uint4 rx[NTK], rg[NTF];                       // the next tile's rows, in flight while the current one is multiplied
     if (tile < n_tiles) {
-        load_rows_bf16<NTK>(cx, tile << 5, p.n_rows, lane, rx);
-        load_rows_bf16<NTF>(cg, tile << 5, p.n_rows, lane, rg);
+        load_rows_bf16<NTK, false>(cx, tile << 5, p.n_rows, lane, rx);
+        load_rows_bf16<NTF, WIDE>(cg, tile << 5, p.n_rows, lane, rg);
     }
     for (; tile < n_tiles; tile += stride) {
         store_rows_bf16<NTK>(rx, lane, imx);
         store_rows_bf16<NTF>(rg, lane, img);
         if (tile + stride < n_tiles) {
-            load_rows_bf16<NTK>(cx, (tile + stride) << 5, p.n_rows, lane, rx);
-            load_rows_bf16<NTF>(cg, (tile + stride) << 5, p.n_rows, lane, rg);
+            load_rows_bf16<NTK, false>(cx, (tile + stride) << 5, p.n_rows, lane, rx);
+            load_rows_bf16<NTF, WIDE>(cg, (tile + stride) << 5, p.n_rows, lane, rg);
         }
         wave_sync();
         bf16x8 xa[NTK];
@@ -308,14 +316,14 @@ __device__ __forceinline__ void gram_pick_bf16(const GramArgs& p, const GramChun
 {
     if constexpr (WIDE) {
         if (cg.tiles == 12) {
-            gram_block_bf16<NTK, 12>(p, cx, cg, lds);
+            gram_block_bf16<NTK, 12, true>(p, cx, cg, lds);
             return;
         }
     }
-    if (cg.tiles == 8) gram_block_bf16<NTK, 8>(p, cx, cg, lds);
-    else if (cg.tiles == 4) gram_block_bf16<NTK, 4>(p, cx, cg, lds);
-    else if (cg.tiles == 2) gram_block_bf16<NTK, 2>(p, cx, cg, lds);
-    else gram_block_bf16<NTK, 1>(p, cx, cg, lds);
+    if (cg.tiles == 8) gram_block_bf16<NTK, 8, WIDE>(p, cx, cg, lds);
+    else if (cg.tiles == 4) gram_block_bf16<NTK, 4, WIDE>(p, cx, cg, lds);
+    else if (cg.tiles == 2) gram_block_bf16<NTK, 2, WIDE>(p, cx, cg, lds);
+    else gram_block_bf16<NTK, 1, WIDE>(p, cx, cg, lds);
 }
 
 __global__ __launch_bounds__(256, 2) void tall_gram_bf16_kernel(GramArgs p)
@@ -631,39 +639,51 @@ int cut_chunks(const void* base, int64_t ld, int width, size_t esz, int at, int 
         const int tiles = (left >= 12 && cap >= 12) ? 12 : (left >= 8 && cap >= 8) ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
         if (have >= kMaxChunks) return -1;
         out[have++] = GramChunk{static_cast<const unsigned char*>(base) + static_cast<size_t>(col) * esz, ld, tiles, at + col,
-                                0, 0, tiles};
+                                0, 0, 0, 0, kNoPart, kNoPart};
         col += tiles * 16;
     }
     return have;
 }
 
-// G chunks that are whole segments of one width and one row stride, neighbours in dW, become PARTS of one chunk: two (fp32:
-// <= 8 tiles) or up to three (bf16: <= 12 tiles).  `whole[c]` != 0: chunk c is all of its segment.  Returns the new chunk count.
-int join_parts(GramChunk* g, const int* whole, int n, int max_tiles, size_t esz)
+// G chunks that are whole segments and neighbours in dW become PARTS of one chunk: up to three of them, up to `max_tiles` tiles
+// together (fp32: 8, bf16: 12), in one of the tile counts the kernels are instantiated for.  `whole[c]` != 0: chunk c is all of
+// its segment.  Returns the new chunk count.
+int join_parts(GramChunk* g, const int* whole, int n, int max_tiles, size_t esz, bool strides_free)
 {
+    auto instance = [](int t) { return t == 1 || t == 2 || t == 4 || t == 8 || t == 12; };
     int out = 0;
     for (int c = 0; c < n;) {
         GramChunk cur = g[c];
-        int parts = 1;
-        const int t = cur.tiles;
-        if (whole[c] && (t == 1 || t == 2 || t == 4)) {
-            while (c + parts < n && parts < 3 && whole[c + parts] && g[c + parts].tiles == t && g[c + parts].ld == cur.ld &&
-                   g[c + parts].at == cur.at + parts * t * 16) {
-                const int joined = (parts + 1) * t;
-                if (joined > max_tiles || !(joined == 2 || joined == 4 || joined == 8 || joined == 12)) break;
-                ++parts;
+        int parts = 1, tiles = cur.tiles, best_parts = 1, best_tiles = cur.tiles;
+        while (whole[c] && c + parts < n && parts < 3 && whole[c + parts] && g[c + parts].at == cur.at + tiles * 16 &&
+               tiles + g[c + parts].tiles <= max_tiles) {
+            tiles += g[c + parts].tiles;
+            ++parts;
+            bool same_ld = true;
+            for (int q = 1; q < parts; ++q) same_ld = same_ld && g[c + q].ld == cur.ld;
+            // bf16: parts with row strides of their own only in a 12-tile chunk (the wide instance reads them)
+            if (instance(tiles) && (same_ld || strides_free || tiles == 12)) {
+                best_parts = parts;
+                best_tiles = tiles;
             }
         }
         auto offset = [&](const GramChunk& other) {
             return (static_cast<const unsigned char*>(other.p) - static_cast<const unsigned char*>(cur.p)) /
                    static_cast<int64_t>(esz);
         };
-        if (parts >= 2) cur.d1 = offset(g[c + 1]);
-        if (parts == 3) cur.d2 = offset(g[c + 2]);
-        cur.part_tiles = t;
-        cur.tiles = parts * t;
+        if (best_parts >= 2) {
+            cur.c1 = cur.tiles * 16;
+            cur.d1 = offset(g[c + 1]);
+            cur.dl1 = g[c + 1].ld - cur.ld;
+        }
+        if (best_parts == 3) {
+            cur.c2 = cur.c1 + g[c + 1].tiles * 16;
+            cur.d2 = offset(g[c + 2]);
+            cur.dl2 = g[c + 2].ld - cur.ld;
+        }
+        cur.tiles = best_tiles;
         g[out++] = cur;
-        c += parts;
+        c += best_parts;
     }
     return out;
 }
@@ -721,7 +741,7 @@ extern "C" int pygsd_tall_gram(const void* const* xs, const int64_t* ldx, const 
         for (int c = before; c < ng; ++c) g_whole[c] = (ng - before == 1) ? 1 : 0;
         f_total += g_widths[s];
     }
-    ng = join_parts(a.g, g_whole, ng, g_cap, esz);
+    ng = join_parts(a.g, g_whole, ng, g_cap, esz, dtype == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n_elem = static_cast<int64_t>(k_total) * f_total;
     if (n_rows == 0) {

@@ -897,6 +897,110 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_bf16_kernel(Spmm
     }
 }
 
+// ---- two rows per wavefront (round 6 experiment; PYGSD_BF16_PAIR=1) -----------------------------------------------------------
+// F = 64 bf16: a gathered row is 8 lanes x 16 bytes, so a wavefront's 64 lanes cover 8 entries per pass and 32 per unrolled
+// iteration of spmm_vec_bf16_kernel<8> -- a 26-entry row (C5b's average) leaves 6 of 32 slots idle and pays the whole prologue /
+// epilogue for itself.  Here each HALF of the wavefront owns a row: 4 entries per pass, 16 per iteration, the CSR entries of
+// both rows fetched by one load, one halving stage fewer in the reduce-scatter (bit 5 of the lane separates the rows), two
+// columns per lane stored as one dword.  Control flow is wavefront-uniform: both halves run max(len_0, len_1) worth of passes
+// with per-lane predicates.
+__global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_bf16_pair_kernel(SpmmBf16Args p)
+{
+    constexpr int UNROLL = 4;
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int pair = static_cast<int>(blockIdx.x) * kWavesPerBlock + static_cast<int>(threadIdx.x >> 6);
+    const int row = 2 * pair + half;
+    if (2 * pair >= p.n_rows) return;
+    const bool live = row < p.n_rows;
+    const int sub = hl >> 3;                                   // which of the half's 4 concurrent entries
+    const int fl = (hl & 7) * 8;                               // first of this lane's 8 columns
+    const int beg = live ? p.rowptr[row] : 0;
+    const int end = live ? p.rowptr[row + 1] : 0;
+    const int len = end - beg;
+    const int other = __shfl_xor(len, 32);
+    const int longest = __builtin_amdgcn_readfirstlane(len > other ? len : other);
+    f32x2_t acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    const uint16_t* xb = p.x + fl;
+    for (int off = 0; off < longest; off += 32) {
+        const int cnt = (len - off) < 32 ? (len - off) : 32;               // this half's entries of the pass (may be <= 0)
+        const int most = (longest - off) < 32 ? (longest - off) : 32;      // wavefront-uniform
+        int c = 0;
+        float w = 0.f;
+        if (hl < cnt) {
+            c = __builtin_nontemporal_load(p.col + beg + off + hl);
+            w = p.val ? __builtin_nontemporal_load(p.val + beg + off + hl) : 1.f;
+        }
+        for (int u = 0; u < most; u += 4 * UNROLL) {
+            uint4 g[UNROLL];
+            float sc[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const int idx = u + k * 4 + sub;
+                const bool ok = idx < cnt;
+                const int src = (lane & 32) | (idx & 31);                   // the entry sits on a lane of this half
+                const int cj = __shfl(c, src);
+                const float t = __shfl(w, src);
+                sc[k] = ok ? t : 0.f;
+                g[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) g[k] = *reinterpret_cast<const uint4*>(xb + static_cast<int64_t>(cj) * p.ldx);
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const f32x2_t s2 = {sc[k], sc[k]};
+                const uint32_t q[4] = {g[k].x, g[k].y, g[k].z, g[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2_t v = {__uint_as_float(q[j] << 16), __uint_as_float(q[j] & 0xffff0000u)};
+                    acc[j] = __builtin_elementwise_fma(s2, v, acc[j]);
+                }
+            }
+        }
+    }
+    // reduce-scatter over the half's 4 lane groups (lane bits 3 and 4): two columns per lane remain
+    const bool b3 = (lane & 8) != 0;
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float lo0 = acc[j].x, lo1 = acc[j].y, hi0 = acc[j + 2].x, hi1 = acc[j + 2].y;
+        r[2 * j] = add_ror8(b3 ? hi0 : lo0, b3 ? lo0 : hi0);
+        r[2 * j + 1] = add_ror8(b3 ? hi1 : lo1, b3 ? lo1 : hi1);
+    }
+    float v0 = add_swap16(r[0], r[2]), v1 = add_swap16(r[1], r[3]);
+    if (!live) return;
+    const int col = fl + ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2;
+    const float d = p.mean ? static_cast<float>(len > 1 ? len : 1) : 1.f;
+    v0 = (p.mean ? v0 / d : v0) * p.alpha;
+    v1 = (p.mean ? v1 / d : v1) * p.alpha;
+    if (p.acc_f32) {
+        const float* zf = reinterpret_cast<const float*>(p.z);
+        if (zf) {
+            const float2 zz = *reinterpret_cast<const float2*>(zf + static_cast<int64_t>(row) * p.ldz + col);
+            v0 = fmaf(p.beta, zz.x, v0);
+            v1 = fmaf(p.beta, zz.y, v1);
+        }
+        *reinterpret_cast<float2*>(reinterpret_cast<float*>(p.y) + static_cast<int64_t>(row) * p.ldy + col) = make_float2(v0, v1);
+    } else {
+        float z0 = 0.f, z1 = 0.f;
+        if (p.z) {
+            const uint32_t zz = *reinterpret_cast<const uint32_t*>(p.z + static_cast<int64_t>(row) * p.ldz + col);
+            z0 = __uint_as_float(zz << 16);
+            z1 = __uint_as_float(zz & 0xffff0000u);
+        }
+        *reinterpret_cast<uint32_t*>(p.y + static_cast<int64_t>(row) * p.ldy + col) =
+            pack_bf16x2(fmaf(p.beta, z0, v0), fmaf(p.beta, z1, v1));
+    }
+}
+
+// 0 = one row per wavefront (default), 1 = two rows per wavefront at F = 64 (PYGSD_BF16_PAIR; measurement / A-B)
+int bf16_pair_mode()
+{
+    static const int mode = [] {
+        const char* e = getenv("PYGSD_BF16_PAIR");
+        return (e && e[0] == '1') ? 1 : 0;
+    }();
+    return mode;
+}
+
 int launch_spmm_bf16(const SpmmBf16Args& a, hipStream_t stream)
 {
     const dim3 block(kWavesPerBlock * 64);
@@ -907,6 +1011,9 @@ int launch_spmm_bf16(const SpmmBf16Args& a, hipStream_t stream)
         hipLaunchKernelGGL(spmm_vec_bf16_kernel<2>, dim3(gx), block, 0, stream, a);
     } else if (oct <= 4) {
         hipLaunchKernelGGL(spmm_vec_bf16_kernel<4>, dim3(gx), block, 0, stream, a);
+    } else if (oct == 8 && bf16_pair_mode() == 1) {
+        const unsigned gp = ((static_cast<unsigned>(a.n_rows) + 1u) / 2u + kWavesPerBlock - 1) / kWavesPerBlock;
+        hipLaunchKernelGGL(spmm_vec_bf16_pair_kernel, dim3(gp), block, 0, stream, a);
     } else if (oct <= 8) {
         hipLaunchKernelGGL(spmm_vec_bf16_kernel<8>, dim3(gx), block, 0, stream, a);
     } else if (oct <= 16) {
