@@ -221,24 +221,34 @@ def _is_owned(t: torch.Tensor) -> bool:
     return ref is not None and ref() is t
 
 
+def _fingerprint(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """int64[1] fingerprint of a DEVICE tensor (queued, no host read); None for tensors that are not checked (host tensors:
+    the package computes on the device only).  The one place the tests replace to exercise the logic below without a GPU."""
+    if not t.is_cuda:
+        return None
+    from . import _cabi
+    return _cabi.fingerprint(t)
+
+
 def check_unchanged(*tensors: Optional[torch.Tensor]) -> int:
     """Fingerprint the given device tensors and compare with the fingerprints of the same objects at their last check; a tensor
     whose CONTENTS changed while identity, version and storage did not is forgotten by every memo in the process.  One device ->
     host read for all tensors together (none on a first sighting).  Returns the number of tensors found changed."""
     if not (_verify and _enabled):
         return 0
-    from . import _cabi
     done = getattr(_scope, "done", None)                     # tensors a surrounding `verified` scope has checked already
     seen, pairs = set(), []
     for t in tensors:
-        if t is None or not isinstance(t, torch.Tensor) or not t.is_cuda or t.numel() == 0 or id(t) in seen or _is_owned(t):
+        if t is None or not isinstance(t, torch.Tensor) or t.numel() == 0 or id(t) in seen or _is_owned(t):
             continue
         if done is not None:
             if id(t) in done:
                 continue
             done.add(id(t))
         seen.add(id(t))
-        now = _cabi.fingerprint(t)
+        now = _fingerprint(t)
+        if now is None:
+            continue
         before = _FINGERPRINTS.get((t,), "fingerprint")
         if before is None:
             _FINGERPRINTS.put((t,), "fingerprint", now)      # first sighting, or a new version / storage: nothing to compare

@@ -149,3 +149,75 @@ def test_prune_during_get_keeps_the_lru_consistent():
     finally:
         memo._stamp = orig_stamp
     assert m._items[-1].value == 3
+
+
+def _host_fingerprints(monkeypatch):
+    """Strict mode without a GPU: the device fingerprint replaced by a checksum of the host bytes; counts its calls."""
+    calls = []
+
+    def fp(t):
+        calls.append(id(t))
+        data = t.detach().contiguous().view(torch.uint8).reshape(-1).to(torch.int64)
+        weights = torch.arange(1, data.numel() + 1, dtype=torch.int64)
+        return (data * weights).sum().reshape(1)
+    monkeypatch.setattr(memo, "_fingerprint", fp)
+    return calls
+
+
+def test_strict_mode_sees_writes_behind_the_version_counter(monkeypatch):
+    """memo.set_verify(True): a hit is a hit only while the key tensors' CONTENTS are what they were -- a `.data` write (same
+    object, same version, same storage) drops every entry derived from that tensor, in every memo; unchanged tensors keep
+    hitting; owned (derived) tensors are never fingerprinted; a `verified` scope checks each tensor once."""
+    calls = _host_fingerprints(monkeypatch)
+    prev = memo.set_verify(True)
+    try:
+        a, b = torch.arange(12.0), torch.arange(5.0)
+        m1, m2, loose = TensorMemo(4), TensorMemo(4), TensorMemo(4, verify=False)
+        m1.put((a, b), "k", "from a and b")
+        m2.put((a,), "k", "from a")
+        m2.put((b,), "k", "from b")
+        loose.put((a,), "k", "unverified")
+        assert m1.get((a, b), "k") == "from a and b" and m2.get((a,), "k") == "from a"
+        version = a._version
+        a.data[3] = -1.0                                  # behind the version counter
+        assert a._version == version
+        assert m1.get((a, b), "k") is None                # seen: dropped ...
+        assert m2.get((a,), "k") is None                  # ... in every memo that held something derived from `a`
+        assert m2.get((b,), "k") == "from b"              # `b` did not change
+        assert loose.get((a,), "k") is None               # (forgetting is by tensor, whatever the memo's own switch)
+        m2.put((a,), "k", "from the new a")
+        assert m2.get((a,), "k") == "from the new a"      # the new contents are the reference from now on
+        # a derived tensor the package owns is never fingerprinted
+        d = torch.zeros(7)
+        memo.own(d)
+        m1.put((d,), "k", "derived")
+        before = len(calls)
+        assert m1.get((d,), "k") == "derived" and len(calls) == before
+        # one check per tensor and scope, however many lookups
+        before = len(calls)
+        with memo.verified(a, b):
+            n_entry = len(calls) - before
+            for _ in range(5):
+                assert m2.get((a,), "k") == "from the new a" and m2.get((b,), "k") == "from b"
+            assert len(calls) - before == n_entry == 2
+            c = torch.ones(3)
+            m2.put((c,), "k", "from c")                   # a tensor the scope was not opened with: checked once, inside
+            mid = len(calls)
+            m2.get((c,), "k"); m2.get((c,), "k")
+            assert len(calls) == mid
+        m2.get((a,), "k")
+        assert len(calls) > before + 3                    # outside the scope every verified hit checks again
+    finally:
+        memo.set_verify(prev)
+        memo.clear_all()
+
+
+def test_default_mode_does_not_fingerprint(monkeypatch):
+    calls = _host_fingerprints(monkeypatch)
+    assert not memo.verify()
+    a = torch.arange(6.0)
+    m = TensorMemo(2)
+    m.put((a,), 0, "v")
+    a.data[0] = 9.0
+    assert m.get((a,), 0) == "v" and calls == []          # the documented default: identity + version + storage only
+    memo.clear_all()
