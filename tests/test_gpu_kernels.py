@@ -1931,3 +1931,38 @@ def test_content_fingerprint_sees_any_change_and_nothing_else():
     assert fp(torch.empty(0, device=dev())) == 0
     strided = base.t()                                             # non-contiguous view: fingerprinted through a copy
     assert fp(strided) == fp(strided.contiguous())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_generic_gemm_random_shapes_and_strides(dtype):
+    """pygsd_gemm_f32 / pygsd_gemm_bf16 over 60 random problems: odd sizes (1 .. 300), A and / or B as transposed views or column
+    slices of wider matrices, bias on / off, an addend (accumulate) on / off, reductions long enough to be split -- against
+    float64 on the same (already rounded) operands."""
+    from pytorch_geometric_signed_directed_amd.dense import gemm, gemm_bf16
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(2024)
+    for case in range(60):
+        m, n = (int(torch.randint(1, 300, (1,), generator=g)) for _ in range(2))
+        k = int(torch.randint(1, 300, (1,), generator=g)) if case % 6 else int(torch.randint(5000, 9000, (1,), generator=g))
+        ta, tb, sliced = (bool(torch.randint(0, 2, (1,), generator=g)) for _ in range(3))
+        pad = 3 if sliced else 0
+        a_store = torch.randn((k, m + pad) if ta else (m, k + pad), generator=g).to(td).to(dev())
+        b_store = torch.randn((n, k + pad) if tb else (k, n + pad), generator=g).to(td).to(dev())
+        a = (a_store[:, :m].t() if ta else a_store[:, :k])
+        b = (b_store[:, :k].t() if tb else b_store[:, :n])
+        bias = torch.randn(n, generator=g).to(td).to(dev()) if case % 2 else None
+        z = torch.randn(m, n, generator=g).to(dev()) if case % 3 == 0 else None
+        want = a.double() @ b.double()
+        if bias is not None:
+            want = want + bias.double()
+        if z is not None:
+            want = want + z.double()
+        if dtype == "f32":
+            out = None if z is None else z.clone()
+            got = gemm(a, b, bias=bias, out=out, accumulate=z is not None)
+        else:
+            got = gemm_bf16(a, b, bias=bias, addend=z, out_dtype=torch.float32)
+        scale = float(a.double().abs().max() * b.double().abs().max()) * k ** 0.5 + 1.0
+        err = float((got.double() - want).abs().max()) / scale
+        assert got.shape == (m, n) and err <= 2e-6, (case, m, n, k, ta, tb, sliced, err)
