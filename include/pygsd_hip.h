@@ -518,7 +518,8 @@ int pygsd_weighted_sum_f32(const float* const* xs, const float* weights, int32_t
 /* out[j] = <g, xs[j]>, j < k (<= 8): the gradients of SIMPA's hop weights (autograd's reduction of g * cur_h for
  * SIMPA.py:77-93), g read ONCE for all k products.  g: [n_rows, n_cols] with row stride ldg (a column block of the
  * upstream gradient of the concatenated output); xs: HOST array of device pointers to contiguous [n_rows, n_cols]
- * matrices; out: k floats on the device; workspace >= 32 KiB.  fp32 accumulation in a fixed order (deterministic). */
+ * matrices; out: k floats on the device; workspace >= 32 KiB (64 KiB lets k > 4 use the full grid), 8-byte aligned.  Products and sums in float64 in a fixed
+ * order, rounded to fp32 once (deterministic; the correctly rounded dot product of the fp32 operands). */
 int pygsd_dots_f32(const float* g, int64_t ldg, const float* const* xs, int32_t k, int64_t n_rows, int32_t n_cols,
                    float* out, void* workspace, size_t workspace_bytes, void* stream);
 /* ---------------------------------------------------------------------------------------------

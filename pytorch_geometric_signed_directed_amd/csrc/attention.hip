@@ -75,28 +75,38 @@ __global__ __launch_bounds__(256) void gat_alpha_bwd_kernel(const int32_t* __res
     if (skip > 0 && end - beg > skip) return;
     const float* gi = g + static_cast<int64_t>(row) * ldg;
     const float* oi = out + static_cast<int64_t>(row) * ldo;
-    float rd = 0.f;
-    for (int f = lane; f < n_feat; f += 64) rd = fmaf(gi[f], oi[f], rd);
-    rd = wave_sum(rd);                                   // <g_i, out_i>
-    const float ad = a_dst[row];
+    // ds_e = alpha_e (d alpha_e - sum_k alpha_k d alpha_k) slope'(s_e), with d alpha_e = <g_i, h_e>, in the reference's own form
+    // (autograd of torch_geometric.utils.softmax): the row's sum is taken over the SAME d alpha values the entries use, so a row
+    // with one entry gets exactly zero and the row sums of ds (the gradient of a_dst) cancel as the reference's do.  Until round 6
+    // the sum was <g_i, out_i> -- equal in exact arithmetic, but out_i carries its own rounding: 4 x the reference's error in the
+    // attention vectors' gradients on rows of 1 - 2 entries (tests/test_gpu_fuzz.py).  Pass 1 parks d alpha_e in ds_coo (every
+    // slot is read back by the lane that wrote it), pass 2 finishes; `out` is no longer read by this kernel.
+    (void)oi;
     const int t = lane & 15, team = lane >> 4;
+    const float ad = a_dst[row];
+    float sd = 0.f;
     for (int e0 = beg; e0 < end; e0 += 4) {
         const int e = e0 + team;
         float dot = 0.f;
-        int cj = 0;
         if (e < end) {
-            cj = col[e];
-            const float* hj = h + static_cast<int64_t>(cj) * ldh;
+            const float* hj = h + static_cast<int64_t>(col[e]) * ldh;
             for (int f = t; f < n_feat; f += 16) dot = fmaf(gi[f], hj[f], dot);
         }
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) dot += __shfl_xor(dot, off);
         if (e < end && t == 0) {
+            ds_coo[perm[e]] = dot;
+            sd = fmaf(alpha[e], dot, sd);
+        }
+    }
+    sd = wave_sum(sd);
+    for (int e0 = beg; e0 < end; e0 += 4) {
+        const int e = e0 + team;
+        if (e < end && t == 0) {
             const float a = alpha[e];
-            const float s = a_src[cj] + ad;
-            const float ds = a * (dot - rd) * (s > 0.f ? 1.f : slope);
+            const float s = a_src[col[e]] + ad;
             const int p = perm[e];
-            ds_coo[p] = ds;
+            ds_coo[p] = a * (ds_coo[p] - sd) * (s > 0.f ? 1.f : slope);
             alpha_coo[p] = a;
         }
     }
@@ -131,16 +141,13 @@ __global__ __launch_bounds__(256) void gat_alpha_bwd_vec_kernel(const int32_t* _
     const int fl = (lane % LPR) * 4;
     const bool fact = fl < n_feat;
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float rd = 0.f;
-    if (fact) {
-        g4 = *reinterpret_cast<const float4*>(g + static_cast<int64_t>(row) * ldg + fl);
-        const float4 o4 = *reinterpret_cast<const float4*>(out + static_cast<int64_t>(row) * ldo + fl);
-        rd = g4.x * o4.x + g4.y * o4.y + g4.z * o4.z + g4.w * o4.w;
-    }
-#pragma unroll
-    for (int off = 1; off < LPR; off <<= 1) rd += __shfl_xor(rd, off);          // <g_i, out_i> in every lane
+    if (fact) g4 = *reinterpret_cast<const float4*>(g + static_cast<int64_t>(row) * ldg + fl);
+    (void)out; (void)ldo;
     const float ad = a_dst[row];
-    float acc = 0.f;
+    const bool writer = (lane % LPR) == 0;
+    // pass 1: d alpha_e = <g_i, h_e> parked in ds[e], and the row's sum_k alpha_k d alpha_k over those same values (see
+    // gat_alpha_bwd_kernel: the reference's form; every ds slot is read back in pass 2 by the lane that wrote it)
+    float sd = 0.f;
     for (int base = beg; base < end; base += 64) {
         const int cnt = (end - base) < 64 ? (end - base) : 64;
         int c = 0;
@@ -151,13 +158,12 @@ __global__ __launch_bounds__(256) void gat_alpha_bwd_vec_kernel(const int32_t* _
         }
         for (int u = 0; u < cnt; u += NPW * UN) {
             float4 hv[UN];
-            int cj[UN];
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
                 const int idx = u + k * NPW + sub;
-                cj[k] = __shfl(c, idx & 63);
+                const int cj = __shfl(c, idx & 63);
                 hv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (fact && idx < cnt) hv[k] = *reinterpret_cast<const float4*>(h + static_cast<int64_t>(cj[k]) * ldh + fl);
+                if (fact && idx < cnt) hv[k] = *reinterpret_cast<const float4*>(h + static_cast<int64_t>(cj) * ldh + fl);
             }
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
@@ -166,12 +172,33 @@ __global__ __launch_bounds__(256) void gat_alpha_bwd_vec_kernel(const int32_t* _
 #pragma unroll
                 for (int off = 1; off < LPR; off <<= 1) dot += __shfl_xor(dot, off);
                 const float a = __shfl(al, idx & 63);
-                if (idx < cnt && (lane % LPR) == 0) {
-                    const float sc = a_src[cj[k]] + ad;
-                    const float d = a * (dot - rd) * (sc > 0.f ? 1.f : slope);
-                    ds[base + idx] = d;
-                    acc += d;
+                if (idx < cnt && writer) {
+                    ds[base + idx] = dot;
+                    sd = fmaf(a, dot, sd);
                 }
+            }
+        }
+    }
+    sd = wave_sum(sd);
+    // pass 2: ds_e = alpha_e (d alpha_e - sum) slope'(s_e) and its row sum, the gradient of a_dst
+    float acc = 0.f;
+    for (int base = beg; base < end; base += 64) {
+        const int cnt = (end - base) < 64 ? (end - base) : 64;
+        int c = 0;
+        float al = 0.f;
+        if (lane < cnt) {
+            c = col[base + lane];
+            al = alpha[base + lane];
+        }
+        for (int u = 0; u < cnt; u += NPW) {
+            const int idx = u + sub;
+            const float a = __shfl(al, idx & 63);
+            const int cj = __shfl(c, idx & 63);
+            if (idx < cnt && writer) {
+                const float sc = a_src[cj] + ad;
+                const float d = a * (ds[base + idx] - sd) * (sc > 0.f ? 1.f : slope);
+                ds[base + idx] = d;
+                acc += d;
             }
         }
     }

@@ -345,39 +345,49 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(WeightedSumArgs a)
     }
 }
 
-constexpr int kDotBlocks = 1024;
+constexpr int kDotBlocks = 1024;     // at most; fewer where the workspace does not hold blocks x k float64 partials
 
 struct DotsArgs {
     const vec4f* g;
     const vec4f* x[8];
-    float* partial;      // [gridDim.x][k]
+    double* partial;     // [gridDim.x][k]
     int64_t n4, ldg4;
     int32_t k, c4;
 };
 
 // partial[b][j] = this block's share of <g, x_j>, j < k: g (possibly a column block of a wider matrix) is read ONCE for all
-// k products.  Fixed grid and a fixed combination order: deterministic.
+// k products.  Fixed grid and a fixed combination order: deterministic.  Products and sums are taken in FLOAT64 (round 6): an
+// fp32 x fp32 product is exact in double, so the result is the correctly rounded dot product of the fp32 operands whatever
+// the order -- these are reductions over all N x F elements whose value is often a small difference of partial sums in the
+// hundreds, where an fp32 tree leaves 1e-5 absolute (tests/test_gpu_fuzz.py: SIMPA's hop-weight gradients, 20 x the
+// reference's error on one draw).  Cost, measured at C3b (500 k x 64, k = 3): 0.107 ms per launch against 0.088 with fp32
+// sums -- the 4 (k + 1) conversions per lane and step now pace the kernel (issuing two strides of loads per step changed
+// nothing), 0.04 ms of a 2.9 ms step.
 __global__ __launch_bounds__(256) void dots_kernel(DotsArgs a)
 {
-    __shared__ float sm[4][8];
-    float acc[8];
+    __shared__ double sm[4][8];
+    double acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n4;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int64_t r = i / a.c4;
         const vec4f g = a.g[r * a.ldg4 + (i - r * a.c4)];
+        const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (j < a.k) {
                 const vec4f x = a.x[j][i];
-                acc[j] += (g[0] * x[0] + g[1] * x[1]) + (g[2] * x[2] + g[3] * x[3]);
+                acc[j] = fma(g0, static_cast<double>(x[0]), acc[j]);
+                acc[j] = fma(g1, static_cast<double>(x[1]), acc[j]);
+                acc[j] = fma(g2, static_cast<double>(x[2]), acc[j]);
+                acc[j] = fma(g3, static_cast<double>(x[3]), acc[j]);
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float v = acc[j];
+        double v = acc[j];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][j] = v;
     }
@@ -387,13 +397,13 @@ __global__ __launch_bounds__(256) void dots_kernel(DotsArgs a)
             (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
-// out[j] = sum_b partial[b][j]: one block, 32 threads per product
-__global__ __launch_bounds__(256) void dots_finish_kernel(const float* __restrict__ partial, int n_partials, int k,
+// out[j] = sum_b partial[b][j], rounded to fp32 once: one block, 32 threads per product
+__global__ __launch_bounds__(256) void dots_finish_kernel(const double* __restrict__ partial, int n_partials, int k,
                                                           float* __restrict__ out)
 {
-    __shared__ float sm[256];
+    __shared__ double sm[256];
     const int j = threadIdx.x >> 5, t = threadIdx.x & 31;
-    float acc = 0.f;
+    double acc = 0.0;
     if (j < k)
         for (int b = t; b < n_partials; b += 32) acc += partial[static_cast<int64_t>(b) * k + j];
     sm[threadIdx.x] = acc;
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(256) void dots_finish_kernel(const float* __restric
         if (t < off) sm[threadIdx.x] += sm[threadIdx.x + off];
         __syncthreads();
     }
-    if (t == 0 && j < k) out[j] = sm[threadIdx.x];
+    if (t == 0 && j < k) out[j] = static_cast<float>(sm[threadIdx.x]);
 }
 }  // namespace
 
@@ -438,8 +448,8 @@ extern "C" int pygsd_dots_f32(const float* g, int64_t ldg, const float* const* x
 {
     PYGSD_REQUIRE(k >= 1 && k <= 8 && n_rows >= 0 && n_cols >= 0 && n_cols % 4 == 0,
                   "pygsd_dots_f32: 1..8 operands of rows that are multiples of 4 elements");
-    PYGSD_REQUIRE(out && workspace && workspace_bytes >= sizeof(float) * kDotBlocks * 8,
-                  "pygsd_dots_f32: null output or workspace smaller than %zu bytes", sizeof(float) * kDotBlocks * 8);
+    PYGSD_REQUIRE(out && workspace && workspace_bytes >= 32768 && reinterpret_cast<uintptr_t>(workspace) % 8 == 0,
+                  "pygsd_dots_f32: null output, or workspace smaller than 32 KiB or not 8-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n_rows == 0 || n_cols == 0) {
         PYGSD_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * k, s));
@@ -453,17 +463,21 @@ extern "C" int pygsd_dots_f32(const float* g, int64_t ldg, const float* const* x
         a.x[j] = reinterpret_cast<const vec4f*>(xs[j]);
     }
     a.g = reinterpret_cast<const vec4f*>(g);
-    a.partial = static_cast<float*>(workspace);
+    a.partial = static_cast<double*>(workspace);
     a.c4 = n_cols / 4;
     a.n4 = n_rows * a.c4;
     a.ldg4 = ldg / 4;
     a.k = k;
     ProfScope prof(PYGSD_K_ELEMENTWISE, s);
     int64_t blocks = (a.n4 + kBlock - 1) / kBlock;
+    // (1024 blocks keep ~64 KB of loads in flight per CU, what the stream needs; 64 KiB of workspace hold their partials for
+    //  any k, the interface's minimum of 32 KiB for k <= 4 -- beyond that the grid shrinks to what the workspace holds)
+    const int64_t fit = static_cast<int64_t>(workspace_bytes / (sizeof(double) * static_cast<size_t>(k)));
     if (blocks > kDotBlocks) blocks = kDotBlocks;
+    if (blocks > fit) blocks = fit;
     hipLaunchKernelGGL(dots_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, a);
     if (int rc = check_launch("dots_kernel")) return rc;
-    hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, s, static_cast<const float*>(workspace),
+    hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, s, static_cast<const double*>(workspace),
                        static_cast<int>(blocks), k, out);
     return check_launch("dots_finish_kernel");
 }

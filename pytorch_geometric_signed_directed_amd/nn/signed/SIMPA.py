@@ -43,11 +43,11 @@ def dots(g, tensors):
     tensors = [t.contiguous() for t in tensors]
     rows, cols = (1, g.numel()) if g.dim() != 2 else (g.size(0), g.size(1))
     out = torch.empty(k, dtype=torch.float32, device=g.device)
-    ws = torch.empty(8192, dtype=torch.float32, device=g.device)
+    ws = torch.empty(8192, dtype=torch.float64, device=g.device)      # 64 KiB: 1024 blocks x 8 products, float64 partials
     ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors])
     with _cabi.on_device(g.device):
         _cabi.check(_cabi.lib().pygsd_dots_f32(_cabi.ptr(g), cols, ptrs, k, rows, cols, _cabi.ptr(out), _cabi.ptr(ws),
-                                               ws.numel() * 4, _cabi.stream_ptr()), "pygsd_dots_f32")
+                                               ws.numel() * 8, _cabi.stream_ptr()), "pygsd_dots_f32")
     return out
 
 
@@ -186,8 +186,9 @@ class _StreamFn(torch.autograd.Function):
                     return res.view(shape)
                 flat.index_copy_(0, torch.tensor(which, device=g.device), res)
             else:
+                gd = g.reshape(-1).double()                              # widths the kernel does not vectorise: the same float64 sums
                 for wi, v in terms:
-                    flat[wi] = torch.dot(g.reshape(-1), nodes[v].reshape(-1))
+                    flat[wi] = torch.dot(gd, nodes[v].reshape(-1).double())
             return out
 
         return (materialise(0) if need[0] else None, materialise(1) if need[1] else None,

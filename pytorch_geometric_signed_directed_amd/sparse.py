@@ -454,8 +454,12 @@ def spmm_rows_into(csr: CSR, val: Optional[Tensor], x: Tensor, y: Tensor, row_lo
     ldy = y.stride(0)
     if y.stride(1) != 1:
         raise ValueError("spmm_rows_into: output rows must have unit inner stride")
-    if csr.nnz == 0:
-        if not accumulate:
+    if csr.nnz == 0:                                     # edgeless operator: y = 0 (+ z) -- nothing to gather, no launch
+        if z is not None:
+            if accumulate or row_lo or z.dtype != y.dtype or z.size(0) != y.size(0):
+                raise ValueError("spmm_rows_into: z comes without accumulate / row offsets and has the output's dtype and height")
+            y[row_lo:row_hi].copy_(z[row_lo:row_hi, :f])
+        elif not accumulate:
             y[row_lo:row_hi].zero_()
         return
     esz = 2 if (bf16 and not mixed) else 4

@@ -181,6 +181,49 @@ def test_empty_and_degenerate_inputs():
     ei = torch.zeros(2, 1, dtype=torch.long)
     out = spmm(Pattern(ei.to(d), 1, 1), torch.full((1, 4), 3.0).to(d), torch.tensor([0.5]).to(d))
     assert out.cpu().tolist() == [[1.5] * 4]
+    # an edgeless operator with an addend: y = z in every form (the in-place one returned zeros until round 6 -- found by
+    # tests/test_gpu_fuzz.py through an SGCNConv without positive edges)
+    from pytorch_geometric_signed_directed_amd.sparse import spmm_rows_into
+    pat = Pattern(torch.zeros(2, 0, dtype=torch.long).to(d), 6, 6)
+    x, z = torch.randn(6, 8).to(d), torch.randn(6, 16).to(d)
+    assert torch.equal(spmm(pat, x, None, z=z[:, :8].contiguous(), beta=1.0), z[:, :8])
+    for mean in (False, True):
+        y = torch.full((6, 8), 7.0, device=d)
+        spmm_rows_into(pat.fwd, None, x, y, mean=mean, z=z[:, 8:])
+        assert torch.equal(y, z[:, 8:])
+    y = torch.full((6, 8), 7.0, device=d)
+    spmm_rows_into(pat.fwd, None, x, y, accumulate=True)
+    assert float((y - 7.0).abs().max()) == 0.0
+    spmm_rows_into(pat.fwd, None, x, y)
+    assert float(y.abs().max()) == 0.0
+
+
+def test_sgcn_conv_without_positive_or_negative_edges():
+    """Either edge list may be empty: that half's aggregate is zero and its own-feature block must survive (the fused path
+    adds the aggregate onto the own block inside the SpMM's epilogue -- with no entries there is no launch)."""
+    from pytorch_geometric_signed_directed_amd.nn import SGCNConv
+    g = torch.Generator().manual_seed(77)
+    n = 40
+    some, none = torch.randint(0, n, (2, 90), generator=g), torch.zeros(2, 0, dtype=torch.long)
+    for first, in_dim, out_dim in ((True, 16, 12), (False, 16, 12), (True, 8, 24), (False, 5, 7)):
+        x = torch.randn(n, in_dim if first else 2 * in_dim, generator=g)
+        up = torch.randn(n, 2 * out_dim, generator=g)
+        for pos, neg in ((none, some), (some, none), (none, none)):
+            torch.manual_seed(5)
+            layer = SGCNConv(in_dim, out_dim, first, norm_emb=True)
+            prm = {k: v.detach().clone().requires_grad_() for k, v in layer.named_parameters()}
+            xo = x.clone().requires_grad_()
+            want = R.sgcn_conv(xo, pos, neg, (prm["lin_b.weight"], prm["lin_b.bias"]), (prm["lin_u.weight"], prm["lin_u.bias"]),
+                               first, in_dim, True)
+            (want * up).sum().backward()
+            layer.to(dev())
+            xd = x.to(dev()).requires_grad_()
+            out = layer(xd, pos.to(dev()), neg.to(dev()))
+            (out * up.to(dev())).sum().backward()
+            close(out, want.detach())
+            close(xd.grad, xo.grad)
+            for k, p in layer.named_parameters():
+                close(p.grad, prm[k].grad, norm=True, what="d " + k)
 
 
 # ------------------------------------------------------------------ autograd through the kernels

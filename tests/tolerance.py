@@ -71,7 +71,7 @@ def single_thread():
         torch.set_num_threads(before)
 
 
-def close_arbitrated(got, reference_sequence, truth64, tol=TOL, what="", norm=False):
+def close_arbitrated(got, reference_sequence, truth64, tol=TOL, what="", norm=False, slack=1.5, slack_ref=2.0):
     """For checks whose fp32 REFERENCE sits within a hair of the bar itself: float64 is the arbiter.
 
         err(got, float64)  <=  max(tol, 1.5 * err(reference sequence in fp32, float64))
@@ -92,16 +92,16 @@ def close_arbitrated(got, reference_sequence, truth64, tol=TOL, what="", norm=Fa
     _, ref_mixed, ref_rel, _ = errors(reference_sequence, truth64)
     _, vs_ref_mixed, vs_ref_rel, _ = errors(got, reference_sequence)
     mine, theirs, apart = (rel, ref_rel, vs_ref_rel) if norm else (mixed, ref_mixed, vs_ref_mixed)
-    bar = max(tol, 1.5 * theirs)
-    bar_ref = max(tol, 2.0 * theirs)
+    bar = max(tol, slack * theirs)             # (slack / slack_ref: 1.5 / 2 everywhere but the randomised runs of
+    bar_ref = max(tol, slack_ref * theirs)     #  tests/test_gpu_fuzz.py, which say why they take 3 / 4)
     test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
     RECORDS.append({"test": test, "what": what + " (float64 arbiter)", "max_abs_err": abs_err, "max_mixed_err": mixed,
                     "max_norm_rel_err": rel, "max_abs_want": top, "bar": "norm" if norm else "abs", "tol": bar,
                     "reference_sequence_err_vs_f64": theirs, "hip_vs_reference_sequence": apart,
                     "hip_vs_reference_sequence_bar": bar_ref})
-    assert mine <= bar, (f"{what} vs float64: {mine:.3e} > max({tol}, 1.5 x {theirs:.3e} of the fp32 reference "
+    assert mine <= bar, (f"{what} vs float64: {mine:.3e} > max({tol}, {slack} x {theirs:.3e} of the fp32 reference "
                          f"sequence) (max abs err {abs_err:.3e}, |want| <= {top:.3g})")
-    assert apart <= bar_ref, (f"{what} vs the fp32 reference sequence: {apart:.3e} > max({tol}, 2 x {theirs:.3e} = the reference's "
+    assert apart <= bar_ref, (f"{what} vs the fp32 reference sequence: {apart:.3e} > max({tol}, {slack_ref} x {theirs:.3e} = the reference's "
                               f"own distance from float64) (HIP vs float64 {mine:.3e}, |want| <= {top:.3g})")
     return abs_err
 
