@@ -247,6 +247,36 @@ def test_fuzz_spmm2_forward_backward():
     run_rounds("spmm2", one)
 
 
+def test_fuzz_spmm_bf16_storage():
+    """bf16 features (BASELINE config C5's storage): against the fp32 oracle on the bf16-ROUNDED inputs; on top of the
+    accumulation bar only the final rounding of the result to bf16 (relative 2^-8) -- the bound of
+    test_spmm_bf16_vs_oracle_on_rounded_inputs."""
+    from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
+    bad = []
+    for seed, rng in rounds("spmm_bf16"):
+        n, ei = draw_graph(rng)
+        f, e = width(rng, 260 if rng.random() < 0.15 else 150), ei.size(1)
+        weighted, mean, with_z = rng.random() < 0.6, rng.random() < 0.3, rng.random() < 0.3
+        x = normal(rng, n, f).to(torch.bfloat16)
+        w = torch.from_numpy(rng.random(e).astype(np.float32)) if weighted else None
+        z = normal(rng, n, f).to(torch.bfloat16) if with_z and not mean else None
+        alpha, beta = (2.0, -1.0) if z is not None else (1.0, 0.0)
+        with single_thread():
+            want = alpha * R.propagate(x.double(), ei, None if w is None else w.double(), n, reduce="mean" if mean else "add")
+            if z is not None:
+                want = want + beta * z.double()
+        got = spmm(Pattern(ei.to(D), n, n), x.to(D), None if w is None else w.to(D), z=None if z is None else z.to(D),
+                   alpha=alpha, beta=beta, reduce="mean" if mean else "add")
+        if got.dtype != torch.bfloat16:
+            bad.append(f"seed {seed}: result dtype {got.dtype}")
+            continue
+        err = (got.double().cpu() - want).abs()
+        bound = want.abs() * 2.0 ** -8 + 1e-5 * max(1.0, float(want.abs().max()) if want.numel() else 1.0)
+        if not bool((err <= bound).all()):
+            bad.append(f"seed {seed} n={n} e={e} f={f} w={weighted} mean={mean} z={z is not None}: worst excess {float((err - bound).max()):.3e}")
+    assert not bad, "\n".join(bad[:20])
+
+
 # ------------------------------------------------------------------ a1 / a2: MagNetConv, MSConv
 @pytest.mark.parametrize("signed", [False, True])
 def test_fuzz_magnetic_layers(signed):
@@ -277,18 +307,31 @@ def test_fuzz_magnetic_layers(signed):
             idx = R.magnetic_laplacian(ei, w, n, q, None, signed, absdeg)[0][0]
             radius = torch.zeros(n).index_add_(0, idx, (re * re + im * im).sqrt())
             lam = float(max(radius.max().item(), 1.0) * (1.0 + 0.5 * rng.random()))
+        # a trainable q (through the phase and the SDDMM edge-value gradients; the reference refuses it without normalisation,
+        # MagNetConv.py:58-59) and an edge_weight that requires grad (the differentiable Laplacian build)
+        train_q = norm == "sym" and q > 0.0 and rng.random() < 0.25
+        train_w = w is not None and e > 0 and rng.random() < 0.3
         if signed:
-            layer = MSConv(f_in, f_out, k, q, False, normalization=norm, bias=bias, absolute_degree=absdeg)
+            layer = MSConv(f_in, f_out, k, q, train_q, normalization=norm, bias=bias, absolute_degree=absdeg)
         else:
-            layer = MagNetConv(f_in, f_out, k, q, False, normalization=norm, bias=bias)
+            layer = MagNetConv(f_in, f_out, k, q, train_q, normalization=norm, bias=bias)
         params = {"weight": normal(rng, k + 1, f_in, f_out) * 0.3, "bias": normal(rng, f_out) if bias else None}
-        layer.load_state_dict({kk: v for kk, v in params.items() if v is not None})
+        state = {kk: v for kk, v in params.items() if v is not None}
+        if train_q:
+            # every forward replaces the parameter by Parameter(clamp(q, 0, 0.25)) (MagNetConv.py:141-142): the oracle gets the
+            # clamped value, and the gradient is that of the parameter the layer holds AFTER the forward
+            state["q"] = torch.tensor([q], dtype=torch.float32)
+            params["q"] = state["q"].clamp(0, 0.25)
+        if train_w:
+            params["w_edge"] = w
+        layer.load_state_dict(state)
         layer.to(D)
         t = {"xr": normal(rng, n, f_in), "xi": normal(rng, n, f_in)}
         up = [normal(rng, n, f_out), normal(rng, n, f_out)]
 
         def ref(dtype, lv):
-            op = R.magnet_operator(ei, cast(w, dtype), n, q, norm, 2.0 if lam is None else lam, signed, absdeg, dtype)
+            op = R.magnet_operator(ei, lv["w_edge"] if train_w else cast(w, dtype), n, lv["q"] if train_q else q, norm,
+                                   2.0 if lam is None else lam, signed, absdeg, dtype)
             return R.magnet_conv(lv["xr"], lv["xi"], op, lv["weight"], lv["bias"], duplicate=False)
 
         # parameter gradients come from the module's own parameters on the product side
@@ -299,9 +342,16 @@ def test_fuzz_magnetic_layers(signed):
                 res.append(grads(ref(dtype, lv), [cast(u, dtype) for u in up], lv))
         lv = {kk: leaf(v, torch.float32, D) for kk, v in t.items()}
         lv.update(weight=layer.weight, bias=layer.bias if bias else None)
-        got = grads(layer(lv["xr"], lv["xi"], ei.to(D), None if w is None else w.to(D), lambda_max=lam), [u.to(D) for u in up], lv)
-        what = f"n={n} e={e} {f_in}->{f_out} K={k} q={q:.3f} norm={norm} lam={lam} bias={bias} w={'none' if w is None else 'yes'}"
-        return what, got, res[0], res[1], ("d_weight", "d_bias")
+        if train_w:
+            lv["w_edge"] = leaf(w, torch.float32, D)
+        w_dev = lv["w_edge"] if train_w else (None if w is None else w.to(D))
+        out = layer(lv["xr"], lv["xi"], ei.to(D), w_dev, lambda_max=lam)
+        if train_q:
+            lv["q"] = layer.q
+        got = grads(out, [u.to(D) for u in up], lv)
+        what = (f"n={n} e={e} {f_in}->{f_out} K={k} q={q:.3f} norm={norm} lam={lam} bias={bias} w={'none' if w is None else 'yes'} "
+                f"train_q={train_q} train_w={train_w}")
+        return what, got, res[0], res[1], ("d_weight", "d_bias", "d_q")
 
     run_rounds("msconv" if signed else "magnet", one)
 
@@ -482,6 +532,41 @@ def test_fuzz_gat_conv():
         return what, got, res[0], res[1], tuple("d_" + k for k in params)
 
     run_rounds("gat", one)
+
+
+def test_fuzz_snea_conv_toy_sizes():
+    """SNEAConv (tanh attention over positive and negative incoming edges, target-row messages, partial self loops) against
+    the node-by-node float64 formula of oracle/small_f64_torch.py -- plain Python per node, so graphs of <= 60 nodes; no fp32
+    reference sequence exists at this level, the bar is the literal one against float64."""
+    from oracle import small_f64_torch as F64
+    from pytorch_geometric_signed_directed_amd.nn import SNEAConv
+    from tolerance import close
+    for seed, rng in rounds("snea"):
+        n = int(rng.integers(2, 60))
+        edges = lambda m: torch.from_numpy(rng.integers(0, n, (2, int(rng.integers(0, m)))).astype(np.int64))  # noqa: E731
+        pos, neg = edges(5 * n), edges(3 * n)
+        if rng.random() < 0.3 and pos.size(1):
+            pos[1, :max(1, pos.size(1) // 2)] = int(rng.integers(0, n))         # one long row
+        in_dim, out_dim, first = int(rng.integers(1, 12)), int(rng.integers(1, 12)), bool(rng.random() < 0.5)
+        layer = SNEAConv(in_dim, out_dim, first)
+        params = {k: normal(rng, *v.shape) * 0.4 for k, v in layer.state_dict().items()}
+        layer.load_state_dict(params)
+        layer.to(D)
+        x, up = normal(rng, n, in_dim if first else 2 * in_dim), normal(rng, n, 2 * out_dim)
+        p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+        x64 = x.double().requires_grad_()
+        o64 = F64.snea_conv(x64, pos.numpy(), neg.numpy(), (p64["lin_b.weight"], p64["lin_b.bias"]), (p64["lin_u.weight"], p64["lin_u.bias"]),
+                            (p64["alpha_b.weight"], p64["alpha_b.bias"]), (p64["alpha_u.weight"], p64["alpha_u.bias"]), first, in_dim)
+        o64.backward(up.double())
+        xd = x.to(D).requires_grad_()
+        out = layer(xd, pos.to(D), neg.to(D))
+        out.backward(up.to(D))
+        tag = f"snea seed={seed} n={n} e+={pos.size(1)} e-={neg.size(1)} {in_dim}->{out_dim} first={first}"
+        close(out, o64.detach(), what=tag + " out")
+        close(xd.grad, x64.grad, what=tag + " dx")
+        for k, p in layer.named_parameters():
+            want = p64[k].grad if p64[k].grad is not None else torch.zeros_like(p64[k])      # (a branch without any edge)
+            close(torch.zeros_like(p) if p.grad is None else p.grad, want, norm=True, what=f"{tag} d {k}")
 
 
 # ------------------------------------------------------------------ the dense kernels at arbitrary widths
