@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PYGSD_ABI_VERSION 16
+#define PYGSD_ABI_VERSION 17
 
 /* ABI version of the loaded library (== PYGSD_ABI_VERSION it was built with). */
 int pygsd_version(void);
@@ -278,7 +278,7 @@ int pygsd_maglap_assemble_csr(const int64_t* out_row, const int64_t* out_col, co
                               float lambda_max, float diag_shift, int32_t* rowptr, int32_t* col,
                               float* vb_real, float* vb_imag, float* vf_real, float* vf_imag, void* stream);
 int pygsd_maglap_values(const int64_t* out_row, const int64_t* out_col, const float* a_sym,
-                        const float* theta, const float* deg, int64_t num_unique, float q, int32_t sym,
+                        const float* theta, const float* deg, int64_t num_unique, double q, int32_t sym,
                         float* off_real, float* off_imag, float* mir_real, float* mir_imag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -305,7 +305,7 @@ int pygsd_magop_workspace(int64_t n_edges, int32_t n, int32_t weighted, size_t* 
 int pygsd_magop_stage1(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
                        int32_t is_signed, int32_t absolute_degree, int32_t sym, void* workspace,
                        size_t workspace_bytes, int32_t* rowptr, float* deg, int64_t* d_info, void* stream);
-int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, int32_t sym, float lambda_max,
+int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, double q, int32_t sym, float lambda_max,
                        float diag_shift, void* workspace, size_t workspace_bytes, const int32_t* rowptr,
                        const float* deg, int32_t* col, float* vb_real, float* vb_imag, float* vf_real,
                        float* vf_imag, void* stream);
@@ -339,7 +339,7 @@ int pygsd_magop_stage1_sorted(const int64_t* row, const int64_t* col, const floa
  * phase: 0 = the whole build; 1 = everything up to the row pointer -- d_info is final when this part has run, so the caller can
  * queue its device -> host read of d_info here and then call again with phase = 2 (same arguments, untouched workspace) for the
  * kernel that writes the slots: the host then learns the sizes while 40 % of the build is still running, instead of after it. */
-int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, float q, float lambda_max,
+int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, double q, float lambda_max,
                      float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr, float* deg, int32_t* ccol,
                      float* vb_real, float* vb_imag, float* vf_real, float* vf_imag, int64_t* d_info, int32_t phase, void* stream);
 /* The same one-call build for weights that are all +1 or -1 (round 5) -- the signed graphs of MSConv / MSGNN
@@ -354,7 +354,7 @@ int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, in
  * another degree convention, and for the graphs the bucket form does not take (see above; here <= 2^24 nodes).  Arguments,
  * workspace (pygsd_magop_workspace(n_edges, n, 0)), outputs, d_info and `phase` as pygsd_magop_unit. */
 int pygsd_magop_unit_signed(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n, int32_t is_signed,
-                            int32_t absolute_degree, int32_t sym, float q, float lambda_max, float diag_shift, void* workspace,
+                            int32_t absolute_degree, int32_t sym, double q, float lambda_max, float diag_shift, void* workspace,
                             size_t workspace_bytes, int32_t* rowptr, float* deg, int32_t* ccol, float* vb_real, float* vb_imag,
                             float* vf_real, float* vf_imag, int64_t* d_info, int32_t phase, void* stream);
 

@@ -82,18 +82,18 @@ PROTOTYPES = {
     "pygsd_maglap_assemble_csr": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "pygsd_maglap_values": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
+    "pygsd_maglap_values": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                                       c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_magop_workspace": (c_int32, [c_int64, c_int32, c_int32, ctypes.POINTER(c_size_t)]),
     "pygsd_magop_stage1": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                      c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pygsd_magop_stage1_sorted": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                             c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "pygsd_magop_stage2": (c_int32, [c_int64, c_int32, c_int32, c_float, c_int32, c_float, c_float, c_void_p, c_size_t,
+    "pygsd_magop_stage2": (c_int32, [c_int64, c_int32, c_int32, c_double, c_int32, c_float, c_float, c_void_p, c_size_t,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "pygsd_magop_unit": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_float, c_float, c_void_p, c_size_t,
+    "pygsd_magop_unit": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_double, c_float, c_float, c_void_p, c_size_t,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
-    "pygsd_magop_unit_signed": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_float,
+    "pygsd_magop_unit_signed": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_double, c_float,
                                           c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int32, c_void_p]),
     "pygsd_self_loops_workspace": (c_int32, [c_int64, ctypes.POINTER(c_size_t)]),
@@ -151,7 +151,7 @@ PROTOTYPES = {
     "pygsd_prof_reset": (c_int32, []),
     "pygsd_prof_collect": (c_int32, [c_int32, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class PieceLayoutStruct(ctypes.Structure):

@@ -504,7 +504,7 @@ extern "C" int pygsd_maglap_assemble_csr(const int64_t* out_row, const int64_t* 
 }
 
 extern "C" int pygsd_maglap_values(const int64_t* out_row, const int64_t* out_col, const float* a_sym,
-                                   const float* theta, const float* deg, int64_t num_unique, float q,
+                                   const float* theta, const float* deg, int64_t num_unique, double q,
                                    int32_t sym, float* off_real, float* off_imag, float* mir_real,
                                    float* mir_imag, void* stream)
 {
@@ -514,8 +514,10 @@ extern "C" int pygsd_maglap_values(const int64_t* out_row, const int64_t* out_co
     PYGSD_REQUIRE((mir_real == nullptr) == (mir_imag == nullptr), "pygsd_maglap_values: mirror outputs must be given together");
     hipStream_t s = static_cast<hipStream_t>(stream);
     ProfScope prof(PYGSD_K_BUILD, s);
-    // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64
-    const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * static_cast<double>(q));
+    // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64: ONE rounding, of the product
+    // -- q arrives as a double for that reason (until ABI v17 it was a float, i.e. rounded before the multiplication: one ulp
+    // of 2 pi q, 2e-3 rad on a phase argument of 15 456 -- a pair joined by that many parallel edges, tests/test_gpu_fuzz.py)
+    const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * q);
     hipLaunchKernelGGL(lap_values, dim3(grid_for(num_unique)), dim3(kBlock), 0, s, out_row, out_col, a_sym, theta,
                        deg, num_unique, two_pi_q, sym, off_real, off_imag, mir_real, mir_imag);
     return check_launch("lap_values");

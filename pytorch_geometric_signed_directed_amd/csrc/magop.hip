@@ -1993,7 +1993,7 @@ extern "C" int pygsd_magop_stage1_sorted(const int64_t* row, const int64_t* col,
                              stream, true);
 }
 
-extern "C" int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, float q, int32_t sym, float lambda_max,
+extern "C" int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, double q, int32_t sym, float lambda_max,
                                   float diag_shift, void* workspace, size_t workspace_bytes, const int32_t* rowptr,
                                   const float* deg, int32_t* col, float* vb_real, float* vb_imag, float* vf_real,
                                   float* vf_imag, void* stream)
@@ -2010,8 +2010,8 @@ extern "C" int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, 
     if (int rc = magop_layout(n_edges, n, weighted, &l)) return rc;
     PYGSD_REQUIRE(workspace_bytes >= l.total, "pygsd_magop_stage2: workspace too small");
     char* base = align256(workspace);
-    // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64
-    const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * static_cast<double>(q));
+    // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64 (one rounding: q is a double)
+    const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * q);
     const int64_t m = 2 * n_edges;
     int32_t* rs = reinterpret_cast<int32_t*>(base + l.rs);
     if (m > 0) {
@@ -2029,7 +2029,7 @@ extern "C" int pygsd_magop_stage2(int64_t n_edges, int32_t n, int32_t weighted, 
 // w == NULL: unit weights (pygsd_magop_unit).  w != NULL: weights that must all be +1 or -1 (pygsd_magop_unit_signed; -1 only with
 // allow_neg) -- the bucket form only; a graph its plan does not take is reported like an over-long row (d_info[1] != 0).
 static int magop_unit_impl(const int64_t* row, const int64_t* col, const float* w, int32_t allow_neg, int64_t n_edges, int32_t n,
-                           int32_t sym, float q, float lambda_max, float diag_shift, void* workspace, size_t workspace_bytes,
+                           int32_t sym, double q, float lambda_max, float diag_shift, void* workspace, size_t workspace_bytes,
                            int32_t* rowptr, float* deg, int32_t* ccol, float* vb_real, float* vb_imag, float* vf_real,
                            float* vf_imag, int64_t* d_info, int32_t phase, void* stream)
 {
@@ -2060,8 +2060,8 @@ static int magop_unit_impl(const int64_t* row, const int64_t* col, const float* 
     }
     int32_t* ucnt = reinterpret_cast<int32_t*>(base + l.ucnt);
     int32_t* left = reinterpret_cast<int32_t*>(base + l.shift);
-    // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64
-    const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * static_cast<double>(q));
+    // torch evaluates 1j*2*pi*q as a double-precision Python complex, then casts it to complex64 (one rounding: q is a double)
+    const float two_pi_q = static_cast<float>(2.0 * 3.14159265358979323846 * q);
     UnitArgs a{keys_b, keys_a, rs, deg, cnt16, lut, rowptr, ccol, vb_real, vb_imag, vf_real, vf_imag, ucnt, left, d_info,
                m > 0 ? m : 1, n, sym, two_pi_q, lambda_max, diag_shift, reinterpret_cast<float*>(base + l.n_long)};
     const int64_t per_block = 4 * kRowsPerWave;
@@ -2154,7 +2154,7 @@ static int magop_unit_impl(const int64_t* row, const int64_t* col, const float* 
     return check_launch("unit_write_chunks");
 }
 
-extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, float q,
+extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t n_edges, int32_t n, int32_t sym, double q,
                                 float lambda_max, float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr,
                                 float* deg, int32_t* ccol, float* vb_real, float* vb_imag, float* vf_real, float* vf_imag,
                                 int64_t* d_info, int32_t phase, void* stream)
@@ -2164,7 +2164,7 @@ extern "C" int pygsd_magop_unit(const int64_t* row, const int64_t* col, int64_t 
 }
 
 extern "C" int pygsd_magop_unit_signed(const int64_t* row, const int64_t* col, const float* w, int64_t n_edges, int32_t n,
-                                       int32_t is_signed, int32_t absolute_degree, int32_t sym, float q, float lambda_max,
+                                       int32_t is_signed, int32_t absolute_degree, int32_t sym, double q, float lambda_max,
                                        float diag_shift, void* workspace, size_t workspace_bytes, int32_t* rowptr, float* deg,
                                        int32_t* ccol, float* vb_real, float* vb_imag, float* vf_real, float* vf_imag,
                                        int64_t* d_info, int32_t phase, void* stream)

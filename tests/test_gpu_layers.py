@@ -209,6 +209,42 @@ def test_magnetic_edge_weight_gradient(name, signed):
     close_arbitrated(w_dev.grad, w_cpu.grad, w_64.grad, what="d edge_weight")
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("form", ["default", "two_stage", "generic"])
+def test_magnetic_phase_of_a_pair_joined_by_thousands_of_parallel_edges(weighted, form, monkeypatch):
+    """The phase argument of an entry is 2 pi q (A - A^T): a pair joined by 15 000 parallel edges has an argument of 15 000,
+    and the reference's 1j * 2 * pi * q is a double-precision Python scalar rounded to complex64 ONCE
+    (get_magnetic_Laplacian.py:68).  q therefore crosses the C ABI as a double; as a float (until ABI v17) the product was
+    rounded twice -- one ulp of 2 pi q, 2e-3 rad at this argument, 1e-3 in the operator and 4e-3 in the layer's output
+    (found by tests/test_gpu_fuzz.py).  Every build: the bucket forms, the two-stage one, the generic pipeline."""
+    from pytorch_geometric_signed_directed_amd.nn import MagNetConv, _magnetic
+    from pytorch_geometric_signed_directed_amd.utils import _laplacian
+    if form == "two_stage":
+        monkeypatch.setattr(_laplacian, "_UNIT_BUILD", False)
+    elif form == "generic":
+        monkeypatch.setattr(_magnetic, "_FUSED_BUILD", False)
+    n, q = 400, 0.31741536925161906
+    g = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, n, (2, 6000), generator=g)
+    ei = torch.cat([ei, torch.tensor([[7], [11]]).expand(2, 15456)], dim=1)[:, torch.randperm(6000 + 15456, generator=g)]
+    w = (torch.rand(ei.size(1), generator=g) + 0.5) if weighted else None
+    x_r, x_i = torch.randn(n, 8, generator=g), torch.randn(n, 8, generator=g)
+    op64 = R.magnet_operator(ei, None if w is None else w.double(), n, q, "sym", 2.0, dtype=torch.float64)
+    op32 = R.magnet_operator(ei, w, n, q, "sym", 2.0)
+    torch.manual_seed(1)
+    layer = MagNetConv(8, 8, 1, q, False).to(D)
+    o_r, o_i = layer(x_r.to(D), x_i.to(D), ei.to(D), None if w is None else w.to(D))
+    ei_r, ei_i, n_r, n_i = layer.cached_result
+    assert torch.equal(ei_r.cpu(), op32[0]) and torch.equal(ei_i.cpu(), op32[1])
+    # no further from float64 than the reference's own fp32 build (+ 1e-6): the same roundings of the same argument
+    for got, ref32, ref64 in ((n_r, op32[2], op64[2]), (n_i, op32[3], op64[3])):
+        mine, theirs = (got.cpu().double() - ref64).abs().max().item(), (ref32.double() - ref64).abs().max().item()
+        assert mine <= 2.0 * theirs + 1e-6, (mine, theirs)
+    w_r, w_i = R.magnet_conv(x_r, x_i, op32, layer.weight.detach().cpu(), layer.bias.detach().cpu(), duplicate=False)
+    close(o_r, w_r)
+    close(o_i, w_i)
+
+
 def test_node_ids_outside_the_graph_raise_index_error():
     """ids >= num_nodes / negative ids raise (as the reference's index_select / scatter_add_ do)
     instead of reading or writing device memory out of bounds."""

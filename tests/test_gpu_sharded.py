@@ -347,6 +347,87 @@ def _fuzz_magnetic_round(rank, world, seed):
     return what, res
 
 
+def _fuzz_other_round(rank, world, seed):
+    """One random ShardedSGCNConv / ShardedSIMPA / ShardedDiGCNConv (fp32) case, as _fuzz_magnetic_round: the graph may leave
+    ranks without a single positive or negative entry, widths 4 ... 128, SIMPA hops 1 ... 3, DiGCN phases 1 ... 3."""
+    import numpy as np
+    from oracle import ref_layers as R
+    from pytorch_geometric_signed_directed_amd.parallel import ShardedDiGCNConv, ShardedSGCNConv, ShardedSIMPA, all_gather_rows
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 2 * world)) if rng.random() < 0.1 else int(rng.integers(world, 2000))
+
+    def edges(density):
+        e = int(n * density)
+        a = rng.integers(0, n, (2, e))
+        if e and rng.random() < 0.3 and n > 2:            # everything among the first nodes: ranks without an entry
+            a = a % int(rng.integers(1, n))
+        if e and rng.random() < 0.2:
+            a[1, :max(1, e // 3)] = rng.integers(0, n)    # a hub row
+        return torch.from_numpy(a.astype(np.int64))
+
+    pos, neg = edges(float(rng.choice([0.0, 2.0, 8.0]))), edges(float(rng.choice([0.0, 1.0, 10.0])))
+    f32 = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32))      # noqa: E731
+    weights = lambda e: torch.from_numpy((rng.random(e) + 0.25).astype(np.float32))           # noqa: E731
+    kind = str(rng.choice(["sgcn", "simpa", "digcn"]))
+    pool = [4, 8, 12, 16, 32, 64, 128]
+    if kind == "sgcn":
+        first = bool(rng.random() < 0.5)
+        out_dim = int(rng.choice(pool[:5]))
+        in_dim = int(rng.choice([p_ for p_ in pool if p_ >= out_dim]))
+        bias = bool(rng.random() < 0.7)
+        layer = ShardedSGCNConv(in_dim, out_dim, first, n, pos.to(dev), neg.to(dev), bias=bias, device=dev)
+        xs = [f32(n, in_dim if first else 2 * in_dim)]
+        what = f"sgcn {in_dim}->{out_dim} first={first} bias={bias}"
+    elif kind == "simpa":
+        hop, fill, directed = int(rng.integers(1, 4)), float(rng.choice([0.5, 1.0, 0.2])), bool(rng.random() < 0.5)
+        w_p, w_n = weights(pos.size(1)), weights(neg.size(1))
+        f = int(rng.choice(pool))
+        layer = ShardedSIMPA(hop, fill, n, pos.to(dev), w_p.to(dev), neg.to(dev), w_n.to(dev), directed, device=dev)
+        xs = [f32(n, f) for _ in range(4 if directed else 2)]
+        what = f"simpa f={f} hop={hop} fill={fill} directed={directed}"
+    else:
+        f_in, f_out, phases = int(rng.choice(pool)), int(rng.choice(pool)), int(rng.integers(1, 4))
+        w_p = (f32(pos.size(1)) * 0.3)
+        layer = ShardedDiGCNConv(f_in, f_out, n, pos.to(dev), w_p.to(dev), device=dev, phases=phases)
+        xs = [f32(n, f_in)]
+        what = f"digcn {f_in}->{f_out} phases={phases}"
+    what = f"seed={seed} n={n} e+={pos.size(1)} e-={neg.size(1)} " + what
+    values = {k: f32(*v.shape) * 0.4 + (0.5 if kind == "simpa" else 0.0) for k, v in layer.named_parameters()}
+    with torch.no_grad():
+        for k, prm in layer.named_parameters():
+            prm.copy_(values[k])
+    local = [layer.shard_rows(x.to(dev)).requires_grad_() for x in xs]
+    out = layer(*local)
+    go = f32(n, out.size(1))
+    (out * layer.shard_rows(go.to(dev))).sum().backward()
+    got = [layer.plan.unshard_rows(all_gather_rows(t.detach().contiguous())).cpu() for t in [out] + [a.grad for a in local]]
+    got += [prm.grad.cpu() if prm.grad is not None else torch.zeros_like(prm).cpu() for _, prm in layer.named_parameters()]
+    if rank:
+        return what, {}
+    refs = []
+    for dtype in (torch.float32, torch.float64):
+        leaf = lambda t: t.detach().clone().to(dtype).requires_grad_()      # noqa: E731
+        ri = [leaf(x) for x in xs]
+        sd = {k: leaf(v) for k, v in values.items()}
+        if kind == "sgcn":
+            want = R.sgcn_conv(ri[0], pos, neg, (sd["lin_b.weight"], sd.get("lin_b.bias")), (sd["lin_u.weight"], sd.get("lin_u.bias")),
+                               first, in_dim)
+        elif kind == "simpa":
+            want = R.simpa(pos, w_p.to(dtype), neg, w_n.to(dtype), ri[0], ri[1], sd, hop, fill, directed, *ri[2:])
+        else:
+            want = R.digcn_conv(ri[0], pos, w_p.to(dtype), sd["weight"], sd.get("bias"))
+        (want * go.to(dtype)).sum().backward()
+        zero = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)      # noqa: E731
+        refs.append([want.detach()] + [zero(x) for x in ri] + [zero(sd[k]) for k, _ in layer.named_parameters()])
+    names = ["out"] + [f"d_x{i}" for i in range(len(xs))] + ["d_" + k for k, _ in layer.named_parameters()]
+    res = {}
+    for i, (g_, r32, r64) in enumerate(zip(got, *refs)):
+        pick_err = 1 if i > len(xs) else 0                                   # parameters: row reductions, max norm
+        res[names[i]] = (_errs([(g_, r64)])[pick_err], _errs([(r32, r64)])[pick_err])
+    return what, res
+
+
 def _fuzz_suite(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
@@ -355,14 +436,16 @@ def _fuzz_suite(rank, world, port, ret):
         out = []
         for r in range(FUZZ_ROUNDS):
             out.append(_fuzz_magnetic_round(rank, world, FUZZ_SEED + 7919 * world + r))
+            out.append(_fuzz_other_round(rank, world, FUZZ_SEED + 104729 * world + r))
         ret[rank] = out
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_fuzz_sharded_magnetic_layers(world):
-    """Random sharded MagNetConv / MSConv cases (see _fuzz_magnetic_round) on `world` ranks sharing the test box's GPU; every
+def test_fuzz_sharded_layers(world):
+    """Random sharded MagNetConv / MSConv and SGCNConv / SIMPA / DiGCNConv cases (see _fuzz_magnetic_round, _fuzz_other_round)
+    on `world` ranks sharing the test box's GPU; every
     output and gradient within max(1e-5, 3 x the fp32 reference sequence's own error) of float64 -- the bar, and the reason
     for the 3, of tests/test_gpu_fuzz.py.  PYGSD_FUZZ_ROUNDS / PYGSD_FUZZ_SEED as there."""
     ret = mp.Manager().dict()
