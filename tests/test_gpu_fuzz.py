@@ -35,6 +35,7 @@ D = torch.device("cuda:0")
 ROUNDS = int(os.environ.get("PYGSD_FUZZ_ROUNDS", "6"))
 SEED0 = int(os.environ.get("PYGSD_FUZZ_SEED", "1000"))
 MAX_N = int(os.environ.get("PYGSD_FUZZ_MAX_NODES", "2500"))
+MAX_E = int(os.environ.get("PYGSD_FUZZ_MAX_EDGES", "60000"))
 SKIPPED = {"non_finite_reference": 0}
 STATS = {}
 
@@ -52,7 +53,7 @@ def draw_graph(rng, n_lo=1):
     an isolated tail / no edges at all."""
     n = int(rng.integers(n_lo, MAX_N + 1)) if rng.random() < 0.8 else int(rng.integers(n_lo, 40))
     density = float(rng.choice([0.0, 0.5, 2.0, 8.0, 30.0]))
-    e = int(min(n * density, 60000))
+    e = int(min(n * density, MAX_E))
     if density and rng.random() < 0.2:
         e = int(rng.integers(1, 8))
     src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
@@ -610,7 +611,7 @@ def test_fuzz_report():
     """Not a check: leaves the run's counts (per target: rounds, checks, how many sat above the literal 1e-5 bar, above the
     suite's 1.5 x bar, above this file's 3 x bar) in the output and, when PYGSD_FUZZ_LOG names a path, in <path>.json."""
     import json
-    report = {"rounds_per_target": ROUNDS, "first_seed": SEED0, "max_nodes": MAX_N,
+    report = {"rounds_per_target": ROUNDS, "first_seed": SEED0, "max_nodes": MAX_N, "max_edges": MAX_E,
               "skipped_non_finite_reference": SKIPPED["non_finite_reference"], "targets": STATS}
     print(json.dumps(report, indent=1))
     if os.environ.get("PYGSD_FUZZ_LOG"):
