@@ -573,6 +573,59 @@ def test_fuzz_snea_conv_toy_sizes():
             close(torch.zeros_like(p) if p.grad is None else p.grad, want, norm=True, what=f"{tag} d {k}")
 
 
+def test_fuzz_cut_and_imbalance_objectives():
+    """SSSNET's three cut objectives and DIGRAC's imbalance objective (the per-cluster sparse mat-vecs as HIP
+    SpMMs) on random signed / directed weighted graphs of <= 300 nodes and 2 ... 8 clusters against the dense float64
+    formulas of oracle/small_f64_torch.py: values and the gradient of the probabilities, max-norm bar (they are sums over
+    all nodes), literal 1e-5 against float64."""
+    import scipy.sparse as sp
+    from oracle import small_f64_torch as F64
+    from pytorch_geometric_signed_directed_amd.utils import (Prob_Balanced_Normalized_Loss, Prob_Balanced_Ratio_Loss, Prob_Imbalance_Loss,
+                                                             Unhappy_Ratio)
+    from tolerance import close
+    for seed, rng in rounds("losses"):
+        n, k = int(rng.integers(4, 300)), int(rng.integers(2, 9))
+        e = int(n * float(rng.choice([0.5, 3.0, 10.0])))
+        r, c = rng.integers(0, n, e), rng.integers(0, n, e)
+        prob0 = torch.softmax(normal(rng, n, k) * float(rng.choice([0.3, 2.0])), dim=1)
+        tag = f"losses seed={seed} n={n} e={e} K={k}"
+        # signed weights, stored as SSSNET stores them: positive and negative part of one scipy matrix
+        w = rng.standard_normal(e)
+        a = sp.coo_matrix((w, (r, c)), shape=(n, n)).tocsr()
+        a_p, a_n = a.maximum(0), (-a).maximum(0)
+        a_p.eliminate_zeros()
+        a_n.eliminate_zeros()
+        if (a_p - a_n).nnz:
+            for i, cls in enumerate((Prob_Balanced_Normalized_Loss, Prob_Balanced_Ratio_Loss, Unhappy_Ratio)):
+                prob = prob0.to(D).requires_grad_()
+                val = cls(a_p, a_n)(prob)
+                val.sum().backward()
+                p64 = prob0.double().requires_grad_()
+                v64 = F64.cut_losses(a_p.toarray(), a_n.toarray(), p64)[i]
+                v64.backward()
+                close(val.reshape(-1), v64.detach().reshape(-1), norm=True, what=f"{tag} {cls.__name__}")
+                close(prob.grad, p64.grad, norm=True, what=f"{tag} d prob {cls.__name__}")
+        # DIGRAC: nonnegative directed weights, every normalisation; gradients exist on the 'sort' branch only
+        wd = rng.random(e) + 0.1
+        dense = np.zeros((n, n))
+        np.add.at(dense, (r, c), wd)
+        ei = torch.from_numpy(np.stack([r, c]).astype(np.int64))
+        adj = torch.sparse_coo_tensor(ei.to(D), torch.from_numpy(wd.astype(np.float32)).to(D), (n, n)).coalesce()
+        pairs = k * (k - 1) // 2
+        sel = int(rng.integers(1, pairs + 1))
+        for norm in ("vol_sum", "vol_min", "vol_max", "plain"):
+            for thr in ("sort", "std", "naive"):
+                prob = prob0.to(D).requires_grad_()
+                val = Prob_Imbalance_Loss(sel)(prob, adj, k, norm, thr)
+                p64 = prob0.double().requires_grad_()
+                v64 = F64.imbalance_loss(p64, dense, k, sel, norm, thr)
+                close(val.reshape(-1), v64.detach().reshape(-1), norm=True, what=f"{tag} imbalance {norm} {thr} sel={sel}")
+                if thr == "sort" and v64.requires_grad:
+                    val.sum().backward()
+                    v64.sum().backward()
+                    close(prob.grad, p64.grad, norm=True, what=f"{tag} d prob imbalance {norm} sel={sel}")
+
+
 # ------------------------------------------------------------------ the dense kernels at arbitrary widths
 def test_fuzz_tall_products():
     from pytorch_geometric_signed_directed_amd import dense
@@ -595,14 +648,28 @@ def test_fuzz_tall_products():
 
         got, r32, r64 = three_ways(ref, prod, t, {"w": wt, "b": b}, up)
         # the segmented entry points themselves (what the layers call: no concatenation), forward only
-        xd = [x.to(D) for x in xs]
+        # the segments as the layers hand them over: contiguous matrices, or column slices of one wider matrix (row stride)
+        sliced = rng.random() < 0.4
+        if sliced:
+            wide = torch.cat([normal(rng, n, 3)] + xs + [normal(rng, n, 5)], 1).to(D)
+            edges_ = np.cumsum([3] + segs)
+            xd = [wide[:, int(edges_[i]):int(edges_[i + 1])] for i in range(len(segs))]
+        else:
+            xd = [x.to(D) for x in xs]
         got["segmented"] = dense.tall_product(xd, wt.to(D), False, None if b is None else b.to(D))
-        got["gram"] = dense.tall_gram(xd, [up[0].to(D)])
+        # the weight gradient with the upstream gradient in 1 ... 3 column segments (SGCNConv: [g | g_a])
+        cuts = sorted(set(int(c) for c in rng.integers(1, max(f_out, 2), int(rng.integers(0, 3))) if c < f_out))
+        gd = up[0].to(D)
+        gs = [gd[:, a:b_].contiguous() for a, b_ in zip([0] + cuts, cuts + [f_out])]
+        got["gram"] = dense.tall_gram(xd, gs)
+        got["transposed"] = dense.tall_product(gs, wt.to(D), True)            # dx = [g_0 | g_1 | ...] W^T
         for r, dtype in ((r32, torch.float32), (r64, torch.float64)):
             r["segmented"] = r["out0"]
             with single_thread():
                 r["gram"] = torch.cat(xs, 1).to(dtype).t() @ up[0].to(dtype)
-        return f"n={n} widths={segs}->{f_out} bias={bias}", got, r32, r64, ("d_w", "d_b", "gram")
+                r["transposed"] = up[0].to(dtype) @ wt.to(dtype).t()
+        what = f"n={n} widths={segs}->{f_out} bias={bias} sliced={sliced} g-cuts={cuts}"
+        return what, got, r32, r64, ("d_w", "d_b", "gram")
 
     run_rounds("tall", one)
 

@@ -75,7 +75,9 @@ for it in range(cases):
     s2 = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, 2.0, -1.0, sgn, True, True)
     ones = torch.ones_like(sgn)
     s3 = L._unit_operator_csr(row, col, ei.size(1), n, sym, 0.25, 2.0, -1.0, ones, False, True)
-    ok_s = (s1 is None) == (a is None) and same(s1, s2) and (s3 is None) == (a is None)
+    # (the +-1 form exists for the bucket plan only: where the plan refuses a graph -- e.g. 100 edges per node -- the unweighted
+    #  build falls back to its sort form and is still taken, the +-1 one steps aside for the two-stage pipeline: both None then)
+    ok_s = (s1 is None or a is not None) and same(s1, s2) and (s3 is None) == (s1 is None)
     if s1 is not None and ei.size(1) <= 6_000_000:                # (the generic pipeline is the slow one)
         ok_s = ok_s and same(s1, generic(ei, sgn, n, sym, True, True)) and same(s3, generic(ei, ones, n, sym, False, True))
     elif s3 is not None:
