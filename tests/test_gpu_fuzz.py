@@ -21,6 +21,7 @@ PYGSD_FUZZ_ROUNDS (default 6 per target, so the suite stays short) sets the leng
 run.  A case whose float64 reference is itself non-finite (a degenerate normalisation) is skipped and counted -- the
 non-finite contract of the products is tests/test_gpu_nonfinite.py's subject.
 """
+import copy
 import os
 
 import numpy as np
@@ -672,6 +673,113 @@ def test_fuzz_tall_products():
         return what, got, r32, r64, ("d_w", "d_b", "gram")
 
     run_rounds("tall", one)
+
+
+def test_fuzz_memo_never_serves_a_stale_operator():
+    """The operator / pattern memos (memo.py: keyed on tensor identity, in-place version and storage) under random histories:
+    one long-lived instance of every uncached layer is called again and again while its graph tensors are, at random, left
+    alone, edited in place through torch (version bump), replaced by an equal copy, replaced by different content, freed
+    and re-allocated (the storage may come back at the same address), moved through `.clone()` of a view ...; after every
+    step the output must equal, BIT FOR BIT, that of a never-used copy of the layer called on clones of the graph tensors.  Writes that bypass the
+    version counter (`.data`, raw pointers) are the documented exception (strict mode: tests/test_gpu_layers.py)."""
+    from pytorch_geometric_signed_directed_amd import memo
+    from pytorch_geometric_signed_directed_amd.nn import DGCNConv, Conv_Base, GATConv, MagNetConv, MSConv, SGCNConv, SIMPA
+
+    def same(a, b):
+        a = a if isinstance(a, (tuple, list)) else (a,)
+        b = b if isinstance(b, (tuple, list)) else (b,)
+        return all(torch.equal(x, y) for x, y in zip(a, b))
+
+    bad = []
+    for seed, rng in rounds("memo"):
+        n = int(rng.integers(8, 600))
+
+        def graph(m=None):
+            e = int(n * float(rng.choice([1.0, 4.0, 12.0]))) if m is None else m
+            return (torch.from_numpy(rng.integers(0, n, (2, e)).astype(np.int64)).to(D),
+                    torch.from_numpy((rng.random(e) + 0.25).astype(np.float32)).to(D))
+
+        f = int(rng.choice([4, 8, 16, 20]))
+        torch.manual_seed(seed)
+        kind = str(rng.choice(["magnet", "msconv", "dgcn", "conv_base", "simpa", "sgcn", "gat"]))
+        x = normal(rng, n, f).to(D)
+        x2 = normal(rng, n, f).to(D)
+        state = {"ei": None, "w": None, "ei2": None, "w2": None}
+        state["ei"], state["w"] = graph()
+        state["ei2"], state["w2"] = graph()
+        if kind == "magnet":
+            layer = MagNetConv(f, f, 2, 0.25, False).to(D)
+            call = lambda m, st: m(x, x2, st["ei"], st["w"])                                # noqa: E731
+        elif kind == "msconv":
+            layer = MSConv(f, f, 1, 0.1, False).to(D)
+            call = lambda m, st: m(x, x2, st["ei"], st["w"])                                # noqa: E731
+        elif kind == "dgcn":
+            layer = DGCNConv()
+            call = lambda m, st: m(x, st["ei"], st["w"])                                    # noqa: E731
+        elif kind == "conv_base":
+            layer = Conv_Base(0.5)
+            call = lambda m, st: m(x, st["ei"], st["w"])                                    # noqa: E731
+        elif kind == "simpa":
+            layer = SIMPA(2, 0.5, False).to(D)
+            call = lambda m, st: m(st["ei"], st["w"], st["ei2"], st["w2"], x, x2)           # noqa: E731
+        elif kind == "sgcn":
+            layer = SGCNConv(f, f, True).to(D)
+            call = lambda m, st: m(x, st["ei"], st["ei2"])                                  # noqa: E731
+        else:
+            layer = GATConv(f, 8).to(D)
+            call = lambda m, st: m(x, st["ei"])                                             # noqa: E731
+        pristine = copy.deepcopy(layer)                    # never called: no history of its own (per-instance memos included)
+        history = []
+        for step in range(int(rng.integers(4, 10))):
+            act = str(rng.choice(["same", "same", "edit_index", "edit_weight", "equal_copy", "new_graph", "realloc", "swap", "resize"]))
+            which = "2" if (rng.random() < 0.3 and kind in ("simpa", "sgcn")) else ""
+            ei, w = state["ei" + which], state["w" + which]
+            if act == "edit_index" and ei.size(1):
+                j = int(rng.integers(0, ei.size(1)))
+                ei[int(rng.integers(0, 2)), j] = int(rng.integers(0, n))
+            elif act == "edit_weight" and w.numel():
+                w[int(rng.integers(0, w.numel()))] += 0.5
+            elif act == "equal_copy":
+                state["ei" + which], state["w" + which] = ei.clone(), w.clone()
+            elif act == "new_graph":
+                state["ei" + which], state["w" + which] = graph()
+            elif act == "realloc":                         # free, then allocate the same shape again: often the same address
+                shape = ei.size(1)
+                state["ei" + which] = state["w" + which] = None
+                del ei, w
+                state["ei" + which], state["w" + which] = graph(shape)
+            elif act == "swap" and kind in ("simpa", "sgcn"):
+                state["ei"], state["ei2"] = state["ei2"], state["ei"]
+                state["w"], state["w2"] = state["w2"], state["w"]
+            elif act == "resize":                          # a slice of the same storage: same data pointer, fewer entries
+                keep = max(1, state["ei" + which].size(1) // 2)
+                state["ei" + which] = state["ei" + which][:, :keep]
+                state["w" + which] = state["w" + which][:keep]
+            history.append(act + which)
+            with torch.no_grad():
+                got = call(layer, state)
+                # the reference: a never-used copy of the layer on CLONES of the graph tensors -- new identities, which no memo
+                # (per-instance or module-level) can have seen; the process-wide switch is not touched (switching it off clears
+                # every memo, which would also wipe what the long-lived layer is being tested for remembering)
+                want = call(copy.deepcopy(pristine), {k: v.clone() for k, v in state.items()})
+            if not same(got, want):
+                bad.append(f"seed {seed} {kind} n={n} f={f} after {history}")
+                break
+    assert not bad, "\n".join(bad[:20])
+
+
+def test_fuzz_memo_check_would_see_a_memo_that_ignores_versions(monkeypatch):
+    """The check above has teeth: with the in-place version taken out of the memo's key (what a memo keyed on identity and
+    storage alone would be) the same histories must produce stale operators, and the check must say so."""
+    from pytorch_geometric_signed_directed_amd import memo
+    real = memo._stamp
+    monkeypatch.setattr(memo, "_stamp", lambda t: None if t is None else (0,) + tuple(real(t)[1:]))
+    memo.clear_all()
+    try:
+        with pytest.raises(AssertionError, match="after"):
+            test_fuzz_memo_never_serves_a_stale_operator()
+    finally:
+        memo.clear_all()
 
 
 def test_fuzz_report():
