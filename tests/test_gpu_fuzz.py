@@ -702,32 +702,30 @@ def test_fuzz_memo_never_serves_a_stale_operator():
         f = int(rng.choice([4, 8, 16, 20]))
         torch.manual_seed(seed)
         kind = str(rng.choice(["magnet", "msconv", "dgcn", "conv_base", "simpa", "sgcn", "gat"]))
-        x = normal(rng, n, f).to(D)
-        x2 = normal(rng, n, f).to(D)
-        state = {"ei": None, "w": None, "ei2": None, "w2": None}
+        state = {"ei": None, "w": None, "ei2": None, "w2": None, "x": normal(rng, n, f).to(D), "x2": normal(rng, n, f).to(D)}
         state["ei"], state["w"] = graph()
         state["ei2"], state["w2"] = graph()
         if kind == "magnet":
             layer = MagNetConv(f, f, 2, 0.25, False).to(D)
-            call = lambda m, st: m(x, x2, st["ei"], st["w"])                                # noqa: E731
+            call = lambda m, st: m(st["x"], st["x2"], st["ei"], st["w"])                                # noqa: E731
         elif kind == "msconv":
             layer = MSConv(f, f, 1, 0.1, False).to(D)
-            call = lambda m, st: m(x, x2, st["ei"], st["w"])                                # noqa: E731
+            call = lambda m, st: m(st["x"], st["x2"], st["ei"], st["w"])                                # noqa: E731
         elif kind == "dgcn":
             layer = DGCNConv()
-            call = lambda m, st: m(x, st["ei"], st["w"])                                    # noqa: E731
+            call = lambda m, st: m(st["x"], st["ei"], st["w"])                                    # noqa: E731
         elif kind == "conv_base":
             layer = Conv_Base(0.5)
-            call = lambda m, st: m(x, st["ei"], st["w"])                                    # noqa: E731
+            call = lambda m, st: m(st["x"], st["ei"], st["w"])                                    # noqa: E731
         elif kind == "simpa":
             layer = SIMPA(2, 0.5, False).to(D)
-            call = lambda m, st: m(st["ei"], st["w"], st["ei2"], st["w2"], x, x2)           # noqa: E731
+            call = lambda m, st: m(st["ei"], st["w"], st["ei2"], st["w2"], st["x"], st["x2"])           # noqa: E731
         elif kind == "sgcn":
             layer = SGCNConv(f, f, True).to(D)
-            call = lambda m, st: m(x, st["ei"], st["ei2"])                                  # noqa: E731
+            call = lambda m, st: m(st["x"], st["ei"], st["ei2"])                                  # noqa: E731
         else:
             layer = GATConv(f, 8).to(D)
-            call = lambda m, st: m(x, st["ei"])                                             # noqa: E731
+            call = lambda m, st: m(st["x"], st["ei"])                                             # noqa: E731
         pristine = copy.deepcopy(layer)                    # never called: no history of its own (per-instance memos included)
         history = []
         for step in range(int(rng.integers(4, 10))):
@@ -756,12 +754,19 @@ def test_fuzz_memo_never_serves_a_stale_operator():
                 state["ei" + which] = state["ei" + which][:, :keep]
                 state["w" + which] = state["w" + which][:keep]
             history.append(act + which)
-            with torch.no_grad():
-                got = call(layer, state)
-                # the reference: a never-used copy of the layer on CLONES of the graph tensors -- new identities, which no memo
-                # (per-instance or module-level) can have seen; the process-wide switch is not touched (switching it off clears
-                # every memo, which would also wipe what the long-lived layer is being tested for remembering)
-                want = call(copy.deepcopy(pristine), {k: v.clone() for k, v in state.items()})
+            # forward and backward (the transposed operator and its value arrays are memoised too): outputs and the input
+            # gradient.  The reference: a never-used copy of the layer on CLONES of the graph tensors -- new identities, which
+            # no memo (per-instance or module-level) can have seen; the process-wide switch is not touched (switching it off
+            # clears every memo, which would also wipe what the long-lived layer is being tested for remembering)
+            def run(m, st):
+                st = dict(st, x=st["x"].detach().clone().requires_grad_())
+                out = call(m, st)
+                out = out if isinstance(out, (tuple, list)) else (out,)
+                sum(o.sum() for o in out).backward()
+                return tuple(o.detach() for o in out) + (st["x"].grad,)
+
+            got = run(layer, state)
+            want = run(copy.deepcopy(pristine), {k: v.clone() for k, v in state.items()})
             if not same(got, want):
                 bad.append(f"seed {seed} {kind} n={n} f={f} after {history}")
                 break
