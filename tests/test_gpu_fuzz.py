@@ -192,6 +192,39 @@ def three_ways(reference, product, tensors, params, upstream):
     return got, res[0], res[1]
 
 
+# ------------------------------------------------------------------ structure work: bit-exact
+def test_fuzz_structure_kernels_bit_exact():
+    """COO -> CSR (stable by segment id: the reference's scatter order inside a row) and the key sort under every layer, on
+    random sizes from empty to 3 M entries, skewed ids, rectangular shapes: row pointer, column ids and the permutation
+    identical to a stable host sort."""
+    from pytorch_geometric_signed_directed_amd.sparse import csr_from_coo
+    from pytorch_geometric_signed_directed_amd.sparse_build import sort_keys
+    for seed, rng in rounds("structure"):
+        n_seg, n_src = int(10 ** rng.uniform(0, 5.5)), int(10 ** rng.uniform(0, 5.5))
+        nnz = int(10 ** rng.uniform(0, 6.5)) if rng.random() < 0.9 else 0
+        seg = rng.integers(0, n_seg, nnz)
+        if nnz and rng.random() < 0.4:                              # skew: a few segments take most entries
+            seg[:nnz // 2] = rng.integers(0, max(1, n_seg // 100), nnz // 2)
+        src = rng.integers(0, n_src, nnz)
+        seg_t, src_t = torch.from_numpy(seg.astype(np.int64)), torch.from_numpy(src.astype(np.int64))
+        csr = csr_from_coo(seg_t.to(D), src_t.to(D), n_seg, n_src)
+        order = torch.sort(seg_t, stable=True).indices
+        want_ptr = torch.zeros(n_seg + 1, dtype=torch.long)
+        want_ptr[1:] = torch.bincount(seg_t, minlength=n_seg).cumsum(0)
+        tag = f"seed {seed} segments={n_seg} sources={n_src} nnz={nnz}"
+        assert torch.equal(csr.rowptr.cpu().long(), want_ptr), tag
+        assert torch.equal(csr.perm.cpu().long(), order), tag
+        assert torch.equal(csr.col.cpu().long(), src_t[order]), tag
+        bits = int(rng.integers(1, 41))
+        m = int(10 ** rng.uniform(0, 6)) if rng.random() < 0.9 else 0
+        keys = torch.from_numpy(rng.integers(0, 2 ** min(bits, 12), m).astype(np.int64))     # many duplicates: stability shows
+        if bits > 12:
+            keys = keys * (2 ** (bits - 12)) + torch.from_numpy(rng.integers(0, 2, m).astype(np.int64))
+        skeys, perm = sort_keys(keys.to(D), bits)
+        want = torch.sort(keys, stable=True)
+        assert torch.equal(skeys.cpu(), want.values) and torch.equal(perm.cpu().long(), want.indices), f"seed {seed} sort m={m} bits={bits}"
+
+
 # ------------------------------------------------------------------ the sparse products themselves
 def test_fuzz_spmm_forward_backward():
     from pytorch_geometric_signed_directed_amd.sparse import Pattern, spmm
