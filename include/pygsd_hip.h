@@ -145,8 +145,12 @@ int pygsd_sddmm_coo_f32(const int32_t* ia, const int32_t* ib, int64_t nnz,
  *   pygsd_gat_alpha_csr_f32    : alpha[e] = softmax over CSR row r of leaky_relu(a_src[col[e]] + a_dst[r])
  *                                (max-shifted exp, denominator + 1e-16), CSR order.  The weighted sum
  *                                out = sum alpha * h[col] is then pygsd_spmm_csr_f32 with val = alpha.
- *   pygsd_gat_alpha_bwd_csr_f32: ds[e] = alpha[e] * (<g_r, h_col[e]> - <g_r, out_r>) * lrelu'(s_e), the
- *                                gradient w.r.t. the pre-activation score s_e = a_src[col] + a_dst[r];
+ *   pygsd_gat_alpha_bwd_csr_f32: ds[e] = alpha[e] * (d_e - sum_k alpha[k] d_k) * lrelu'(s_e) with d_e = <g_r, h_col[e]>
+ *                                and the sum over row r -- the backward of torch_geometric.utils.softmax in its
+ *                                own form, so that a one-entry row gives exactly 0 and row sums cancel as the
+ *                                reference's do (round 6; before: <g_r, out_r> for the sum, equal in exact
+ *                                arithmetic only.  `out` is still read for rows handled by the long_rows path);
+ *                                the gradient w.r.t. the pre-activation score s_e = a_src[col] + a_dst[r];
  *                                written, together with alpha, in COO order through perm (so that
  *                                d a_src / d a_dst are row sums over the two CSR orientations).
  * long_rows (may be NULL; every entry point of this section and the segment / SNEA ones below take it): hub

@@ -74,14 +74,13 @@ __global__ __launch_bounds__(256) void gat_alpha_bwd_kernel(const int32_t* __res
     const int beg = rowptr[row], end = rowptr[row + 1];
     if (skip > 0 && end - beg > skip) return;
     const float* gi = g + static_cast<int64_t>(row) * ldg;
-    const float* oi = out + static_cast<int64_t>(row) * ldo;
     // ds_e = alpha_e (d alpha_e - sum_k alpha_k d alpha_k) slope'(s_e), with d alpha_e = <g_i, h_e>, in the reference's own form
     // (autograd of torch_geometric.utils.softmax): the row's sum is taken over the SAME d alpha values the entries use, so a row
     // with one entry gets exactly zero and the row sums of ds (the gradient of a_dst) cancel as the reference's do.  Until round 6
     // the sum was <g_i, out_i> -- equal in exact arithmetic, but out_i carries its own rounding: 4 x the reference's error in the
     // attention vectors' gradients on rows of 1 - 2 entries (tests/test_gpu_fuzz.py).  Pass 1 parks d alpha_e in ds_coo (every
     // slot is read back by the lane that wrote it), pass 2 finishes; `out` is no longer read by this kernel.
-    (void)oi;
+    (void)out; (void)ldo;
     const int t = lane & 15, team = lane >> 4;
     const float ad = a_dst[row];
     float sd = 0.f;
