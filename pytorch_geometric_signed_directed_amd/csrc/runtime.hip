@@ -360,9 +360,9 @@ struct DotsArgs {
 // fp32 x fp32 product is exact in double, so the result is the correctly rounded dot product of the fp32 operands whatever
 // the order -- these are reductions over all N x F elements whose value is often a small difference of partial sums in the
 // hundreds, where an fp32 tree leaves 1e-5 absolute (tests/test_gpu_fuzz.py: SIMPA's hop-weight gradients, 20 x the
-// reference's error on one draw).  Cost, measured at C3b (500 k x 64, k = 3): 0.107 ms per launch against 0.088 with fp32
-// sums -- the 4 (k + 1) conversions per lane and step now pace the kernel (issuing two strides of loads per step changed
-// nothing), 0.04 ms of a 2.9 ms step.
+// reference's error on one draw).  Cost, measured at C3b (500 k x 64, k = 3): 93 us per launch against 88 with fp32 sums by
+// rocprofv3 (107 against 88 by the in-process recorder) -- the 4 (k + 1) conversions per lane and step now pace the kernel
+// (issuing two strides of loads per step changed nothing).
 __global__ __launch_bounds__(256) void dots_kernel(DotsArgs a)
 {
     __shared__ double sm[4][8];
