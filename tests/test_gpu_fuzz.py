@@ -179,15 +179,30 @@ def leaf(t, dtype, device=None):
     return None if t is None else t.detach().to(dtype=dtype, device=device).clone().requires_grad_()
 
 
-def three_ways(reference, product, tensors, params, upstream):
+def leaf_dev(t, rng=None):
+    """The product side's differentiable copy of an input.  Three times in ten a feature matrix arrives as the layers of a
+    model hand it over: a COLUMN SLICE of a wider matrix (row stride > width, start not 16-byte aligned unless the left pad
+    happens to be a multiple of 4) -- the gradient is then taken with respect to that view."""
+    if t is None:
+        return None
+    t = t.detach().to(device=D, dtype=torch.float32)
+    if t.dim() == 2 and rng is not None and rng.random() < 0.3:
+        left, right = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+        wide = torch.cat([t.new_zeros(t.size(0), left), t, t.new_zeros(t.size(0), right)], 1).requires_grad_()
+        return wide[:, left:left + t.size(1)]
+    return t.clone().requires_grad_()
+
+
+def three_ways(reference, product, tensors, params, upstream, rng=None):
     """reference(dtype, leaves) on the host in fp32 and float64, product(leaves) on the GPU; leaves = differentiable copies
-    of `tensors` (inputs) and `params`."""
+    of `tensors` (inputs; with `rng`, sometimes as column slices: leaf_dev) and `params`."""
     res = []
     with single_thread():
         for dtype in (torch.float32, torch.float64):
             lv = {k: leaf(v, dtype) for k, v in {**tensors, **params}.items()}
             res.append(grads(reference(dtype, lv), [cast(u, dtype) for u in upstream], lv))
-    lv = {k: leaf(v, torch.float32, D) for k, v in {**tensors, **params}.items()}
+    lv = {k: leaf_dev(v, rng) for k, v in tensors.items()}
+    lv.update({k: leaf(v, torch.float32, D) for k, v in params.items()})
     got = grads(product(lv), [u.to(D) for u in upstream], lv)
     return got, res[0], res[1]
 
@@ -253,7 +268,7 @@ def test_fuzz_spmm_forward_backward():
             return spmm(Pattern(ei.to(D), n_in, n_out, flow), lv["x"], lv["w"], z=None if z is None else lv["z"].detach(),
                         alpha=alpha, beta=beta, reduce=reduce)
 
-        got, r32, r64 = three_ways(ref, prod, {"x": x, "w": w, "z": z}, {}, up)
+        got, r32, r64 = three_ways(ref, prod, {"x": x, "w": w, "z": z}, {}, up, rng)
         for d in (got, r32, r64):
             d.pop("d_z", None)                               # Z is an epilogue operand of the kernel, not differentiated
         return f"n={n_in}x{n_out} e={e} f={f} w={weighted} {reduce} {flow} z={with_z}", got, r32, r64, ()
@@ -276,7 +291,7 @@ def test_fuzz_spmm2_forward_backward():
         def prod(lv):
             return spmm2(Pattern(ei.to(D), n, n), lv["xa"], lv["xb"], lv["wa"], lv["wb"])
 
-        got, r32, r64 = three_ways(ref, prod, t, {}, up)
+        got, r32, r64 = three_ways(ref, prod, t, {}, up, rng)
         return f"n={n} e={e} f={f}", got, r32, r64, ()
 
     run_rounds("spmm2", one)
@@ -375,7 +390,7 @@ def test_fuzz_magnetic_layers(signed):
             for dtype in (torch.float32, torch.float64):
                 lv = {kk: leaf(v, dtype) for kk, v in {**t, **params}.items()}
                 res.append(grads(ref(dtype, lv), [cast(u, dtype) for u in up], lv))
-        lv = {kk: leaf(v, torch.float32, D) for kk, v in t.items()}
+        lv = {kk: leaf_dev(v, rng) for kk, v in t.items()}
         lv.update(weight=layer.weight, bias=layer.bias if bias else None)
         if train_w:
             lv["w_edge"] = leaf(w, torch.float32, D)
@@ -409,7 +424,7 @@ def test_fuzz_digcn_conv():
             for dtype in (torch.float32, torch.float64):
                 lv = {k: leaf(v, dtype) for k, v in {"x": x, **params}.items()}
                 res.append(grads(R.digcn_conv(lv["x"], ei, cast(w, dtype), lv["weight"], lv["bias"]), [cast(up[0], dtype)], lv))
-        lv = {"x": leaf(x, torch.float32, D), "weight": layer.weight, "bias": layer.bias if bias else None}
+        lv = {"x": leaf_dev(x, rng), "weight": layer.weight, "bias": layer.bias if bias else None}
         got = grads(layer(lv["x"], ei.to(D), w.to(D)), [up[0].to(D)], lv)
         return f"n={n} e={ei.size(1)} {f_in}->{f_out} bias={bias}", got, res[0], res[1], ("d_weight", "d_bias")
 
@@ -438,7 +453,7 @@ def test_fuzz_normalised_propagates(which):
             layer = Conv_Base(fill, add_self_loops=loops, normalize=normalize)
             ref = lambda dtype, lv: R.conv_base(lv["x"], ei, cast(w, dtype), fill, loops, normalize)
             what = f"fill={fill}"
-        got, r32, r64 = three_ways(ref, lambda lv: layer(lv["x"], ei.to(D), None if w is None else w.to(D)), {"x": x}, {}, up)
+        got, r32, r64 = three_ways(ref, lambda lv: layer(lv["x"], ei.to(D), None if w is None else w.to(D)), {"x": x}, {}, up, rng)
         return f"n={n} e={ei.size(1)} f={f} loops={loops} normalize={normalize} w={w is not None} {what}", got, r32, r64, ()
 
     run_rounds(which, one)
@@ -470,7 +485,7 @@ def test_fuzz_simpa(directed):
                 out = R.simpa(ei_p, cast(w_p, dtype), ei_n, cast(w_n, dtype), lv["x_p"], lv["x_n"], lv, hop, fill, directed,
                               lv.get("x_pt"), lv.get("x_nt"))
                 res.append(grads(out, [cast(up[0], dtype)], lv))
-        lv = {k: leaf(v, torch.float32, D) for k, v in t.items()}
+        lv = {k: leaf_dev(v, rng) for k, v in t.items()}
         lv.update(dict(layer.named_parameters()))
         dw = lambda v: None if v is None else v.to(D)
         out = layer(ei_p.to(D), dw(w_p), ei_n.to(D), dw(w_n), lv["x_p"], lv["x_n"], lv.get("x_pt"), lv.get("x_nt"))
@@ -499,7 +514,7 @@ def test_fuzz_dimpa():
                 lv = {k: leaf(v, dtype) for k, v in {**t, **params}.items()}
                 out = R.dimpa(lv["x_s"], lv["x_t"], ei, cast(w, dtype), lv["_w_s"], lv["_w_t"], hop, fill)
                 res.append(grads(out, [cast(up[0], dtype)], lv))
-        lv = {k: leaf(v, torch.float32, D) for k, v in t.items()}
+        lv = {k: leaf_dev(v, rng) for k, v in t.items()}
         lv.update(dict(layer.named_parameters()))
         got = grads(layer(lv["x_s"], lv["x_t"], ei.to(D), None if w is None else w.to(D)), [up[0].to(D)], lv)
         return f"n={n} e={ei.size(1)} f={f} hop={hop} fill={fill} w={w is not None}", got, res[0], res[1], ("d__w_s", "d__w_t")
@@ -528,7 +543,7 @@ def test_fuzz_sgcn_conv():
                 out = R.sgcn_conv(lv["x"], pos, neg, (lv["lin_b.weight"], lv.get("lin_b.bias")),
                                   (lv["lin_u.weight"], lv.get("lin_u.bias")), first, in_dim, norm_emb)
                 res.append(grads(out, [cast(up[0], dtype)], lv))
-        lv = {"x": leaf(x, torch.float32, D)}
+        lv = {"x": leaf_dev(x, rng)}
         lv.update(dict(layer.named_parameters()))
         got = grads(layer(lv["x"], pos.to(D), neg.to(D)), [up[0].to(D)], lv)
         hub = max([int(torch.bincount(e[0], minlength=1).max()) for e in (pos, neg) if e.size(1)] + [0])
@@ -560,7 +575,7 @@ def test_fuzz_gat_conv():
                 out = R.gat_conv(lv["x"], ei, lv["lin.weight"], lv["att_src"], lv["att_dst"], lv.get("bias"), heads, concat,
                                  add_self_loops=loops)
                 res.append(grads(out, [cast(up[0], dtype)], lv))
-        lv = {"x": leaf(x, torch.float32, D)}
+        lv = {"x": leaf_dev(x, rng)}
         lv.update(dict(conv.named_parameters()))
         got = grads(conv(lv["x"], ei.to(D)), [up[0].to(D)], lv)
         what = f"n={n} e={ei.size(1)} {f_in}->{f_out} heads={heads} concat={concat} bias={bias} loops={loops}"
@@ -680,7 +695,7 @@ def test_fuzz_tall_products():
         def prod(lv):
             return dense.tall_linear(torch.cat([lv[f"x{i}"] for i in range(len(segs))], 1), lv["w"], lv["b"])
 
-        got, r32, r64 = three_ways(ref, prod, t, {"w": wt, "b": b}, up)
+        got, r32, r64 = three_ways(ref, prod, t, {"w": wt, "b": b}, up, rng)
         # the segmented entry points themselves (what the layers call: no concatenation), forward only
         # the segments as the layers hand them over: contiguous matrices, or column slices of one wider matrix (row stride)
         sliced = rng.random() < 0.4
