@@ -12,7 +12,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from ... import _cabi
+from ... import _cabi, memo
 from ..._cabi import check, ptr, stream_ptr
 from ...dense import tall_linear
 from ...sparse import (GLOBAL_PATTERNS, Pattern, _rows, _spmm_raw, gather_values, segment_long_rows_arg,
@@ -108,7 +108,7 @@ class GATConv(nn.Module):
             self.bias = nn.Parameter(torch.empty(heads * out_channels if concat else out_channels))
         else:
             self.register_parameter('bias', None)
-        self._loops_memo = None
+        self._loops_memo = memo.TensorMemo(1)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -120,13 +120,13 @@ class GATConv(nn.Module):
 
     def _with_self_loops(self, edge_index, n):
         """remove_self_loops then add_self_loops (pure function of the edge list; memoised on the tensor)."""
-        m = self._loops_memo
-        if m is not None and m[0] is edge_index and m[1] == (edge_index._version, n):
-            return m[2]
+        hit = self._loops_memo.get((edge_index,), n)
+        if hit is not None:
+            return hit
         from ...utils._norm import add_remaining_self_loops
         out, _ = add_remaining_self_loops(edge_index, None, 1.0, n, with_weights=False)
-        self._loops_memo = (edge_index, (edge_index._version, n), out)
-        return out
+        memo.own(out)                      # derived here, held by nobody else: the pattern lookup need not re-check its content
+        return self._loops_memo.put((edge_index,), n, out)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         _cabi.require_gpu(x, edge_index)

@@ -729,9 +729,10 @@ def test_fuzz_memo_never_serves_a_stale_operator():
     alone, edited in place through torch (version bump), replaced by an equal copy, replaced by different content, freed
     and re-allocated (the storage may come back at the same address), moved through `.clone()` of a view ...; after every
     step the output must equal, BIT FOR BIT, that of a never-used copy of the layer called on clones of the graph tensors.  Writes that bypass the
-    version counter (`.data`, raw pointers) are the documented exception (strict mode: tests/test_gpu_layers.py)."""
+    version counter (`.data`, raw pointers) are the documented exception of the default mode; under PYGSD_MEMO_VERIFY=1
+    (strict mode: content fingerprints) the histories include them."""
     from pytorch_geometric_signed_directed_amd import memo
-    from pytorch_geometric_signed_directed_amd.nn import DGCNConv, Conv_Base, GATConv, MagNetConv, MSConv, SGCNConv, SIMPA
+    from pytorch_geometric_signed_directed_amd.nn import DGCNConv, DIMPA, Conv_Base, GATConv, MagNetConv, MSConv, SGCNConv, SIMPA, SNEAConv
 
     def same(a, b):
         a = a if isinstance(a, (tuple, list)) else (a,)
@@ -749,7 +750,7 @@ def test_fuzz_memo_never_serves_a_stale_operator():
 
         f = int(rng.choice([4, 8, 16, 20]))
         torch.manual_seed(seed)
-        kind = str(rng.choice(["magnet", "msconv", "dgcn", "conv_base", "simpa", "sgcn", "gat"]))
+        kind = str(rng.choice(["magnet", "msconv", "dgcn", "conv_base", "simpa", "dimpa", "sgcn", "snea", "gat"]))
         state = {"ei": None, "w": None, "ei2": None, "w2": None, "x": normal(rng, n, f).to(D), "x2": normal(rng, n, f).to(D)}
         state["ei"], state["w"] = graph()
         state["ei2"], state["w2"] = graph()
@@ -768,6 +769,12 @@ def test_fuzz_memo_never_serves_a_stale_operator():
         elif kind == "simpa":
             layer = SIMPA(2, 0.5, False).to(D)
             call = lambda m, st: m(st["ei"], st["w"], st["ei2"], st["w2"], st["x"], st["x2"])           # noqa: E731
+        elif kind == "dimpa":
+            layer = DIMPA(2, 0.5).to(D)
+            call = lambda m, st: m(st["x"], st["x2"], st["ei"], st["w"])                          # noqa: E731
+        elif kind == "snea":
+            layer = SNEAConv(f, 8, True).to(D)
+            call = lambda m, st: m(st["x"], st["ei"], st["ei2"])                                  # noqa: E731
         elif kind == "sgcn":
             layer = SGCNConv(f, f, True).to(D)
             call = lambda m, st: m(st["x"], st["ei"], st["ei2"])                                  # noqa: E731
@@ -777,14 +784,21 @@ def test_fuzz_memo_never_serves_a_stale_operator():
         pristine = copy.deepcopy(layer)                    # never called: no history of its own (per-instance memos included)
         history = []
         for step in range(int(rng.integers(4, 10))):
-            act = str(rng.choice(["same", "same", "edit_index", "edit_weight", "equal_copy", "new_graph", "realloc", "swap", "resize"]))
-            which = "2" if (rng.random() < 0.3 and kind in ("simpa", "sgcn")) else ""
+            acts = ["same", "same", "edit_index", "edit_weight", "equal_copy", "new_graph", "realloc", "swap", "resize"]
+            if memo.verify():                          # strict mode (PYGSD_MEMO_VERIFY=1): writes BEHIND the version counter too
+                acts += ["data_edit_index", "data_edit_weight"]
+            act = str(rng.choice(acts))
+            which = "2" if (rng.random() < 0.3 and kind in ("simpa", "sgcn", "snea")) else ""
             ei, w = state["ei" + which], state["w" + which]
             if act == "edit_index" and ei.size(1):
                 j = int(rng.integers(0, ei.size(1)))
                 ei[int(rng.integers(0, 2)), j] = int(rng.integers(0, n))
             elif act == "edit_weight" and w.numel():
                 w[int(rng.integers(0, w.numel()))] += 0.5
+            elif act == "data_edit_index" and ei.size(1):
+                ei.data[int(rng.integers(0, 2)), int(rng.integers(0, ei.size(1)))] = int(rng.integers(0, n))
+            elif act == "data_edit_weight" and w.numel():
+                w.data[int(rng.integers(0, w.numel()))] += 0.5
             elif act == "equal_copy":
                 state["ei" + which], state["w" + which] = ei.clone(), w.clone()
             elif act == "new_graph":
@@ -794,7 +808,7 @@ def test_fuzz_memo_never_serves_a_stale_operator():
                 state["ei" + which] = state["w" + which] = None
                 del ei, w
                 state["ei" + which], state["w" + which] = graph(shape)
-            elif act == "swap" and kind in ("simpa", "sgcn"):
+            elif act == "swap" and kind in ("simpa", "sgcn", "snea"):
                 state["ei"], state["ei2"] = state["ei2"], state["ei"]
                 state["w"], state["w2"] = state["w2"], state["w"]
             elif act == "resize":                          # a slice of the same storage: same data pointer, fewer entries
@@ -825,6 +839,8 @@ def test_fuzz_memo_check_would_see_a_memo_that_ignores_versions(monkeypatch):
     """The check above has teeth: with the in-place version taken out of the memo's key (what a memo keyed on identity and
     storage alone would be) the same histories must produce stale operators, and the check must say so."""
     from pytorch_geometric_signed_directed_amd import memo
+    if memo.verify():
+        pytest.skip("strict mode (PYGSD_MEMO_VERIFY=1) checks contents: it sees the edits whatever the key holds")
     real = memo._stamp
     monkeypatch.setattr(memo, "_stamp", lambda t: None if t is None else (0,) + tuple(real(t)[1:]))
     memo.clear_all()
