@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from ...dense import matmul
+from ...memo import TensorMemo
 from ...sparse import Pattern, spmm
 
 
@@ -28,13 +29,13 @@ class Prob_Imbalance_Loss(torch.nn.Module):
                 for j in range(i + 1, K):
                     if (F[i, j] + F[j, i]) > 0:
                         self.sel += 1
-        self._memo = None
+        self._memo = TensorMemo(1)
 
     def _operator(self, A):
         """(pattern computing A @ X, values, colsum(A) + rowsum(A)) for a sparse COO / dense adjacency."""
-        m = self._memo
-        if m is not None and m[0] is A and m[1] == A._version:
-            return m[2]
+        hit = None if A.is_sparse else self._memo.get((A,), "operator")
+        if hit is not None:
+            return hit
         if A.is_sparse:
             A = A.coalesce()
             idx, val = A.indices(), A.values().float()
@@ -47,8 +48,9 @@ class Prob_Imbalance_Loss(torch.nn.Module):
         deg = torch.zeros(n, dtype=torch.float32, device=val.device)
         deg = deg.index_add(0, idx[0], val).index_add(0, idx[1], val)
         out = (pat, val, deg)
-        self._memo = (A, A._version, out) if not A.is_sparse else None
-        return out
+        # (dense adjacency: one nonzero() scan per tensor and in-place version; memo.TensorMemo -- weakly held, its opt-outs
+        #  and strict mode apply.  A sparse tensor has no version counter worth trusting: rebuilt per call)
+        return out if A.is_sparse else self._memo.put((A,), "operator", out)
 
     def forward(self, P: torch.FloatTensor, A: torch.Tensor, K: int, normalization: str = 'vol_sum',
                 threshold: str = 'sort') -> torch.FloatTensor:

@@ -209,18 +209,17 @@ class Sign_Triangle_Loss(nn.Module):
         super().__init__()
         self.lin = nn.Linear(emb_dim * 2, 1)
         self.edge_weight = edge_weight
-        self._memo = []
+        self._memo = TensorMemo(4)      # per edge list and in-place version (weakly held; memo.py's opt-outs and strict mode)
 
     def _weights(self, edge_index: Tensor, device) -> Tensor:
-        for src, ver, w in self._memo:
-            if src is edge_index and ver == edge_index._version:
-                return w
+        hit = self._memo.get((edge_index,), "triangle weights")
+        if hit is not None:
+            return hit
         import numpy as np
         ij = edge_index.detach().cpu().numpy()
         w = np.asarray(self.edge_weight.tocsr()[ij[0], ij[1]]).reshape(-1, 1)
         w = torch.from_numpy(w).to(device)
-        self._memo = (self._memo + [(edge_index, edge_index._version, w)])[-4:]
-        return w
+        return self._memo.put((edge_index,), "triangle weights", w)
 
     def forward(self, z: Tensor, pos_edge_index: Tensor, neg_edge_index: Tensor) -> Tensor:
         dim = z.size(1)                      # lin([z_i, z_j]) = z_i W_1^T + (z_j W_2^T + b), evaluated per node
