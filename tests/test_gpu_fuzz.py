@@ -723,6 +723,92 @@ def test_fuzz_tall_products():
     run_rounds("tall", one)
 
 
+def test_fuzz_two_forwards_before_one_backward():
+    """One layer instance applied to two different inputs before a single backward of the summed objective (a layer shared
+    between branches of a model; gradient accumulation over micro-batches with one backward): whatever the first forward
+    saved for its backward must survive the second forward -- no saved tensor may live in a buffer the next call reuses.
+    Input gradients must equal, bit for bit, those of two separate forward / backward passes; parameter gradients (one
+    accumulation order against another) to the max-norm bar."""
+    from pytorch_geometric_signed_directed_amd.nn import (DGCNConv, DIMPA, Conv_Base, DiGCNConv, GATConv, MagNetConv, MSConv,
+                                                          SGCNConv, SIMPA, SNEAConv)
+    from tolerance import close
+    for seed, rng in rounds("twice"):
+        n, ei = draw_graph(rng, n_lo=2)
+        e = ei.size(1)
+        ei2 = torch.from_numpy(rng.integers(0, n, (2, int(rng.integers(0, 4 * n + 1)))).astype(np.int64)).to(D)
+        eid, w = ei.to(D), positive(rng, e).to(D)
+        w2 = positive(rng, ei2.size(1)).to(D)
+        f = int(rng.choice([4, 8, 12, 16, 20, 64]))
+        kind = str(rng.choice(["magnet_k1", "magnet_k2", "msconv", "digcn", "dgcn", "conv_base", "simpa", "dimpa", "sgcn", "snea", "gat"]))
+        torch.manual_seed(seed)
+        two = kind in ("magnet_k1", "magnet_k2", "msconv", "simpa", "dimpa")          # layers that take two feature matrices
+        if kind.startswith("magnet"):
+            layer = MagNetConv(f, f, 1 if kind == "magnet_k1" else 2, 0.25, False).to(D)
+            call = lambda a, b: layer(a, b, eid, w)                                   # noqa: E731
+        elif kind == "msconv":
+            layer = MSConv(f, f, 2, 0.1, False).to(D)
+            call = lambda a, b: layer(a, b, eid, w)                                   # noqa: E731
+        elif kind == "digcn":
+            layer = DiGCNConv(f, f).to(D)
+            call = lambda a, b: layer(a, eid, w)                                      # noqa: E731
+        elif kind == "dgcn":
+            layer = DGCNConv()
+            call = lambda a, b: layer(a, eid, w)                                      # noqa: E731
+        elif kind == "conv_base":
+            layer = Conv_Base(0.5)
+            call = lambda a, b: layer(a, eid, w)                                      # noqa: E731
+        elif kind == "simpa":
+            layer = SIMPA(2, 0.5, False).to(D)
+            call = lambda a, b: layer(eid, w, ei2, w2, a, b)                          # noqa: E731
+        elif kind == "dimpa":
+            layer = DIMPA(2, 0.5).to(D)
+            call = lambda a, b: layer(a, b, eid, w)                                   # noqa: E731
+        elif kind == "sgcn":
+            layer = SGCNConv(f, f, True).to(D)
+            call = lambda a, b: layer(a, eid, ei2)                                    # noqa: E731
+        elif kind == "snea":
+            layer = SNEAConv(f, 8, True).to(D)
+            call = lambda a, b: layer(a, eid, ei2)                                    # noqa: E731
+        else:
+            layer = GATConv(f, 8).to(D)
+            call = lambda a, b: layer(a, eid)                                         # noqa: E731
+        xs = [normal(rng, n, f).to(D) for _ in range(4)]
+
+        def objective(out, salt):
+            out = out if isinstance(out, (tuple, list)) else (out,)
+            return sum((o * torch.sin(torch.arange(o.numel(), device=D, dtype=torch.float32).view_as(o) * (0.37 + salt) + k)).sum()
+                       for k, o in enumerate(out))
+
+        def leaves():
+            return [x.clone().requires_grad_() for x in xs]
+
+        params = list(layer.parameters()) if isinstance(layer, torch.nn.Module) else []
+        # together: two forwards, one backward
+        a = leaves()
+        for p_ in params:
+            p_.grad = None
+        (objective(call(a[0], a[1]), 0.0) + objective(call(a[2], a[3]), 0.5)).backward()
+        g_joint = [t.grad for t in a]
+        p_joint = [None if p_.grad is None else p_.grad.clone() for p_ in params]
+        # apart: forward / backward, forward / backward (parameter gradients accumulate)
+        b = leaves()
+        for p_ in params:
+            p_.grad = None
+        objective(call(b[0], b[1]), 0.0).backward()
+        objective(call(b[2], b[3]), 0.5).backward()
+        tag = f"twice seed={seed} {kind} n={n} e={e} f={f}"
+        for i, (gj, ga) in enumerate(zip(g_joint, [t.grad for t in b])):
+            if not two and i in (1, 3):
+                continue
+            assert (gj is None) == (ga is None), tag
+            if gj is not None:
+                assert torch.equal(gj, ga), f"{tag}: input gradient {i} differs by {float((gj - ga).abs().max()):.3e}"
+        for pj, p_ in zip(p_joint, params):
+            assert (pj is None) == (p_.grad is None), tag
+            if pj is not None:
+                close(pj, p_.grad, norm=True, what=tag + " parameter gradient")
+
+
 def test_fuzz_memo_never_serves_a_stale_operator():
     """The operator / pattern memos (memo.py: keyed on tensor identity, in-place version and storage) under random histories:
     one long-lived instance of every uncached layer is called again and again while its graph tensors are, at random, left

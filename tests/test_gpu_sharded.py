@@ -428,6 +428,74 @@ def _fuzz_other_round(rank, world, seed):
     return what, res
 
 
+def _fuzz_twice_round(rank, world, seed):
+    """One sharded layer applied to two inputs before ONE backward of the summed objective, against two separate forward /
+    backward passes: the engine's send / receive / return buffers are reused by every call, so nothing the first forward
+    saved for its backward may live in them.  Input-gradient shards bit for bit, parameter gradients to 1e-5 (max norm);
+    (description, worst input-gradient difference over all ranks, worst parameter-gradient error over all ranks)."""
+    import numpy as np
+    from pytorch_geometric_signed_directed_amd.parallel import ShardedDiGCNConv, ShardedMagNetConv, ShardedSGCNConv, ShardedSIMPA
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(world, 1500))
+    e = int(n * float(rng.choice([1.0, 6.0, 15.0])))
+    ei = torch.from_numpy(rng.integers(0, n, (2, e)).astype(np.int64)).to(dev)
+    ei2 = torch.from_numpy(rng.integers(0, n, (2, max(1, e // 2))).astype(np.int64)).to(dev)
+    w = torch.from_numpy((rng.random(e) + 0.25).astype(np.float32)).to(dev)
+    w2 = torch.from_numpy((rng.random(ei2.size(1)) + 0.25).astype(np.float32)).to(dev)
+    f = int(rng.choice([8, 16, 32, 64]))
+    kind = str(rng.choice(["magnet_rows", "magnet_grid", "magnet_k1", "digcn", "sgcn", "simpa"]))
+    phases, chunks = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    torch.manual_seed(seed)
+    if kind.startswith("magnet"):
+        cols = [c for c in (2, 4, 8) if world % c == 0 and f % (4 * c) == 0]
+        grid = kind == "magnet_grid" and cols
+        layer = ShardedMagNetConv(f, f, 1 if kind == "magnet_k1" else 2, 0.25, n, ei, w, device=dev, layout="grid" if grid else "rows",
+                                  grid_cols=int(rng.choice(cols)) if grid else None, phases=phases, return_chunks=chunks)
+        n_in, call = 2, (lambda a, b: layer(a, b))
+    elif kind == "digcn":
+        layer = ShardedDiGCNConv(f, f, n, ei, w * 0.2, device=dev, phases=phases)
+        n_in, call = 1, (lambda a, b: layer(a))
+    elif kind == "sgcn":
+        layer = ShardedSGCNConv(f, f // 2, True, n, ei, ei2, device=dev)
+        n_in, call = 1, (lambda a, b: layer(a))
+    else:
+        layer = ShardedSIMPA(2, 0.5, n, ei, w, ei2, w2, False, device=dev)
+        n_in, call = 2, (lambda a, b: layer(a, b))
+    with torch.no_grad():
+        for prm in layer.parameters():
+            prm.uniform_(-0.5, 0.5)
+            dist.broadcast(prm.data, 0)
+    xs = [layer.shard_rows(torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev)) for _ in range(4)]
+
+    def objective(out, salt):
+        out = out if isinstance(out, (tuple, list)) else (out,)
+        return sum((o * torch.sin(torch.arange(o.numel(), device=dev, dtype=torch.float32).view_as(o) * (0.37 + salt) + k)).sum()
+                   for k, o in enumerate(out))
+
+    params = list(layer.parameters())
+
+    def run(joint):
+        leaves = [x.clone().requires_grad_() for x in xs]
+        for prm in params:
+            prm.grad = None
+        if joint:
+            (objective(call(leaves[0], leaves[1]), 0.0) + objective(call(leaves[2], leaves[3]), 0.5)).backward()
+        else:
+            objective(call(leaves[0], leaves[1]), 0.0).backward()
+            objective(call(leaves[2], leaves[3]), 0.5).backward()
+        used = [0, 1, 2, 3] if n_in == 2 else [0, 2]
+        return [leaves[i].grad.clone() for i in used], [prm.grad.clone() for prm in params]
+
+    gj, pj = run(True)
+    ga, pa = run(False)
+    worst_x = max(float((a - b).abs().max()) if a.numel() else 0.0 for a, b in zip(gj, ga))
+    worst_p = max(float((a - b).abs().max()) / max(1.0, float(b.abs().max())) for a, b in zip(pj, pa))
+    t = torch.tensor([worst_x, worst_p], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return f"seed={seed} {kind} n={n} e={e} f={f} phases={phases} chunks={chunks}", float(t[0]), float(t[1])
+
+
 def _fuzz_suite(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
@@ -437,6 +505,7 @@ def _fuzz_suite(rank, world, port, ret):
         for r in range(FUZZ_ROUNDS):
             out.append(_fuzz_magnetic_round(rank, world, FUZZ_SEED + 7919 * world + r))
             out.append(_fuzz_other_round(rank, world, FUZZ_SEED + 104729 * world + r))
+            out.append(("twice",) + _fuzz_twice_round(rank, world, FUZZ_SEED + 15485863 * world + r))
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -452,7 +521,11 @@ def test_fuzz_sharded_layers(world):
     mp.spawn(_fuzz_suite, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert len(ret) == world
     bad, gross, checks = [], [], 0
-    for what, res in ret[0]:
+    twice = [r for r in ret[0] if r[0] == "twice"]
+    stale = [f"{what}: input gradients differ by {dx:.3e}, parameter gradients by {dp:.3e}" for _, what, dx, dp in twice
+             if dx != 0.0 or not dp <= 1e-5]
+    assert not stale, "two forwards before one backward:\n" + "\n".join(stale[:20])
+    for what, res in (r for r in ret[0] if r[0] != "twice"):
         for name, (mine, theirs) in res.items():
             checks += 1
             if not mine <= max(1e-5, 3.0 * theirs):
