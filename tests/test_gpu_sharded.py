@@ -496,6 +496,62 @@ def _fuzz_twice_round(rank, world, seed):
     return f"seed={seed} {kind} n={n} e={e} f={f} phases={phases} chunks={chunks}", float(t[0]), float(t[1])
 
 
+def _fuzz_input_cache_round(rank, world, seed):
+    """The opt-in input-exchange memo (`cache_input_exchange=True`: while x_real / x_imag are the same tensors at the same
+    in-place version, the forward's inbound exchange is not repeated) under a random history of steps -- same tensors,
+    in-place edits through torch, fresh tensors, a backward in between: every output within 1e-5 (1 + |.|) of a twin layer's
+    without the memo.  (description, worst such difference over all steps and ranks)."""
+    import numpy as np
+    from pytorch_geometric_signed_directed_amd.parallel import ShardedMagNetConv
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(world, 1200))
+    e = int(n * float(rng.choice([2.0, 10.0])))
+    ei = torch.from_numpy(rng.integers(0, n, (2, e)).astype(np.int64)).to(dev)
+    f = int(rng.choice([8, 16, 32]))
+    cols = [c for c in (2, 4, 8) if world % c == 0 and f % (4 * c) == 0]
+    grid = bool(cols) and rng.random() < 0.5
+    kw = dict(device=dev, layout="grid" if grid else "rows", grid_cols=int(rng.choice(cols)) if grid else None,
+              phases=int(rng.integers(1, 3)), return_chunks=int(rng.integers(1, 3)))
+    torch.manual_seed(seed)
+    cached = ShardedMagNetConv(f, f, int(rng.integers(1, 3)), 0.25, n, ei, None, cache_input_exchange=True, **kw)
+    plain = ShardedMagNetConv(f, f, cached.weight.size(0) - 1, 0.25, n, ei, None, cache_input_exchange=False, **kw)
+    with torch.no_grad():
+        for a, b in zip(cached.parameters(), plain.parameters()):
+            dist.broadcast(a.data, 0)
+            b.copy_(a)
+    fresh = lambda: cached.shard_rows(torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(dev))   # noqa: E731
+    xr, xi = fresh(), fresh()
+    differ, history = 0.0, []
+    for _ in range(int(rng.integers(4, 9))):
+        act = str(rng.choice(["same", "same", "edit_real", "edit_imag", "new_real", "new_both", "train_step"]))
+        history.append(act)
+        if act == "edit_real" and xr.numel():
+            xr[int(rng.integers(0, xr.size(0))), int(rng.integers(0, f))] += 1.0
+        elif act == "edit_imag" and xi.numel():
+            xi.mul_(1.5)
+        elif act == "new_real":
+            xr = fresh()
+        elif act == "new_both":
+            xr, xi = fresh(), fresh()
+        if act == "train_step":
+            outs = []
+            for layer in (cached, plain):
+                a, b = xr.clone().requires_grad_(), xi.clone().requires_grad_()
+                o = layer(a, b)
+                (o[0].sum() + o[1].sum()).backward()
+                outs.append((o[0].detach(), o[1].detach(), a.grad, b.grad))
+        else:
+            with torch.no_grad():
+                outs = [layer(xr, xi) for layer in (cached, plain)]
+        # (a remembered exchange lets the product run over all columns at once instead of phase by phase: another order of
+        #  the same fp32 sums -- rounding apart, never the O(1) of a stale input: the edits add 1.0 / scale by 1.5)
+        differ = max([differ] + [float(((p_ - q_).abs() / (1.0 + q_.abs())).max()) for p_, q_ in zip(*outs) if p_.numel()])
+    t = torch.tensor([float(differ)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return f"seed={seed} n={n} e={e} f={f} {kw['layout']} history={history}", float(t[0])
+
+
 def _fuzz_suite(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
@@ -506,6 +562,7 @@ def _fuzz_suite(rank, world, port, ret):
             out.append(_fuzz_magnetic_round(rank, world, FUZZ_SEED + 7919 * world + r))
             out.append(_fuzz_other_round(rank, world, FUZZ_SEED + 104729 * world + r))
             out.append(("twice",) + _fuzz_twice_round(rank, world, FUZZ_SEED + 15485863 * world + r))
+            out.append(("input_cache",) + _fuzz_input_cache_round(rank, world, FUZZ_SEED + 32452843 * world + r))
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -525,7 +582,9 @@ def test_fuzz_sharded_layers(world):
     stale = [f"{what}: input gradients differ by {dx:.3e}, parameter gradients by {dp:.3e}" for _, what, dx, dp in twice
              if dx != 0.0 or not dp <= 1e-5]
     assert not stale, "two forwards before one backward:\n" + "\n".join(stale[:20])
-    for what, res in (r for r in ret[0] if r[0] != "twice"):
+    stale = [f"{what}: differs by {k:.3e}" for tag, what, k in (r for r in ret[0] if r[0] == "input_cache") if not k <= 1e-5]
+    assert not stale, "input-exchange memo served a stale exchange:\n" + "\n".join(stale[:20])
+    for what, res in (r for r in ret[0] if r[0] not in ("twice", "input_cache")):
         for name, (mine, theirs) in res.items():
             checks += 1
             if not mine <= max(1e-5, 3.0 * theirs):
