@@ -341,3 +341,112 @@ def test_layers_propagate_a_non_finite_feature_as_the_oracle(layer):
         conv.to(d)
         got = conv(x.to(d), ei.to(d), ew.to(d))
         same_special_values_and_close(got, want, "DiGCNConv")
+
+
+# ------------------------------------------------------------------ randomised planting
+def _sprinkle(rng, t, count, big=False):
+    """`count` special values at random places of a matrix: infinities of either sign, NaN, exact zeros, values that fit eight
+    mantissa bits, tiny and subnormal ones; big: ONE magnitude next to the largest bf16 (3.3e38 below it, 3.4e38 above) as
+    well.  One only, and its partners are kept below 0.2 by the caller: where several such terms meet in one sum, whether a
+    PARTIAL sum passes FLT_MAX depends on the order of accumulation -- the reference's matmul does not define one (it
+    computes rr and ii apart and overflows where rr - ii, accumulated together, does not)."""
+    import numpy as np
+    kinds = [INF, -INF, NAN, 0.0, 0.5, -0.25, TINY, SUB]
+    n, k = t.shape
+    for _ in range(count):
+        t[int(rng.integers(0, n)), int(rng.integers(0, k))] = float(rng.choice(np.array(kinds)))
+    if big:
+        t[int(rng.integers(0, n)), int(rng.integers(0, k))] = float(rng.choice(np.array([BIG, -BIG, HUGE, -HUGE])))
+    return t
+
+
+def test_fuzz_non_finite_values_through_the_dense_products():
+    """Random shapes (the kernels' own tile shapes and the generic fallbacks), random special values at random places of
+    operands, weights and gradients, through tall_product (plain and transposed), tall_gram and the magnetic dense stage in
+    their DEFAULT forms: NaN / +inf / -inf exactly where fp32 `torch.matmul` puts them on the CPU, the finite rest to the bar
+    (float64 arbitrates).  PYGSD_FUZZ_ROUNDS / PYGSD_FUZZ_SEED as in tests/test_gpu_fuzz.py."""
+    import os
+    import numpy as np
+    from pytorch_geometric_signed_directed_amd.dense import (dense_bwd_raw, dense_fwd_raw, dense_supported, set_dense_f32_exact,
+                                                             set_tall_f32_exact, tall_gram, tall_product)
+    rounds, seed0 = int(os.environ.get("PYGSD_FUZZ_ROUNDS", "6")), int(os.environ.get("PYGSD_FUZZ_SEED", "1000"))
+    d = dev()
+    widths = [4, 8, 16, 20, 32, 48, 64, 96, 128, 192, 256]
+    for r in range(rounds):
+        rng = np.random.default_rng(seed0 + 7 * r)
+        normal = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))      # noqa: E731
+        n = int(rng.integers(1, 6000)) if rng.random() < 0.8 else int(rng.integers(1, 40))
+        # ---- tall product / gram
+        segs = [int(rng.choice(widths[:9])) for _ in range(int(rng.integers(1, 4)))]
+        k, f_out = sum(segs), int(rng.choice(widths))
+        big = rng.random() < 0.5                                  # one near-FLT_MAX value in x; its partners stay below 0.2
+        x, w = _sprinkle(rng, normal(n, k), int(rng.integers(0, 12)), big), normal(k, f_out) * 0.2
+        up = normal(n, f_out)
+        if big:
+            w, up = w.clamp(-0.2, 0.2), up.clamp(-0.2, 0.2)
+        w = _sprinkle(rng, w, int(rng.integers(0, 6)))
+        up = _sprinkle(rng, up, int(rng.integers(0, 8)))
+        bias = normal(f_out) if rng.random() < 0.5 else None
+        tag = f"seed {seed0 + 7 * r} n={n} widths={segs}->{f_out}"
+        with single_thread():
+            want = x @ w if bias is None else x @ w + bias
+            want_t, want_g = up @ w.t(), x.t() @ up
+            t64 = x.double() @ w.double() if bias is None else x.double() @ w.double() + bias.double()
+            t64_t, t64_g = up.double() @ w.double().t(), x.double().t() @ up.double()
+        xs, at = [], 0
+        for wd in segs:
+            xs.append(x[:, at:at + wd].contiguous().to(d))
+            at += wd
+        prev = set_tall_f32_exact(False)
+        try:
+            got = tall_product(xs, w.to(d), False, None if bias is None else bias.to(d))
+            got_t = tall_product([up.to(d)], w.to(d), True)
+            got_g = tall_gram(xs, [up.to(d)])
+        finally:
+            set_tall_f32_exact(prev)
+        same_special_values_and_close(got, want, tag + " product", truth64=t64)
+        same_special_values_and_close(got_t, want_t, tag + " transposed product", truth64=t64_t)
+        same_special_values_and_close(got_g, want_g, tag + " gram", norm=True, truth64=t64_g)
+        # ---- magnetic dense stage
+        f_in, f_o, k1 = int(rng.choice([64, 128])), int(rng.choice([64, 128])), int(rng.integers(1, 4))
+        if not dense_supported(f_in, f_o, k1):
+            continue
+        a = [normal(n, f_in) for _ in range(k1)]
+        b = [normal(n, f_in) for _ in range(k1)]
+        big = int(rng.integers(0, 2 * k1)) if rng.random() < 0.5 else -1      # which of the 2 (K+1) term matrices gets the one
+        for j, t in enumerate(a + b):
+            _sprinkle(rng, t, int(rng.integers(0, 4)), j == big)
+        wm, gr, gi = normal(k1, f_in, f_o) * 0.3, normal(n, f_o), normal(n, f_o)
+        if big >= 0:
+            wm, gr, gi = wm.clamp(-0.2, 0.2), gr.clamp(-0.1, 0.1), gi.clamp(-0.1, 0.1)
+        for kk in range(k1):
+            _sprinkle(rng, wm[kk], int(rng.integers(0, 3)))
+        bm = normal(f_o)
+        gr, gi = _sprinkle(rng, gr, int(rng.integers(0, 4))), _sprinkle(rng, gi, int(rng.integers(0, 4)))
+
+        def reference(dtype):
+            at_ = [t.detach().clone().to(dtype).requires_grad_() for t in a]
+            bt_ = [t.detach().clone().to(dtype).requires_grad_() for t in b]
+            wt_, bi_ = wm.detach().clone().to(dtype).requires_grad_(), bm.detach().clone().to(dtype).requires_grad_()
+            with single_thread():
+                rr = sum(at_[j] @ wt_[j] for j in range(k1))
+                ii = sum(bt_[j] @ wt_[j] for j in range(k1))
+                o_r, o_i = rr - ii + bi_, rr + ii + bi_
+                torch.autograd.backward([o_r, o_i], [gr.to(dtype), gi.to(dtype)])
+            return o_r, o_i, at_, bt_, wt_, bi_
+
+        w32, w64 = reference(torch.float32), reference(torch.float64)
+        prev = set_dense_f32_exact(False)
+        try:
+            o_r, o_i = dense_fwd_raw([t.to(d) for t in a], [t.to(d) for t in b], wm.to(d), bm.to(d))
+            da, db, dw, dbias = dense_bwd_raw([t.to(d) for t in a], [t.to(d) for t in b], wm.to(d), gr.to(d), gi.to(d))
+        finally:
+            set_dense_f32_exact(prev)
+        tag = f"seed {seed0 + 7 * r} n={n} dense {f_in}->{f_o} K+1={k1}"
+        same_special_values_and_close(o_r, w32[0], tag + " out_real", truth64=w64[0])
+        same_special_values_and_close(o_i, w32[1], tag + " out_imag", truth64=w64[1])
+        for j in range(k1):
+            same_special_values_and_close(da[j], w32[2][j].grad, tag + f" dA_{j}", truth64=w64[2][j].grad)
+            same_special_values_and_close(db[j], w32[3][j].grad, tag + f" dB_{j}", truth64=w64[3][j].grad)
+        same_special_values_and_close(dw, w32[4].grad, tag + " dW", norm=True, truth64=w64[4].grad)
+        same_special_values_and_close(dbias, w32[5].grad, tag + " dbias", norm=True, truth64=w64[5].grad)
