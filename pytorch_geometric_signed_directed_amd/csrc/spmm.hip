@@ -120,6 +120,18 @@ __device__ __forceinline__ void gather_step(int u, int cnt, int sub, bool fact, 
     }
 }
 
+// second summation level of a long row (spmm_vec_kernel): slot (+)= the batch's partial sum, the accumulator starts again
+__device__ __forceinline__ void flush_level(float4& slot, float4& acc, bool first)
+{
+    if (first) {
+        slot = acc;
+    } else {
+        const float4 t = slot;
+        slot = make_float4(t.x + acc.x, t.y + acc.y, t.z + acc.z, t.w + acc.w);
+    }
+    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // DEEP = true : deepest step 16 (8 per operator in the dual kernel) row fetches per lane in flight, ~125
 //               VGPRs, 4 waves/SIMD -- measured best on rows with >= 28 (dual) / 48 (single) neighbours
 //               (the 41-neighbour benchmark rows of the dual kernel: +1.5 % over the light variant).
@@ -147,6 +159,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_kernel(SpmmArgs 
     float4 acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* xa = p.xa + fl;
     const float* xb = DUAL ? p.xb + fl : nullptr;
+    // Rows of more than one 64-entry batch: a second summation level.  Each batch's partial sum is added to a per-lane slot in
+    // LDS and the register accumulator starts again from zero, so a lane group's chain is 64 / NPW entries long, then one add per
+    // batch -- a 4 000-entry row errs like a sum of ~60 terms, not ~1 000 (round 6: the randomised tests' outliers were such rows,
+    // summed like the reference's sequential scatter).  The slot lives in LDS, not in registers: the deep dual variant sits 6
+    // registers under its 4-wavefront budget.  Rows of one batch (every row of the benchmark graphs) never touch it: bitwise as before.
+    __shared__ float4 lvl2[kWavesPerBlock * 64 * (DUAL ? 2 : 1)];
+    float4* slot = lvl2 + (threadIdx.x * (DUAL ? 2 : 1));
+    const bool multi = end - beg > 64;                  // (wave-uniform)
 
     for (int base = beg; base < end; base += 64) {
         const int cnt = (end - base) < 64 ? (end - base) : 64;
@@ -171,6 +191,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_vec_kernel(SpmmArgs 
         }
         for (; u < cnt; u += NPW * 2)
             gather_step<LPR, DUAL, 2>(u, cnt, sub, fact, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
+        if (multi) {
+            flush_level(slot[0], acc_a, base == beg);
+            if (DUAL) flush_level(slot[DUAL ? 1 : 0], acc_b, base == beg);
+        }
+    }
+    if (multi) {
+        acc_a = slot[0];
+        if (DUAL) acc_b = slot[DUAL ? 1 : 0];
     }
 
     reduce_groups<LPR>(acc_a);
@@ -226,6 +254,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm2_k1_dense_kernel(Spm
     float4 acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* xa = p.xa + fl;
     const float* xb = p.xb + fl;
+    __shared__ float4 lvl2[kWavesPerBlock * 64 * 2];
+    float4* slot = lvl2 + threadIdx.x * 2;
+    const bool multi = end - beg > 64;
     for (int base = beg; base < end; base += 64) {
         const int cnt = (end - base) < 64 ? (end - base) : 64;
         int c = 0;
@@ -244,6 +275,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm2_k1_dense_kernel(Spm
         }
         for (; u < cnt; u += NPW * 2)
             gather_step<LPR, true, 2>(u, cnt, sub, true, c, wa, wb, xa, xb, p.ldx, acc_a, acc_b);
+        if (multi) {                                    // (the same second level as spmm_vec_kernel: bitwise the composed path)
+            flush_level(slot[0], acc_a, base == beg);
+            flush_level(slot[1], acc_b, base == beg);
+        }
+    }
+    if (multi) {
+        acc_a = slot[0];
+        acc_b = slot[1];
     }
     // the row's own features (T_0): loaded behind the gather loop, so that the loop keeps the plain kernel's register count
     // (and with it 4 wavefronts per SIMD); their latency overlaps the butterfly and the T_1 stores
@@ -439,6 +478,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_packed_kernel(SpmmAr
     float4 acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* xa = p.xa + fl;
     const float* xb = DUAL ? p.xb + fl : nullptr;
+    // (second summation level for rows of more than 64 entries, as in spmm_vec_kernel: here a lane group sums its whole row, so
+    //  the slot takes the partial sum of every 64-entry chunk the row takes part in)
+    __shared__ float4 lvl2[kWavesPerBlock * 64 * (DUAL ? 2 : 1)];
+    float4* slot = lvl2 + (threadIdx.x * (DUAL ? 2 : 1));
+    const bool multi = mine && deg > 64;
     while (true) {
         const unsigned long long work = __ballot(pos < stop);
         if (work == 0) break;
@@ -480,7 +524,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmm_packed_kernel(SpmmAr
                 if (DUAL) fma4(acc_b, sb[k], gb[k]);
             }
         }
-        if (pos < hi) pos = hi;
+        if (pos < hi) {
+            if (multi) {
+                flush_level(slot[0], acc_a, pos == beg);
+                if (DUAL) flush_level(slot[DUAL ? 1 : 0], acc_b, pos == beg);
+            }
+            pos = hi;
+        }
+    }
+    if (multi) {
+        acc_a = slot[0];
+        if (DUAL) acc_b = slot[DUAL ? 1 : 0];
     }
     if (mine && fact) {
         const int64_t yo = row * p.ldy + fl;
