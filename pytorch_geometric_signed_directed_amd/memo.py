@@ -33,7 +33,8 @@ Switches:
     memo.set_enabled(False)                         (whole process, at run time)
     Layer(..., operator_memo=False)                 (one layer; MagNetConv / MSConv / DGCNConv / Conv_Base)
 
-Lookups and insertions are serialised by a lock (DataLoader threads, multi-stream callers).
+Lookups and insertions are serialised by a lock (DataLoader threads).  Streams: an entry remembers the HIP stream it was last
+produced / used on; a hit from another stream makes that stream wait for it first (`_order_after`).
 """
 import os
 import threading
@@ -81,10 +82,37 @@ def clear_all() -> None:
 
 
 class _Entry:
-    __slots__ = ("refs", "stamps", "extra", "value")
+    __slots__ = ("refs", "stamps", "extra", "value", "stream_ptr", "stream")
 
-    def __init__(self, refs, stamps, extra, value):
+    def __init__(self, refs, stamps, extra, value, stream_ptr=None, stream=None):
         self.refs, self.stamps, self.extra, self.value = refs, stamps, extra, value
+        self.stream_ptr, self.stream = stream_ptr, stream      # the HIP stream the value was last produced / used on
+
+
+def _raw_stream(tensors):
+    """Raw handle of the current HIP stream of the key tensors' device (None for host tensors): two integer calls into torch."""
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            return torch._C._cuda_getCurrentRawStream(t.device.index if t.device.index is not None else torch._C._cuda_getDevice())
+    return None
+
+
+def _order_after(entry, tensors):
+    """A memoised value is device data queued on SOME stream -- the one its miss ran on, or the one a later hit finished a lazily
+    built member on (a pattern's transposed CSR, a value array).  A caller on another stream has synchronised with the tensors
+    it passes in, not with that stream: before it uses the entry, its stream waits for everything queued so far on the
+    entry's last stream, and becomes the entry's stream.  Same stream (every single-stream program): one integer compare."""
+    if entry.stream_ptr is None:
+        return
+    now = _raw_stream(tensors)
+    if now is None or now == entry.stream_ptr:
+        return
+    dev = next(t.device for t in tensors if t is not None and t.is_cuda)
+    cur = torch.cuda.current_stream(dev)
+    done = torch.cuda.Event()
+    done.record(entry.stream)
+    cur.wait_event(done)
+    entry.stream_ptr, entry.stream = now, cur
 
 
 def _stamp(t: Optional[torch.Tensor]):
@@ -150,6 +178,7 @@ class TensorMemo:
                     except ValueError:
                         pass
                     self._items.append(e)
+                    _order_after(e, tensors)                 # (a caller on another stream waits for the entry's)
                     return (e.value,)
         return None
 
@@ -165,8 +194,10 @@ class TensorMemo:
                     m._prune()
 
             refs = tuple(None if t is None else weakref.ref(t, gone) for t in tensors)
+            raw = _raw_stream(tensors)
+            stream = None if raw is None else torch.cuda.current_stream(next(t.device for t in tensors if t is not None and t.is_cuda))
             with self._lock:
-                self._items.append(_Entry(refs, tuple(_stamp(t) for t in tensors), extra, value))
+                self._items.append(_Entry(refs, tuple(_stamp(t) for t in tensors), extra, value, raw, stream))
                 if len(self._items) > self.capacity:
                     self._items.pop(0)
         return value

@@ -237,7 +237,8 @@ class Pattern:
             return None
         if memo.verify():
             memo.check_unchanged(w)                  # strict mode: the permuted copy below is only as good as w's contents
-        key = (id(w), which)
+        # (the current stream is part of the key: a permuted copy queued on one stream is not handed to another)
+        key = (id(w), which, torch._C._cuda_getCurrentRawStream(w.device.index) if w.is_cuda else None)
         hit = self._vcache.get(key)
         if hit is not None and hit[0]() is w and hit[1] == (w._version, memo.content_epoch()):
             return hit[2]

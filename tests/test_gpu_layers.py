@@ -2,6 +2,7 @@
 Python (tests/golden/*.npz, written by oracle/gen_golden.py) and against the oracle at seeded
 mid-size inputs.  Bar (tests/tolerance.py): per element |got - want| <= 1e-5 (1 + |want|) on outputs and input gradients;
 the max-norm form only for reductions over the N rows (parameter gradients, objectives), marked norm=True."""
+import copy
 import functools
 
 import numpy as np
@@ -1024,6 +1025,69 @@ def test_uncached_layer_reuses_the_operator_only_for_unmodified_graph_tensors():
     assert layer._operator is not op4
     want = fresh(ei, w, 3.0)
     close(o5[0], want[0].detach().cpu().numpy()); close(o5[1], want[1].detach().cpu().numpy())
+
+
+@pytest.mark.parametrize("kind", ["conv_base", "magnet", "sgcn"])
+def test_memoised_operator_is_ordered_across_streams(kind):
+    """A memoised operator is device data queued on the stream its miss ran on.  A second caller on ANOTHER stream has
+    synchronised with the tensors it passes, not with that stream: the hit must make its stream wait (memo._order_after).
+    Stream 1 is kept busy by a 40 ms spin kernel, then builds the operator; stream 2 calls the same layer with the same graph
+    tensors at once -- without the ordering it multiplies with an operator that has not been written yet."""
+    from pytorch_geometric_signed_directed_amd import _cabi, memo
+    from pytorch_geometric_signed_directed_amd.nn import Conv_Base, MagNetConv, SGCNConv
+    memo.clear_all()
+    g = torch.Generator().manual_seed(9)
+    n, e, f = 20000, 300000, 16
+    ei, ei2 = torch.randint(0, n, (2, e), generator=g).to(D), torch.randint(0, n, (2, e // 2), generator=g).to(D)
+    w = (torch.rand(e, generator=g) + 0.5).to(D)
+    x, x2 = torch.randn(n, f, generator=g).to(D), torch.randn(n, f, generator=g).to(D)
+    torch.manual_seed(2)
+    if kind == "conv_base":
+        make, call = (lambda: Conv_Base(0.5)), (lambda m: m(x, ei, w))
+    elif kind == "magnet":
+        proto = MagNetConv(f, f, 2, 0.25, False).to(D)
+        make, call = (lambda: copy.deepcopy(proto)), (lambda m: torch.cat(m(x, x2, ei, w), 1))
+    else:
+        proto = SGCNConv(f, f, True).to(D)
+        make, call = (lambda: copy.deepcopy(proto)), (lambda m: m(x, ei, ei2))
+    with torch.no_grad():
+        want = call(make())
+        torch.cuda.synchronize()
+        memo.clear_all()
+        layer = make()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(s1):
+            _cabi.check(_cabi.lib().pygsd_spin_us(40000.0, _cabi.stream_ptr()), "pygsd_spin_us")
+            y1 = call(layer)                       # miss: the build is queued behind the spin
+        with torch.cuda.stream(s2):
+            y2 = call(layer)                       # hit, on another stream
+        torch.cuda.synchronize()
+    assert torch.equal(y1, want)
+    assert torch.equal(y2, want), float((y2 - want).abs().max())
+
+
+def test_memo_hit_on_another_stream_waits_for_the_value():
+    """The mechanism itself, where the window is as wide as the test makes it (a layer's miss reads sizes back to the host,
+    which narrows the real window to the build's last kernel): a value queued behind a 40 ms spin on stream 1 is memoised;
+    the hit on stream 2 must not let stream 2 read it before it is written."""
+    from pytorch_geometric_signed_directed_amd import _cabi, memo
+    m = memo.TensorMemo(2)
+    key = torch.zeros(4, device=D)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        _cabi.check(_cabi.lib().pygsd_spin_us(40000.0, _cabi.stream_ptr()), "pygsd_spin_us")
+        value = torch.zeros(1 << 20, device=D)
+        value.add_(7.0)                               # queued behind the spin
+        m.put((key,), "k", value)
+    with torch.cuda.stream(s2):
+        hit = m.get((key,), "k")
+        assert hit is value
+        seen = hit.clone()                            # stream 2 reads the memoised value
+    torch.cuda.synchronize()
+    assert float(seen.min()) == 7.0 and float(seen.max()) == 7.0
+    with torch.cuda.stream(s2):                       # the entry now lives on stream 2: a hit there waits for nothing
+        assert m.get((key,), "k") is value
 
 
 def test_operator_memo_opt_out_and_weak_keys():
