@@ -884,6 +884,65 @@ def test_fuzz_hipgraph_replay_equals_eager():
                     assert torch.equal(g_, w_.detach()), f"{tag}: tensor {i} differs by {float((g_ - w_).abs().max()):.3e}"
 
 
+def test_fuzz_threads_and_streams_share_layers():
+    """Four host threads, each on its own HIP stream, call the SAME layer instances on the SAME graph tensors in random order
+    (forward + backward), with the memos cleared now and then by one of them: every result bit for bit the one computed
+    alone beforehand.  Exercises the memo locks, the ordering of hits across streams, the thread-local error state of the
+    C-ABI and the allocator-owned workspaces."""
+    import threading
+    from pytorch_geometric_signed_directed_amd import memo
+    from pytorch_geometric_signed_directed_amd.nn import DGCNConv, Conv_Base, GATConv, MagNetConv, SGCNConv, SIMPA
+    rng = np.random.default_rng(SEED0 + 77)
+    n, f = 3000, 16
+    ei = torch.from_numpy(rng.integers(0, n, (2, 40000)).astype(np.int64)).to(D)
+    ei2 = torch.from_numpy(rng.integers(0, n, (2, 15000)).astype(np.int64)).to(D)
+    w, w2 = positive(rng, 40000).to(D), positive(rng, 15000).to(D)
+    xs = [normal(rng, n, f).to(D) for _ in range(3)]
+    torch.manual_seed(5)
+    layers = {"magnet": MagNetConv(f, f, 2, 0.25, False).to(D), "dgcn": DGCNConv(), "conv_base": Conv_Base(0.5),
+              "simpa": SIMPA(2, 0.5, False).to(D).requires_grad_(False), "sgcn": SGCNConv(f, f, True).to(D), "gat": GATConv(f, 8).to(D)}
+    calls = {"magnet": lambda m, a, b: torch.cat(m(a, b, ei, w), 1), "dgcn": lambda m, a, b: m(a, ei, w),
+             "conv_base": lambda m, a, b: m(a, ei, w), "simpa": lambda m, a, b: m(ei, w, ei2, w2, a, b),
+             "sgcn": lambda m, a, b: m(a, ei, ei2), "gat": lambda m, a, b: m(a, ei)}
+
+    def run(kind, i, j):
+        a, b = xs[i].clone().requires_grad_(), xs[j].clone().requires_grad_()
+        out = calls[kind](layers[kind], a, b)
+        (out * out).sum().backward(inputs=[a])          # (parameter gradients are not accumulated: the threads share the modules)
+        return out.detach(), a.grad
+
+    want = {(k, i, j): run(k, i, j) for k in layers for i in range(3) for j in range(3)}
+    torch.cuda.synchronize()
+    memo.clear_all()
+    errors = []
+
+    def worker(tid):
+        try:
+            trng = np.random.default_rng(SEED0 + 1000 + tid)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for it in range(6 * max(ROUNDS, 4)):
+                    kind = str(trng.choice(list(layers)))
+                    i, j = int(trng.integers(0, 3)), int(trng.integers(0, 3))
+                    if tid == 0 and it % 7 == 3:
+                        memo.clear_all()
+                    out, grad = run(kind, i, j)
+                    stream.synchronize()
+                    ro, rg = want[(kind, i, j)]
+                    if not (torch.equal(out, ro) and torch.equal(grad, rg)):
+                        errors.append(f"thread {tid} iteration {it} {kind}: out {float((out - ro).abs().max()):.3e} grad {float((grad - rg).abs().max()):.3e}")
+                        return
+        except Exception as exc:                         # noqa: BLE001 -- reported by the main thread
+            errors.append(f"thread {tid}: {type(exc).__name__}: {exc}")
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, "\n".join(errors[:10])
+
+
 def test_fuzz_memo_never_serves_a_stale_operator():
     """The operator / pattern memos (memo.py: keyed on tensor identity, in-place version and storage) under random histories:
     one long-lived instance of every uncached layer is called again and again while its graph tensors are, at random, left
