@@ -327,6 +327,45 @@ def test_fuzz_spmm_bf16_storage():
     assert not bad, "\n".join(bad[:20])
 
 
+def test_fuzz_digcn_conv_bf16_storage():
+    """DiGCNConv with bf16 parameters and features (BASELINE config C5's storage) at random widths -- the tiled bf16 shapes
+    and everything the generic bf16 GEMM catches -- forward, input gradient and parameter gradients against the fp32 oracle
+    on the bf16-rounded operands.  Every stored value (projection, product, gradient) is rounded to 8 bits of mantissa:
+    relative 2^-8 of the quantity's scale per rounding, up to three roundings on the way to a gradient -- bound 3 * 2^-8 of
+    the max norm (the bound of the sharded bf16 tests)."""
+    from pytorch_geometric_signed_directed_amd.nn import DiGCNConv
+    bad = []
+    for seed, rng in rounds("digcn_bf16"):
+        n, ei = draw_graph(rng)
+        f_in, f_out, bias = width(rng), width(rng), rng.random() < 0.7
+        w = (normal(rng, ei.size(1)) * 0.3)
+        x, up = normal(rng, n, f_in), normal(rng, n, f_out)
+        weight, b = normal(rng, f_in, f_out) * 0.3, (normal(rng, f_out) if bias else None)
+        rnd = lambda t: None if t is None else t.to(torch.bfloat16).float()      # noqa: E731
+        xo, wo, bo = rnd(x).requires_grad_(), rnd(weight).requires_grad_(), (None if b is None else rnd(b).requires_grad_())
+        with single_thread():
+            want = R.digcn_conv(xo, ei, w, wo, bo)
+            (want * rnd(up)).sum().backward()
+        layer = DiGCNConv(f_in, f_out, bias=bias)
+        layer.load_state_dict({k: v for k, v in (("weight", weight), ("bias", b)) if v is not None})
+        layer.to(D).to(torch.bfloat16)
+        xd = x.to(D).to(torch.bfloat16).requires_grad_()
+        out = layer(xd, ei.to(D), w.to(D))
+        (out.float() * rnd(up).to(D)).sum().backward()
+        pairs = [("out", out, want.detach()), ("dx", xd.grad, xo.grad), ("dweight", layer.weight.grad, wo.grad)]
+        if bias:
+            pairs.append(("dbias", layer.bias.grad, bo.grad))
+        for name, got, ref in pairs:
+            if got is None or got.dtype != torch.bfloat16:
+                bad.append(f"seed {seed} {name}: {None if got is None else got.dtype}")
+                continue
+            err = float((got.float().cpu() - ref).abs().max()) if ref.numel() else 0.0
+            scale = max(1.0, float(ref.abs().max())) if ref.numel() else 1.0
+            if not err <= 3 * 2.0 ** -8 * scale:
+                bad.append(f"seed {seed} n={n} e={ei.size(1)} {f_in}->{f_out} bias={bias} {name}: {err:.3e} > 3 * 2^-8 * {scale:.3g}")
+    assert not bad, "\n".join(bad[:20])
+
+
 # ------------------------------------------------------------------ a1 / a2: MagNetConv, MSConv
 @pytest.mark.parametrize("signed", [False, True])
 def test_fuzz_magnetic_layers(signed):
