@@ -1114,6 +1114,10 @@ def test_fuzz_report():
     """Not a check: leaves the run's counts (per target: rounds, checks, how many sat above the literal 1e-5 bar, above the
     suite's 1.5 x bar, above this file's 3 x bar) in the output and, when PYGSD_FUZZ_LOG names a path, in <path>.json."""
     import json
+    from pytorch_geometric_signed_directed_amd import _cabi
+    routes = _cabi.library_routes()
+    # every product of the rounds above was fp32 or bf16, at widths from 1 to 300: none may have reached hipBLASLt / rocBLAS
+    assert not routes, f"dense products took a library route during the randomised rounds: {routes}"
     report = {"rounds_per_target": ROUNDS, "first_seed": SEED0, "max_nodes": MAX_N, "max_edges": MAX_E,
               "skipped_non_finite_reference": SKIPPED["non_finite_reference"], "targets": STATS}
     print(json.dumps(report, indent=1))
