@@ -354,6 +354,17 @@ _LIBRARY_WARNED = set()
 _library_lock = threading.Lock()
 
 
+def c16(t):
+    """`t` contiguous AND starting on a 16-byte boundary, as the float4 / bf16x8 kernels address their operands.  `.contiguous()`
+    alone does not give that: a ONE-ROW column slice of a wider matrix is contiguous as it stands, wherever it starts (a graph of
+    one node fed from a padded feature matrix: found by tests/test_gpu_fuzz.py).  Copies only then."""
+    if t is None:
+        return None
+    # (a one-row matrix also keeps whatever row stride its parent had -- meaningless, but the kernels are told it)
+    ok = t.is_contiguous() and t.data_ptr() % 16 == 0 and (t.dim() != 2 or t.size(0) != 1 or t.stride(0) == t.size(1))
+    return t if ok else t.clone(memory_format=torch.contiguous_format)
+
+
 def note_library_route(site, detail=""):
     """Record one library-routed dense product / reduction at `site` (warns once per (site, detail))."""
     key = (site, str(detail))

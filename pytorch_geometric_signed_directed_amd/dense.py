@@ -47,8 +47,8 @@ def dense_fwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, bias: Option
     for t in list(a) + list(b) + [weight]:
         if t.dtype != torch.float32:
             raise TypeError(f"the fused dense stage computes in float32; got {t.dtype}")
-    a = [t.contiguous() for t in a]
-    b = [t.contiguous() for t in b]
+    a = [_cabi.c16(t) for t in a]
+    b = [_cabi.c16(t) for t in b]
     if len(a) != (k1 if last_in is None else k1 - 1) or len(b) != len(a):
         raise ValueError(f"{k1} Chebyshev terms expected, got {len(a)} (+ a piece operand: {last_in is not None})")
     n = a[0].size(0)
@@ -100,16 +100,16 @@ def dense_bwd_raw(a: List[Tensor], b: List[Tensor], weight: Tensor, g_r: Tensor,
     layout (`a` / `b` hold the k1 - 1 terms before it) / its gradients are stored through one -- straight into the send buffers
     of the propagate that takes them; da[k1 - 1] / db[k1 - 1] are None then."""
     k1, f_in, f_out = weight.shape
-    a = [t.contiguous() for t in a]
-    b = [t.contiguous() for t in b]
+    a = [_cabi.c16(t) for t in a]
+    b = [_cabi.c16(t) for t in b]
     if len(a) != (k1 if last_in is None else k1 - 1) or len(b) != len(a):
         raise ValueError(f"{k1} Chebyshev terms expected, got {len(a)} (+ a piece operand: {last_in is not None})")
     if g_r.size(0) > 1 and g_r.stride(0) == 0 and g_i.stride(0) == 0:
         # one row broadcast to every node (the gradient of a loss that sums over the nodes arrives as an expanded
         # tensor): hand the kernel that row with a zero row stride instead of materialising two [N, F] copies
-        g_r, g_i, ldg = g_r[:1].contiguous(), g_i[:1].contiguous(), 0
+        g_r, g_i, ldg = _cabi.c16(g_r[:1]), _cabi.c16(g_i[:1]), 0
     else:
-        g_r, g_i, ldg = g_r.contiguous(), g_i.contiguous(), f_out
+        g_r, g_i, ldg = _cabi.c16(g_r), _cabi.c16(g_i), f_out
     n_full = a[0].size(0)
     n = n_full if rows is None else int(rows)
     dev = weight.device
@@ -192,7 +192,7 @@ def set_fused_k1(on: bool) -> bool:
 def spmm2_k1_dense_raw(csr, va: Tensor, vb: Tensor, x_real: Tensor, x_imag: Tensor, weight: Tensor, bias: Optional[Tensor]):
     """-> (T1_real, T1_imag, out_real, out_imag) of a K = 1, 64 -> 64 magnetic layer in ONE launch."""
     n = csr.n_rows
-    xa, xb = x_real.contiguous(), x_imag.contiguous()
+    xa, xb = _cabi.c16(x_real), _cabi.c16(x_imag)
     w = weight.detach().contiguous()
     bd = None if bias is None else bias.detach().contiguous()
     ta, tb = torch.empty_like(xa), torch.empty_like(xb)
@@ -217,12 +217,12 @@ class MagneticConvFunction(torch.autograd.Function):
         csr, (vr, vi) = op.csr, op.values_fwd
         if (_FUSED_K1 and k1 == 2 and weight.size(1) == 64 and weight.size(2) == 64 and x_real.dtype == torch.float32
                 and csr.n_rows == csr.n_cols == x_real.size(0) and csr.nnz > 0 and csr.hubs() is None):
-            xr, xi = x_real.contiguous(), x_imag.contiguous()
+            xr, xi = _cabi.c16(x_real), _cabi.c16(x_imag)
             t1r, t1i, out_r, out_i = spmm2_k1_dense_raw(csr, vr, vi, xr, xi, weight, bias)
             ctx.op, ctx.k1, ctx.has_bias = op, k1, bias is not None
             ctx.save_for_backward(weight, xr, t1r, xi, t1i)
             return out_r, out_i
-        ta, tb = [x_real.contiguous()], [x_imag.contiguous()]
+        ta, tb = [_cabi.c16(x_real)], [_cabi.c16(x_imag)]
         for k in range(1, k1):
             if k == 1:
                 ya, yb = _spmm2_raw(csr, vr, vi, ta[0], tb[0], None, None, 1.0, 0.0)
@@ -291,7 +291,7 @@ def _row_major16(t: Tensor) -> Tensor:
     vec = 16 // t.element_size()
     if t.stride(1) == 1 and t.stride(0) % vec == 0 and t.stride(0) >= t.size(1) and t.data_ptr() % 16 == 0:
         return t
-    return t.contiguous()
+    return _cabi.c16(t)
 
 
 def tall_product(segments: Sequence[Tensor], w: Tensor, transposed: bool = False, bias: Optional[Tensor] = None,

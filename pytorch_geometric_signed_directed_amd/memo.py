@@ -107,6 +107,8 @@ def _order_after(entry, tensors):
     now = _raw_stream(tensors)
     if now is None or now == entry.stream_ptr:
         return
+    if torch.cuda.is_current_stream_capturing():
+        return      # a captured region cannot wait on work outside it; hipgraph.capture_step joins its warm-up stream before capturing
     dev = next(t.device for t in tensors if t is not None and t.is_cuda)
     cur = torch.cuda.current_stream(dev)
     done = torch.cuda.Event()

@@ -17,7 +17,7 @@ def weighted_sum(tensors, weights, out=None):
     out: where to write it -- a column block of a wider matrix qualifies (unit column stride, 16-byte aligned rows)."""
     import ctypes
     k = len(tensors)
-    tensors = [t.contiguous() for t in tensors]        # (a product at an odd width is a column slice of a padded one)
+    tensors = [_cabi.c16(t) for t in tensors]           # (a product at an odd width is a column slice of a padded one)
     shape = tensors[0].shape
     rows, cols = (1, tensors[0].numel()) if tensors[0].dim() != 2 else (shape[0], shape[1])
     if out is None:
@@ -39,8 +39,8 @@ def dots(g, tensors):
     """[<g, t> for t in tensors] as one fp32 device vector, g read once (pygsd_dots_f32); at most 8 tensors of g's shape."""
     import ctypes
     k = len(tensors)
-    g = g.contiguous()
-    tensors = [t.contiguous() for t in tensors]
+    g = _cabi.c16(g)
+    tensors = [_cabi.c16(t) for t in tensors]
     rows, cols = (1, g.numel()) if g.dim() != 2 else (g.size(0), g.size(1))
     out = torch.empty(k, dtype=torch.float32, device=g.device)
     ws = torch.empty(8192, dtype=torch.float64, device=g.device)      # 64 KiB: 1024 blocks x 8 products, float64 partials

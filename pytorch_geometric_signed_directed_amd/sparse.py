@@ -237,18 +237,20 @@ class Pattern:
             return None
         if memo.verify():
             memo.check_unchanged(w)                  # strict mode: the permuted copy below is only as good as w's contents
-        # (the current stream is part of the key: a permuted copy queued on one stream is not handed to another)
-        key = (id(w), which, torch._C._cuda_getCurrentRawStream(w.device.index) if w.is_cuda else None)
+        key = (id(w), which)
         hit = self._vcache.get(key)
         if hit is not None and hit[0]() is w and hit[1] == (w._version, memo.content_epoch()):
-            return hit[2]
+            memo._order_after(hit[2], (w,))          # (a copy queued on another stream: this one waits for it first)
+            return hit[2].value
         if w.numel() != self.nnz:
             raise ValueError(f"edge value array has {w.numel()} entries, pattern has {self.nnz}")
         csr = self.fwd if which == "fwd" else self.bwd
         out = gather_values(w.detach().reshape(-1), csr.perm)
         if len(self._vcache) > 16:
             self._vcache.clear()
-        self._vcache[key] = (weakref.ref(w), (w._version, memo.content_epoch()), out)
+        raw = memo._raw_stream((w,))
+        mark = memo._Entry(None, None, None, out, raw, None if raw is None else torch.cuda.current_stream(w.device))
+        self._vcache[key] = (weakref.ref(w), (w._version, memo.content_epoch()), mark)
         return out
 
 

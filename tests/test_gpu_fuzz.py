@@ -53,6 +53,8 @@ def draw_graph(rng, n_lo=1):
     """[2, E] int64 of a random digraph on n nodes: plain / one hub row and one hub column / duplicated entries /
     an isolated tail / no edges at all."""
     n = int(rng.integers(n_lo, MAX_N + 1)) if rng.random() < 0.8 else int(rng.integers(n_lo, 40))
+    if rng.random() < 0.04:
+        n = int(rng.integers(n_lo, n_lo + 3))             # one to three nodes: where "contiguous" stops implying anything
     density = float(rng.choice([0.0, 0.5, 2.0, 8.0, 30.0]))
     e = int(min(n * density, MAX_E))
     if density and rng.random() < 0.2:

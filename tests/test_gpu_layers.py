@@ -1066,6 +1066,43 @@ def test_memoised_operator_is_ordered_across_streams(kind):
     assert torch.equal(y2, want), float((y2 - want).abs().max())
 
 
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_one_row_column_slices_reach_the_kernels_aligned(n):
+    """A feature matrix that is a column slice of a wider one and starts off a 16-byte boundary: with ONE row it is
+    "contiguous" as it stands, so `.contiguous()` hands the float4 kernels an unaligned pointer (SIMPA on a one-node graph
+    raised `operand 0 ... not 16-byte aligned`; found by tests/test_gpu_fuzz.py after 1 200 rounds).  Every layer, widths
+    the vector kernels take: same result as on a fresh copy of the slice."""
+    from pytorch_geometric_signed_directed_amd.nn import (DGCNConv, DIMPA, Conv_Base, DiGCNConv, GATConv, MagNetConv, MSConv,
+                                                          SGCNConv, SIMPA, SNEAConv)
+    g = torch.Generator().manual_seed(n)
+    f = 16
+    ei = torch.randint(0, n, (2, 3 * n), generator=g).to(D)
+    ei2 = torch.randint(0, n, (2, 2 * n), generator=g).to(D)
+    w, w2 = (torch.rand(3 * n, generator=g) + 0.5).to(D), (torch.rand(2 * n, generator=g) + 0.5).to(D)
+    wide = torch.randn(n, 2 * f + 3, generator=g).to(D)
+    a, b = wide[:, 1:1 + f], wide[:, 2 + f:2 + 2 * f]                   # 4 and 8 bytes off a 16-byte boundary
+    assert a.data_ptr() % 16 != 0 and b.data_ptr() % 16 != 0
+    torch.manual_seed(n)
+    cases = [(MagNetConv(f, f, 1, 0.25, False).to(D), lambda m, x, y: m(x, y, ei, w)),
+             (MagNetConv(f, f, 2, 0.25, False).to(D), lambda m, x, y: m(x, y, ei, w)),
+             (MSConv(f, f, 2, 0.1, False).to(D), lambda m, x, y: m(x, y, ei, w)),
+             (DiGCNConv(f, f).to(D), lambda m, x, y: m(x, ei, w)), (DGCNConv(), lambda m, x, y: m(x, ei, w)),
+             (Conv_Base(0.5), lambda m, x, y: m(x, ei, w)), (SIMPA(2, 0.5, False).to(D), lambda m, x, y: m(ei, w, ei2, w2, x, y)),
+             (SIMPA(1, 0.5, True).to(D), lambda m, x, y: m(ei, w, ei2, w2, x, y, y, x)), (DIMPA(2, 0.5).to(D), lambda m, x, y: m(x, y, ei, w)),
+             (SGCNConv(f, f, True).to(D), lambda m, x, y: m(x, ei, ei2)), (SNEAConv(f, 8, True).to(D), lambda m, x, y: m(x, ei, ei2)),
+             (GATConv(f, 8).to(D), lambda m, x, y: m(x, ei))]
+    for layer, call in cases:
+        outs = []
+        for x, y in ((a, b), (a.clone(), b.clone())):
+            x, y = x.detach().requires_grad_(), y.detach().requires_grad_()
+            out = call(layer, x, y)
+            out = out if isinstance(out, (tuple, list)) else (out,)
+            sum((o * o).sum() for o in out).backward()
+            outs.append([o.detach() for o in out] + [x.grad])
+        for p_, q_ in zip(*outs):
+            close(p_, q_, what=type(layer).__name__)
+
+
 def test_memo_hit_on_another_stream_waits_for_the_value():
     """The mechanism itself, where the window is as wide as the test makes it (a layer's miss reads sizes back to the host,
     which narrows the real window to the build's last kernel): a value queued behind a 40 ms spin on stream 1 is memoised;
