@@ -1545,6 +1545,49 @@ class ShardedSGCNConv(_GradSync, torch.nn.Module):
         return self._arm(_zero_pad_rows(self.plan, torch.cat(halves, dim=1)))
 
 
+class _HopTerm(torch.autograd.Function):
+    """w * x for a one-element hop weight w: the weight's gradient <g, x> -- a sum over all local rows and columns -- is
+    taken in float64 (pygsd_dots_f32, as the single-device SIMPA does; an fp32 tree leaves ~1e-5 on sums whose partial
+    sums are in the hundreds: tests/test_gpu_sharded.py -k fuzz), the per-rank sums are then added by `_GradSync`."""
+
+    @staticmethod
+    def forward(ctx, w, x):
+        ctx.save_for_backward(w, x)
+        return x * w
+
+    @staticmethod
+    def backward(ctx, g):
+        w, x = ctx.saved_tensors
+        gw = gx = None
+        if ctx.needs_input_grad[1]:
+            gx = g * w
+        if ctx.needs_input_grad[0]:
+            if g.is_cuda and g.dim() == 2 and g.size(1) % 4 == 0 and g.dtype == torch.float32 and x.dtype == torch.float32:
+                from .nn.signed.SIMPA import dots
+                gw = dots(g, [x]).reshape(w.shape)
+            else:
+                gw = (g.double() * x.double()).sum().to(w.dtype).reshape(w.shape)
+        return gw, gx
+
+
+class _HopWeights:
+    """wp[h] * x through `_HopTerm`."""
+
+    def __init__(self, w: Tensor):
+        self.w = w
+
+    def __getitem__(self, h):
+        return _Hop(self.w[h])
+
+
+class _Hop:
+    def __init__(self, w: Tensor):
+        self.w = w
+
+    def __mul__(self, x: Tensor) -> Tensor:
+        return _HopTerm.apply(self.w, x)
+
+
 class ShardedSIMPA(_GradSync, torch.nn.Module):
     """SIMPA (reference nn/signed/SIMPA.py:52-144, the aggregation of SSSNET) over a node-range-sharded graph: the hop
     schedule of the un-sharded layer, every product of the random-walk operators A_p = D^-1 (A+ + fill I), A_n = D^-1 A-
@@ -1595,6 +1638,7 @@ class ShardedSIMPA(_GradSync, torch.nn.Module):
 
     def _stream(self, kp: str, kn: str, x_pos: Tensor, x_neg: Tensor, wp: Tensor, wn: Tensor) -> Tensor:
         """[feat_p | feat_n] of one (positive, negative) pair in the reference's accumulation order (SIMPA.py:77-93)."""
+        wp, wn = _HopWeights(wp), _HopWeights(wn)
         feat_p, feat_n = wp[0] * x_pos, None
         cur_p, aux_n, j, last = x_pos, x_neg, 0, self._hop_p - 1
         for h in range(self._hop_p):
