@@ -199,3 +199,24 @@ def test_library_routes_are_counted_and_announced_once():
     assert len([w for w in seen if "unit-test site" in str(w.message)]) == 2
     _cabi.reset_library_routes()
     assert _cabi.library_routes() == {}
+
+
+def test_c16_gives_contiguous_aligned_canonically_strided_operands():
+    """`_cabi.c16`: what the float4 kernels are handed.  A one-row column slice is contiguous wherever it starts and keeps its
+    parent's row stride -- both have to go (tests/test_gpu_layers.py::test_one_row_column_slices_reach_the_kernels_aligned runs
+    the layers on such inputs); tensors that already qualify are passed through untouched."""
+    import torch
+    from pytorch_geometric_signed_directed_amd import _cabi
+    wide = torch.arange(2 * 35, dtype=torch.float32).reshape(2, 35)
+    assert _cabi.c16(None) is None
+    whole = torch.zeros(4, 16)
+    assert _cabi.c16(whole) is whole
+    one = wide[:1, 1:17]                                   # one row, 4 bytes off the buffer's start, row stride 35
+    assert one.is_contiguous() and one.stride(0) == 35
+    got = _cabi.c16(one)
+    assert got.data_ptr() % 16 == 0 and got.stride() == (16, 1) and torch.equal(got, one) and got is not one
+    two = wide[:, 4:20]                                    # two rows: not contiguous
+    got = _cabi.c16(two)
+    assert got.is_contiguous() and got.data_ptr() % 16 == 0 and torch.equal(got, two)
+    row = torch.zeros(1, 16)
+    assert _cabi.c16(row) is row                           # a fresh one-row matrix has canonical strides
